@@ -1,0 +1,66 @@
+"""ctypes loader for librdmnet_hip.so.  There is no CPU fallback: a missing library or a failing
+call raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librdmnet_hip.so')
+
+c_void = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_size = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rdmnet_hip.h one to one
+SIGNATURES = {
+    'rdm_abi_version': (c_int, []),
+    'rdm_last_error': (ctypes.c_char_p, []),
+    'rdm_rehash_schedule': (c_int, [c_i64, c_void, c_void, c_int]),
+    'rdm_grid_subsample_workspace_bytes': (c_size, [c_i64, c_int]),
+    'rdm_grid_subsample': (c_int, [c_void, c_i64, c_void, c_int, c_f32, c_void, c_void, c_void, c_size,
+                                   c_void]),
+    'rdm_radius_neighbors_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
+    'rdm_radius_neighbors': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_int, c_f32, c_int,
+                                     c_void, c_void, c_void, c_void, c_void, c_size, c_void]),
+}
+
+_lib = None
+
+
+def build():
+    """Compile the library in-tree (hipcc cross-compiles for gfx950 without a GPU)."""
+    import subprocess
+    subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j8'], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `make -C rdmnet_amd/csrc` '
+                '(or __graft_entry__.build()); there is no CPU fallback')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().rdm_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(f'{what} failed with code {code}: {msg}')
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, 0 for None."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,110 @@
+// Shared host/device helpers for librdmnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+namespace rdm {
+
+// Error codes returned by every C-ABI entry point (0 = ok).
+enum : int {
+  RDM_OK = 0,
+  RDM_ERR_ARG = -1,       // bad argument (null pointer, negative size, unsupported shape)
+  RDM_ERR_WORKSPACE = -2, // caller workspace too small
+  RDM_ERR_HIP = -3,       // HIP runtime error (message in rdm_last_error())
+  RDM_ERR_CAPACITY = -4,  // a data-dependent capacity was exceeded on the device
+};
+
+void set_error(const char* fmt, ...);
+
+#define RDM_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::rdm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                       __LINE__);                                                        \
+      return ::rdm::RDM_ERR_HIP;                                                         \
+    }                                                                                    \
+  } while (0)
+
+#define RDM_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::rdm::set_error(__VA_ARGS__);      \
+      return ::rdm::RDM_ERR_ARG;          \
+    }                                     \
+  } while (0)
+
+inline int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+    return RDM_ERR_HIP;
+  }
+  return RDM_OK;
+}
+
+template <typename T>
+inline T ceil_div(T a, T b) {
+  return (a + b - 1) / b;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace.
+struct Arena {
+  char* base;
+  size_t cap;
+  size_t off = 0;
+  bool ok = true;
+  Arena(void* p, size_t n) : base(static_cast<char*>(p)), cap(n) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T));
+    if (base == nullptr || off + bytes > cap) {
+      ok = false;
+      off += bytes;
+      return nullptr;
+    }
+    T* r = reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+#ifdef __HIPCC__
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Relaxed agent-scope load: bypasses this CU's L1, so it observes L2 atomics of other waves.
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
+}  // namespace rdm

@@ -1,0 +1,487 @@
+// a1 -- voxel-grid barycentre subsampling, bit-exact with the reference INCLUDING its output order.
+//
+// Reference: geotransformer/extensions/cpu/grid_subsampling/grid_subsampling_cpu.cpp:3-48.
+// The reference emits voxels in the iteration order of a libstdc++ std::unordered_map<size_t, ...>
+// filled in point order.  That order is a deterministic function of (a) the distinct voxel keys in
+// first-occurrence order and (b) the container's growth schedule:
+//   * inserting into an empty bucket puts the node at the FRONT of the global list, inserting into
+//     an occupied bucket puts it at the front of that bucket's run  (hashtable.h
+//     _M_insert_bucket_begin), and a rehash re-inserts every node in current list order with the
+//     same rule (_M_rehash_aux);
+//   * hence after each growth stage the list is  sort by (first-time-of-bucket desc, time desc)
+//     where `time` = position in [previous list ++ newly inserted keys].
+// Each stage is therefore a data-parallel regrouping (atomicMin / atomicAdd per bucket, one
+// suffix scan, tiny per-bucket sorts); no serial pointer chasing is needed.  One 1024-thread
+// workgroup per cloud runs all stages; the growth schedule itself comes from libstdc++'s own
+// _Prime_rehash_policy on the host (rdm_rehash_schedule), so it follows the installed library.
+//
+// Float semantics (must not be contracted): origin = floor(min * (float)(1/v)) * v,
+// i = floor((p - origin) / v) with an IEEE fp32 divide, sums are sequential fp32 adds in point
+// order, output = sum * (float)(1.0 / count).
+#pragma clang fp contract(off)
+
+#include <unordered_map>  // std::__detail::_Prime_rehash_policy
+
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+constexpr int kT = 1024;
+constexpr int kMaxStages = 40;
+constexpr unsigned long long kEmpty = ~0ull;
+
+struct Schedule {
+  int n;
+  int at[kMaxStages];
+  int buckets[kMaxStages];
+};
+
+struct GridArgs {
+  const float* points;
+  const int64_t* lengths;
+  int batch;
+  float voxel;
+  float* tmp_points;     // [n_points,3] per-cloud results at the cloud's input offset
+  int64_t* out_lengths;  // [batch]
+  // scratch, carved per cloud from arrays sized for the whole batch
+  unsigned long long* ht_keys;  // 4*n + 64*batch
+  unsigned* ht_first;           // same
+  unsigned* ht_rank;            // same
+  unsigned* pt_slot;            // n
+  int* scan;                    // n
+  unsigned long long* ekey;     // n
+  int* ecnt;                    // n
+  int* ebase;                   // n
+  int* efill;                   // n
+  int* list;                    // n
+  float* epts;                  // 3n
+  int* order_a;                 // n
+  int* order_b;                 // n
+  int* bt;                      // n
+  int* off;                     // n
+  int* tmp;                     // n
+  int* bf;                      // 3*n + 64*batch  (bucket first-time)
+  int* bc;                      // same             (bucket count)
+  int* bl;                      // same             (bucket fill)
+  Schedule sched;
+};
+
+__device__ __forceinline__ int block_prefix(int v, int* lds, int& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    int x = lane < (kT / 64) ? lds[lane] : 0;
+    int s = x;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      int t = __shfl_up(s, o, 64);
+      if (lane >= o) s += t;
+    }
+    if (lane < kT / 64) lds[lane] = s - x;
+    if (lane == kT / 64 - 1) lds[kT / 64] = s;
+  }
+  __syncthreads();
+  int res = inc - v + lds[w];
+  total = lds[kT / 64];
+  __syncthreads();
+  return res;
+}
+
+// Exclusive scan of get(i), i in [0,n), written to out[i]; `reverse` scans from the high end
+// (suffix sums).  Returns the total.  All threads of the block must call it.
+template <typename F>
+__device__ int block_scan(int n, F get, int* out, int* lds, bool reverse) {
+  const int per = (n + kT - 1) / kT;
+  int c0 = threadIdx.x * per;
+  if (c0 > n) c0 = n;
+  int c1 = c0 + per;
+  if (c1 > n) c1 = n;
+  int local = 0;
+  for (int i = c0; i < c1; ++i) local += get(reverse ? n - 1 - i : i);
+  int total;
+  int pre = block_prefix(local, lds, total);
+  for (int i = c0; i < c1; ++i) {
+    const int j = reverse ? n - 1 - i : i;
+    const int v = get(j);
+    out[j] = pre;
+    pre += v;
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
+  __shared__ int s_scan[kT / 64 + 2];
+  __shared__ float s_red[2 * 3 * (kT / 64)];
+  __shared__ float s_org[3];
+  __shared__ unsigned long long s_nxy[2];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  int64_t start = 0;
+  for (int i = 0; i < b; ++i) start += a.lengths[i];
+  const int N = static_cast<int>(a.lengths[b]);
+  if (N <= 0) {
+    if (tid == 0) a.out_lengths[b] = 0;
+    return;
+  }
+  const float* P = a.points + 3 * start;
+  const float v = a.voxel;
+
+  // per-cloud regions
+  unsigned ht_cap = 64;
+  while (ht_cap < 2u * static_cast<unsigned>(N)) ht_cap <<= 1;
+  const unsigned ht_mask = ht_cap - 1;
+  const size_t ht_off = 4 * static_cast<size_t>(start) + 64 * static_cast<size_t>(b);
+  unsigned long long* ht_keys = a.ht_keys + ht_off;
+  unsigned* ht_first = a.ht_first + ht_off;
+  unsigned* ht_rank = a.ht_rank + ht_off;
+  unsigned* pt_slot = a.pt_slot + start;
+  int* scan = a.scan + start;
+  unsigned long long* ekey = a.ekey + start;
+  int* ecnt = a.ecnt + start;
+  int* ebase = a.ebase + start;
+  int* efill = a.efill + start;
+  int* list = a.list + start;
+  float* epts = a.epts + 3 * start;
+  int* cur = a.order_a + start;
+  int* nxt = a.order_b + start;
+  int* bt = a.bt + start;
+  int* off = a.off + start;
+  int* tmp = a.tmp + start;
+  const size_t b_off = 3 * static_cast<size_t>(start) + 64 * static_cast<size_t>(b);
+  int* bf = a.bf + b_off;
+  int* bc = a.bc + b_off;
+  int* bl = a.bl + b_off;
+
+  // ---- P0: bounding box (cloud.cpp:4-38), origin and nX, nY (grid_subsampling_cpu.cpp:9-20)
+  {
+    float lo[3] = {P[0], P[1], P[2]}, hi[3] = {P[0], P[1], P[2]};
+    for (int i = tid; i < N; i += kT)
+      for (int d = 0; d < 3; ++d) {
+        const float x = P[3 * i + d];
+        if (x < lo[d]) lo[d] = x;
+        if (x > hi[d]) hi[d] = x;
+      }
+    for (int d = 0; d < 3; ++d)
+      for (int o = 32; o > 0; o >>= 1) {
+        lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+        hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+      }
+    const int w = tid >> 6;
+    if ((tid & 63) == 0)
+      for (int d = 0; d < 3; ++d) {
+        s_red[w * 6 + d] = lo[d];
+        s_red[w * 6 + 3 + d] = hi[d];
+      }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < kT / 64; ++k)
+        for (int d = 0; d < 3; ++d) {
+          lo[d] = fminf(lo[d], s_red[k * 6 + d]);
+          hi[d] = fmaxf(hi[d], s_red[k * 6 + 3 + d]);
+        }
+      const float inv = static_cast<float>(1.0 / static_cast<double>(v));
+      for (int d = 0; d < 3; ++d) s_org[d] = floorf(lo[d] * inv) * v;
+      const double fx = floor(static_cast<double>((hi[0] - s_org[0]) / v)) + 1.0;
+      const double fy = floor(static_cast<double>((hi[1] - s_org[1]) / v)) + 1.0;
+      s_nxy[0] = static_cast<unsigned long long>(static_cast<long long>(fx));
+      s_nxy[1] = static_cast<unsigned long long>(static_cast<long long>(fy));
+    }
+    for (unsigned x = tid; x < ht_cap; x += kT) {
+      ht_keys[x] = kEmpty;
+      ht_first[x] = 0xFFFFFFFFu;
+    }
+    for (int i = tid; i < N; i += kT) {
+      ecnt[i] = 0;
+      efill[i] = 0;
+    }
+    __syncthreads();
+  }
+  const float ox = s_org[0], oy = s_org[1], oz = s_org[2];
+  const unsigned long long nx = s_nxy[0], ny = s_nxy[1];
+
+  // ---- P1: voxel key per point (grid_subsampling_cpu.cpp:28-35) + de-duplication
+  for (int i = tid; i < N; i += kT) {
+    const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+    const unsigned long long ix =
+        static_cast<unsigned long long>(static_cast<long long>(floorf((px - ox) / v)));
+    const unsigned long long iy =
+        static_cast<unsigned long long>(static_cast<long long>(floorf((py - oy) / v)));
+    const unsigned long long iz =
+        static_cast<unsigned long long>(static_cast<long long>(floorf((pz - oz) / v)));
+    const unsigned long long key = ix + nx * iy + nx * ny * iz;
+    unsigned slot = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 40) & ht_mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&ht_keys[slot], kEmpty, key);
+      if (prev == kEmpty || prev == key) break;
+      slot = (slot + 1) & ht_mask;
+    }
+    atomicMin(&ht_first[slot], static_cast<unsigned>(i));
+    pt_slot[i] = slot;
+  }
+  __syncthreads();
+
+  // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map)
+  const int M = block_scan(
+      N, [&](int i) { return ld_agent(&ht_first[pt_slot[i]]) == static_cast<unsigned>(i) ? 1 : 0; },
+      scan, s_scan, false);
+  for (int i = tid; i < N; i += kT) {
+    const unsigned slot = pt_slot[i];
+    if (ld_agent(&ht_first[slot]) == static_cast<unsigned>(i)) {
+      ht_rank[slot] = static_cast<unsigned>(scan[i]);
+      ekey[scan[i]] = ld_agent(&ht_keys[slot]);
+    }
+  }
+  __syncthreads();
+
+  // ---- P3..P6: per-voxel point lists in ascending point order, sequential fp32 sums
+  for (int i = tid; i < N; i += kT) atomicAdd(&ecnt[ht_rank[pt_slot[i]]], 1);
+  __syncthreads();
+  block_scan(M, [&](int e) { return ld_agent(&ecnt[e]); }, ebase, s_scan, false);
+  for (int i = tid; i < N; i += kT) {
+    const int e = static_cast<int>(ht_rank[pt_slot[i]]);
+    const int pos = atomicAdd(&efill[e], 1);
+    list[ebase[e] + pos] = i;
+  }
+  __syncthreads();
+  for (int e = tid; e < M; e += kT) {
+    const int c = ld_agent(&ecnt[e]);
+    int* L = list + ebase[e];
+    for (int x = 1; x < c; ++x) {  // insertion sort: voxels hold a handful of points
+      const int val = L[x];
+      int y = x - 1;
+      while (y >= 0 && L[y] > val) {
+        L[y + 1] = L[y];
+        --y;
+      }
+      L[y + 1] = val;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f;  // SampledData::update, grid_subsampling_cpu.h:17-20
+    for (int x = 0; x < c; ++x) {
+      const int i = L[x];
+      sx += P[3 * i];
+      sy += P[3 * i + 1];
+      sz += P[3 * i + 2];
+    }
+    const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
+    epts[3 * e] = sx * wgt;
+    epts[3 * e + 1] = sy * wgt;
+    epts[3 * e + 2] = sz * wgt;
+  }
+  __syncthreads();
+
+  // ---- P7: replay the container's growth stages to obtain its iteration order
+  for (int j = 0; j < a.sched.n; ++j) {
+    const int k0 = a.sched.at[j];
+    if (k0 >= M) break;
+    int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
+    if (k1 > M) k1 = M;
+    const int B = a.sched.buckets[j];
+    const int n = k1;  // every element ranked < k0 is already in `cur`
+    for (int x = tid; x < B; x += kT) {
+      bf[x] = 0x7fffffff;
+      bc[x] = 0;
+      bl[x] = 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kT) {
+      const int e = t < k0 ? cur[t] : t;
+      const int bkt = static_cast<int>(ekey[e] % static_cast<unsigned long long>(B));
+      bt[t] = bkt;
+      atomicMin(&bf[bkt], t);
+      atomicAdd(&bc[bkt], 1);
+    }
+    __syncthreads();
+    block_scan(
+        n,
+        [&](int t) {
+          const int bkt = bt[t];
+          return ld_agent(&bf[bkt]) == t ? ld_agent(&bc[bkt]) : 0;
+        },
+        off, s_scan, true);
+    for (int t = tid; t < n; t += kT) {
+      const int bkt = bt[t];
+      const int base = off[ld_agent(&bf[bkt])];
+      const int slot = atomicAdd(&bl[bkt], 1);
+      tmp[base + slot] = t;
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += kT) {
+      const int bkt = bt[t];
+      if (ld_agent(&bf[bkt]) != t) continue;
+      const int c = ld_agent(&bc[bkt]);
+      int* L = tmp + off[t];
+      for (int x = 1; x < c; ++x) {  // newest first inside a bucket
+        const int val = L[x];
+        int y = x - 1;
+        while (y >= 0 && L[y] < val) {
+          L[y + 1] = L[y];
+          --y;
+        }
+        L[y + 1] = val;
+      }
+    }
+    __syncthreads();
+    for (int pos = tid; pos < n; pos += kT) {
+      const int t = tmp[pos];
+      nxt[pos] = t < k0 ? cur[t] : t;
+    }
+    __syncthreads();
+    int* sw = cur;
+    cur = nxt;
+    nxt = sw;
+  }
+
+  // ---- P8: emit in list order (grid_subsampling_cpu.cpp:44-47)
+  float* out = a.tmp_points + 3 * start;
+  for (int pos = tid; pos < M; pos += kT) {
+    const int e = cur[pos];
+    out[3 * pos] = epts[3 * e];
+    out[3 * pos + 1] = epts[3 * e + 1];
+    out[3 * pos + 2] = epts[3 * e + 2];
+  }
+  if (tid == 0) a.out_lengths[b] = M;
+}
+
+// Stack the per-cloud results contiguously (grid_subsampling_cpu.cpp:67-68).
+__global__ void compact_clouds_kernel(const float* tmp_points, const int64_t* in_lengths,
+                                      const int64_t* out_lengths, int batch, float* out_points) {
+  const int b = blockIdx.y;
+  int64_t src = 0, dst = 0;
+  for (int i = 0; i < b; ++i) {
+    src += in_lengths[i];
+    dst += out_lengths[i];
+  }
+  const int64_t n = 3 * out_lengths[b];
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    out_points[3 * dst + i] = tmp_points[3 * src + i];
+}
+
+int fill_schedule(int64_t max_elems, Schedule* s) {
+  std::__detail::_Prime_rehash_policy pol;
+  std::size_t bkt = 1;
+  s->n = 0;
+  // Only the insert that overflows the current threshold can trigger a rehash, so jump there.
+  std::size_t k = 0;
+  while (static_cast<int64_t>(k) < max_elems && s->n < kMaxStages) {
+    auto r = pol._M_need_rehash(bkt, k, 1);
+    if (r.first) {
+      bkt = r.second;
+      s->at[s->n] = static_cast<int>(k);
+      s->buckets[s->n] = static_cast<int>(bkt);
+      ++s->n;
+      k = bkt;  // max_load_factor 1.0: the next growth happens when size reaches bucket_count
+    } else {
+      ++k;
+    }
+  }
+  return s->n;
+}
+
+}  // namespace
+
+extern "C" int rdm_rehash_schedule(int64_t max_elems, int64_t* at_host, int64_t* buckets_host,
+                                   int cap) {
+  std::__detail::_Prime_rehash_policy pol;
+  std::size_t bkt = 1;
+  int n = 0;
+  for (int64_t k = 0; k < max_elems; ++k) {  // exhaustive on purpose: this is the check of fill_schedule
+    auto r = pol._M_need_rehash(bkt, static_cast<std::size_t>(k), 1);
+    if (r.first) {
+      bkt = r.second;
+      if (n < cap) {
+        at_host[n] = k;
+        buckets_host[n] = static_cast<int64_t>(bkt);
+      }
+      ++n;
+    }
+  }
+  return n;
+}
+
+extern "C" size_t rdm_grid_subsample_workspace_bytes(int64_t n_points, int batch) {
+  Arena a(nullptr, 0);
+  const size_t n = static_cast<size_t>(n_points > 0 ? n_points : 1);
+  const size_t ht = 4 * n + 64 * static_cast<size_t>(batch);
+  const size_t bk = 3 * n + 64 * static_cast<size_t>(batch);
+  a.take<float>(3 * n);
+  a.take<unsigned long long>(ht);
+  a.take<unsigned>(ht);
+  a.take<unsigned>(ht);
+  a.take<unsigned>(n);
+  a.take<int>(n);
+  a.take<unsigned long long>(n);
+  for (int i = 0; i < 4; ++i) a.take<int>(n);
+  a.take<float>(3 * n);
+  for (int i = 0; i < 5; ++i) a.take<int>(n);
+  for (int i = 0; i < 3; ++i) a.take<int>(bk);
+  return a.off;
+}
+
+extern "C" int rdm_grid_subsample(const float* points, int64_t n_points, const int64_t* lengths,
+                                  int batch, float voxel_size, float* out_points,
+                                  int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(points && lengths && out_points && out_lengths, "rdm_grid_subsample: null pointer");
+  RDM_REQUIRE(batch > 0 && n_points >= 0 && n_points < (1ll << 30),
+              "rdm_grid_subsample: bad sizes (n_points=%lld batch=%d)", (long long)n_points, batch);
+  RDM_REQUIRE(voxel_size > 0.f, "rdm_grid_subsample: voxel_size must be positive");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_points == 0) {
+    RDM_HIP_CHECK(hipMemsetAsync(out_lengths, 0, sizeof(int64_t) * batch, st));
+    return RDM_OK;
+  }
+  Arena ar(ws, ws_bytes);
+  const size_t n = static_cast<size_t>(n_points);
+  const size_t ht = 4 * n + 64 * static_cast<size_t>(batch);
+  const size_t bk = 3 * n + 64 * static_cast<size_t>(batch);
+  GridArgs a;
+  a.points = points;
+  a.lengths = lengths;
+  a.batch = batch;
+  a.voxel = voxel_size;
+  a.out_lengths = out_lengths;
+  a.tmp_points = ar.take<float>(3 * n);
+  a.ht_keys = ar.take<unsigned long long>(ht);
+  a.ht_first = ar.take<unsigned>(ht);
+  a.ht_rank = ar.take<unsigned>(ht);
+  a.pt_slot = ar.take<unsigned>(n);
+  a.scan = ar.take<int>(n);
+  a.ekey = ar.take<unsigned long long>(n);
+  a.ecnt = ar.take<int>(n);
+  a.ebase = ar.take<int>(n);
+  a.efill = ar.take<int>(n);
+  a.list = ar.take<int>(n);
+  a.epts = ar.take<float>(3 * n);
+  a.order_a = ar.take<int>(n);
+  a.order_b = ar.take<int>(n);
+  a.bt = ar.take<int>(n);
+  a.off = ar.take<int>(n);
+  a.tmp = ar.take<int>(n);
+  a.bf = ar.take<int>(bk);
+  a.bc = ar.take<int>(bk);
+  a.bl = ar.take<int>(bk);
+  if (!ar.ok) {
+    set_error("rdm_grid_subsample: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  fill_schedule(n_points + 1, &a.sched);
+  hipLaunchKernelGGL(grid_subsample_kernel, dim3(batch), dim3(kT), 0, st, a);
+  if (int e = launch_status("grid_subsample_kernel")) return e;
+  const int blocks = static_cast<int>(ceil_div<int64_t>(3 * n_points, 256 * 4));
+  hipLaunchKernelGGL(compact_clouds_kernel, dim3(blocks > 0 ? blocks : 1, batch), dim3(256), 0, st,
+                     a.tmp_points, lengths, out_lengths, batch, out_points);
+  return launch_status("compact_clouds_kernel");
+}

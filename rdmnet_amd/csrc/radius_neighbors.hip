@@ -1,0 +1,327 @@
+// a2 -- fixed-radius neighbour search, bit-exact with the reference's nanoflann search.
+//
+// Reference: geotransformer/extensions/cpu/radius_neighbors/radius_neighbors_cpu.cpp:3-91
+// (per-cloud kd-tree, `sorted = true`), nanoflann.hpp:435-441 (metric), :249-250 (strict `<`).
+// The result set of a radius query does not depend on the search structure, so the kd-tree is
+// replaced by a uniform grid (cell edge >= radius) built on the fly:
+//   bbox -> per-cell counts (atomics) -> cell segments (atomic bump allocation, no scan)
+//   -> scatter {x,y,z,index} -> one wavefront per query scans its 27 cells with coalesced float4
+//   loads, keeps hits with wave ballots, sorts (d2, index) keys bitonically in LDS.
+// Float semantics (must not be contracted): d = q - s per axis, d2 = ((dx*dx)+(dy*dy))+(dz*dz),
+// accept iff d2 < radius*radius (all fp32).  Ties in d2 are ordered by index (canonical order; the
+// reference's std::sort leaves them unspecified).
+#pragma clang fp contract(off)
+
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+constexpr int kMaxCells = 1 << 20;   // cells over all clouds of one call
+constexpr int kMaxBatch = 64;
+constexpr int kWavesPerBlock = 4;
+
+struct GridMeta {
+  float org[3];
+  float inv_cell;
+  int dim[3];
+  int cells_per_cloud;
+  int total;  // bump allocator for cell segments
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One block: bounding box of all support points, grid geometry.
+__global__ __launch_bounds__(1024) void rn_bbox_kernel(const float* s, int64_t ns, float radius,
+                                                       int batch, GridMeta* meta) {
+  __shared__ float red[16 * 6];
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int64_t i = threadIdx.x; i < ns; i += blockDim.x)
+    for (int d = 0; d < 3; ++d) {
+      const float x = s[3 * i + d];
+      lo[d] = fminf(lo[d], x);
+      hi[d] = fmaxf(hi[d], x);
+    }
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+    }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 3; ++d) {
+      red[w * 6 + d] = lo[d];
+      red[w * 6 + 3 + d] = hi[d];
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(lo[d], red[k * 6 + d]);
+        hi[d] = fmaxf(hi[d], red[k * 6 + 3 + d]);
+      }
+    // cell edge = 1.001 * radius * m (m = smallest integer for which the grid fits kMaxCells); the
+    // 0.1 % margin keeps |cell(q) - cell(s)| <= 1 for every pair with d2 < r2 despite the rounding
+    // of the binning arithmetic.
+    float cell = radius;
+    int dim[3];
+    for (int m = 1;; ++m) {
+      cell = radius * 1.001f * static_cast<float>(m);
+      double cells = 1.0;
+      for (int d = 0; d < 3; ++d) {
+        const float ext = fmaxf(hi[d] - lo[d], 0.f);
+        double n = floor(static_cast<double>(ext) / static_cast<double>(cell)) + 1.0;
+        if (n > 1.0e6) n = 1.0e6;
+        dim[d] = static_cast<int>(n);
+        cells *= n;
+      }
+      if (cells * batch <= static_cast<double>(kMaxCells)) break;
+    }
+    for (int d = 0; d < 3; ++d) {
+      meta->org[d] = lo[d];
+      meta->dim[d] = dim[d];
+    }
+    meta->inv_cell = 1.0f / cell;
+    meta->cells_per_cloud = dim[0] * dim[1] * dim[2];
+    meta->total = 0;
+  }
+}
+
+__device__ __forceinline__ void cell_of(const GridMeta& g, float x, float y, float z, int& cx,
+                                        int& cy, int& cz) {
+  cx = clampi(static_cast<int>(floorf((x - g.org[0]) * g.inv_cell)), 0, g.dim[0] - 1);
+  cy = clampi(static_cast<int>(floorf((y - g.org[1]) * g.inv_cell)), 0, g.dim[1] - 1);
+  cz = clampi(static_cast<int>(floorf((z - g.org[2]) * g.inv_cell)), 0, g.dim[2] - 1);
+}
+
+// cloud index of stacked row i (batch is tiny)
+__device__ __forceinline__ int cloud_of(const int64_t* lengths, int batch, int64_t i, int64_t& begin) {
+  int64_t acc = 0;
+  for (int b = 0; b < batch; ++b) {
+    const int64_t n = lengths[b];
+    if (i < acc + n) {
+      begin = acc;
+      return b;
+    }
+    acc += n;
+  }
+  begin = acc;
+  return batch;  // beyond the stacked rows
+}
+
+__global__ void rn_count_kernel(const float* s, int64_t ns, const int64_t* s_lengths, int batch,
+                                const GridMeta* meta, int* cell_count, int* pt_cell, int* pt_slot) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= ns) return;
+  const GridMeta g = *meta;
+  int64_t begin;
+  const int b = cloud_of(s_lengths, batch, i, begin);
+  if (b >= batch) {
+    pt_cell[i] = -1;
+    return;
+  }
+  int cx, cy, cz;
+  cell_of(g, s[3 * i], s[3 * i + 1], s[3 * i + 2], cx, cy, cz);
+  const int c = b * g.cells_per_cloud + (cz * g.dim[1] + cy) * g.dim[0] + cx;
+  pt_cell[i] = c;
+  pt_slot[i] = atomicAdd(&cell_count[c], 1);
+}
+
+__global__ void rn_alloc_kernel(GridMeta* meta, int batch, const int* cell_count, int* cell_start) {
+  const int ncell = meta->cells_per_cloud * batch;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
+    const int n = cell_count[c];
+    cell_start[c] = n > 0 ? atomicAdd(&meta->total, n) : 0;
+  }
+}
+
+__global__ void rn_scatter_kernel(const float* s, int64_t ns, const int* pt_cell, const int* pt_slot,
+                                  const int* cell_start, float4* sorted) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= ns) return;
+  const int c = pt_cell[i];
+  if (c < 0) return;
+  float4 v;
+  v.x = s[3 * i];
+  v.y = s[3 * i + 1];
+  v.z = s[3 * i + 2];
+  v.w = __int_as_float(static_cast<int>(i));
+  sorted[cell_start[c] + pt_slot[i]] = v;
+}
+
+// One wavefront per query.
+template <int CAP>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
+    const float* q, int64_t nq, int64_t ns, const int64_t* q_lengths, int batch, float radius,
+    const GridMeta* meta, const int* cell_count, const int* cell_start, const float4* sorted,
+    int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status) {
+  __shared__ unsigned long long keys[kWavesPerBlock][CAP];
+  __shared__ int seg_start[kWavesPerBlock][28];
+  __shared__ int seg_pref[kWavesPerBlock][28];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
+  if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  const GridMeta g = *meta;
+  const float r2 = radius * radius;
+  const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  int64_t begin;
+  const int b = cloud_of(q_lengths, batch, qi, begin);
+
+  volatile unsigned long long* K = keys[wave];
+  int count = 0;
+  if (b < batch) {
+    int cx, cy, cz;
+    cell_of(g, qx, qy, qz, cx, cy, cz);
+    // lanes 0..26 own one neighbouring cell each
+    int my_n = 0, my_start = 0;
+    if (lane < 27) {
+      const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+      const int x = cx + dx, y = cy + dy, z = cz + dz;
+      if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+        const int c = b * g.cells_per_cloud + (z * g.dim[1] + y) * g.dim[0] + x;
+        my_n = cell_count[c];
+        my_start = cell_start[c];
+      }
+    }
+    int inc = my_n;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane < 27) {
+      seg_start[wave][lane] = my_start;
+      seg_pref[wave][lane] = inc - my_n;
+    }
+    const int total = __shfl(inc, 26, 64);
+    if (lane == 27) seg_pref[wave][27] = total;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    for (int base = 0; base < total; base += 64) {
+      const int t = base + lane;
+      bool hit = false;
+      unsigned long long key = 0;
+      if (t < total) {
+        int seg = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+          if (seg + step < 27 && seg_pref[wave][seg + step] <= t) seg += step;
+        const float4 p = sorted[seg_start[wave][seg] + (t - seg_pref[wave][seg])];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        float d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        hit = d2 < r2;
+        key = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) |
+              static_cast<unsigned>(__float_as_int(p.w));
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < CAP) K[pos] = key;
+      }
+      count += __popcll(m);
+    }
+  }
+  if (count > CAP) {
+    if (lane == 0) atomicExch(status, 1);
+  }
+  if (lane == 0) {
+    if (out_counts) out_counts[qi] = count;
+    if (out_max) atomicMax(out_max, count);
+  }
+  if (width <= 0) return;
+
+  const int n = count < CAP ? count : CAP;
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // bitonic sort of p2 keys by one wavefront (LDS, lock-step)
+  for (int k = 2; k <= p2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < p2; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = K[i], c = K[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > c) == up) {
+            K[i] = c;
+            K[ixj] = a;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  // offset of this cloud's supports is already folded in (indices are global rows)
+  int64_t* row = out_idx + qi * static_cast<int64_t>(width);
+  for (int c = lane; c < width; c += 64)
+    row[c] = c < n ? static_cast<int64_t>(K[c] & 0xffffffffull) : ns;
+}
+
+}  // namespace
+
+extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch) {
+  (void)n_q;
+  (void)batch;
+  rdm::Arena a(nullptr, 0);
+  const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
+  a.take<GridMeta>(1);
+  a.take<int>(kMaxCells);
+  a.take<int>(kMaxCells);
+  a.take<int>(ns);
+  a.take<int>(ns);
+  a.take<float4>(ns);
+  return a.off;
+}
+
+extern "C" int rdm_radius_neighbors(const float* q_points, int64_t n_q, const float* s_points,
+                                    int64_t n_s, const int64_t* q_lengths, const int64_t* s_lengths,
+                                    int batch, float radius, int width, int64_t* out_idx,
+                                    int32_t* out_counts, int32_t* out_max, int32_t* status, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q_lengths && s_lengths && status, "rdm_radius_neighbors: null pointer");
+  RDM_REQUIRE(n_q >= 0 && n_s >= 0 && n_s < (1ll << 31) && batch > 0 && batch <= kMaxBatch,
+              "rdm_radius_neighbors: bad sizes (n_q=%lld n_s=%lld batch=%d)", (long long)n_q,
+              (long long)n_s, batch);
+  RDM_REQUIRE(width >= 0 && (width == 0 || out_idx), "rdm_radius_neighbors: width/out_idx mismatch");
+  RDM_REQUIRE(radius > 0.f, "rdm_radius_neighbors: radius must be positive");
+  if (n_q == 0) return RDM_OK;
+  RDM_REQUIRE(q_points && (n_s == 0 || s_points), "rdm_radius_neighbors: null points");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Arena ar(ws, ws_bytes);
+  const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
+  GridMeta* meta = ar.take<GridMeta>(1);
+  int* cell_count = ar.take<int>(kMaxCells);
+  int* cell_start = ar.take<int>(kMaxCells);
+  int* pt_cell = ar.take<int>(ns);
+  int* pt_slot = ar.take<int>(ns);
+  float4* sorted = ar.take<float4>(ns);
+  if (!ar.ok) {
+    set_error("rdm_radius_neighbors: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(rn_bbox_kernel, dim3(1), dim3(1024), 0, st, s_points, n_s, radius, batch, meta);
+  RDM_HIP_CHECK(hipMemsetAsync(cell_count, 0, sizeof(int) * kMaxCells, st));
+  if (n_s > 0) {
+    const int blocks = static_cast<int>(ceil_div<int64_t>(n_s, 256));
+    hipLaunchKernelGGL(rn_count_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, s_lengths,
+                       batch, meta, cell_count, pt_cell, pt_slot);
+    hipLaunchKernelGGL(rn_alloc_kernel, dim3(1024), dim3(256), 0, st, meta, batch, cell_count,
+                       cell_start);
+    hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, pt_cell,
+                       pt_slot, cell_start, sorted);
+  }
+  const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
+  hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
+                     q_points, n_q, n_s, q_lengths, batch, radius, meta, cell_count, cell_start,
+                     sorted, width, out_idx, out_counts, out_max, status);
+  return launch_status("rn_query_kernel");
+}

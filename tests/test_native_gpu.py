@@ -1,0 +1,100 @@
+"""GPU parity: rdmnet_amd.ext (HIP, through the C-ABI) vs the oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pyramid import build_levels, search_calls, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ext():
+    from rdmnet_amd import ext
+    return ext
+
+
+def gpu_grid(ext):
+    def f(p, l, v):
+        sp, sl = ext.grid_subsampling(torch.from_numpy(p).cuda(), torch.from_numpy(l).cuda(), float(v))
+        return sp.cpu().numpy(), sl.cpu().numpy()
+    return f
+
+
+def gpu_radius(ext, q, s, ql, sl, r, **kw):
+    return ext.radius_neighbors(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(ql).cuda(),
+                                torch.from_numpy(sl).cuda(), float(r), **kw).cpu().numpy()
+
+
+@pytest.mark.parametrize('pair', [('000000', '000004'), ('000000', '000007')])
+def test_pyramid_matches_reference_goldens(ext, scans, golden_dir, pair):
+    golden = np.load(os.path.join(golden_dir, 'native_golden.npz'))
+    a, b = scans['s' + pair[0]], scans['s' + pair[1]]
+    tag = f'{pair[0]}_{pair[1]}'
+    P, L = build_levels(gpu_grid(ext), np.concatenate([a, b]), np.array([len(a), len(b)], dtype=np.int64))
+    for lvl in range(1, 5):
+        assert np.array_equal(L[lvl], golden[f'{tag}/lengths{lvl}'])
+        assert np.array_equal(P[lvl], golden[f'{tag}/points{lvl}']), f'level {lvl}: values or order differ'
+    for name, q, s, ql, sl, r, lim in search_calls(P, L):
+        idx = gpu_radius(ext, q, s, ql, sl, r)
+        key = f'{tag}/{name}'
+        assert idx.shape[1] == int(golden[key + '/width'])
+        assert np.array_equal((idx < s.shape[0]).sum(1), golden[key + '/counts'])
+        assert np.array_equal(sha(idx[:, :lim]), golden[key + '/sha'])
+        lim_idx = gpu_radius(ext, q, s, ql, sl, r, width=lim)  # direct truncated path
+        assert np.array_equal(lim_idx, idx[:, :lim])
+
+
+def test_random_and_edge_clouds_match_oracle(ext, oracle_native):
+    o = oracle_native.restatement()
+    rng = np.random.default_rng(1)
+    cases = [(1, 1, 1.0), (7, 300, 3.0), (2500, 1800, 15.0), (3000, 1, 30.0), (64, 64, 0.05)]
+    for n0, n1, scale in cases:
+        pts = (rng.standard_normal((n0 + n1, 3)) * scale).astype(np.float32)
+        pts[: min(n0, 3)] = pts[0]  # exact duplicates -> ties, multi-point voxels
+        lens = np.array([n0, n1], dtype=np.int64)
+        for voxel in (0.6, 2.4):
+            po, lo = o.grid_subsampling(pts, lens, np.float32(voxel))
+            pg, lg = gpu_grid(ext)(pts, lens, np.float32(voxel))
+            assert np.array_equal(lo, lg) and np.array_equal(po, pg), (n0, n1, scale, voxel)
+            io = o.radius_neighbors(po, pts, lo, lens, np.float32(voxel * 2.125))
+            ig = gpu_radius(ext, po, pts, lo, lens, voxel * 2.125)
+            assert np.array_equal(io, ig), (n0, n1, scale, voxel)
+
+
+def test_empty_cloud_in_batch(ext, oracle_native):
+    o = oracle_native.restatement()
+    pts = np.random.default_rng(2).standard_normal((50, 3)).astype(np.float32)
+    lens = np.array([50, 0], dtype=np.int64)
+    po, lo = o.grid_subsampling(pts, lens, np.float32(0.5))
+    pg, lg = gpu_grid(ext)(pts, lens, np.float32(0.5))
+    assert np.array_equal(lo, lg) and np.array_equal(po, pg)
+    assert np.array_equal(o.radius_neighbors(pts, pts, lens, lens, np.float32(1.0)), gpu_radius(ext, pts, pts, lens, lens, 1.0))
+
+
+def test_synthetic_full_size_properties(ext):
+    """BASELINE-size check through size-independent properties: voxel occupancy is idempotent
+    (re-subsampling with the same voxel cannot merge further than one point per voxel changes),
+    neighbour rows are sorted by distance, symmetric and contain the query itself."""
+    from rdmnet_amd import synthetic
+    ref, src, _ = synthetic.make_pair(3)
+    pts = np.concatenate([ref, src])
+    lens = np.array([len(ref), len(src)], dtype=np.int64)
+    p1, l1 = gpu_grid(ext)(pts, lens, np.float32(0.6))
+    assert l1.sum() == p1.shape[0] and 0 < p1.shape[0] < pts.shape[0]
+    idx = gpu_radius(ext, p1, p1, l1, l1, 1.275)
+    n = p1.shape[0]
+    assert (idx[:, 0] == np.arange(n)).all()  # self first (d2 = 0)
+    valid = idx < n
+    pp = np.concatenate([p1, np.full((1, 3), 1e6, np.float32)])
+    d = ((pp[idx] - p1[:, None]) ** 2).sum(-1)
+    assert (np.diff(np.where(valid, d, np.inf), axis=1) >= -1e-6).all()
+    rows = np.repeat(np.arange(n), valid.sum(1))
+    cols = idx[valid]
+    fwd = set(zip(rows.tolist()[:20000], cols.tolist()[:20000]))
+    allp = set(zip(rows.tolist(), cols.tolist()))
+    assert all((c, r) in allp for r, c in fwd)
+    # clouds never mix
+    assert (cols[rows < l1[0]] < l1[0]).all() and (cols[rows >= l1[0]] >= l1[0]).all()
