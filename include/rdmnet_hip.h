@@ -70,6 +70,55 @@ int rdm_radius_neighbors(const float* q_points, int64_t n_q, const float* s_poin
                          int32_t* out_max, int32_t* status, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* ---- dense contraction ---------------------------------------------------------------------
+ * C[b] = act((A[b] (m x k) * op(B[b])) / rowdiv[row] + bias[col]) in fp32 on the f32 MFMA.
+ * trans_b = 0: B is [k, n] row-major (pre-transposed nn.Linear weights, KPConv weights viewed
+ * [15*C_in, C_out]); trans_b = 1: B is [n, k] row-major.  act: 0 none, 1 ReLU, 2 LeakyReLU(0.1).
+ * Replaces torch.nn.Linear / torch.matmul / torch.einsum call sites of the path, e.g.
+ * geotransformer/modules/kpconv/kpconv.py:107-110, modules/kpconv/modules.py:77,
+ * experiments/model_infer.py:310-311.  k, lda, ldb must be multiples of 4 (zero padded), A and B
+ * 16-byte aligned.  ws (rdm_gemm_workspace_bytes) enables deterministic split-K; may be NULL.   */
+size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches);
+int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,
+             int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c, int64_t m,
+             int64_t n, int64_t k, int batches, const float* bias, const float* rowdiv, int act,
+             void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a4: KPConv neighbourhood aggregation ---------------------------------------------------
+ * Replaces the gather half of KPConv.forward (geotransformer/modules/kpconv/kpconv.py:91-105,
+ * 113-115): wf[m, k*c + ch] = sum_h max(0, 1 - |s[idx[m,h]] - q[m] - kp[k]| / sigma) * feats[idx[m,h], ch]
+ * and nn[m] = max(1, #neighbours whose feature row sums to > 0) (as float).  Pad indices (>= n_s)
+ * are the reference's shadow point/zero row.  s_positive[i] = (sum_c feats[i,c] > 0), see
+ * rdm_row_positive / rdm_group_norm.  width (optional device int32) caps the row width like the
+ * reference's `[:, :min(limit, max_count)]`.  c in {1, 32, 64, 128, 256, 512}; h <= 128.
+ * The second half of the convolution is rdm_gemm(wf, W[15*c, c'], rowdiv = nn, bias).          */
+int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                      const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                      const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                      const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
+                      void* stream);
+int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld, uint8_t* out, void* stream);
+
+/* ---- a5: block glue --------------------------------------------------------------------------
+ * rdm_group_norm: y = act(GroupNorm(x) [+ residual]) with statistics over ALL n rows
+ *   (geotransformer/modules/kpconv/modules.py:33-50, 53-83, 204-225); optionally also writes the
+ *   positive-row flag of y.  rdm_layer_norm: y = act(LayerNorm(x [+ residual]))
+ *   (torch.nn.LayerNorm call sites: modules/transformer/vanilla_transformer.py:79,101, output_layer.py:13,20, rdmnet/vote/vote.py:58-77).
+ * rdm_gather_max: modules/kpconv/functional.py:54-67.  rdm_upsample_concat: functional.py:6-22 +
+ *   the torch.cat of experiments/backbone.py:131-143; pad columns of y are zeroed.              */
+size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c);
+int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx, int groups, const float* gamma,
+                   const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y,
+                   int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
+int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
+                   int64_t ldr, const float* gamma, const float* beta, float eps, int act, float* y,
+                   int64_t ldy, void* stream);
+int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
+                   int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
+int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1,
+                        const int64_t* idx, int64_t ldi, const float* skip, int64_t c2, int64_t ld2,
+                        int64_t m, float* y, int64_t ldy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

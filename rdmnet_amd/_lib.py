@@ -23,6 +23,21 @@ SIGNATURES = {
     'rdm_radius_neighbors_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_radius_neighbors': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_int, c_f32, c_int,
                                      c_void, c_void, c_void, c_void, c_void, c_size, c_void]),
+    'rdm_gemm_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
+    'rdm_gemm': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_i64, c_i64, c_i64, c_i64,
+                         c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_void]),
+    'rdm_kpconv_gather': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
+                                  c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
+    'rdm_row_positive': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void]),
+    'rdm_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'rdm_group_norm': (c_int, [c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_f32, c_void, c_i64, c_int,
+                               c_void, c_i64, c_void, c_void, c_size, c_void]),
+    'rdm_layer_norm': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_f32, c_int, c_void,
+                               c_i64, c_void]),
+    'rdm_gather_max': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_i64,
+                               c_void]),
+    'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,
+                                    c_void, c_i64, c_void]),
 }
 
 _lib = None

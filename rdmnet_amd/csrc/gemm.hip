@@ -1,0 +1,286 @@
+// fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 157 TF peak).
+//
+//   C[b] = act( (A[b] (MxK) * op(B[b])) / rowdiv[m] + bias[n] )
+//     op(B) = B            B stored [K, N] row-major   (trans_b = 0; pre-transposed weights)
+//     op(B) = B^T          B stored [N, K] row-major   (trans_b = 1; activations, e.g. f_r * f_s^T)
+//
+// Used for every dense contraction of the path that is not an attention: Linear layers of the
+// KPConv blocks (modules/kpconv/modules.py:53-101), the [M, 15*C] x [15*C, C'] kernel-weight
+// contraction of KPConv (modules/kpconv/kpconv.py:107-110), transformer projections / FFN, the vote
+// MLP, coarse-matching similarities and the batched patch score einsum (model_infer.py:310-311).
+//
+// Tiling: 256 threads = 4 wavefronts; block tile BM x BN x 16, LDS double-buffered, operands stored
+// k-major in LDS so a 32x32x2 fragment read is two conflict-free 128-B rows.  Split-K (partials +
+// fixed-order reduce, no atomics => deterministic) keeps the small-M / huge-K coarse levels busy.
+// Requirements: lda, ldb, K multiples of 4 and 16-byte aligned bases (callers pad with zeros).
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;    // [N] or null
+  const float* rowdiv;  // [M] or null
+  int M, N, K;
+  int lda, ldb, ldc;
+  long long sa, sb, sc;  // batch strides (elements)
+  int act;               // 0 none, 1 relu, 2 leaky-relu(0.1)
+  int splits;            // split-K factor (partials go to `part`)
+  float* part;           // [batch*splits, M, N] when splits > 1
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return v > 0.f ? v : 0.1f * v;
+  return v;
+}
+
+constexpr int BK = 16;
+
+template <int BM, int BN, int WM, int WN, bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
+  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+  __shared__ float As[2][BK][LDA_S];
+  __shared__ float Bs[2][BK][LDB_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+  const float* A = g.A + batch * g.sa;
+  const float* B = g.B + batch * g.sb;
+
+  // K range of this split (multiples of BK)
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int per = (ktiles + g.splits - 1) / g.splits;
+  const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
+
+  constexpr int A_V = BM / 64;                      // float4 per thread for the A tile
+  constexpr int B_N4 = BK * BN / 4;                 // float4 in the B tile
+  constexpr int B_V = (B_N4 + 255) / 256;           // float4 per thread for the B tile
+  float4 ra[A_V], rb[B_V];
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+      const int gm = m0 + row, gk = k0 + kc;
+      ra[i] = (gm < g.M && gk < g.K)
+                  ? *reinterpret_cast<const float4*>(A + static_cast<long long>(gm) * g.lda + gk)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (TRANS_B) {
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+        const int gn = n0 + row, gk = k0 + kc;
+        rb[i] = (row < BN && gn < g.N && gk < g.K)
+                    ? *reinterpret_cast<const float4*>(B + static_cast<long long>(gn) * g.ldb + gk)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + i * 256;
+        const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+        const int gk = idx < B_N4 ? k0 + k : g.K, gn = n0 + n4;
+        const float* p = B + static_cast<long long>(gk) * g.ldb + gn;
+        if (gk < g.K && gn + 3 < g.ldb) {
+          rb[i] = *reinterpret_cast<const float4*>(p);
+        } else {
+          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gk < g.K) {
+            if (gn < g.ldb) rb[i].x = p[0];
+            if (gn + 1 < g.ldb) rb[i].y = p[1];
+            if (gn + 2 < g.ldb) rb[i].z = p[2];
+          }
+        }
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+      As[buf][kc + 0][row] = ra[i].x;
+      As[buf][kc + 1][row] = ra[i].y;
+      As[buf][kc + 2][row] = ra[i].z;
+      As[buf][kc + 3][row] = ra[i].w;
+    }
+    if (TRANS_B) {
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+        if (row >= BN) continue;
+        Bs[buf][kc + 0][row] = rb[i].x;
+        Bs[buf][kc + 1][row] = rb[i].y;
+        Bs[buf][kc + 2][row] = rb[i].z;
+        Bs[buf][kc + 3][row] = rb[i].w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_V; ++i) {
+        const int idx = tid + i * 256;
+        const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+        if (idx < B_N4) *reinterpret_cast<float4*>(&Bs[buf][k][n4]) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt0 < kt1) {
+    load_tiles(kt0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  const int lk = lane >> 5, li = lane & 31;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tiles(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = As[buf][kk + lk][wm * TM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+  const bool partial = g.splits > 1;
+  float* C = partial ? g.part + static_cast<long long>(blockIdx.z) * g.M * g.N : g.C + batch * g.sc;
+  const int ldc = partial ? g.N : g.ldc;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * TN + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= g.M) continue;
+        float v = acc[i][j][r];
+        if (!partial) {
+          if (g.rowdiv) v = v / g.rowdiv[row];
+          v = apply_act(v + bv, g.act);
+        }
+        C[static_cast<long long>(row) * ldc + col] = v;
+      }
+    }
+}
+
+__global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
+  const long long total = static_cast<long long>(batches) * g.M * g.N;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(i % g.N);
+    const int m = static_cast<int>((i / g.N) % g.M);
+    const int b = static_cast<int>(i / (static_cast<long long>(g.M) * g.N));
+    const float* p = g.part + (static_cast<long long>(b) * g.splits) * g.M * g.N +
+                     static_cast<long long>(m) * g.N + n;
+    float v = 0.f;
+    for (int s = 0; s < g.splits; ++s) v += p[static_cast<long long>(s) * g.M * g.N];  // fixed order
+    if (g.rowdiv) v = v / g.rowdiv[m];
+    if (g.bias) v += g.bias[n];
+    g.C[b * g.sc + static_cast<long long>(m) * g.ldc + n] = apply_act(v, g.act);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
+  dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
+  if (trans_b)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g);
+}
+
+}  // namespace
+
+extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
+  // worst case split factor is 16
+  return align_up(static_cast<size_t>(m) * static_cast<size_t>(n) * 16 * sizeof(float) *
+                  static_cast<size_t>(batches > 0 ? batches : 1));
+}
+
+extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,
+                        int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c,
+                        int64_t m, int64_t n, int64_t k, int batches, const float* bias,
+                        const float* rowdiv, int act, void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(a && b && c, "rdm_gemm: null pointer");
+  RDM_REQUIRE(m >= 0 && n >= 0 && k >= 0 && batches >= 1, "rdm_gemm: bad sizes");
+  if (m == 0 || n == 0) return RDM_OK;
+  RDM_REQUIRE(k % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
+              "rdm_gemm: K (%lld), lda (%lld), ldb (%lld) must be multiples of 4 (pad with zeros)",
+              (long long)k, (long long)lda, (long long)ldb);
+  RDM_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
+              "rdm_gemm: A and B must be 16-byte aligned");
+  RDM_REQUIRE(act >= 0 && act <= 2, "rdm_gemm: unknown activation %d", act);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GemmArgs g;
+  g.A = a; g.B = b; g.C = c; g.bias = bias; g.rowdiv = rowdiv;
+  g.M = static_cast<int>(m); g.N = static_cast<int>(n); g.K = static_cast<int>(k);
+  g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
+  g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
+  g.act = act; g.splits = 1; g.part = nullptr;
+
+  // tile choice
+  enum { T128, T64, T128x32 } tile;
+  if (n <= 32) tile = T128x32;
+  else if (m >= 2048 && n >= 128) tile = T128;
+  else tile = T64;
+  const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
+  const long long tiles = static_cast<long long>(ceil_div<int64_t>(m, bm)) * ceil_div<int64_t>(n, bn) * batches;
+  const int ktiles = static_cast<int>(ceil_div<int64_t>(k, BK));
+  if (tiles < 256 && ktiles >= 32) {
+    int s = static_cast<int>(ceil_div<long long>(512, tiles));
+    if (s > 16) s = 16;
+    if (s > ktiles / 8) s = ktiles / 8;
+    const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
+    if (s > 1 && ws && ws_bytes >= need) {
+      g.splits = s;
+      g.part = static_cast<float*>(ws);
+    }
+  }
+  switch (tile) {
+    case T128: launch<128, 128, 2, 2>(g, batches, trans_b != 0, st); break;
+    case T64: launch<64, 64, 2, 2>(g, batches, trans_b != 0, st); break;
+    case T128x32: launch<128, 32, 4, 1>(g, batches, trans_b != 0, st); break;
+  }
+  if (int e = launch_status("gemm_kernel")) return e;
+  if (g.splits > 1) {
+    const long long total = static_cast<long long>(batches) * m * n;
+    const int blocks = static_cast<int>(std::min<long long>(ceil_div<long long>(total, 256), 2048));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, batches);
+    return launch_status("splitk_reduce_kernel");
+  }
+  return RDM_OK;
+}

@@ -1,0 +1,244 @@
+// a4 -- KPConv neighbourhood aggregation (the gather-bound half of the rigid kernel-point convolution).
+//
+// Reference: geotransformer/modules/kpconv/kpconv.py:79-122.  For every query m:
+//   rel_h   = s_points[idx[m,h]] - q_points[m]                  (pad index -> point at +1e6)   :91-93
+//   w[h,k]  = max(0, 1 - sqrt(|rel_h - kp_k|^2) / sigma)                                       :96-99
+//   WF[m, k, c] = sum_h w[h,k] * s_feats[idx[m,h], c]           (pad index -> zero row)        :103-105
+//   nn[m]   = max(1, #{h : sum_c s_feats[idx[m,h], c] > 0})                                    :113-115
+// The second half, out = (WF viewed [M, 15*C]) x W[15*C, C'] / nn + bias (:107-121), is a dense GEMM
+// and runs in rdm_gemm with `rowdiv = nn`.
+//
+// Mapping: one wavefront per query.  Phase 1 loads the index row coalesced and stages the relative
+// neighbour positions in LDS.  Phase 2 walks the neighbours four at a time; the 15 kernel-point
+// influences of those four neighbours ARE the A operand of v_mfma_f32_16x16x4_f32 (lane = (neighbour
+// g, kernel point j)) and the gathered feature rows are the B operand, fetched as 8/16-byte vectors
+// (16 lanes x 16 B = one contiguous 256-B piece of a feature row, four rows per instruction).  The
+// channel -> tile assignment is permuted (channel = 16*VEC*u + VEC*j + e) so that both the gathers and
+// the WF stores are vector accesses.
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKP = 15;          // kernel points (cfg.backbone.kernel_size)
+constexpr int kMaxH = 128;       // neighbour slots per query
+constexpr int kWaves = 4;
+
+struct KpArgs {
+  const float* q_points;   // [M,3]
+  const float* s_points;   // [Ns,3]
+  const float* s_feats;    // [Ns, ldf]
+  const unsigned char* s_pos;  // [Ns] 1 iff sum_c feats > 0
+  const int64_t* idx;      // [M, ldi]
+  const float* kp;         // [15,3]
+  const int32_t* width;    // optional device int: effective row width (min(limit, max_count))
+  float* wf;               // [M, ldw] (>= 15*C)
+  float* nn;               // [M]
+  int M, Ns, H, C;
+  int ldf, ldi, ldw;
+  float sigma;
+};
+
+template <int VEC, int U>
+__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
+  __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = bit pattern of the support row (or -1)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * kWaves + wave;
+  if (m >= a.M) return;
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);
+  const int g = lane >> 4, j = lane & 15;
+
+  // ---- phase 1: neighbour rows, relative positions, positive-row count
+  const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+  int positives = 0;
+  for (int h = lane; h < H; h += 64) {
+    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+    float4 v;
+    if (id >= 0 && id < a.Ns) {
+      v.x = a.s_points[3 * id] - qx;
+      v.y = a.s_points[3 * id + 1] - qy;
+      v.z = a.s_points[3 * id + 2] - qz;
+      v.w = __int_as_float(static_cast<int>(id));
+      positives += a.s_pos[id];
+    } else {  // shadow neighbour: point at 1e6, zero features
+      v.x = 1.0e6f - qx;
+      v.y = 1.0e6f - qy;
+      v.z = 1.0e6f - qz;
+      v.w = __int_as_float(-1);
+    }
+    nb[wave][h] = v;
+  }
+  positives = wave_sum_i(positives);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
+              kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  f32x4 acc[VEC * U];
+#pragma unroll
+  for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- phase 2: four neighbours per step
+  for (int h0 = 0; h0 < H; h0 += 4) {
+    const int h = h0 + g;
+    float w = 0.f;
+    int id = -1;
+    if (h < H) {
+      const float4 v = nb[wave][h];
+      id = __float_as_int(v.w);
+      const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      w = fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma);
+      if (j >= kKP || id < 0) w = 0.f;
+    }
+    const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float f[VEC];
+      if (id >= 0) {
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(row + 16 * VEC * u);
+          f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+        } else if (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(row + 16 * VEC * u);
+          f[0] = t.x; f[1] = t.y;
+        } else {
+          f[0] = row[16 * VEC * u];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        acc[u * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f[e], acc[u * VEC + e], 0, 0, 0);
+    }
+  }
+
+  // ---- store WF[m, k, c]: accumulator row = 4*g + r = kernel point, column j
+  float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * g + r;
+    if (k >= kKP) continue;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float* p = out + k * a.C + 16 * VEC * u + VEC * j;
+      if (VEC == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(acc[u * 4 + 0][r], acc[u * 4 + 1][r],
+                                                    acc[u * 4 + 2][r], acc[u * 4 + 3][r]);
+      } else if (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(acc[u * 2 + 0][r], acc[u * 2 + 1][r]);
+      } else {
+        p[0] = acc[u][r];
+      }
+    }
+  }
+  if (lane == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+}
+
+// First layer (C_in = 1, features == 1 for every real point, reference dataset.py:187-188 and
+// model_infer.py:113): WF[m,k] = sum_h w[h,k] * f[idx], no matrix core needed.
+__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * kWaves + wave;
+  if (m >= a.M) return;
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);
+  const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+  float acc[kKP];
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) acc[k] = 0.f;
+  int positives = 0;
+  for (int h = lane; h < H; h += 64) {
+    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+    if (id < 0 || id >= a.Ns) continue;
+    const float f = a.s_feats[id * a.ldf];
+    positives += a.s_pos[id];
+    const float rx = a.s_points[3 * id] - qx, ry = a.s_points[3 * id + 1] - qy,
+                rz = a.s_points[3 * id + 2] - qz;
+#pragma unroll
+    for (int k = 0; k < kKP; ++k) {
+      const float dx = rx - a.kp[3 * k], dy = ry - a.kp[3 * k + 1], dz = rz - a.kp[3 * k + 2];
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      acc[k] += fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma) * f;
+    }
+  }
+  positives = wave_sum_i(positives);
+  float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) {
+    const float s = wave_sum(acc[k]);
+    if (lane == 0) out[k] = s;
+  }
+  if (lane == 0) {
+    for (int k = kKP; k < a.ldw; ++k) out[k] = 0.f;
+    a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+  }
+}
+
+// 1 iff the row sum is positive (kpconv.py:113-114); one wavefront per row, fixed summation order.
+__global__ void row_positive_kernel(const float* x, int n, int c, int ld, unsigned char* out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) s += x[static_cast<int64_t>(row) * ld + i];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s > 0.f ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld, uint8_t* out,
+                                void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && out && n >= 0 && c > 0, "rdm_row_positive: bad arguments");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(row_positive_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
+                     static_cast<int>(ld), out);
+  return launch_status("row_positive_kernel");
+}
+
+extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                 const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                 const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                 const float* kernel_points, float sigma, float* wf, int64_t ldw,
+                                 float* nn, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
+              "rdm_kpconv_gather: null pointer");
+  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0 && h <= kMaxH, "rdm_kpconv_gather: bad sizes (h=%lld, max %d)",
+              (long long)h, kMaxH);
+  RDM_REQUIRE(c == 1 || (c % 32 == 0 && c <= 512), "rdm_kpconv_gather: unsupported channel count %lld",
+              (long long)c);
+  RDM_REQUIRE(ldw >= kKP * c && (c == 1 || (ldf % 4 == 0 && ldw % 4 == 0)),
+              "rdm_kpconv_gather: ldw/ldf must be padded");
+  if (m == 0) return RDM_OK;
+  KpArgs a;
+  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive;
+  a.idx = idx; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
+  a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
+  a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
+  a.ldw = static_cast<int>(ldw); a.sigma = sigma;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(ceil_div<int64_t>(m, kWaves)), block(64 * kWaves);
+  switch (c) {
+    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1>), grid, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1>), grid, block, 0, st, a); break;
+    case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 2>), grid, block, 0, st, a); break;
+    case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 4>), grid, block, 0, st, a); break;
+    case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 8>), grid, block, 0, st, a); break;
+    default:
+      set_error("rdm_kpconv_gather: channel count %lld has no kernel instance", (long long)c);
+      return RDM_ERR_ARG;
+  }
+  return launch_status("kpconv_gather_kernel");
+}

@@ -1,0 +1,252 @@
+// a5 -- normalisation, activation and the neighbour pooling ops of the KPConv blocks.
+//
+//   GroupNorm over a stacked cloud (modules/kpconv/modules.py:33-50): the (N, C) feature matrix is
+//     normalised as one (1, C, N) sample, i.e. statistics per group span ALL rows of BOTH clouds.
+//     Three launches: per-block column partials (fp64, fixed order) -> per-channel scale/shift ->
+//     fused apply (+ optional residual add, LeakyReLU(0.1), and the "row sum > 0" flag the next
+//     KPConv needs, kpconv.py:113-114).
+//   LayerNorm rows (transformer / vote MLP), with optional residual input and ReLU.
+//   maxpool (modules/kpconv/functional.py:54-67) and nearest upsample + concat
+//     (functional.py:6-22, experiments/backbone.py:131-143).
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+constexpr int kGnRowsPerBlock = 256;
+
+// partial[blk][0][c] = sum, partial[blk][1][c] = sum of squares over this block's rows
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, int c, int ld,
+                                                         double* partial) {
+  const int r0 = blockIdx.x * kGnRowsPerBlock;
+  const int r1 = min(n, r0 + kGnRowsPerBlock);
+  for (int col = threadIdx.x; col < c; col += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const double v = x[static_cast<int64_t>(r) * ld + col];
+      s += v;
+      ss += v * v;
+    }
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * c + col] = s;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = ss;
+  }
+}
+
+// one block: reduce partials -> scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+                                                           int c, int groups, const float* gamma,
+                                                           const float* beta, float eps, float* scale,
+                                                           float* shift) {
+  extern __shared__ double sh[];  // [2*c]
+  for (int col = threadIdx.x; col < c; col += blockDim.x) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + col];
+      ss += partial[(static_cast<int64_t>(b) * 2 + 1) * c + col];
+    }
+    sh[col] = s;
+    sh[c + col] = ss;
+  }
+  __syncthreads();
+  const int cpg = c / groups;
+  for (int col = threadIdx.x; col < c; col += blockDim.x) {
+    const int g0 = (col / cpg) * cpg;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+      s += sh[g0 + k];
+      ss += sh[c + g0 + k];
+    }
+    const double cnt = static_cast<double>(n) * cpg;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + static_cast<double>(eps));
+    const double gsc = rstd * static_cast<double>(gamma[col]);
+    scale[col] = static_cast<float>(gsc);
+    shift[col] = static_cast<float>(static_cast<double>(beta[col]) - mean * gsc);
+  }
+}
+
+// y = act(x*scale + shift (+ res)); optional positive-row flag.  One wavefront per row.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, int c, int ldx,
+                                                       const float* scale, const float* shift,
+                                                       const float* res, int ldr, int act, float* y,
+                                                       int ldy, unsigned char* positive) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  float rs = 0.f;
+  for (int col = lane; col < c; col += 64) {
+    float v = x[static_cast<int64_t>(row) * ldx + col] * scale[col] + shift[col];
+    if (res) v += res[static_cast<int64_t>(row) * ldr + col];
+    if (act == 2) v = v > 0.f ? v : 0.1f * v;
+    else if (act == 1) v = v > 0.f ? v : 0.f;
+    y[static_cast<int64_t>(row) * ldy + col] = v;
+    rs += v;
+  }
+  if (positive) {
+    rs = wave_sum(rs);
+    if (lane == 0) positive[row] = rs > 0.f ? 1 : 0;
+  }
+}
+
+// y = act(LayerNorm(x (+ res)) * gamma + beta); one wavefront per row, c <= 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, int c, int ldx,
+                                                        const float* res, int ldr,
+                                                        const float* gamma, const float* beta,
+                                                        float eps, int act, float* y, int ldy) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  float v[32];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int col = lane + 64 * i;
+    v[i] = 0.f;
+    if (col < c) {
+      v[i] = x[static_cast<int64_t>(row) * ldx + col];
+      if (res) v[i] += res[static_cast<int64_t>(row) * ldr + col];
+      s += v[i];
+    }
+  }
+  const float mean = wave_sum(s) / static_cast<float>(c);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int col = lane + 64 * i;
+    if (col < c) {
+      const float d = v[i] - mean;
+      ss += d * d;
+    }
+  }
+  const float rstd = 1.0f / __fsqrt_rn(wave_sum(ss) / static_cast<float>(c) + eps);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int col = lane + 64 * i;
+    if (col < c) {
+      float o = (v[i] - mean) * rstd * gamma[col] + beta[col];
+      if (act == 1) o = o > 0.f ? o : 0.f;
+      y[static_cast<int64_t>(row) * ldy + col] = o;
+    }
+  }
+}
+
+// out[m, c] = max_h x[idx[m,h], c], pad rows count as zeros.  One wavefront per (row, 256 channels).
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
+                                                         const int64_t* idx, int m_total, int h, int ldi,
+                                                         const int32_t* width, float* y, int ldy) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= m_total) return;
+  const int lane = threadIdx.x & 63;
+  const int c0 = blockIdx.y * 256 + lane * 4;
+  if (c0 >= c) return;
+  int H = h;
+  if (width) H = min(H, *width);
+  float4 best = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+  for (int k = 0; k < H; ++k) {
+    const int64_t id = idx[static_cast<int64_t>(m) * ldi + k];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0 && id < ns) v = *reinterpret_cast<const float4*>(x + id * ldx + c0);
+    best.x = fmaxf(best.x, v.x);
+    best.y = fmaxf(best.y, v.y);
+    best.z = fmaxf(best.z, v.z);
+    best.w = fmaxf(best.w, v.w);
+  }
+  *reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy + c0) = best;
+}
+
+// y[m, 0:c1] = coarse[idx[m,0]] (pad -> 0), y[m, c1:c1+c2] = skip[m], y[m, c1+c2:ldy] = 0
+__global__ void upsample_concat_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+                                       const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
+                                       int m_total, float* y, int ldy) {
+  const int m = blockIdx.x;
+  const int64_t id = idx[static_cast<int64_t>(m) * ldi];
+  const bool ok = id >= 0 && id < n_coarse;
+  for (int col = threadIdx.x; col < ldy; col += blockDim.x) {
+    float v = 0.f;
+    if (col < c1) v = ok ? coarse[id * ld1 + col] : 0.f;
+    else if (col < c1 + c2) v = skip[static_cast<int64_t>(m) * ld2 + (col - c1)];
+    y[static_cast<int64_t>(m) * ldy + col] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c) {
+  const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(n > 0 ? n : 1, kGnRowsPerBlock));
+  return rdm::align_up(nblk * 2 * c * sizeof(double)) + rdm::align_up(2 * c * sizeof(float));
+}
+
+extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
+                              const float* gamma, const float* beta, float eps, const float* residual,
+                              int64_t ldr, int act, float* y, int64_t ldy, uint8_t* positive, void* ws,
+                              size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && gamma && beta && y, "rdm_group_norm: null pointer");
+  RDM_REQUIRE(n >= 0 && c > 0 && groups > 0 && c % groups == 0 && c <= 4096,
+              "rdm_group_norm: bad sizes (n=%lld c=%lld groups=%d)", (long long)n, (long long)c, groups);
+  if (n == 0) return RDM_OK;
+  const int nblk = static_cast<int>(ceil_div<int64_t>(n, kGnRowsPerBlock));
+  Arena ar(ws, ws_bytes);
+  double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c);
+  float* ss = ar.take<float>(2 * c);
+  if (!ar.ok) {
+    set_error("rdm_group_norm: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, st, x, static_cast<int>(n),
+                     static_cast<int>(c), static_cast<int>(ldx), partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 2 * c * sizeof(double), st, partial, nblk,
+                     static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
+                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
+                     static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
+  return launch_status("group_norm kernels");
+}
+
+extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
+                              int64_t ldr, const float* gamma, const float* beta, float eps, int act,
+                              float* y, int64_t ldy, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && gamma && beta && y, "rdm_layer_norm: null pointer");
+  RDM_REQUIRE(n >= 0 && c > 0 && c <= 2048, "rdm_layer_norm: bad sizes");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
+                     static_cast<int>(ldx), residual, static_cast<int>(ldr), gamma, beta, eps, act, y,
+                     static_cast<int>(ldy));
+  return launch_status("layernorm_kernel");
+}
+
+extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx,
+                              int64_t m, int64_t h, int64_t ldi, const int32_t* width, float* y,
+                              int64_t ldy, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && idx && y, "rdm_gather_max: null pointer");
+  RDM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && h > 0, "rdm_gather_max: bad sizes");
+  if (m == 0) return RDM_OK;
+  hipLaunchKernelGGL(gather_max_kernel, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n_s),
+                     static_cast<int>(c), static_cast<int>(ldx), idx, static_cast<int>(m),
+                     static_cast<int>(h), static_cast<int>(ldi), width, y, static_cast<int>(ldy));
+  return launch_status("gather_max_kernel");
+}
+
+extern "C" int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1,
+                                   const int64_t* idx, int64_t ldi, const float* skip, int64_t c2,
+                                   int64_t ld2, int64_t m, float* y, int64_t ldy, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(coarse && idx && skip && y, "rdm_upsample_concat: null pointer");
+  RDM_REQUIRE(ldy >= c1 + c2, "rdm_upsample_concat: ldy too small");
+  if (m == 0) return RDM_OK;
+  hipLaunchKernelGGL(upsample_concat_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse),
+                     static_cast<int>(c1), static_cast<int>(ld1), idx, static_cast<int>(ldi), skip,
+                     static_cast<int>(c2), static_cast<int>(ld2), static_cast<int>(m), y,
+                     static_cast<int>(ldy));
+  return launch_status("upsample_concat_kernel");
+}
