@@ -1,0 +1,127 @@
+"""GPU parity of the individual HIP operators (through the C-ABI) against fp32/fp64 torch CPU
+restatements of the same reference formulas.  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from rdmnet_amd import ops
+    return ops
+
+
+def padded(t, device='cuda'):
+    """[n, c] tensor -> device view with row stride padded to a multiple of 4 (pads zeroed)."""
+    n, c = t.shape
+    ld = (c + 3) // 4 * 4
+    buf = torch.zeros((n, ld), dtype=torch.float32, device=device)
+    buf[:, :c] = t.to(device)
+    return buf[:, :c]
+
+
+@pytest.mark.parametrize('m,k,n,trans_b', [(1, 4, 1, False), (77, 36, 33, False), (300, 128, 257, False),
+                                            (2236, 1284, 1024, False), (842, 7680, 512, False),
+                                            (39609, 480, 32, False), (5000, 64, 128, False),
+                                            (332, 256, 316, True), (129, 2048, 128, False)])
+def test_gemm_matches_fp64(ops, m, k, n, trans_b):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(n, k, generator=g) if trans_b else torch.randn(k, n, generator=g)
+    bias = torch.randn(n, generator=g)
+    rowdiv = torch.randint(1, 9, (m,), generator=g).float()
+    ref = (a.double() @ (b.double().t() if trans_b else b.double())) / rowdiv.double()[:, None] + bias.double()
+    ref = F.leaky_relu(ref, 0.1)
+    bd = b.cuda() if trans_b else padded(b)
+    out = ops.gemm(padded(a), bd, k, n, trans_b=trans_b, bias=bias.cuda(), rowdiv=rowdiv.cuda(), act=ops.ACT_LEAKY)
+    err = (out.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-6 * scale * max(1.0, np.sqrt(k) / 8), (err, scale)  # fp32 accumulation over k terms
+
+
+def test_gemm_batched_patch_scores(ops):
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(5, 128, 256, generator=g), torch.randn(5, 128, 256, generator=g)
+    out = ops.gemm_batched(a.cuda(), b.cuda(), 256)
+    ref = torch.einsum('bnd,bmd->bnm', a.double(), b.double())
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize('c,h,m,ns', [(1, 65, 500, 700), (32, 65, 400, 900), (64, 63, 300, 500), (128, 69, 200, 300),
+                                      (256, 70, 150, 200), (512, 81, 90, 100), (32, 3, 50, 60)])
+def test_kpconv_gather_matches_reference_formula(ops, c, h, m, ns):
+    """kpconv.py:91-105,113-115 restated in fp64 on random clouds with pad slots."""
+    g = torch.Generator().manual_seed(c + h)
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_pts = s_pts[torch.randint(0, ns, (m,), generator=g)] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g) if c > 1 else torch.ones(ns, 1)
+    idx = torch.randint(0, ns, (m, h), generator=g)
+    n_valid = torch.randint(0, h + 1, (m,), generator=g)
+    idx = torch.where(torch.arange(h)[None] < n_valid[:, None], idx, torch.full_like(idx, ns))
+    kp = torch.randn(15, 3, generator=g)
+    sigma = 1.7
+    sp = torch.cat([s_pts, torch.full((1, 3), 1e6)]).double()
+    sf = torch.cat([feats, torch.zeros(1, c)]).double()
+    rel = sp[idx] - q_pts.double()[:, None]
+    infl = torch.clamp(1 - ((rel[:, :, None] - kp.double()) ** 2).sum(-1).sqrt() / sigma, min=0)
+    ref = torch.einsum('mhk,mhc->mkc', infl, sf[idx]).reshape(m, 15 * c)
+    pos = (feats.sum(1) > 0)
+    nn_ref = torch.cat([pos, torch.zeros(1, dtype=torch.bool)])[idx].sum(1).clamp(min=1).float()
+    wf, nn = ops.kpconv_gather(q_pts.cuda(), s_pts.cuda(), padded(feats), ops.row_positive(padded(feats)),
+                               idx.cuda(), kp.cuda(), sigma)
+    assert torch.equal(nn[:m].cpu(), nn_ref)
+    got = wf.cpu().double()[:, :15 * c]
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_kpconv_gather_width_cap(ops):
+    g = torch.Generator().manual_seed(3)
+    ns, m, h, c = 200, 64, 20, 32
+    s_pts, feats = torch.randn(ns, 3, generator=g), torch.randn(ns, c, generator=g)
+    idx = torch.randint(0, ns, (m, h), generator=g)
+    kp = torch.randn(15, 3, generator=g)
+    args = (s_pts[:m].cuda(), s_pts.cuda(), padded(feats), ops.row_positive(padded(feats)))
+    wf_full, _ = ops.kpconv_gather(*args, idx[:, :7].contiguous().cuda(), kp.cuda(), 1.0)
+    wf_cap, _ = ops.kpconv_gather(*args, idx.cuda(), kp.cuda(), 1.0, width=torch.tensor([7], dtype=torch.int32).cuda())
+    assert torch.equal(wf_full, wf_cap)
+
+
+@pytest.mark.parametrize('n,c', [(5000, 32), (3001, 128), (842, 2048), (7, 64)])
+def test_group_norm_matches_torch(ops, n, c):
+    g = torch.Generator().manual_seed(n)
+    x, res = torch.randn(n, c, generator=g) * 3 + 1, torch.randn(n, c, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    ref = F.group_norm(x.double().t()[None], 32, gamma.double(), beta.double(), 1e-5)[0].t()
+    ref2 = F.leaky_relu(ref + res.double(), 0.1)
+    y, pos = ops.group_norm(padded(x), gamma.cuda(), beta.cuda(), 32, act=ops.ACT_LEAKY, residual=padded(res),
+                            want_positive=True)
+    assert (y.cpu().double() - ref2).abs().max().item() <= 2e-5
+    clear = ref2.sum(1).abs() > 1e-3
+    assert torch.equal(pos[:n].cpu().bool()[clear], (ref2.sum(1) > 0)[clear])
+
+
+def test_layer_norm_matches_torch(ops):
+    g = torch.Generator().manual_seed(5)
+    for n, c in [(431, 128), (842, 512), (3, 256)]:
+        x, res = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+        gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+        ref = F.relu(F.layer_norm((x + res).double(), (c,), gamma.double(), beta.double()))
+        y = ops.layer_norm(padded(x), gamma.cuda(), beta.cuda(), residual=padded(res), act=ops.ACT_RELU)
+        assert (y.cpu().double() - ref).abs().max().item() <= 1e-5
+
+
+def test_pooling_ops_are_exact(ops):
+    g = torch.Generator().manual_seed(9)
+    ns, m, h, c = 300, 120, 17, 256
+    x = torch.randn(ns, c, generator=g)
+    idx = torch.randint(0, ns + 1, (m, h), generator=g)  # includes pad index ns
+    xp = torch.cat([x, torch.zeros(1, c)])
+    assert torch.equal(ops.gather_max(padded(x), idx.cuda()).cpu(), xp[idx].max(1)[0])
+    coarse, skip = torch.randn(ns, 257, generator=g), torch.randn(m, 1024, generator=g)
+    y = ops.upsample_concat(padded(coarse), idx.cuda(), padded(skip))
+    cp = torch.cat([coarse, torch.zeros(1, 257)])
+    assert torch.equal(y.cpu(), torch.cat([cp[idx[:, 0]], skip], 1))
+    assert y.stride(0) == 1284 and torch.count_nonzero(torch.as_strided(y, (m, 3), (1284, 1), 1281)) == 0
