@@ -115,9 +115,84 @@ int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const floa
                    int64_t ldy, void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
+/* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the
+ * padded index_select of geotransformer/modules/ops/index_select.py:4-31 and boolean-mask selects). */
+int rdm_gather_rows(const void* x, int64_t n_src, int64_t words, int64_t ldx, const int64_t* idx, int64_t m,
+                    void* y, int64_t ldy, void* stream);
 int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1,
                         const int64_t* idx, int64_t ldi, const float* skip, int64_t c2, int64_t ld2,
                         int64_t m, float* y, int64_t ldy, void* stream);
+
+/* ---- a7: 3DRoFormer attention ------------------------------------------------------------------
+ * rdm_rope: in-place learned rotary embedding of q (and k when non-NULL): pair p of row r is rotated
+ *   by theta = 2*pi*sigmoid(emb[r, p]) (rdmnet/thdroformer/thdroformer.py:56-85; emb has d_model/2
+ *   columns = heads x 16).
+ * rdm_attention: out = softmax(q k^T / sqrt(head_dim)) v per head, heads packed along the columns
+ *   (thdroformer.py:20-40 with k=None, :112-139; geotransformer/modules/transformer/
+ *   vanilla_transformer.py:51-66).  head_dim must be 32.                                        */
+int rdm_rope(float* q, int64_t ldq, float* k, int64_t ldk, const float* emb, int64_t lde, int64_t n,
+             int64_t d_model, void* stream);
+int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                  float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads, int head_dim, void* stream);
+
+/* ---- a8/a9 helpers ------------------------------------------------------------------------------
+ * rdm_vote_shift: xyz + clamp(offset[:, :3], +-limit) (rdmnet/vote/vote.py:98-108).
+ * rdm_sigmoid_column: clamp(sigmoid(x[:, 0]), 0, 1) of a strided column (experiments/model_infer.py:161-162).
+ * rdm_l2_normalize: F.normalize(x, p=2, dim=1) (experiments/model_infer.py:248-249).              */
+int rdm_vote_shift(const float* xyz, const float* offsets, int64_t ldo, int64_t n, float lx, float ly,
+                   float lz, float* out, void* stream);
+int rdm_sigmoid_column(const float* x, int64_t ldx, int64_t n, float* out, void* stream);
+int rdm_l2_normalize(const float* x, int64_t ldx, int64_t n, int64_t c, float* y, int64_t ldy, void* stream);
+
+/* ---- a10: NMS -----------------------------------------------------------------------------------
+ * keep[i] = 1 iff no lower-index neighbour of row i is kept: the greedy index-order sweep of
+ * NMS.forward (rdmnet/vote/vote.py:33-40) given the radius-neighbour rows of the shifted nodes.
+ * rdm_compact_indices: order-preserving list of kept rows in [begin, end) and their count (the
+ * boolean-mask selects of experiments/model_infer.py:221-229).                                   */
+int rdm_nms(const int64_t* idx, int64_t n, int64_t h, int64_t ldi, const int32_t* width, uint8_t* keep,
+            void* stream);
+int rdm_compact_indices(const uint8_t* keep, int64_t begin, int64_t end, int32_t* order, int32_t* count,
+                        void* stream);
+
+/* ---- a11: point-to-node grouping -----------------------------------------------------------------
+ * Replaces point_to_node_partition (geotransformer/modules/ops/pointcloud_partition.py:60-107) for
+ * one cloud: every point joins its nearest node (first minimum of the reference's fp32 distance
+ * formula), every node keeps its k nearest OWN points ascending by (distance, index); unused slots
+ * hold n_points / mask 0.  status != 0 if a node owns more than 4096 points.                     */
+size_t rdm_point_to_node_workspace_bytes(int64_t n_points, int64_t n_nodes);
+int rdm_point_to_node(const float* points, int64_t n_points, const float* nodes, int64_t n_nodes, int k,
+                      int64_t* knn_idx, uint8_t* knn_mask, uint8_t* node_mask, int32_t* status, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ---- a12: coarse matching -------------------------------------------------------------------------
+ * Replaces SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:
+ * 14-61).  scores holds f_ref . f_src^T on entry (rdm_gemm, trans_b) and the dual-normalised
+ * matching scores on return; the k best (descending, ties by flat index) are written as node
+ * indices + scores, *out_count = min(k, #non-empty pairs).                                        */
+size_t rdm_coarse_matching_workspace_bytes(int64_t m, int64_t n);
+int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t ld, const uint8_t* ref_mask,
+                        const uint8_t* src_mask, int dual_normalization, int k, int64_t* ref_idx,
+                        int64_t* src_idx, float* out_scores, int32_t* out_count, void* ws, size_t ws_bytes,
+                        void* stream);
+
+/* ---- a14: Sinkhorn ---------------------------------------------------------------------------------
+ * Replaces LearnableLogOptimalTransport.forward (geotransformer/modules/sinkhorn/
+ * learnable_sinkhorn.py:13-66): scores [batch, m, n], masks [batch, m] / [batch, n] (1 = valid),
+ * alpha = dustbin score (device scalar), out [batch, m+1, n+1].  m, n <= 128.                     */
+int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64_t n, const uint8_t* row_mask,
+                 const uint8_t* col_mask, const float* alpha, int iters, float* out, void* stream);
+
+/* ---- a15/a16: local-to-global registration ----------------------------------------------------------
+ * Replaces LocalGlobalRegistration.forward (geotransformer/modules/geotransformer/
+ * local_global_registration.py:204-243; k=1, dustbin, non-mutual) including weighted_procrustes
+ * (geotransformer/modules/registration/procrustes.py:6-73) without the reference's host SVD.
+ * Outputs have capacity batch*2*side rows; counts[0..2] = {n_correspondences, n_hypotheses, best}. */
+size_t rdm_lgr_workspace_bytes(int64_t batch);
+int rdm_lgr(const float* log_scores, const float* ref_knn_points, const float* src_knn_points,
+            const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int64_t batch, int64_t side,
+            float acceptance_radius, int correspondence_threshold, int num_refinement_steps, float* ref_corr,
+            float* src_corr, float* corr_scores, float* transform, int32_t* counts, void* ws, size_t ws_bytes,
+            void* stream);
 
 #ifdef __cplusplus
 }

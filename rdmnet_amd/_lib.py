@@ -38,6 +38,25 @@ SIGNATURES = {
                                c_void]),
     'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,
                                     c_void, c_i64, c_void]),
+    'rdm_gather_rows': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_void]),
+    'rdm_rope': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void]),
+    'rdm_attention': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
+                              c_void]),
+    'rdm_vote_shift': (c_int, [c_void, c_void, c_i64, c_i64, c_f32, c_f32, c_f32, c_void, c_void]),
+    'rdm_sigmoid_column': (c_int, [c_void, c_i64, c_i64, c_void, c_void]),
+    'rdm_l2_normalize': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void]),
+    'rdm_nms': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void]),
+    'rdm_compact_indices': (c_int, [c_void, c_i64, c_i64, c_void, c_void, c_void]),
+    'rdm_point_to_node_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'rdm_point_to_node': (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void, c_void,
+                                  c_size, c_void]),
+    'rdm_coarse_matching_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'rdm_coarse_matching': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_void, c_void, c_void,
+                                    c_void, c_void, c_size, c_void]),
+    'rdm_sinkhorn': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_void, c_void]),
+    'rdm_lgr_workspace_bytes': (c_size, [c_i64]),
+    'rdm_lgr': (c_int, [c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_f32, c_int, c_int, c_void, c_void,
+                        c_void, c_void, c_void, c_void, c_size, c_void]),
 }
 
 _lib = None

@@ -1,0 +1,237 @@
+// a7 -- 3DRoFormer attention: learned rotary embedding + fused softmax(QK^T/sqrt(d)) V.
+//
+// Reference: rdmnet/thdroformer/thdroformer.py:56-85 (RotaryPositionalEmbedding.forward),
+// :20-40 (dynamic_attention, k=None => dense softmax), :88-139 (RPEMultiHeadAttention),
+// geotransformer/modules/transformer/vanilla_transformer.py:51-66 (cross attention).
+//
+// rdm_rope: theta = 2*pi*sigmoid(emb) per (token, head, pair); (x0, x1) -> (x0 cos - x1 sin,
+//   x1 cos + x0 sin) applied in place to q and k.
+// rdm_attention: one wavefront = 16 queries of one head (d = 32).  S^T = K Q^T is formed with
+//   v_mfma_f32_16x16x4_f32 (the contraction index is permuted so every lane reads 8 contiguous
+//   floats of its key/query row), softmax runs online in registers (the 16 columns of the MFMA
+//   result are the 16 queries, so a lane owns one query and 4 keys: the row reduction is 3 adds and
+//   two cross-lane steps), and P is fed straight back as the A operand of the P V MFMAs -- no LDS, no
+//   score matrix in memory.  It is MFMA work because it is a genuine dense contraction; at <= 450
+//   tokens the op is latency- not throughput-bound.
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kHeadDim = 32;
+
+__global__ void rope_kernel(float* q, int ldq, float* k, int ldk, const float* emb, int lde, int n,
+                            int pairs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * pairs) return;
+  const int row = i / pairs, p = i % pairs;
+  const float e = emb[static_cast<int64_t>(row) * lde + p];
+  const float sig = 1.0f / (1.0f + expf(-e));
+  const float theta = sig * 3.14159265359f * 2.0f;
+  const float c = cosf(theta), s = sinf(theta);
+  float* a = q + static_cast<int64_t>(row) * ldq + 2 * p;
+  const float q0 = a[0], q1 = a[1];
+  a[0] = q0 * c + (-q1) * s;
+  a[1] = q1 * c + q0 * s;
+  if (k) {
+    float* b = k + static_cast<int64_t>(row) * ldk + 2 * p;
+    const float k0 = b[0], k1 = b[1];
+    b[0] = k0 * c + (-k1) * s;
+    b[1] = k1 * c + k0 * s;
+  }
+}
+
+struct AttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* out;
+  int nq, nk, heads;
+  int ldq, ldk, ldv, ldo;
+  float inv_scale;  // sqrt(d)
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  const int q0 = tile * 16;
+  if (q0 >= a.nq) return;
+  const int head = blockIdx.y;
+  const int g = lane >> 4, x = lane & 15;
+  const int hoff = head * kHeadDim;
+
+  // Q fragment: query q0+x, features 8g .. 8g+7 of this head (contraction index = 8*kappa + step)
+  float qf[8];
+  {
+    const int qi = min(q0 + x, a.nq - 1);
+    const float4* p = reinterpret_cast<const float4*>(a.q + static_cast<int64_t>(qi) * a.ldq + hoff + 8 * g);
+    const float4 u = p[0], w = p[1];
+    qf[0] = u.x; qf[1] = u.y; qf[2] = u.z; qf[3] = u.w;
+    qf[4] = w.x; qf[5] = w.y; qf[6] = w.z; qf[7] = w.w;
+  }
+  float m_run = -INFINITY, l_run = 0.f;   // per query x (replicated over g)
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // O[query 4g+r][d = 2x + t]
+
+  for (int k0 = 0; k0 < a.nk; k0 += 16) {
+    // ---- S^T[key 4g'+r][query x] over this key tile
+    float kf[8];
+    {
+      const int ki = min(k0 + x, a.nk - 1);
+      const float4* p = reinterpret_cast<const float4*>(a.k + static_cast<int64_t>(ki) * a.ldk + hoff + 8 * g);
+      const float4 u = p[0], w = p[1];
+      kf[0] = u.x; kf[1] = u.y; kf[2] = u.z; kf[3] = u.w;
+      kf[4] = w.x; kf[5] = w.y; kf[6] = w.z; kf[7] = w.w;
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s, 0, 0, 0);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[r] = (k0 + 4 * g + r < a.nk) ? s[r] / a.inv_scale : -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+    f32x4 p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = expf(s[r] - m_new);
+      psum += p[r];
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // ---- rescale O rows (query 4g+r lives in lane 4g+r of group 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ar = __shfl(alpha, 4 * g + r, 64);
+      o0[r] *= ar;
+      o1[r] *= ar;
+    }
+    // ---- O += P V : step st uses key 4*kappa + st from lane group kappa, i.e. register st of p
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int ki = min(k0 + 4 * g + st, a.nk - 1);
+      const float2 vv = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(ki) * a.ldv + hoff + 2 * x);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv.x, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv.y, o1, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q0 + 4 * g + r;
+    const float lr = __shfl(l_run, 4 * g + r, 64);
+    if (qi < a.nq) {
+      float2 o = make_float2(o0[r] / lr, o1[r] / lr);
+      *reinterpret_cast<float2*>(a.out + static_cast<int64_t>(qi) * a.ldo + hoff + 2 * x) = o;
+    }
+  }
+}
+
+// vote.py:98-108: xyz + clamp(offset, -limit, +limit)
+__global__ void vote_shift_kernel(const float* xyz, const float* off, int ldo, int n, float lx, float ly,
+                                  float lz, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 3) return;
+  const int row = i / 3, d = i % 3;
+  const float lim = d == 0 ? lx : (d == 1 ? ly : lz);
+  float o = off[static_cast<int64_t>(row) * ldo + d];
+  o = o > lim ? lim : o;
+  o = o < -lim ? -lim : o;
+  out[i] = xyz[i] + o;
+}
+
+// sigmoid + clamp[0,1] of a strided column (model_infer.py:161-162, 171-172, 199-202)
+__global__ void sigmoid_kernel(const float* x, int ldx, int n, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 1.0f / (1.0f + expf(-x[static_cast<int64_t>(i) * ldx]));
+  out[i] = fminf(fmaxf(s, 0.f), 1.f);
+}
+
+// F.normalize(p=2, dim=1) (model_infer.py:248-249); one wavefront per row
+__global__ void l2_normalize_kernel(const float* x, int ldx, int n, int c, float* y, int ldy) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) {
+    const float v = x[static_cast<int64_t>(row) * ldx + i];
+    s += v * v;
+  }
+  const float nrm = fmaxf(__fsqrt_rn(wave_sum(s)), 1e-12f);
+  for (int i = lane; i < c; i += 64) y[static_cast<int64_t>(row) * ldy + i] = x[static_cast<int64_t>(row) * ldx + i] / nrm;
+}
+
+}  // namespace
+
+extern "C" int rdm_rope(float* q, int64_t ldq, float* k, int64_t ldk, const float* emb, int64_t lde,
+                        int64_t n, int64_t d_model, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q && emb && n >= 0 && d_model % 2 == 0, "rdm_rope: bad arguments");
+  if (n == 0) return RDM_OK;
+  const int pairs = static_cast<int>(d_model / 2);
+  hipLaunchKernelGGL(rope_kernel, dim3(ceil_div<int64_t>(n * pairs, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), q, static_cast<int>(ldq), k, static_cast<int>(ldk), emb,
+                     static_cast<int>(lde), static_cast<int>(n), pairs);
+  return launch_status("rope_kernel");
+}
+
+extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                             int64_t ldv, float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads,
+                             int head_dim, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q && k && v && out, "rdm_attention: null pointer");
+  RDM_REQUIRE(head_dim == kHeadDim, "rdm_attention: head_dim must be %d", kHeadDim);
+  RDM_REQUIRE(n_q >= 0 && n_k > 0 && heads > 0, "rdm_attention: bad sizes");
+  RDM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 2 == 0 && ldo % 2 == 0, "rdm_attention: strides must be padded");
+  if (n_q == 0) return RDM_OK;
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.nq = static_cast<int>(n_q); a.nk = static_cast<int>(n_k); a.heads = heads;
+  a.ldq = static_cast<int>(ldq); a.ldk = static_cast<int>(ldk); a.ldv = static_cast<int>(ldv);
+  a.ldo = static_cast<int>(ldo);
+  a.inv_scale = sqrtf(static_cast<float>(head_dim));
+  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div<int64_t>(n_q, 64), heads), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return launch_status("attention_kernel");
+}
+
+extern "C" int rdm_vote_shift(const float* xyz, const float* offsets, int64_t ldo, int64_t n, float lx,
+                              float ly, float lz, float* out, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(xyz && offsets && out && n >= 0, "rdm_vote_shift: bad arguments");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(vote_shift_kernel, dim3(ceil_div<int64_t>(3 * n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), xyz, offsets, static_cast<int>(ldo), static_cast<int>(n), lx,
+                     ly, lz, out);
+  return launch_status("vote_shift_kernel");
+}
+
+extern "C" int rdm_sigmoid_column(const float* x, int64_t ldx, int64_t n, float* out, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && out && n >= 0, "rdm_sigmoid_column: bad arguments");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(ceil_div<int64_t>(n, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n), out);
+  return launch_status("sigmoid_kernel");
+}
+
+extern "C" int rdm_l2_normalize(const float* x, int64_t ldx, int64_t n, int64_t c, float* y, int64_t ldy,
+                                void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && y && n >= 0 && c > 0, "rdm_l2_normalize: bad arguments");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n),
+                     static_cast<int>(c), y, static_cast<int>(ldy));
+  return launch_status("l2_normalize_kernel");
+}

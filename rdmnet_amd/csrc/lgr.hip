@@ -1,0 +1,389 @@
+// a15/a16 -- dense correspondence extraction and local-to-global registration, entirely on the GPU.
+//
+// Reference: geotransformer/modules/geotransformer/local_global_registration.py:49-91
+// (compute_correspondence_matrix, k = 1, dustbin, non-mutual), :145-202 (local_to_global_registration),
+// :93-136 (convert_to_batch), geotransformer/modules/registration/procrustes.py:6-73 (weighted
+// Kabsch; the reference moves H to the CPU for torch.svd -- here nothing leaves the device).
+//
+// Stages (one launch each, sizes stay on the device):
+//   extract   per patch: S = exp(log scores); row/column top-1 incl. dustbin; keep (i,j) iff it beats
+//             the dustbin from either side and both points are valid; list them row-major (the order
+//             of torch.nonzero)                                                            :204-243
+//   layout    exclusive scan of the per-patch counts, chunk list = patches with >= 3 matches
+//   gather    stacked correspondences (ref point, src point, score) in patch order
+//   local     per chunk: weighted Procrustes                                               :175-181
+//   score     per chunk: #correspondences (of ALL) with residual < acceptance radius       :182-187
+//   refine    first argmax, then 1 + (steps-1) global Procrustes rounds                    :188-200
+// The rotation is obtained with Horn's quaternion form of the Kabsch problem (largest eigenvector of
+// a symmetric 4x4, Jacobi in fp64): identical to V diag(1,1,det) U^T wherever that is unique, and
+// the identity for a zero covariance like torch.svd.  Sums are accumulated in fp64.
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+constexpr int kSide = 128;           // points per patch
+constexpr int kPerPatch = 2 * kSide; // upper bound of matches per patch (one per row + one per column)
+
+struct LgrBuffers {
+  int32_t* patch_count;   // [B]
+  int32_t* patch_offset;  // [B]
+  int32_t* chunk_patch;   // [B]
+  int32_t* meta;          // [0] = C, [1] = number of chunks, [2] = best chunk
+  int32_t* local_i;       // [B, kPerPatch]
+  int32_t* local_j;       // [B, kPerPatch]
+  float* local_s;         // [B, kPerPatch]
+  float* chunk_T;         // [B, 12]
+  int32_t* chunk_inliers; // [B]
+};
+
+// ------------------------------------------------------------------------------------------ extract
+__global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_scores, int side,
+                                                          const unsigned char* ref_mask,
+                                                          const unsigned char* src_mask, LgrBuffers w) {
+  extern __shared__ float S[];  // [(side+1)][(side+1)] row-major, ld = side + 2 (odd for side = 128? 130 even)
+  __shared__ int rowarg[kSide + 1], colarg[kSide + 1];
+  __shared__ unsigned char rowok[kSide + 1], colok[kSide + 1];
+  __shared__ int rowcnt[kSide + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n1 = side + 1, ld = n1 | 1;
+  const float* L = log_scores + static_cast<int64_t>(b) * n1 * n1;
+  for (int t = tid; t < n1 * n1; t += 256) S[(t / n1) * ld + (t % n1)] = expf(L[t]);
+  __syncthreads();
+  if (tid < side) {  // top-1 of row tid over all columns (first maximum), must beat the dustbin column
+    const int i = tid;
+    float best = S[i * ld];
+    int arg = 0;
+    for (int j = 1; j < n1; ++j) {
+      const float v = S[i * ld + j];
+      if (v > best) {
+        best = v;
+        arg = j;
+      }
+    }
+    rowarg[i] = arg;
+    rowok[i] = (arg < side && best > S[i * ld + side]) ? 1 : 0;
+  } else if (tid >= 128 && tid < 128 + side) {  // top-1 of column over all rows, must beat the dustbin row
+    const int j = tid - 128;
+    float best = S[j];
+    int arg = 0;
+    for (int i = 1; i < n1; ++i) {
+      const float v = S[i * ld + j];
+      if (v > best) {
+        best = v;
+        arg = i;
+      }
+    }
+    colarg[j] = arg;
+    colok[j] = (arg < side && best > S[side * ld + j]) ? 1 : 0;
+  }
+  __syncthreads();
+  const unsigned char* rm = ref_mask + static_cast<int64_t>(b) * side;
+  const unsigned char* cm = src_mask + static_cast<int64_t>(b) * side;
+  auto is_corr = [&](int i, int j) {
+    return rm[i] && cm[j] && ((rowok[i] && rowarg[i] == j) || (colok[j] && colarg[j] == i));
+  };
+  if (tid < side) {
+    int c = 0;
+    for (int j = 0; j < side; ++j) c += is_corr(tid, j) ? 1 : 0;
+    rowcnt[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < side; ++i) {
+      const int c = rowcnt[i];
+      rowcnt[i] = acc;
+      acc += c;
+    }
+    w.patch_count[b] = acc;
+  }
+  __syncthreads();
+  if (tid < side) {
+    int pos = rowcnt[tid];
+    for (int j = 0; j < side; ++j)
+      if (is_corr(tid, j)) {
+        const int64_t o = static_cast<int64_t>(b) * kPerPatch + pos++;
+        w.local_i[o] = tid;
+        w.local_j[o] = j;
+        w.local_s[o] = S[tid * ld + j];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ layout
+__global__ __launch_bounds__(1024) void lgr_layout_kernel(int batch, int min_corr, LgrBuffers w) {
+  if (threadIdx.x != 0) return;  // batch <= a few hundred: a serial scan is a few microseconds
+  int acc = 0, chunks = 0;
+  for (int b = 0; b < batch; ++b) {
+    const int c = w.patch_count[b];
+    w.patch_offset[b] = acc;
+    acc += c;
+    if (c >= min_corr) w.chunk_patch[chunks++] = b;
+  }
+  w.meta[0] = acc;
+  w.meta[1] = chunks;
+  w.meta[2] = -1;
+}
+
+__global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, int side, LgrBuffers w,
+                                  float* ref_corr, float* src_corr, float* corr_scores) {
+  const int b = blockIdx.x;
+  const int cnt = w.patch_count[b], off = w.patch_offset[b];
+  for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+    const int64_t o = static_cast<int64_t>(b) * kPerPatch + t;
+    const float* r = ref_knn + (static_cast<int64_t>(b) * side + w.local_i[o]) * 3;
+    const float* s = src_knn + (static_cast<int64_t>(b) * side + w.local_j[o]) * 3;
+    for (int d = 0; d < 3; ++d) {
+      ref_corr[3 * (off + t) + d] = r[d];
+      src_corr[3 * (off + t) + d] = s[d];
+    }
+    corr_scores[off + t] = w.local_s[o];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ Procrustes
+__device__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// Largest eigenvector of the symmetric 4x4 `a` (cyclic Jacobi, fp64).  q = (w, x, y, z).
+__device__ void horn_quaternion(double a[4][4], double q[4]) {
+  double vmat[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 24; ++sweep) {
+    double offd = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int r = p + 1; r < 4; ++r) offd += a[p][r] * a[p][r];
+    if (offd < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int r = p + 1; r < 4; ++r) {
+        if (fabs(a[p][r]) < 1e-300) continue;
+        const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {
+          const double akp = a[k][p], akr = a[k][r];
+          a[k][p] = c * akp - s * akr;
+          a[k][r] = s * akp + c * akr;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double apk = a[p][k], ark = a[r][k];
+          a[p][k] = c * apk - s * ark;
+          a[r][k] = s * apk + c * ark;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = vmat[k][p], vkr = vmat[k][r];
+          vmat[k][p] = c * vkp - s * vkr;
+          vmat[k][r] = s * vkp + c * vkr;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; ++i)
+    if (a[i][i] > a[best][best]) best = i;
+  double nrm = 0.0;
+  for (int k = 0; k < 4; ++k) nrm += vmat[k][best] * vmat[k][best];
+  nrm = sqrt(nrm);
+  for (int k = 0; k < 4; ++k) q[k] = vmat[k][best] / nrm;
+}
+
+// Weighted rigid fit src -> ref over entries [x0, x1) (procrustes.py:36-73).  Every thread of the
+// block must call it; T (3x4, row-major R|t) is valid in all threads on return.
+__device__ void block_procrustes(const float* src, const float* ref, const float* wts, const unsigned char* gate,
+                                 int x0, int x1, double* red, double T[12]) {
+  double sw = 0.0;
+  for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
+    float w = wts[i];
+    if (gate && !gate[i]) w = 0.f;
+    if (w < 0.f) w = 0.f;  // weight_thresh = 0
+    sw += w;
+  }
+  sw = block_sum(sw, red) + 1e-5;
+  double cs[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
+  for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
+    float w = wts[i];
+    if ((gate && !gate[i]) || w < 0.f) w = 0.f;
+    const double wn = w / sw;
+    for (int d = 0; d < 3; ++d) {
+      cs[d] += wn * src[3 * i + d];
+      cr[d] += wn * ref[3 * i + d];
+    }
+  }
+  for (int d = 0; d < 3; ++d) {
+    cs[d] = block_sum(cs[d], red);
+    cr[d] = block_sum(cr[d], red);
+  }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H[a][b] = sum w (s_a - cs_a)(r_b - cr_b)
+  for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
+    float w = wts[i];
+    if ((gate && !gate[i]) || w < 0.f) w = 0.f;
+    const double wn = w / sw;
+    double s[3], r[3];
+    for (int d = 0; d < 3; ++d) {
+      s[d] = src[3 * i + d] - cs[d];
+      r[d] = ref[3 * i + d] - cr[d];
+    }
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) H[3 * a + b] += wn * s[a] * r[b];
+  }
+  for (int k = 0; k < 9; ++k) H[k] = block_sum(H[k], red);
+  const double Sxx = H[0], Sxy = H[1], Sxz = H[2], Syx = H[3], Syy = H[4], Syz = H[5], Szx = H[6], Szy = H[7],
+               Szz = H[8];
+  double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                    {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                    {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                    {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+  double q[4];
+  horn_quaternion(N, q);
+  const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw),     2 * (qx * qz + qy * qw),
+                 2 * (qx * qy + qz * qw),     1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                 2 * (qx * qz - qy * qw),     2 * (qy * qz + qx * qw),     1 - 2 * (qx * qx + qy * qy)};
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) T[4 * a + b] = R[3 * a + b];
+    T[4 * a + 3] = cr[a] - (R[3 * a] * cs[0] + R[3 * a + 1] * cs[1] + R[3 * a + 2] * cs[2]);
+  }
+}
+
+// residual < radius in the reference's fp32 arithmetic (apply_transform + linalg.norm)
+__device__ __forceinline__ bool is_inlier(const float* T, const float* src, const float* ref, int i, float radius) {
+  const float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+  const float ax = fmaf(z, T[2], fmaf(y, T[1], x * T[0])) + T[3];
+  const float ay = fmaf(z, T[6], fmaf(y, T[5], x * T[4])) + T[7];
+  const float az = fmaf(z, T[10], fmaf(y, T[9], x * T[8])) + T[11];
+  const float dx = ref[3 * i] - ax, dy = ref[3 * i + 1] - ay, dz = ref[3 * i + 2] - az;
+  return __fsqrt_rn((dx * dx + dy * dy) + dz * dz) < radius;
+}
+
+// one 64-thread block per chunk: local Procrustes, then inlier count over ALL correspondences
+__global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, const float* src_corr,
+                                                        const float* scores, float radius, LgrBuffers w) {
+  __shared__ double red[8];
+  __shared__ float Tf[12];
+  __shared__ int cnt_sh;
+  const int chunk = blockIdx.x;
+  if (chunk >= w.meta[1]) return;
+  const int b = w.chunk_patch[chunk];
+  const int x0 = w.patch_offset[b], x1 = x0 + w.patch_count[b];
+  double T[12];
+  block_procrustes(src_corr, ref_corr, scores, nullptr, x0, x1, red, T);
+  if (threadIdx.x < 12) {
+    Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
+    w.chunk_T[12 * chunk + threadIdx.x] = Tf[threadIdx.x];
+  }
+  if (threadIdx.x == 0) cnt_sh = 0;
+  __syncthreads();
+  const int C = w.meta[0];
+  int c = 0;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) c += is_inlier(Tf, src_corr, ref_corr, i, radius) ? 1 : 0;
+  c = wave_sum_i(c);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&cnt_sh, c);
+  __syncthreads();
+  if (threadIdx.x == 0) w.chunk_inliers[chunk] = cnt_sh;
+}
+
+// single block: pick the hypothesis, refine globally
+__global__ __launch_bounds__(1024) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
+                                                          const float* scores, float radius, int steps,
+                                                          LgrBuffers w, unsigned char* gate, float* out_T) {
+  __shared__ double red[16];
+  __shared__ float Tf[12];
+  const int C = w.meta[0], chunks = w.meta[1];
+  double T[12];
+  if (chunks > 0) {
+    if (threadIdx.x == 0) {
+      int best = 0;
+      for (int k = 1; k < chunks; ++k)
+        if (w.chunk_inliers[k] > w.chunk_inliers[best]) best = k;  // first maximum (torch.argmax)
+      w.meta[2] = best;
+      for (int k = 0; k < 12; ++k) Tf[k] = w.chunk_T[12 * best + k];
+    }
+  } else {  // degenerate: no patch reaches the threshold -> start from all correspondences (:189-194)
+    block_procrustes(src_corr, ref_corr, scores, nullptr, 0, C, red, T);
+    if (threadIdx.x < 12) Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
+  }
+  __syncthreads();
+  for (int step = 0; step < steps; ++step) {
+    for (int i = threadIdx.x; i < C; i += blockDim.x) gate[i] = is_inlier(Tf, src_corr, ref_corr, i, radius) ? 1 : 0;
+    __syncthreads();
+    block_procrustes(src_corr, ref_corr, scores, gate, 0, C, red, T);
+    __syncthreads();
+    if (threadIdx.x < 12) Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) {
+    const int r = threadIdx.x / 4, c = threadIdx.x % 4;
+    out_T[threadIdx.x] = r < 3 ? Tf[4 * r + c] : (c == 3 ? 1.f : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t rdm_lgr_workspace_bytes(int64_t batch) {
+  rdm::Arena a(nullptr, 0);
+  const size_t b = static_cast<size_t>(batch > 0 ? batch : 1);
+  a.take<int32_t>(b); a.take<int32_t>(b); a.take<int32_t>(b); a.take<int32_t>(4);
+  a.take<int32_t>(b * kPerPatch); a.take<int32_t>(b * kPerPatch); a.take<float>(b * kPerPatch);
+  a.take<float>(b * 12); a.take<int32_t>(b);
+  a.take<unsigned char>(b * kPerPatch);
+  return a.off;
+}
+
+// log_scores [batch, side+1, side+1] (Sinkhorn output), knn points [batch, side, 3], masks [batch, side].
+// Outputs (capacity batch*2*side rows): ref_corr/src_corr [.,3], corr_scores [.], transform [16],
+// counts [3] = {n_correspondences, n_hypotheses, best_hypothesis} (device int32).
+extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, const float* src_knn_points,
+                       const uint8_t* ref_knn_masks, const uint8_t* src_knn_masks, int64_t batch, int64_t side,
+                       float acceptance_radius, int correspondence_threshold, int num_refinement_steps,
+                       float* ref_corr, float* src_corr, float* corr_scores, float* transform, int32_t* counts,
+                       void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(log_scores && ref_knn_points && src_knn_points && ref_knn_masks && src_knn_masks && ref_corr &&
+                  src_corr && corr_scores && transform && counts, "rdm_lgr: null pointer");
+  RDM_REQUIRE(batch > 0 && side > 0 && side <= kSide, "rdm_lgr: bad sizes (batch=%lld side=%lld)",
+              (long long)batch, (long long)side);
+  Arena ar(ws, ws_bytes);
+  const size_t b = static_cast<size_t>(batch);
+  LgrBuffers w;
+  w.patch_count = ar.take<int32_t>(b);
+  w.patch_offset = ar.take<int32_t>(b);
+  w.chunk_patch = ar.take<int32_t>(b);
+  w.meta = ar.take<int32_t>(4);
+  w.local_i = ar.take<int32_t>(b * kPerPatch);
+  w.local_j = ar.take<int32_t>(b * kPerPatch);
+  w.local_s = ar.take<float>(b * kPerPatch);
+  w.chunk_T = ar.take<float>(b * 12);
+  w.chunk_inliers = ar.take<int32_t>(b);
+  unsigned char* gate = ar.take<unsigned char>(b * kPerPatch);
+  if (!ar.ok) {
+    set_error("rdm_lgr: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int S = static_cast<int>(side), B = static_cast<int>(batch);
+  const size_t lds = sizeof(float) * (S + 1) * ((S + 1) | 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lgr_extract_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lgr_extract_kernel, dim3(B), dim3(256), lds, st, log_scores, S, ref_knn_masks, src_knn_masks, w);
+  hipLaunchKernelGGL(lgr_layout_kernel, dim3(1), dim3(64), 0, st, B, correspondence_threshold, w);
+  hipLaunchKernelGGL(lgr_gather_kernel, dim3(B), dim3(64), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,
+                     src_corr, corr_scores);
+  hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(1024), 0, st, ref_corr, src_corr, corr_scores,
+                     acceptance_radius, num_refinement_steps, w, gate, transform);
+  RDM_HIP_CHECK(hipMemcpyAsync(counts, w.meta, 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return launch_status("lgr kernels");
+}

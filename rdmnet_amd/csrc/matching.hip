@@ -1,0 +1,456 @@
+// a10 NMS, a11 point-to-node grouping, a12 coarse superpoint matching.
+//
+// All three produce INDEX tensors, so their arithmetic restates the reference's CPU arithmetic
+// literally (no contraction except where the reference's BLAS fuses):
+//   pairwise_distance (modules/ops/pairwise_distance.py:4-31): d = (|x|^2 - 2*xy) + |y|^2, clamp 1e-12,
+//   with |x|^2 = (x0*x0 + x1*x1) + x2*x2 and xy = fma(x2,y2, fma(x1,y1, x0*y0)) -- the order the
+//   reference's sgemm uses for k = 3 (verified bit-for-bit against torch.matmul when the goldens
+//   were generated, tests/golden/oracle_vs_reference.json).
+#pragma clang fp contract(off)
+
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+// ---------------------------------------------------------------------------------------------
+// NMS (rdmnet/vote/vote.py:13-40): greedy in index order, keep[i] = !any(keep[nbr(i)]) evaluated
+// when only indices < i have been decided.  keep[i] therefore depends on lower-index neighbours
+// only, which makes it the lexicographically-first maximal independent set; it is resolved in
+// parallel rounds (a node is final once a lower neighbour is kept, or all lower neighbours are
+// final and none is kept).  One workgroup; rounds <= longest dependency chain.
+__global__ __launch_bounds__(1024) void nms_kernel(const int64_t* idx, int n, int h, int ldi,
+                                                   const int32_t* width, unsigned char* keep) {
+  extern __shared__ unsigned char state[];  // 0 undecided, 1 kept, 2 suppressed
+  __shared__ int pending;
+  int H = h;
+  if (width) H = min(H, *width);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) state[i] = 0;
+  __syncthreads();
+  for (int round = 0; round <= n; ++round) {
+    if (threadIdx.x == 0) pending = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      if (state[i] != 0) continue;
+      bool any_kept = false, any_open = false;
+      for (int c = 0; c < H; ++c) {
+        const int64_t j = idx[static_cast<int64_t>(i) * ldi + c];
+        if (j < 0 || j >= i) continue;  // later nodes are still False when i is visited (vote.py:36-38)
+        const unsigned char s = state[j];
+        any_kept |= (s == 1);
+        any_open |= (s == 0);
+      }
+      // a racing read of a neighbour that flips this round only delays the decision by one round
+      if (any_kept) state[i] = 2;
+      else if (!any_open) state[i] = 1;
+      else pending = 1;
+    }
+    __syncthreads();
+    if (pending == 0) break;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) keep[i] = state[i] == 1 ? 1 : 0;
+}
+
+// order-preserving compaction of kept rows: dst row = number of kept rows before it
+__global__ __launch_bounds__(1024) void compact_index_kernel(const unsigned char* keep, int begin, int end,
+                                                             int32_t* order, int32_t* count) {
+  __shared__ int wsum[17];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = begin; i0 < end; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const int flag = (i < end && keep[i]) ? 1 : 0;
+    int inc = flag;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0;
+      for (int k = 0; k < 16; ++k) {
+        const int t = wsum[k];
+        wsum[k] = acc;
+        acc += t;
+      }
+      wsum[16] = acc;
+    }
+    __syncthreads();
+    if (flag) order[base + wsum[w] + inc - 1] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[16];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// point_to_node_partition (modules/ops/pointcloud_partition.py:60-107)
+__device__ __forceinline__ float ref_sq_dist(float x0, float x1, float x2, float xn, float y0, float y1,
+                                             float y2, float yn) {
+  const float xy = fmaf(x2, y2, fmaf(x1, y1, x0 * y0));
+  float d = (xn - 2.f * xy) + yn;
+  return d < 1e-12f ? 1e-12f : d;
+}
+
+// one thread per point: owner = argmin over nodes (first minimum), d_own = that distance
+__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
+                                                         int32_t* owner, float* d_own, int32_t* node_count) {
+  extern __shared__ float sn[];  // [m][4]: x, y, z, |node|^2
+  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+    const float a = nodes[3 * j], b = nodes[3 * j + 1], c = nodes[3 * j + 2];
+    sn[4 * j] = a;
+    sn[4 * j + 1] = b;
+    sn[4 * j + 2] = c;
+    sn[4 * j + 3] = (a * a + b * b) + c * c;
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float y0 = points[3 * i], y1 = points[3 * i + 1], y2 = points[3 * i + 2];
+  const float yn = (y0 * y0 + y1 * y1) + y2 * y2;
+  float best = INFINITY;
+  int arg = 0;
+  for (int j = 0; j < m; ++j) {
+    const float d = ref_sq_dist(sn[4 * j], sn[4 * j + 1], sn[4 * j + 2], sn[4 * j + 3], y0, y1, y2, yn);
+    if (d < best) {
+      best = d;
+      arg = j;
+    }
+  }
+  owner[i] = arg;
+  d_own[i] = best;
+  atomicAdd(&node_count[arg], 1);
+}
+
+// one wavefront per node: its points sorted by (d, index), first k kept (topk largest=False)
+template <int CAP>
+__global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, const float* d_own, int n, int m,
+                                                        int k, const int32_t* node_count, int64_t* knn_idx,
+                                                        unsigned char* knn_mask, unsigned char* node_mask,
+                                                        int32_t* status) {
+  __shared__ unsigned long long keys[CAP];
+  const int node = blockIdx.x, lane = threadIdx.x;
+  const int cnt = node_count[node];
+  if (lane == 0) node_mask[node] = cnt > 0 ? 1 : 0;
+  if (cnt > CAP && lane == 0) atomicExch(status, 1);
+  volatile unsigned long long* K = keys;
+  int filled = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool mine = i < n && owner[i] == node;
+    const unsigned long long mm = __ballot(mine);
+    if (mine) {
+      const int pos = filled + __popcll(mm & ((1ull << lane) - 1ull));
+      if (pos < CAP) K[pos] = (static_cast<unsigned long long>(__float_as_uint(d_own[i])) << 32) | static_cast<unsigned>(i);
+    }
+    filled += __popcll(mm);
+  }
+  const int cn = filled < CAP ? filled : CAP;
+  int p2 = 1;
+  while (p2 < cn) p2 <<= 1;
+  for (int i = cn + lane; i < p2; i += 64) K[i] = ~0ull;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int kk = 2; kk <= p2; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < p2; i += 64) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = K[i], c = K[ixj];
+          if ((a > c) == ((i & kk) == 0)) {
+            K[i] = c;
+            K[ixj] = a;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  for (int c = lane; c < k; c += 64) {
+    const bool ok = c < cn;
+    knn_idx[static_cast<int64_t>(node) * k + c] = ok ? static_cast<int64_t>(K[c] & 0xffffffffull) : n;
+    knn_mask[static_cast<int64_t>(node) * k + c] = ok ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SuperPointMatching (modules/geotransformer/superpoint_matching.py:14-61)
+// scores = exp(-clamp(2 - 2*xy, 1e-12)) over non-empty nodes, rows/cols of empty nodes are 0
+__global__ void coarse_scores_kernel(float* s, int m, int n, int ld, const unsigned char* rmask,
+                                     const unsigned char* cmask) {
+  const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (t >= static_cast<int64_t>(m) * n) return;
+  const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
+  float v = 0.f;
+  if (rmask[i] && cmask[j]) {
+    float d = 2.0f - 2.0f * s[static_cast<int64_t>(i) * ld + j];
+    d = d < 1e-12f ? 1e-12f : d;
+    v = expf(-d);
+  }
+  s[static_cast<int64_t>(i) * ld + j] = v;
+}
+// rsum[i] = sum_j s[i,j] (one wavefront per row); csum[j] = sum_i s[i,j] (one thread per column)
+__global__ void coarse_rowsum_kernel(const float* s, int m, int n, int ld, float* rsum) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= m) return;
+  float acc = 0.f;
+  for (int j = threadIdx.x & 63; j < n; j += 64) acc += s[static_cast<int64_t>(i) * ld + j];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) rsum[i] = acc;
+}
+__global__ void coarse_colsum_kernel(const float* s, int m, int n, int ld, float* csum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+  for (int i = 0; i < m; ++i) acc += s[static_cast<int64_t>(i) * ld + j];
+  csum[j] = acc;
+}
+__global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* rsum, const float* csum,
+                                   const unsigned char* rmask, const unsigned char* cmask) {
+  const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (t >= static_cast<int64_t>(m) * n) return;
+  const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
+  float v = -1.f;  // empty nodes never enter the ranking (they are removed before topk in the reference)
+  if (rmask[i] && cmask[j]) {
+    const float x = s[static_cast<int64_t>(i) * ld + j];
+    v = rsum ? (x / rsum[i]) * (x / csum[j]) : x;
+  }
+  s[static_cast<int64_t>(i) * ld + j] = v;
+}
+
+// Global top-k (k <= 1024) of an m x n matrix, descending, ties by ascending flat index.
+// One workgroup: three radix-select passes on the float bit pattern, then a bitonic sort.
+__global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n, int ld, int k,
+                                                    int64_t* out_row, int64_t* out_col, float* out_val,
+                                                    int32_t* out_count) {
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned long long cand[2048];
+  __shared__ unsigned sh_prefix, sh_need, sh_ncand;
+  __shared__ unsigned wcnt[17];
+  const int64_t total = static_cast<int64_t>(m) * n;
+  // count eligible (>= 0) entries
+  if (threadIdx.x == 0) sh_ncand = 0;
+  __syncthreads();
+  unsigned elig = 0;
+  for (int64_t t = threadIdx.x; t < total; t += blockDim.x)
+    elig += s[(t / n) * ld + (t % n)] >= 0.f ? 1 : 0;
+  atomicAdd(&sh_ncand, elig);
+  __syncthreads();
+  const int kk = min<int64_t>(k, sh_ncand);
+  __syncthreads();
+  if (kk == 0) {
+    if (threadIdx.x == 0) *out_count = 0;
+    return;
+  }
+  // radix select the kk-th largest bit pattern (non-negative floats order like unsigned ints)
+  unsigned prefix = 0, need = kk;  // among values whose high bits == prefix, find the need-th largest
+  const int shifts[3] = {20, 8, 0};
+  const int bits[3] = {12, 12, 8};
+  unsigned mask_hi = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+      const float v = s[(t / n) * ld + (t % n)];
+      if (v < 0.f) continue;
+      const unsigned u = __float_as_uint(v);
+      if ((u & mask_hi) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0;
+      int b = nb - 1;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= need) break;
+        acc += hist[b];
+      }
+      sh_prefix = prefix | (static_cast<unsigned>(b) << shifts[pass]);
+      sh_need = need - acc;
+    }
+    __syncthreads();
+    prefix = sh_prefix;
+    need = sh_need;
+    mask_hi |= static_cast<unsigned>(nb - 1) << shifts[pass];
+    __syncthreads();
+  }
+  // prefix = exact bit pattern of the kk-th largest value; `need` of the entries equal to it are kept
+  // (lowest flat indices first); everything greater is kept.
+  if (threadIdx.x == 0) sh_ncand = 0;
+  __syncthreads();
+  // greater-than entries: any order (sorted below)
+  for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
+    const float v = s[(t / n) * ld + (t % n)];
+    if (v < 0.f) continue;
+    const unsigned u = __float_as_uint(v);
+    if (u > prefix) {
+      const unsigned pos = atomicAdd(&sh_ncand, 1u);
+      if (pos < 2048) cand[pos] = (static_cast<unsigned long long>(~u) << 32) | static_cast<unsigned>(t);
+    }
+  }
+  __syncthreads();
+  const unsigned n_gt = sh_ncand;
+  __syncthreads();
+  // equal entries in ascending flat index: chunked ordered scan
+  if (threadIdx.x == 0) sh_need = 0;  // reused: number of equal entries taken so far
+  __syncthreads();
+  for (int64_t t0 = 0; t0 < total && sh_need < need; t0 += blockDim.x) {
+    const int64_t t = t0 + threadIdx.x;
+    bool eq = false;
+    if (t < total) {
+      const float v = s[(t / n) * ld + (t % n)];
+      eq = v >= 0.f && __float_as_uint(v) == prefix;
+    }
+    // ordered rank inside the chunk
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long bm = __ballot(eq);
+    if (lane == 0) wcnt[w] = __popcll(bm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0;
+      for (int q = 0; q < 16; ++q) {
+        const unsigned c = wcnt[q];
+        wcnt[q] = acc;
+        acc += c;
+      }
+      wcnt[16] = acc;
+    }
+    __syncthreads();
+    if (eq) {
+      const unsigned r = sh_need + wcnt[w] + __popcll(bm & ((1ull << lane) - 1ull));
+      if (r < need) cand[n_gt + r] = (static_cast<unsigned long long>(~prefix) << 32) | static_cast<unsigned>(t);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_need += wcnt[16];
+    __syncthreads();
+  }
+  // sort kk candidates: key = (~value bits, flat index) ascending == value desc, index asc
+  int p2 = 1;
+  while (p2 < kk) p2 <<= 1;
+  for (int i = kk + threadIdx.x; i < p2; i += blockDim.x) cand[i] = ~0ull;
+  __syncthreads();
+  for (int a = 2; a <= p2; a <<= 1)
+    for (int j = a >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < p2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = cand[i], y = cand[ixj];
+          if ((x > y) == ((i & a) == 0)) {
+            cand[i] = y;
+            cand[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < kk; i += blockDim.x) {
+    const unsigned long long c = cand[i];
+    const unsigned flat = static_cast<unsigned>(c & 0xffffffffull);
+    out_row[i] = flat / n;
+    out_col[i] = flat % n;
+    out_val[i] = __uint_as_float(~static_cast<unsigned>(c >> 32));
+  }
+  if (threadIdx.x == 0) *out_count = kk;
+}
+
+}  // namespace
+
+extern "C" int rdm_nms(const int64_t* idx, int64_t n, int64_t h, int64_t ldi, const int32_t* width,
+                       uint8_t* keep, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(idx && keep && n >= 0 && h > 0, "rdm_nms: bad arguments");
+  RDM_REQUIRE(n <= 150000, "rdm_nms: at most 150000 nodes (LDS-resident state)");
+  if (n == 0) return RDM_OK;
+  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), static_cast<size_t>(n), static_cast<hipStream_t>(stream),
+                     idx, static_cast<int>(n), static_cast<int>(h), static_cast<int>(ldi), width, keep);
+  return launch_status("nms_kernel");
+}
+
+extern "C" int rdm_compact_indices(const uint8_t* keep, int64_t begin, int64_t end, int32_t* order,
+                                   int32_t* count, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(keep && order && count && begin >= 0 && end >= begin, "rdm_compact_indices: bad arguments");
+  hipLaunchKernelGGL(compact_index_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), keep,
+                     static_cast<int>(begin), static_cast<int>(end), order, count);
+  return launch_status("compact_index_kernel");
+}
+
+extern "C" size_t rdm_point_to_node_workspace_bytes(int64_t n_points, int64_t n_nodes) {
+  rdm::Arena a(nullptr, 0);
+  a.take<int32_t>(n_points > 0 ? n_points : 1);
+  a.take<float>(n_points > 0 ? n_points : 1);
+  a.take<int32_t>(n_nodes > 0 ? n_nodes : 1);
+  return a.off;
+}
+
+extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const float* nodes, int64_t n_nodes,
+                                 int k, int64_t* knn_idx, uint8_t* knn_mask, uint8_t* node_mask,
+                                 int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(points && nodes && knn_idx && knn_mask && node_mask && status, "rdm_point_to_node: null pointer");
+  RDM_REQUIRE(n_points > 0 && n_nodes > 0 && k > 0 && n_nodes <= 8192,
+              "rdm_point_to_node: bad sizes (points=%lld nodes=%lld)", (long long)n_points, (long long)n_nodes);
+  Arena ar(ws, ws_bytes);
+  int32_t* owner = ar.take<int32_t>(n_points);
+  float* d_own = ar.take<float>(n_points);
+  int32_t* node_count = ar.take<int32_t>(n_nodes);
+  if (!ar.ok) {
+    set_error("rdm_point_to_node: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  RDM_HIP_CHECK(hipMemsetAsync(node_count, 0, sizeof(int32_t) * n_nodes, st));
+  hipLaunchKernelGGL(p2n_assign_kernel, dim3(ceil_div<int64_t>(n_points, 256)), dim3(256),
+                     static_cast<size_t>(n_nodes) * 16, st, points, static_cast<int>(n_points), nodes,
+                     static_cast<int>(n_nodes), owner, d_own, node_count);
+  hipLaunchKernelGGL(p2n_select_kernel<4096>, dim3(static_cast<unsigned>(n_nodes)), dim3(64), 0, st, owner, d_own,
+                     static_cast<int>(n_points), static_cast<int>(n_nodes), k, node_count, knn_idx, knn_mask,
+                     node_mask, status);
+  return launch_status("point_to_node kernels");
+}
+
+extern "C" size_t rdm_coarse_matching_workspace_bytes(int64_t m, int64_t n) {
+  rdm::Arena a(nullptr, 0);
+  a.take<float>(m > 0 ? m : 1);
+  a.take<float>(n > 0 ? n : 1);
+  return a.off;
+}
+
+// scores: in = f_ref . f_src^T  [m, n] (ld), overwritten with the dual-normalised matching scores.
+extern "C" int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t ld, const uint8_t* ref_mask,
+                                   const uint8_t* src_mask, int dual_normalization, int k, int64_t* ref_idx,
+                                   int64_t* src_idx, float* out_scores, int32_t* out_count, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(scores && ref_mask && src_mask && ref_idx && src_idx && out_scores && out_count,
+              "rdm_coarse_matching: null pointer");
+  RDM_REQUIRE(m > 0 && n > 0 && k > 0 && k <= 1024 && m * n < (1ll << 31), "rdm_coarse_matching: bad sizes");
+  Arena ar(ws, ws_bytes);
+  float* rsum = ar.take<float>(m);
+  float* csum = ar.take<float>(n);
+  if (!ar.ok) {
+    set_error("rdm_coarse_matching: workspace too small");
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = static_cast<int>(m), N = static_cast<int>(n), LD = static_cast<int>(ld);
+  const int eb = static_cast<int>(ceil_div<int64_t>(m * n, 256));
+  hipLaunchKernelGGL(coarse_scores_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD, ref_mask, src_mask);
+  if (dual_normalization) {
+    hipLaunchKernelGGL(coarse_rowsum_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, scores, M, N, LD, rsum);
+    hipLaunchKernelGGL(coarse_colsum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, scores, M, N, LD, csum);
+  }
+  hipLaunchKernelGGL(coarse_dual_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD,
+                     dual_normalization ? rsum : static_cast<const float*>(nullptr),
+                     dual_normalization ? csum : static_cast<const float*>(nullptr), ref_mask, src_mask);
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
+                     out_count);
+  return launch_status("coarse matching kernels");
+}

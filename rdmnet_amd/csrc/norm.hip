@@ -173,7 +173,30 @@ __global__ void upsample_concat_kernel(const float* coarse, int n_coarse, int c1
   }
 }
 
+// y[i, :] = x[idx[i], :] as raw 32-bit words; rows with idx outside [0, n_src) become zeros
+__global__ void gather_rows_kernel(const uint32_t* x, int n_src, int c, int ldx, const int64_t* idx, int m,
+                                   uint32_t* y, int ldy) {
+  const int row = blockIdx.x;
+  const int64_t id = idx[row];
+  const bool ok = id >= 0 && id < n_src;
+  for (int col = threadIdx.x; col < c; col += blockDim.x)
+    y[static_cast<int64_t>(row) * ldy + col] = ok ? x[id * ldx + col] : 0u;
+}
+
 }  // namespace
+
+extern "C" int rdm_gather_rows(const void* x, int64_t n_src, int64_t words, int64_t ldx, const int64_t* idx,
+                               int64_t m, void* y, int64_t ldy, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && idx && y && words > 0, "rdm_gather_rows: bad arguments");
+  if (m == 0) return RDM_OK;
+  const int threads = words >= 256 ? 256 : (words >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>(m)), dim3(threads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<int>(n_src),
+                     static_cast<int>(words), static_cast<int>(ldx), idx, static_cast<int>(m),
+                     static_cast<uint32_t*>(y), static_cast<int>(ldy));
+  return launch_status("gather_rows_kernel");
+}
 
 extern "C" size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c) {
   const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(n > 0 ? n : 1, kGnRowsPerBlock));

@@ -94,6 +94,15 @@ class RDMNet:
                 continue
             else:
                 vec(name)
+        # fused attention projections: q|k|v for self layers, q and k|v for cross layers
+        for name in [n for n in S if n.endswith('attention.attention.proj_q.weight')]:
+            p = name[:-len('.attention.attention.proj_q.weight')]
+            a = p + '.attention.attention'
+            wq, wk, wv = S[a + '.proj_q.weight'], S[a + '.proj_k.weight'], S[a + '.proj_v.weight']
+            bq, bk, bv = S[a + '.proj_q.bias'], S[a + '.proj_k.bias'], S[a + '.proj_v.bias']
+            W[p + '.qkv'] = _dev_linear(np.concatenate([wq, wk, wv], 0), np.concatenate([bq, bk, bv]), dev)[:2]
+            W[p + '.q'] = _dev_linear(wq, bq, dev)[:2]
+            W[p + '.kv'] = _dev_linear(np.concatenate([wk, wv], 0), np.concatenate([bk, bv]), dev)[:2]
         self._w = W
         return W
 
@@ -163,10 +172,184 @@ class RDMNet:
         l3 = self._unary('decoder.decoder3', ops.upsample_concat(l4, up[2], feats[2]))
         return self._linear('decoder.decoder2.mlp', ops.upsample_concat(l3, up[1], feats[1]))
 
+    # ------------------------------------------------------------------ 3DRoFormer
+    def _attention_layer(self, p, x, mem, emb, heads):
+        """RPEAttentionLayer / AttentionLayer + AttentionOutput (thdroformer.py:142-202,
+        vanilla_transformer.py:69-129, output_layer.py:6-21)."""
+        W, d = self._w, x.shape[1]
+        if mem is x:  # self attention: one fused q|k|v projection
+            qkv = ops.gemm(x, W[p + '.qkv'][0], d, 3 * d, bias=W[p + '.qkv'][1])
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            q = ops.gemm(x, W[p + '.q'][0], d, d, bias=W[p + '.q'][1])
+            kv = ops.gemm(mem, W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
+            k, v = kv[:, :d], kv[:, d:]
+        if emb is not None:
+            ops.rope(q, k, emb)
+        hid = ops.attention(q, k, v, heads)
+        hid = self._linear(p + '.attention.linear', hid)
+        y = ops.layer_norm(hid, W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], residual=x)
+        z = self._linear(p + '.output.expand', y, act=ACT_RELU)
+        z = self._linear(p + '.output.squeeze', z)
+        return ops.layer_norm(z, W[p + '.output.norm.weight'], W[p + '.output.norm.bias'], residual=y)
+
+    def _thdroformer(self, name, ref_pts4, src_pts4, ref_x, src_x, num_layers, out_ref, out_src):
+        """rdmnet/thdroformer/thdroformer.py:266-347 (+ RPEConditionalTransformer.forward :227-251)."""
+        heads = self.cfg.thdroformer.num_heads
+        e0 = self._linear(name + '.embedding.proj', ref_pts4)
+        e1 = self._linear(name + '.embedding.proj', src_pts4)
+        f0 = self._linear(name + '.in_proj', ref_x)
+        f1 = self._linear(name + '.in_proj', src_x)
+        for i in range(2 * num_layers):
+            p = f'{name}.transformer.layers.{i}'
+            if i % 2 == 0:
+                f0 = self._attention_layer(p, f0, f0, e0, heads)
+                f1 = self._attention_layer(p, f1, f1, e1, heads)
+            else:
+                f0 = self._attention_layer(p, f0, f1, None, heads)
+                f1 = self._attention_layer(p, f1, f0, None, heads)  # sequential: sees the updated f0
+        self._linear(name + '.out_proj', f0, out=out_ref)
+        self._linear(name + '.out_proj', f1, out=out_src)
+
+    @staticmethod
+    def _pts4(pts):
+        """[n,3] -> [n,4] zero padded (K of the positional Linear must be a multiple of 4)."""
+        out = torch.zeros((pts.shape[0], 4), dtype=torch.float32, device=pts.device)
+        out[:, :3] = pts
+        return out
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, data_dict, taps=None):
-        raise NotImplementedError('assembled in stages; see forward_backbone for the encoder/decoder slice')
+        """experiments/model_infer.py:109-354 (inference).  `data_dict` as produced by the collate
+        (rdmnet_amd.collate or the reference's), tensors on the GPU."""
+        if not self.use_vote:
+            raise NotImplementedError('inference without the vote layer is undefined in the reference '
+                                      '(model_infer.py:179-246 leaves ref_points_c unset)')
+        W, cfg, dev = self._prepare(), self.cfg, self.device
+        t = cfg.thdroformer
+        taps = taps if taps is not None else {}
+        out = {}
+        L = data_dict['lengths']
+        lens = torch.stack([L[-1], L[1], L[0]]).cpu()  # one sync: the ref/src split of three levels
+        n_c, n_f, n_0 = int(lens[0, 0]), int(lens[1, 0]), int(lens[2, 0])
+        pts_c, pts_f, pts = data_dict['points'][-1], data_dict['points'][1], data_dict['points'][0]
+        N_c = pts_c.shape[0]
+        out.update(ori_ref_points_c=pts_c[:n_c], ori_src_points_c=pts_c[n_c:], ref_points_f=pts_f[:n_f],
+                   src_points_f=pts_f[n_f:], ref_points=pts[:n_0], src_points=pts[n_0:])
+
+        feats = self.encoder(data_dict, taps)
+        f_c = feats[-1]
+        taps['feats_c_enc'] = f_c
+
+        # transformer #1 -> stacked [ref; src] (256 features + n2p logit in column 256)
+        buf_c = ops.feat_empty(N_c, t.output_dim + 1, dev)
+        pts_c4 = self._pts4(pts_c)
+        self._thdroformer('transformer', pts_c4[:n_c], pts_c4[n_c:], f_c[:n_c], f_c[n_c:], t.num_layers,
+                          buf_c[:n_c, :t.output_dim], buf_c[n_c:, :t.output_dim])
+        x_c = buf_c[:, :t.output_dim]
+        taps['t1_ref'], taps['t1_src'] = x_c[:n_c], x_c[n_c:]
+        self._linear('proj_n2p_score', x_c, out=buf_c[:, t.output_dim:])
+        n2p = ops.sigmoid_column(buf_c[:, t.output_dim:])
+
+        feats[-1] = buf_c
+        dec = self.decoder(feats, data_dict)
+        taps['decoder'] = dec
+        feats_f = dec[:, :cfg.backbone.output_dim]
+        p2p = ops.sigmoid_column(dec[:, cfg.backbone.output_dim:])
+        out.update(ref_p2p_scores_c=p2p[:n_f], src_p2p_scores_c=p2p[n_f:])
+
+        # vote layer (rdmnet/vote/vote.py:83-117)
+        h = x_c
+        for i in range(len(cfg.Vote.MLPS)):
+            h = self._linear(f'vote.mlp_modules.{3 * i}', h)
+            h = ops.layer_norm(h, W[f'vote.mlp_modules.{3 * i + 1}.weight'], W[f'vote.mlp_modules.{3 * i + 1}.bias'],
+                               act=ACT_RELU)
+        off = self._linear('vote.ctr_reg', h)
+        shifted = ops.vote_shift(pts_c, off, cfg.Vote.MAX_TRANSLATE_RANGE)
+        vfeats = ops.layer_norm(x_c, W['vote.out_proj.0.weight'], W['vote.out_proj.0.bias'], residual=off[:, 3:])
+        taps['vote_xyz'], taps['vote_feats'] = shifted, vfeats
+        out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:])
+        n2n = ops.sigmoid_column(self._linear('proj_n2n_score', vfeats))
+
+        # NMS (vote.py:13-40): neighbours of the shifted nodes, greedy sweep, order-preserving compaction
+        flags = torch.zeros(8, dtype=torch.int32, device=dev)  # [max_count, status, n_ref, n_src, p2n status...]
+        nms_idx = ops.radius_search_device(shifted, shifted, L[-1], L[-1], cfg.Vote.NMS_radius,
+                                           cfg.neighbor_limits[-1], flags)
+        keep = ops.nms(nms_idx, flags)
+        taps['nms_mask'], taps['nms_idx'] = keep, nms_idx
+        order = torch.empty((N_c,), dtype=torch.int32, device=dev)
+        ops.compact_indices(keep, 0, n_c, order, flags[2:])
+        ops.compact_indices(keep, n_c, N_c, order[n_c:], flags[3:])
+        fl = flags.cpu()  # sync: kept-node counts size everything downstream
+        if int(fl[1]) != 0:
+            raise RuntimeError('radius search capacity exceeded in NMS')
+        m_r, m_s = int(fl[2]), int(fl[3])
+        sel = torch.cat([order[:m_r], order[n_c:n_c + m_s]]).to(torch.int64)
+        nodes = ops.gather_rows(shifted, sel)
+        ref_c, src_c = nodes[:m_r], nodes[m_r:]
+        sel_feats = ops.gather_rows(vfeats, sel)
+        scores3 = ops.gather_rows(torch.stack([n2p, n2n], 1), sel)
+        out.update(ref_n2p_scores_c=scores3[:m_r, 0], src_n2p_scores_c=scores3[m_r:, 0],
+                   ref_n2n_scores_c=scores3[:m_r, 1], src_n2n_scores_c=scores3[m_r:, 1],
+                   ref_points_c=ref_c, src_points_c=src_c)
+
+        # transformer #2 on the surviving nodes
+        buf2 = ops.feat_empty(m_r + m_s, t.output_dim, dev)
+        nodes4 = self._pts4(nodes)
+        self._thdroformer('transformer2', nodes4[:m_r], nodes4[m_r:], sel_feats[:m_r], sel_feats[m_r:],
+                          t.num_layers2, buf2[:m_r], buf2[m_r:])
+        taps['t2_ref'], taps['t2_src'] = buf2[:m_r], buf2[m_r:]
+        fn = ops.l2_normalize(buf2)
+        rfn, sfn = fn[:m_r], fn[m_r:]
+        out.update(ref_feats_c=rfn, src_feats_c=sfn)
+
+        # point-to-node grouping + coarse matching
+        k_pts = cfg.model.num_points_in_patch
+        r_nmask, r_knn, r_kmask = ops.point_to_node(pts_f[:n_f], ref_c, k_pts, flags[4:])
+        s_nmask, s_knn, s_kmask = ops.point_to_node(pts_f[n_f:], src_c, k_pts, flags[4:])
+        taps.update(ref_node_masks=r_nmask, src_node_masks=s_nmask, ref_knn=r_knn, src_knn=s_knn,
+                    ref_knn_masks=r_kmask, src_knn_masks=s_kmask)
+        out.update(ref_feats_f=feats_f[:n_f], src_feats_f=feats_f[n_f:])
+        sim = ops.gemm(rfn, sfn, t.output_dim, m_s, trans_b=True)
+        r_sel, s_sel, node_scores, n_sel = ops.coarse_matching(sim, r_nmask, s_nmask, cfg.coarse_matching.num_correspondences,
+                                                               cfg.coarse_matching.dual_normalization)
+        B = int(n_sel.item())  # sync: number of patch correspondences (256 unless the clouds are tiny)
+        r_sel, s_sel, node_scores = r_sel[:B], s_sel[:B], node_scores[:B]
+        taps['node_corr_scores'] = node_scores
+        out.update(ref_node_corr_indices=r_sel, src_node_corr_indices=s_sel)
+
+        # patches: indices, masks, points, features
+        r_idx, s_idx = ops.gather_rows(r_knn, r_sel), ops.gather_rows(s_knn, s_sel)            # [B,k] i64
+        r_pm, s_pm = ops.gather_rows(r_kmask, r_sel), ops.gather_rows(s_kmask, s_sel)          # [B,k] u8
+        r_pts = ops.gather_rows(pts_f[:n_f], r_idx.view(-1)).view(B, k_pts, 3)
+        s_pts = ops.gather_rows(pts_f[n_f:], s_idx.view(-1)).view(B, k_pts, 3)
+        c_f = cfg.backbone.output_dim
+        r_pf = ops.gather_rows(feats_f[:n_f], r_idx.view(-1), out=torch.empty((B * k_pts, c_f), dtype=torch.float32, device=dev))
+        s_pf = ops.gather_rows(feats_f[n_f:], s_idx.view(-1), out=torch.empty((B * k_pts, c_f), dtype=torch.float32, device=dev))
+        out.update(ref_node_corr_knn_points=r_pts, src_node_corr_knn_points=s_pts,
+                   ref_node_corr_knn_masks=r_pm.bool(), src_node_corr_knn_masks=s_pm.bool())
+        patch_scores = ops.gemm_batched(r_pf.view(B, k_pts, c_f), s_pf.view(B, k_pts, c_f), c_f, rowdiv=self._sqrt_c(c_f, k_pts))
+        taps['patch_scores'] = patch_scores
+        ms = ops.sinkhorn(patch_scores, r_pm, s_pm, W['optimal_transport.alpha'], cfg.model.num_sinkhorn_iterations)
+        out['matching_scores'] = ms
+
+        fm = cfg.fine_matching
+        rc, sc, cs, T, counts = ops.lgr(ms, r_pts, s_pts, r_pm, s_pm, fm.acceptance_radius, fm.correspondence_threshold,
+                                        fm.num_refinement_steps)
+        cn = torch.cat([counts, flags[4:5]]).cpu()  # sync: number of correspondences (+ capacity status)
+        if int(cn[3]) != 0:
+            raise RuntimeError('point_to_node: a node owns more than 4096 points')
+        C = int(cn[0])
+        taps['lgr'] = {'n_hypotheses': int(cn[1]), 'best': int(cn[2])}
+        out.update(ref_corr_points=rc[:C], src_corr_points=sc[:C], corr_scores=cs[:C], estimated_transform=T)
+        return out
+
+    def _sqrt_c(self, c, rows):
+        key = ('sqrt_c', c, rows)
+        if key not in self._w:
+            self._w[key] = torch.full((rows,), float(c) ** 0.5, dtype=torch.float32, device=self.device)
+        return self._w[key]
 
     __call__ = forward
 

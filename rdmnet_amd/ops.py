@@ -65,14 +65,14 @@ def gemm(a, b, k, n, *, trans_b=False, bias=None, rowdiv=None, act=ACT_NONE, out
     return out
 
 
-def gemm_batched(a, b, k, *, trans_b=True, out=None):
-    """a [B, m, >=k], b [B, n, >=k] contiguous batches -> out [B, m, n]."""
+def gemm_batched(a, b, k, *, trans_b=True, out=None, rowdiv=None):
+    """a [B, m, >=k], b [B, n, >=k] contiguous batches -> out [B, m, n] (/ rowdiv[row])."""
     L = _lib.lib()
     B, m, n = a.shape[0], a.shape[1], b.shape[1]
     if out is None:
         out = torch.empty((B, m, n), dtype=torch.float32, device=a.device)
     _lib.check(L.rdm_gemm(a.data_ptr(), a.stride(1), a.stride(0), b.data_ptr(), b.stride(1), b.stride(0),
-                          int(trans_b), out.data_ptr(), out.stride(1), out.stride(0), m, n, k, B, 0, 0, ACT_NONE, 0, 0,
+                          int(trans_b), out.data_ptr(), out.stride(1), out.stride(0), m, n, k, B, 0, _lib.ptr(rowdiv), ACT_NONE, 0, 0,
                           _lib.stream_ptr()), 'rdm_gemm(batched)')
     return out
 
@@ -139,3 +139,158 @@ def upsample_concat(coarse, idx, skip):
                                      skip.data_ptr(), c2, _ld(skip), m, y.data_ptr(), _ld(y), _lib.stream_ptr()),
                'rdm_upsample_concat')
     return y
+
+
+def gather_rows(x, idx, out=None):
+    """out[i] = x[idx[i]] bitwise (any 4-byte-multiple row type); out-of-range index -> zero row.
+    x: [n, ...] with contiguous trailing dims (row stride may be padded), idx int64 [m]."""
+    L = _lib.lib()
+    n, m = x.shape[0], idx.shape[0]
+    row_bytes = x[0].numel() * x.element_size() if n > 0 else 0
+    tail = tuple(x.shape[1:])
+    assert row_bytes % 4 == 0 and (x.stride(0) * x.element_size()) % 4 == 0
+    if out is None:
+        out = torch.empty((m,) + tail, dtype=x.dtype, device=x.device)
+    _lib.check(L.rdm_gather_rows(x.data_ptr(), n, row_bytes // 4, x.stride(0) * x.element_size() // 4, idx.data_ptr(), m,
+                                 out.data_ptr(), out.stride(0) * out.element_size() // 4, _lib.stream_ptr()),
+               'rdm_gather_rows')
+    return out
+
+
+def rope(q, k, emb):
+    L = _lib.lib()
+    _lib.check(L.rdm_rope(q.data_ptr(), _ld(q), _lib.ptr(k), _ld(k) if k is not None else 0, emb.data_ptr(), _ld(emb),
+                          q.shape[0], q.shape[1], _lib.stream_ptr()), 'rdm_rope')
+
+
+def attention(q, k, v, heads, out=None):
+    L = _lib.lib()
+    nq, d = q.shape
+    if out is None:
+        out = feat_empty(nq, d, q.device)
+    _lib.check(L.rdm_attention(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
+                               nq, k.shape[0], heads, d // heads, _lib.stream_ptr()), 'rdm_attention')
+    return out
+
+
+def vote_shift(xyz, offsets, limits):
+    L = _lib.lib()
+    out = torch.empty_like(xyz)
+    _lib.check(L.rdm_vote_shift(xyz.data_ptr(), offsets.data_ptr(), _ld(offsets), xyz.shape[0], float(limits[0]),
+                                float(limits[1]), float(limits[2]), out.data_ptr(), _lib.stream_ptr()), 'rdm_vote_shift')
+    return out
+
+
+def sigmoid_column(x_col):
+    """clamp(sigmoid(x), 0, 1) of a (possibly strided) single column view [n, 1] or [n]."""
+    L = _lib.lib()
+    n = x_col.shape[0]
+    out = torch.empty((max(n, 1),), dtype=torch.float32, device=x_col.device)
+    _lib.check(L.rdm_sigmoid_column(x_col.data_ptr(), x_col.stride(0), n, out.data_ptr(), _lib.stream_ptr()),
+               'rdm_sigmoid_column')
+    return out[:n]
+
+
+def l2_normalize(x):
+    L = _lib.lib()
+    y = feat_empty(x.shape[0], x.shape[1], x.device)
+    _lib.check(L.rdm_l2_normalize(x.data_ptr(), _ld(x), x.shape[0], x.shape[1], y.data_ptr(), _ld(y), _lib.stream_ptr()),
+               'rdm_l2_normalize')
+    return y
+
+
+def radius_search_device(q, s, q_lengths, s_lengths, radius, width, flags):
+    """Truncated radius search entirely on the device.  flags: int32[2] = [max_count, status] (zeroed by
+    the caller).  Returns idx [nq, width]; the effective width is min(width, flags[0]) (device value)."""
+    L = _lib.lib()
+    nq, ns, batch = q.shape[0], s.shape[0], q_lengths.shape[0]
+    ws = scratch(q.device, L.rdm_radius_neighbors_workspace_bytes(nq, ns, batch))
+    out = torch.empty((max(nq, 1), width), dtype=torch.int64, device=q.device)
+    _lib.check(L.rdm_radius_neighbors(q.data_ptr(), nq, s.data_ptr(), ns, q_lengths.data_ptr(), s_lengths.data_ptr(), batch,
+                                      float(radius), width, out.data_ptr(), 0, flags.data_ptr(), flags[1:].data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_radius_neighbors')
+    return out[:nq]
+
+
+def grid_subsample_device(points, lengths, voxel):
+    """-> (out_points [n,3] capacity buffer, out_lengths int64[batch]) without synchronising."""
+    L = _lib.lib()
+    n, batch = points.shape[0], lengths.shape[0]
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=points.device)
+    out_len = torch.empty((batch,), dtype=torch.int64, device=points.device)
+    ws = scratch(points.device, L.rdm_grid_subsample_workspace_bytes(n, batch))
+    _lib.check(L.rdm_grid_subsample(points.data_ptr(), n, lengths.data_ptr(), batch, float(voxel), out.data_ptr(),
+                                    out_len.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_grid_subsample')
+    return out, out_len
+
+
+def nms(idx, width_dev):
+    L = _lib.lib()
+    n = idx.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.uint8, device=idx.device)
+    _lib.check(L.rdm_nms(idx.data_ptr(), n, idx.shape[1], idx.stride(0), _lib.ptr(width_dev), keep.data_ptr(),
+                         _lib.stream_ptr()), 'rdm_nms')
+    return keep[:n]
+
+
+def compact_indices(keep, begin, end, order, count):
+    L = _lib.lib()
+    _lib.check(L.rdm_compact_indices(keep.data_ptr(), begin, end, order.data_ptr(), count.data_ptr(), _lib.stream_ptr()),
+               'rdm_compact_indices')
+
+
+def point_to_node(points, nodes, k, status):
+    L = _lib.lib()
+    n, m = points.shape[0], nodes.shape[0]
+    knn = torch.empty((m, k), dtype=torch.int64, device=points.device)
+    kmask = torch.empty((m, k), dtype=torch.uint8, device=points.device)
+    nmask = torch.empty((m,), dtype=torch.uint8, device=points.device)
+    ws = scratch(points.device, L.rdm_point_to_node_workspace_bytes(n, m))
+    _lib.check(L.rdm_point_to_node(points.data_ptr(), n, nodes.data_ptr(), m, k, knn.data_ptr(), kmask.data_ptr(),
+                                   nmask.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_point_to_node')
+    return nmask, knn, kmask
+
+
+def coarse_matching(scores, ref_mask, src_mask, k, dual=True):
+    """scores [m, n] view (overwritten) -> (ref_idx i64[k], src_idx i64[k], scores f32[k], count i32[1])."""
+    L = _lib.lib()
+    m, n = scores.shape
+    dev = scores.device
+    ri = torch.empty((k,), dtype=torch.int64, device=dev)
+    si = torch.empty((k,), dtype=torch.int64, device=dev)
+    sc = torch.empty((k,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = scratch(dev, L.rdm_coarse_matching_workspace_bytes(m, n))
+    _lib.check(L.rdm_coarse_matching(scores.data_ptr(), m, n, _ld(scores), ref_mask.data_ptr(), src_mask.data_ptr(),
+                                     int(dual), k, ri.data_ptr(), si.data_ptr(), sc.data_ptr(), cnt.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_coarse_matching')
+    return ri, si, sc, cnt
+
+
+def sinkhorn(scores, row_mask, col_mask, alpha, iters):
+    L = _lib.lib()
+    b, m, n = scores.shape
+    out = torch.empty((b, m + 1, n + 1), dtype=torch.float32, device=scores.device)
+    _lib.check(L.rdm_sinkhorn(scores.data_ptr(), b, m, n, row_mask.data_ptr(), col_mask.data_ptr(), alpha.data_ptr(), iters,
+                              out.data_ptr(), _lib.stream_ptr()), 'rdm_sinkhorn')
+    return out
+
+
+def lgr(log_scores, ref_pts, src_pts, ref_mask, src_mask, radius, min_corr, steps):
+    """-> (ref_corr [cap,3], src_corr [cap,3], scores [cap], T [4,4], counts i32[3]) -- counts[0] rows are valid."""
+    L = _lib.lib()
+    b, side = ref_mask.shape
+    dev = log_scores.device
+    cap = b * 2 * side
+    rc = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    sc = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    cs = torch.empty((cap,), dtype=torch.float32, device=dev)
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    counts = torch.empty((3,), dtype=torch.int32, device=dev)
+    ws = scratch(dev, L.rdm_lgr_workspace_bytes(b))
+    _lib.check(L.rdm_lgr(log_scores.data_ptr(), ref_pts.data_ptr(), src_pts.data_ptr(), ref_mask.data_ptr(),
+                         src_mask.data_ptr(), b, side, float(radius), int(min_corr), int(steps), rc.data_ptr(), sc.data_ptr(),
+                         cs.data_ptr(), T.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_lgr')
+    return rc, sc, cs, T, counts
