@@ -55,6 +55,8 @@ def gemm(a, b, k, n, *, trans_b=False, bias=None, rowdiv=None, act=ACT_NONE, out
     (trans_b False) or [n, >=k] view (trans_b True); k must be a multiple of 4."""
     L = _lib.lib()
     m = a.shape[0]
+    if a.stride(-1) != 1 or b.stride(-1) != 1:
+        raise ValueError('gemm operands must be row-major (unit column stride)')
     if out is None:
         out = feat_empty(m, n, a.device)
     ws_bytes = L.rdm_gemm_workspace_bytes(m, n, 1)

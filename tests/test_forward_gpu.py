@@ -54,7 +54,7 @@ def test_transformer_stage(ctx):
     net, o, ops = ctx['net'], ctx['otaps'], ctx['ops']
     n_c = int(ctx['odata']['lengths'][-1][0])
     pts = ctx['odata']['points'][-1].cuda()
-    fc = o['feats_c_enc'].cuda()
+    fc = o['feats_c_enc'].contiguous().cuda()
     buf = ops.feat_empty(pts.shape[0], 256, 'cuda')
     p4 = net._pts4(pts)
     net._thdroformer('transformer', p4[:n_c], p4[n_c:], fc[:n_c], fc[n_c:], 4, buf[:n_c], buf[n_c:])
