@@ -31,6 +31,7 @@ class RDMNet:
         self._state = None   # name -> numpy float32
         self._w = None       # prepared device tensors
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
+        self.profile = None  # list -> per-KPConv-layer HIP-event records (bench.py)
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def cuda(self, device=None):
@@ -115,10 +116,25 @@ class RDMNet:
         return ops.group_norm(x, self._w[name + '.norm.weight'], self._w[name + '.norm.bias'],
                               self.cfg.backbone.group_norm, act=act, residual=residual, want_positive=want_positive)
 
-    def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None):
+    def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None, pooled_channels=0):
         b, cin, cout = self._w[name + '.weights']
+        prof = self.profile
+        if prof is not None:
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
         wf, nn = ops.kpconv_gather(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, width)
-        return ops.gemm(wf, b, b.shape[0], cout, bias=self._w[name + '.bias'], rowdiv=nn)
+        if prof is not None:
+            e1.record()
+        y = ops.gemm(wf, b, b.shape[0], cout, bias=self._w[name + '.bias'], rowdiv=nn)
+        if prof is not None:
+            e2.record()
+            m, h = idx.shape
+            # SURVEY.md §8d algorithmic bytes of one KPConv layer (padded slots counted, int64 indices, fp32):
+            #   M*H*(8 + 12 + 4*C_in) + 4*M*C_out   (+ M*H*(8 + 4*C_block_in) for the strided shortcut pool)
+            nbytes = m * h * (8 + 12 + 4 * cin) + 4 * m * cout + (m * h * (8 + 4 * pooled_channels) if pooled_channels else 0)
+            prof.append({'name': name, 'm': m, 'h': h, 'cin': cin, 'cout': cout, 'bytes': nbytes,
+                         'gather_bytes': m * h * (8 + 12 + 4 * cin), 'events': (e0, e1, e2)})
+        return y
 
     def _unary(self, name, x, act=ACT_LEAKY, residual=None, want_positive=False):
         return self._gn(name + '.norm', self._linear(name + '.mlp', x), act=act, residual=residual,
@@ -134,7 +150,7 @@ class RDMNet:
             y, y_pos = self._unary(name + '.unary1', x, want_positive=True)
         else:
             y, y_pos = x, (x_pos if x_pos is not None else ops.row_positive(x))
-        y = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width)
+        y = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width, pooled_channels=x.shape[1] if strided else 0)
         y = self._gn(name + '.norm_conv', y, act=ACT_LEAKY)
         sc = ops.gather_max(x, idx, width) if strided else x
         if (name + '.unary_shortcut.mlp') in W:
