@@ -43,31 +43,51 @@ def make_pairs(n_pairs, cache_dir):
     return pairs
 
 
-def cpu_baseline(pairs, cfg, state, budget_s=25.0):
-    """The CPU port (oracle restatement) of the same path on the host cores, bounded sample."""
+def _cpu_baseline_worker(cache_dir, n_pairs, threads, budget_s):
+    """Runs in a child process (so a pathological host cannot stall the bench): the CPU port
+    (oracle restatement) of the same path, bounded sample."""
     from oracle import forward as ofw
     from oracle import native
+    from rdmnet_amd import config, weights
+    cfg = config.make_cfg()
+    W = ofw.to_torch(weights.synthetic_state_dict(cfg, seed=0))
     impl = native.reference() or native.restatement()
-    W = ofw.to_torch(state)
-    torch.set_num_threads(os.cpu_count() or 1)
-    t_all, n = 0.0, 0
-    t_pre = t_fwd = 0.0
+    torch.set_num_threads(threads)
+    pairs = make_pairs(n_pairs, cache_dir)
+    t_all = t_pre = t_fwd = 0.0
+    n = 0
     for ref, src, _ in pairs:
         t0 = time.perf_counter()
         data = ofw.pyramid(np.concatenate([ref, src]), np.array([len(ref), len(src)], np.int64), cfg, impl=impl)
         t1 = time.perf_counter()
         ofw.forward(W, cfg, data, impl=impl)
         t2 = time.perf_counter()
-        t_pre += t1 - t0
-        t_fwd += t2 - t1
-        t_all += t2 - t0
-        n += 1
+        t_pre, t_fwd, t_all, n = t_pre + t1 - t0, t_fwd + t2 - t1, t_all + t2 - t0, n + 1
         if t_all > budget_s:
             break
     kind_native = 'reference C++ (oracle/_ref)' if native.reference() is not None else 'restatement C++'
-    return {'value': n / t_all, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} pair(s) of the bench workload; collate = {kind_native} single-thread kd-tree/hash map '
-                      f'({t_pre / n:.2f} s/pair), forward = oracle/forward.py torch fp32 on all cores ({t_fwd / n:.2f} s/pair)'}
+    print('CPU_BASELINE ' + json.dumps({
+        'value': n / t_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+        'sample': f'{n} pair(s) of the bench workload; collate = {kind_native}, single-thread kd-tree/hash map '
+                  f'({t_pre / n:.2f} s/pair); forward = oracle/forward.py, torch fp32 on {threads} threads '
+                  f'({t_fwd / n:.2f} s/pair)'}))
+
+
+def cpu_baseline(cache_dir, n_pairs, timeout_s=150):
+    import subprocess
+    threads = max(1, min(os.cpu_count() or 1, 16))  # more threads make torch's small CPU ops slower, not faster
+    code = (f'import sys; sys.path.insert(0, {ROOT!r}); import bench; '
+            f'bench._cpu_baseline_worker({cache_dir!r}, {n_pairs}, {threads}, 20.0)')
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    try:
+        p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in p.stdout.splitlines():
+            if line.startswith('CPU_BASELINE '):
+                return json.loads(line[len('CPU_BASELINE '):])
+        return {'value': None, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'sample': 'failed: ' + p.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+                'sample': f'did not finish one pair within {timeout_s} s'}
 
 
 def main():
@@ -192,7 +212,7 @@ def main():
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            result['cpu_baseline'] = cpu_baseline(pairs, cfg, state)
+            result['cpu_baseline'] = cpu_baseline(args.cache, args.pairs)
         else:
             result['cpu_baseline'] = None
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
