@@ -6,7 +6,8 @@
 //
 // rdm_rope: theta = 2*pi*sigmoid(emb) per (token, head, pair); (x0, x1) -> (x0 cos - x1 sin,
 //   x1 cos + x0 sin) applied in place to q and k.
-// rdm_attention: one wavefront = 16 queries of one head (d = 32).  S^T = K Q^T is formed with
+// rdm_attention: one workgroup = 16 queries of one head (d = 32), its four wavefronts split the
+//   keys and merge their online-softmax partials through LDS.  S^T = K Q^T is formed with
 //   v_mfma_f32_16x16x4_f32 (the contraction index is permuted so every lane reads 8 contiguous
 //   floats of its key/query row), softmax runs online in registers (the 16 columns of the MFMA
 //   result are the 16 queries, so a lane owns one query and 4 keys: the row reduction is 3 adds and
@@ -54,11 +55,13 @@ struct AttnArgs {
   float inv_scale;  // sqrt(d)
 };
 
+// One workgroup = 16 queries of one head; its 4 wavefronts split the key tiles (tile % 4 == wave)
+// and merge their online-softmax partials (m, l, O) through LDS at the end.
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+  __shared__ float sm[4][16], sl[4][16];
+  __shared__ float so[4][16][kHeadDim + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + wave;
-  const int q0 = tile * 16;
-  if (q0 >= a.nq) return;
+  const int q0 = blockIdx.x * 16;
   const int head = blockIdx.y;
   const int g = lane >> 4, x = lane & 15;
   const int hoff = head * kHeadDim;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;   // per query x (replicated over g)
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // O[query 4g+r][d = 2x + t]
 
-  for (int k0 = 0; k0 < a.nk; k0 += 16) {
+  for (int k0 = wave * 16; k0 < a.nk; k0 += 64) {
     // ---- S^T[key 4g'+r][query x] over this key tile
     float kf[8];
     {
@@ -84,6 +87,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       const float4 u = p[0], w = p[1];
       kf[0] = u.x; kf[1] = u.y; kf[2] = u.z; kf[3] = u.w;
       kf[4] = w.x; kf[5] = w.y; kf[6] = w.z; kf[7] = w.w;
+    }
+    float2 vv[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int ki = min(k0 + 4 * g + st, a.nk - 1);
+      vv[st] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(ki) * a.ldv + hoff + 2 * x);
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -119,20 +128,38 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     // ---- O += P V : step st uses key 4*kappa + st from lane group kappa, i.e. register st of p
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const int ki = min(k0 + 4 * g + st, a.nk - 1);
-      const float2 vv = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(ki) * a.ldv + hoff + 2 * x);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv.x, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv.y, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].x, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].y, o1, 0, 0, 0);
     }
+  }
+  // ---- merge the four partial softmaxes
+  if (g == 0) {
+    sm[wave][x] = m_run;
+    sl[wave][x] = l_run;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int qi = q0 + 4 * g + r;
-    const float lr = __shfl(l_run, 4 * g + r, 64);
-    if (qi < a.nq) {
-      float2 o = make_float2(o0[r] / lr, o1[r] / lr);
-      *reinterpret_cast<float2*>(a.out + static_cast<int64_t>(qi) * a.ldo + hoff + 2 * x) = o;
+    so[wave][4 * g + r][2 * x] = o0[r];
+    so[wave][4 * g + r][2 * x + 1] = o1[r];
+  }
+  __syncthreads();
+  // thread t of the block finalises (query t>>4, features 2*(t&15), +1): 256 threads = 16 x 16 pairs
+  {
+    const int qq = threadIdx.x >> 4, dd = 2 * (threadIdx.x & 15);
+    const int qi = q0 + qq;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mt = fmaxf(mt, sm[w][qq]);
+    float lt = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = sl[w][qq] > 0.f ? expf(sm[w][qq] - mt) : 0.f;  // a wave without keys has l = 0
+      lt += sl[w][qq] * f;
+      a0 += so[w][qq][dd] * f;
+      a1 += so[w][qq][dd + 1] * f;
     }
+    if (qi < a.nq)
+      *reinterpret_cast<float2*>(a.out + static_cast<int64_t>(qi) * a.ldo + hoff + dd) = make_float2(a0 / lt, a1 / lt);
   }
 }
 
@@ -200,7 +227,7 @@ extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_
   a.ldq = static_cast<int>(ldq); a.ldk = static_cast<int>(ldk); a.ldv = static_cast<int>(ldv);
   a.ldo = static_cast<int>(ldo);
   a.inv_scale = sqrtf(static_cast<float>(head_dim));
-  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div<int64_t>(n_q, 64), heads), dim3(256), 0,
+  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div<int64_t>(n_q, 16), heads), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status("attention_kernel");
 }

@@ -145,25 +145,35 @@ __global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, in
 }
 
 // ------------------------------------------------------------------------------------------ Procrustes
-__device__ double block_sum(double v, double* red) {
-  v = wave_sum(v);
+// Sum N values per thread over the block (fixed order); red must hold N * 16 doubles.
+template <int N>
+__device__ void block_sum_n(double (&v)[N], double* red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
   __syncthreads();
-  if (lane == 0) red[wv] = v;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[k * 16 + wv] = v[k];
   __syncthreads();
-  double t = 0.0;
-  for (int i = 0; i < nw; ++i) t += red[i];
-  return t;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
+    v[k] = t;
+  }
 }
 
 // Largest eigenvector of the symmetric 4x4 `a` (cyclic Jacobi, fp64).  q = (w, x, y, z).
 __device__ void horn_quaternion(double a[4][4], double q[4]) {
   double vmat[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
   for (int sweep = 0; sweep < 24; ++sweep) {
-    double offd = 0.0;
-    for (int p = 0; p < 4; ++p)
+    double offd = 0.0, diag = 0.0;
+    for (int p = 0; p < 4; ++p) {
+      diag += a[p][p] * a[p][p];
       for (int r = p + 1; r < 4; ++r) offd += a[p][r] * a[p][r];
-    if (offd < 1e-300) break;
+    }
+    if (offd <= 1e-34 * (diag + offd) || offd < 1e-300) break;  // converged to fp64 round-off
     for (int p = 0; p < 3; ++p)
       for (int r = p + 1; r < 4; ++r) {
         if (fabs(a[p][r]) < 1e-300) continue;
@@ -207,7 +217,11 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
     if (w < 0.f) w = 0.f;  // weight_thresh = 0
     sw += w;
   }
-  sw = block_sum(sw, red) + 1e-5;
+  {
+    double t[1] = {sw};
+    block_sum_n<1>(t, red);
+    sw = t[0] + 1e-5;
+  }
   double cs[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
   for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
     float w = wts[i];
@@ -218,9 +232,13 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
       cr[d] += wn * ref[3 * i + d];
     }
   }
-  for (int d = 0; d < 3; ++d) {
-    cs[d] = block_sum(cs[d], red);
-    cr[d] = block_sum(cr[d], red);
+  {
+    double t[6] = {cs[0], cs[1], cs[2], cr[0], cr[1], cr[2]};
+    block_sum_n<6>(t, red);
+    for (int d = 0; d < 3; ++d) {
+      cs[d] = t[d];
+      cr[d] = t[3 + d];
+    }
   }
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // H[a][b] = sum w (s_a - cs_a)(r_b - cr_b)
   for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
@@ -235,7 +253,7 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
     for (int a = 0; a < 3; ++a)
       for (int b = 0; b < 3; ++b) H[3 * a + b] += wn * s[a] * r[b];
   }
-  for (int k = 0; k < 9; ++k) H[k] = block_sum(H[k], red);
+  block_sum_n<9>(H, red);
   const double Sxx = H[0], Sxy = H[1], Sxz = H[2], Syx = H[3], Syy = H[4], Syz = H[5], Szx = H[6], Szy = H[7],
                Szz = H[8];
   double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
@@ -267,7 +285,7 @@ __device__ __forceinline__ bool is_inlier(const float* T, const float* src, cons
 // one 64-thread block per chunk: local Procrustes, then inlier count over ALL correspondences
 __global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, const float* src_corr,
                                                         const float* scores, float radius, LgrBuffers w) {
-  __shared__ double red[8];
+  __shared__ double red[9 * 16];
   __shared__ float Tf[12];
   __shared__ int cnt_sh;
   const int chunk = blockIdx.x;
@@ -292,10 +310,10 @@ __global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, c
 }
 
 // single block: pick the hypothesis, refine globally
-__global__ __launch_bounds__(1024) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
+__global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
                                                           const float* scores, float radius, int steps,
                                                           LgrBuffers w, unsigned char* gate, float* out_T) {
-  __shared__ double red[16];
+  __shared__ double red[9 * 16];
   __shared__ float Tf[12];
   const int C = w.meta[0], chunks = w.meta[1];
   double T[12];
@@ -382,7 +400,7 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   hipLaunchKernelGGL(lgr_gather_kernel, dim3(B), dim3(64), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,
                      src_corr, corr_scores);
   hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
-  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(1024), 0, st, ref_corr, src_corr, corr_scores,
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), 0, st, ref_corr, src_corr, corr_scores,
                      acceptance_radius, num_refinement_steps, w, gate, transform);
   RDM_HIP_CHECK(hipMemcpyAsync(counts, w.meta, 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return launch_status("lgr kernels");

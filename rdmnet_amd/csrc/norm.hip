@@ -15,22 +15,41 @@ namespace {
 
 using namespace rdm;
 
-constexpr int kGnRowsPerBlock = 256;
+constexpr int kGnRowsPerBlock = 128;
 
-// partial[blk][0][c] = sum, partial[blk][1][c] = sum of squares over this block's rows
+// partial[blk][0][c] = sum, partial[blk][1][c] = sum of squares over this block's 128 rows.
+// 256 threads cover min(C,256) columns x (256/min(C,256)) row lanes so that every wavefront reads
+// whole contiguous row segments; lanes of one column are combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, int c, int ld,
                                                          double* partial) {
+  __shared__ double red[2][256];
   const int r0 = blockIdx.x * kGnRowsPerBlock;
   const int r1 = min(n, r0 + kGnRowsPerBlock);
-  for (int col = threadIdx.x; col < c; col += blockDim.x) {
+  const int cw = c < 256 ? c : 256;   // columns handled per pass (c is a multiple of 32)
+  const int lanes = 256 / cw;         // row lanes
+  const int col_in = threadIdx.x % cw, rl = threadIdx.x / cw;
+  for (int c0 = 0; c0 < c; c0 += cw) {
+    const int col = c0 + col_in;
     double s = 0.0, ss = 0.0;
-    for (int r = r0; r < r1; ++r) {
-      const double v = x[static_cast<int64_t>(r) * ld + col];
-      s += v;
-      ss += v * v;
+    if (rl < lanes && col < c)
+      for (int r = r0 + rl; r < r1; r += lanes) {
+        const double v = x[static_cast<int64_t>(r) * ld + col];
+        s += v;
+        ss += v * v;
+      }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.x < cw && col < c) {
+      double a = 0.0, b = 0.0;
+      for (int k = 0; k < lanes; ++k) {
+        a += red[0][k * cw + threadIdx.x];
+        b += red[1][k * cw + threadIdx.x];
+      }
+      partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * c + col] = a;
+      partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = b;
     }
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * c + col] = s;
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = ss;
+    __syncthreads();
   }
 }
 

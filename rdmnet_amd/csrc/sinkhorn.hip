@@ -2,7 +2,8 @@
 //
 // Reference: geotransformer/modules/sinkhorn/learnable_sinkhorn.py:13-66.
 // One workgroup per patch correspondence; the (valid rows + dustbin) x (valid cols + dustbin) block
-// of the padded score matrix lives in LDS for all iterations.  Masked rows/columns are compacted
+// of the padded score matrix is staged through LDS once and then lives in REGISTERS for all
+// iterations (each thread owns half a row and half a column).  Masked rows/columns are compacted
 // away: in the reference they hold -1e12, so every exp() involving them underflows to exactly 0 and
 // their own potentials evaluate to exactly 0 -- dropping them changes nothing but the summation
 // order.  Masked entries of the output are written as fl(-1e12), the value the reference's
@@ -19,21 +20,18 @@ using namespace rdm;
 
 constexpr int kMaxSide = 128;
 
-__device__ __forceinline__ float group_max(float v, int gsize) {
-  for (int o = gsize >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float group_sum(float v, int gsize) {
-  for (int o = gsize >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+constexpr int kHalf = (kMaxSide + 2) / 2;  // 65: each thread owns half a row and half a column
 
+// 256 threads.  Thread t owns row (t>>1), columns [65*(t&1), 65*(t&1)+65) of the compacted score
+// block in REGISTERS, and likewise half of column (t>>1): the 100 iterations touch LDS only for the
+// broadcast potentials u, v.  A row's two halves are combined with one lane exchange.
 __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int m, int n,
                                                        const unsigned char* row_mask,
                                                        const unsigned char* col_mask, const float* alpha_p,
                                                        int iters, float* out) {
   extern __shared__ float lds[];
-  __shared__ int rows[kMaxSide + 1], cols[kMaxSide + 1];
+  __shared__ int rows[kMaxSide + 2], cols[kMaxSide + 2];
+  __shared__ float u[kMaxSide + 2], v[kMaxSide + 2];
   __shared__ int s_nr, s_nc;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* S = scores + static_cast<int64_t>(b) * m * n;
@@ -56,55 +54,54 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   }
   __syncthreads();
   const int nr = s_nr, nc = s_nc, R = nr + 1, C = nc + 1;
-  const int ldz = C | 1;  // odd stride: column walks are bank-conflict free
+  const int ldz = C | 1;
   float* Z = lds;
-  float* u = Z + R * ldz;
-  float* v = u + R;
-  float* log_mu = v + C;
-  float* log_nu = log_mu + R;
   const float alpha = *alpha_p;
   for (int t = tid; t < R * C; t += 256) {
     const int r = t / C, c = t % C;
     Z[r * ldz + c] = (r < nr && c < nc) ? S[static_cast<int64_t>(rows[r]) * n + cols[c]] : alpha;
   }
   const float norm = -logf(static_cast<float>(nr) + static_cast<float>(nc));
-  for (int r = tid; r < R; r += 256) {
-    log_mu[r] = r < nr ? norm : logf(static_cast<float>(nc)) + norm;
+  for (int r = tid; r < kMaxSide + 2; r += 256) {
     u[r] = 0.f;
-  }
-  for (int c = tid; c < C; c += 256) {
-    log_nu[c] = c < nc ? norm : logf(static_cast<float>(nr)) + norm;
-    v[c] = 0.f;
+    v[r] = 0.f;
   }
   __syncthreads();
 
-  const int gc = C > 32 ? 64 : (C > 16 ? 32 : 16);  // lanes cooperating on one row
-  const int gr = R > 32 ? 64 : (R > 16 ? 32 : 16);  // lanes cooperating on one column
+  const int own = tid >> 1, half = tid & 1, base = half * kHalf;
+  const float log_mu = own < nr ? norm : logf(static_cast<float>(nc)) + norm;
+  const float log_nu = own < nc ? norm : logf(static_cast<float>(nr)) + norm;
+  float zr[kHalf], zc[kHalf];  // -inf marks "outside the block": contributes exp(-inf) = 0
+#pragma unroll
+  for (int i = 0; i < kHalf; ++i) {
+    const int c = base + i;
+    zr[i] = (own < R && c < C) ? Z[own * ldz + c] : -INFINITY;
+    zc[i] = (own < C && c < R) ? Z[c * ldz + own] : -INFINITY;
+  }
+
   for (int it = 0; it < iters; ++it) {
-    {
-      const int grp = tid / gc, l = tid % gc, ngrp = 256 / gc;
-      for (int r = grp; r < R; r += ngrp) {
-        float mx = -INFINITY;
-        for (int c = l; c < C; c += gc) mx = fmaxf(mx, Z[r * ldz + c] + v[c]);
-        mx = group_max(mx, gc);
-        float s = 0.f;
-        for (int c = l; c < C; c += gc) s += expf(Z[r * ldz + c] + v[c] - mx);
-        s = group_sum(s, gc);
-        if (l == 0) u[r] = log_mu[r] - (mx + logf(s));
-      }
+    {  // u = log_mu - logsumexp_c(Z + v)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < kHalf; ++i) mx = fmaxf(mx, zr[i] + v[base + i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < kHalf; ++i) sum += expf(zr[i] + v[base + i] - mx);
+      sum += __shfl_xor(sum, 1, 64);
+      if (half == 0 && own < R) u[own] = log_mu - (mx + logf(sum));
     }
     __syncthreads();
-    {
-      const int grp = tid / gr, l = tid % gr, ngrp = 256 / gr;
-      for (int c = grp; c < C; c += ngrp) {
-        float mx = -INFINITY;
-        for (int r = l; r < R; r += gr) mx = fmaxf(mx, Z[r * ldz + c] + u[r]);
-        mx = group_max(mx, gr);
-        float s = 0.f;
-        for (int r = l; r < R; r += gr) s += expf(Z[r * ldz + c] + u[r] - mx);
-        s = group_sum(s, gr);
-        if (l == 0) v[c] = log_nu[c] - (mx + logf(s));
-      }
+    {  // v = log_nu - logsumexp_r(Z + u)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < kHalf; ++i) mx = fmaxf(mx, zc[i] + u[base + i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < kHalf; ++i) sum += expf(zc[i] + u[base + i] - mx);
+      sum += __shfl_xor(sum, 1, 64);
+      if (half == 0 && own < C) v[own] = log_nu - (mx + logf(sum));
     }
     __syncthreads();
   }
@@ -114,9 +111,14 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   const int total = (m + 1) * (n + 1);
   for (int t = tid; t < total; t += 256) O[t] = masked;
   __syncthreads();
-  for (int t = tid; t < R * C; t += 256) {
-    const int r = t / C, c = t % C;
-    O[static_cast<int64_t>(rows[r]) * (n + 1) + cols[c]] = ((Z[r * ldz + c] + u[r]) + v[c]) - norm;
+  if (own < R) {
+    const float ur = u[own];
+    const int64_t orow = static_cast<int64_t>(rows[own]) * (n + 1);
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) {
+      const int c = base + i;
+      if (c < C) O[orow + cols[c]] = ((zr[i] + ur) + v[c]) - norm;
+    }
   }
 }
 
@@ -129,7 +131,7 @@ extern "C" int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64
   RDM_REQUIRE(batch >= 0 && m > 0 && n > 0 && m <= kMaxSide && n <= kMaxSide && iters >= 0,
               "rdm_sinkhorn: bad sizes (m=%lld n=%lld, max %d)", (long long)m, (long long)n, kMaxSide);
   if (batch == 0) return RDM_OK;
-  const size_t lds = sizeof(float) * (static_cast<size_t>(m + 1) * ((n + 1) | 1) + 2 * (m + 1) + 2 * (n + 1) + 8);
+  const size_t lds = sizeof(float) * (static_cast<size_t>(m + 1) * ((n + 1) | 1) + 8);
   static bool attr_set = false;
   if (!attr_set) {  // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS
     RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel),
