@@ -15,71 +15,76 @@ namespace {
 
 using namespace rdm;
 
-constexpr int kGnRowsPerBlock = 128;
+constexpr int kGnRowsPerBlock = 64;
 
-// partial[blk][0][c] = sum, partial[blk][1][c] = sum of squares over this block's 128 rows.
-// 256 threads cover min(C,256) columns x (256/min(C,256)) row lanes so that every wavefront reads
-// whole contiguous row segments; lanes of one column are combined through LDS in fixed order.
+// partial[blk][0][c] = sum, partial[blk][1][c] = sum of squares over this block's 64 rows.
+// grid = (row blocks, column chunks of 256).  256 threads cover cw = min(C,256) columns x (256/cw)
+// row lanes so that every wavefront reads whole contiguous row segments; the row lanes of a column
+// are combined through LDS in fixed order (fp64 throughout).
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, int c, int ld,
                                                          double* partial) {
   __shared__ double red[2][256];
   const int r0 = blockIdx.x * kGnRowsPerBlock;
   const int r1 = min(n, r0 + kGnRowsPerBlock);
-  const int cw = c < 256 ? c : 256;   // columns handled per pass (c is a multiple of 32)
-  const int lanes = 256 / cw;         // row lanes
+  const int cw = c < 256 ? c : 256;
+  const int lanes = 256 / cw;
   const int col_in = threadIdx.x % cw, rl = threadIdx.x / cw;
-  for (int c0 = 0; c0 < c; c0 += cw) {
-    const int col = c0 + col_in;
-    double s = 0.0, ss = 0.0;
-    if (rl < lanes && col < c)
-      for (int r = r0 + rl; r < r1; r += lanes) {
-        const double v = x[static_cast<int64_t>(r) * ld + col];
-        s += v;
-        ss += v * v;
-      }
-    red[0][threadIdx.x] = s;
-    red[1][threadIdx.x] = ss;
-    __syncthreads();
-    if (threadIdx.x < cw && col < c) {
-      double a = 0.0, b = 0.0;
-      for (int k = 0; k < lanes; ++k) {
-        a += red[0][k * cw + threadIdx.x];
-        b += red[1][k * cw + threadIdx.x];
-      }
-      partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * c + col] = a;
-      partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = b;
+  const int col = blockIdx.y * 256 + col_in;
+  double s = 0.0, ss = 0.0;
+  if (rl < lanes && col < c)
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      const double v = x[static_cast<int64_t>(r) * ld + col];
+      s += v;
+      ss += v * v;
     }
-    __syncthreads();
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < cw && col < c) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < lanes; ++k) {
+      a += red[0][k * cw + threadIdx.x];
+      b += red[1][k * cw + threadIdx.x];
+    }
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * c + col] = a;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = b;
   }
 }
 
-// one block: reduce partials -> scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+// One block per 64 columns (whole groups: C/groups divides 64): 4 lanes per column add the row-block
+// partials in a fixed order, then scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partial, int nblk, int n,
                                                            int c, int groups, const float* gamma,
                                                            const float* beta, float eps, float* scale,
                                                            float* shift) {
-  extern __shared__ double sh[];  // [2*c]
-  for (int col = threadIdx.x; col < c; col += blockDim.x) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+  __shared__ double sh[2][4][64];
+  const int ci = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + ci;
+  double s = 0.0, ss = 0.0;
+  if (col < c)
+    for (int b = lane; b < nblk; b += 4) {
       s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + col];
       ss += partial[(static_cast<int64_t>(b) * 2 + 1) * c + col];
     }
-    sh[col] = s;
-    sh[c + col] = ss;
+  sh[0][lane][ci] = s;
+  sh[1][lane][ci] = ss;
+  __syncthreads();
+  if (lane == 0) {
+    sh[0][0][ci] = ((sh[0][0][ci] + sh[0][1][ci]) + sh[0][2][ci]) + sh[0][3][ci];
+    sh[1][0][ci] = ((sh[1][0][ci] + sh[1][1][ci]) + sh[1][2][ci]) + sh[1][3][ci];
   }
   __syncthreads();
-  const int cpg = c / groups;
-  for (int col = threadIdx.x; col < c; col += blockDim.x) {
-    const int g0 = (col / cpg) * cpg;
-    double s = 0.0, ss = 0.0;
+  if (lane == 0 && col < c) {
+    const int cpg = c / groups;
+    const int g0 = (ci / cpg) * cpg;
+    double gs = 0.0, gss = 0.0;
     for (int k = 0; k < cpg; ++k) {
-      s += sh[g0 + k];
-      ss += sh[c + g0 + k];
+      gs += sh[0][0][g0 + k];
+      gss += sh[1][0][g0 + k];
     }
     const double cnt = static_cast<double>(n) * cpg;
-    const double mean = s / cnt;
-    double var = ss / cnt - mean * mean;
+    const double mean = gs / cnt;
+    double var = gss / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + static_cast<double>(eps));
     const double gsc = rstd * static_cast<double>(gamma[col]);
@@ -228,7 +233,7 @@ extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
                               size_t ws_bytes, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(x && gamma && beta && y, "rdm_group_norm: null pointer");
-  RDM_REQUIRE(n >= 0 && c > 0 && groups > 0 && c % groups == 0 && c <= 4096,
+  RDM_REQUIRE(n >= 0 && c > 0 && groups > 0 && c % groups == 0 && c <= 4096 && 64 % (c / groups) == 0,
               "rdm_group_norm: bad sizes (n=%lld c=%lld groups=%d)", (long long)n, (long long)c, groups);
   if (n == 0) return RDM_OK;
   const int nblk = static_cast<int>(ceil_div<int64_t>(n, kGnRowsPerBlock));
@@ -240,9 +245,9 @@ extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
     return RDM_ERR_WORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, st, x, static_cast<int>(n),
-                     static_cast<int>(c), static_cast<int>(ldx), partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 2 * c * sizeof(double), st, partial, nblk,
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x,
+                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(256), 0, st, partial, nblk,
                      static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
                      static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
