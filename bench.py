@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=1, help='pairs in flight per GPU (host threads, one HIP stream each)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -145,21 +146,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    net.profile = []
+    import threading
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
+
+    def run_range(indices, stream, rec, lat_out, prof_out):
+        ctx = torch.cuda.stream(stream) if stream is not None else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            net.set_thread_profile(prof_out)
+            for slot, i in indices:
+                ts = time.perf_counter()
+                out = step(i)
+                T = out['estimated_transform']  # forward's final sync already happened (correspondence count)
+                if rec is not None:
+                    rec[slot, 0] = (rank + i * world) % len(dev_pairs)
+                    rec[slot, 1] = out['corr_scores'].shape[0]
+                    rec[slot, 3] = T[0, 3]
+                    lat_out.append((time.perf_counter() - ts) * 1e3)
+        finally:
+            net.set_thread_profile(None)
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    def run_all(first, count, rec, lat_out, prof_lists):
+        jobs = [[] for _ in streams]
+        for slot in range(count):
+            jobs[slot % len(streams)].append((slot, first + slot))
+        if len(streams) == 1:
+            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0])
+            return
+        threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k]))
+                   for k in range(len(streams))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+
+    run_all(0, args.warmup, None, [], [None] * len(streams))
     lat = []
+    prof_lists = [[] for _ in streams]
     records = torch.zeros((args.steps, 4), dtype=torch.float32, device=dev)  # [pair_id, n_corr, t_ms, T[0,3]]
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        out = step(args.warmup + i)
-        T = out['estimated_transform']  # forward's final sync already happened (correspondence count)
-        records[i, 0] = (rank + (args.warmup + i) * world) % len(dev_pairs)
-        records[i, 1] = out['corr_scores'].shape[0]
-        records[i, 3] = T[0, 3]
-        lat.append((time.perf_counter() - ts) * 1e3)
+    run_all(args.warmup, args.steps, records, lat, prof_lists)
     if dist is not None:  # the path's only collective: one gather of result records
         gathered = [torch.empty_like(records) for _ in range(world)]
         dist.all_gather(gathered, records)
@@ -175,7 +205,7 @@ def main():
         lat = torch.cat(all_lat).cpu().tolist()
 
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
-    prof, net.profile = net.profile, None
+    prof = [r for pl in prof_lists for r in pl]
     t_total = t_gather = b_total = b_gather = 0.0
     per_layer = {}
     for rec in prof:
@@ -207,7 +237,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'points_per_pair': n_points,
-                       'pairs_per_gpu': args.steps, 'parallelism': f'pairs sharded over {world} GPU(s)'},
+                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams,
+                       'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'roofline': roofline,
         }

@@ -5,6 +5,7 @@ Same operator API as the reference (experiments/model_infer.py:26-107, 109-354, 
 keys, `model(data_dict) -> output_dict` with the reference's keys.  Every tensor op runs in
 librdmnet_hip.so through rdmnet_amd.ops; torch provides device memory and the stream.
 """
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -31,7 +32,7 @@ class RDMNet:
         self._state = None   # name -> numpy float32
         self._w = None       # prepared device tensors
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
-        self.profile = None  # list -> per-KPConv-layer HIP-event records (bench.py)
+        self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py)
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def cuda(self, device=None):
@@ -65,6 +66,10 @@ class RDMNet:
         self._state = new
         self._w = None
         return self
+
+    def set_thread_profile(self, records):
+        """Per-thread list that receives one HIP-event record per KPConv layer (None disables)."""
+        self._tls.profile = records
 
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self):
@@ -118,7 +123,7 @@ class RDMNet:
 
     def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None, pooled_channels=0):
         b, cin, cout = self._w[name + '.weights']
-        prof = self.profile
+        prof = getattr(self._tls, 'profile', None)
         if prof is not None:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
