@@ -90,6 +90,12 @@ def cpu_baseline(cache_dir, n_pairs, timeout_s=150):
                 'sample': f'did not finish one pair within {timeout_s} s'}
 
 
+def pose_error(T_est, T_gt):
+    R = T_gt[:3, :3].T @ T_est[:3, :3].astype(np.float64)
+    ang = 2.0 * np.arcsin(min(1.0, np.linalg.norm(R - np.eye(3)) / (2.0 * np.sqrt(2.0))))
+    return float(np.degrees(ang)), float(np.linalg.norm(T_gt[:3, 3] - T_est[:3, 3]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -113,7 +119,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from rdmnet_amd import collate, config, model, weights
+    from rdmnet_amd import collate, config, model, sharding, weights
     cfg = config.make_cfg()
     state = weights.synthetic_state_dict(cfg, seed=0)
     net = model.create_model(cfg).cuda(local_rank)
@@ -160,9 +166,9 @@ def main():
                 out = step(i)
                 T = out['estimated_transform']  # forward's final sync already happened (correspondence count)
                 if rec is not None:
-                    rec[slot, 0] = (rank + i * world) % len(dev_pairs)
-                    rec[slot, 1] = out['corr_scores'].shape[0]
-                    rec[slot, 3] = T[0, 3]
+                    pid = (rank + i * world) % len(dev_pairs)
+                    rre, rte = pose_error(T.cpu().numpy(), pairs[pid][2])
+                    rec[slot] = torch.tensor([pid, rre, rte, out['corr_scores'].shape[0]])
                     lat_out.append((time.perf_counter() - ts) * 1e3)
         finally:
             net.set_thread_profile(None)
@@ -186,13 +192,12 @@ def main():
     run_all(0, args.warmup, None, [], [None] * len(streams))
     lat = []
     prof_lists = [[] for _ in streams]
-    records = torch.zeros((args.steps, 4), dtype=torch.float32, device=dev)  # [pair_id, n_corr, t_ms, T[0,3]]
+    records = torch.zeros((args.steps, 4), dtype=torch.float32)  # [pair_id, rre_deg, rte_m, n_corr]
     fence()
     t0 = time.perf_counter()
     run_all(args.warmup, args.steps, records, lat, prof_lists)
-    if dist is not None:  # the path's only collective: one gather of result records
-        gathered = [torch.empty_like(records) for _ in range(world)]
-        dist.all_gather(gathered, records)
+    # the path's only collective: one gather of per-pair result records (RCCL)
+    gathered = sharding.gather_records(records.to(dev), world, dist)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -240,6 +245,7 @@ def main():
                        'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams,
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
+            'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,37 @@
+"""Multi-GPU layout of the path: pairs are independent, so they are sharded rank-strided with no
+data-path collective; one all_gather of fixed-size result records ends the run (SURVEY.md §8e;
+replaces the reference's DistributedSampler + per-iteration scalar all_reduce,
+geotransformer/utils/torch.py:16-21,58-60, engine/base_tester.py:123-128)."""
+import torch
+
+
+def pairs_for_rank(n_pairs, rank, world):
+    """Pair ids of `rank`: r, r+W, ... (no padding by repetition, ragged tail allowed)."""
+    return list(range(rank, n_pairs, world))
+
+
+def gather_records(records, world, dist=None):
+    """records: float32 [k, c] tensor of this rank (k may differ per rank).  Returns the list of all
+    ranks' records on every rank (one all_gather of a padded block + the per-rank counts)."""
+    if world == 1 or dist is None:
+        return [records]
+    k = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+    counts = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(counts, k)
+    kmax = int(max(int(c) for c in counts))
+    block = torch.zeros((kmax, records.shape[1]), dtype=records.dtype, device=records.device)
+    block[:records.shape[0]] = records
+    blocks = [torch.zeros_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    return [b[:int(c)] for b, c in zip(blocks, counts)]
+
+
+def summarize(all_records, rre_thresh=5.0, rte_thresh=2.0):
+    """RR / mean RRE / mean RTE over successful pairs (experiments/eval.py:223-237 semantics).
+    Record columns: [pair_id, rre_deg, rte_m, n_corr]."""
+    rec = torch.cat(all_records).cpu()
+    ok = (rec[:, 1] < rre_thresh) & (rec[:, 2] < rte_thresh)
+    n_ok = int(ok.sum())
+    return {'pairs': rec.shape[0], 'recall': n_ok / max(rec.shape[0], 1),
+            'rre_deg': float(rec[ok, 1].mean()) if n_ok else float('nan'),
+            'rte_m': float(rec[ok, 2].mean()) if n_ok else float('nan')}
