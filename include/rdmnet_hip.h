@@ -194,6 +194,72 @@ int rdm_lgr(const float* log_scores, const float* ref_knn_points, const float* s
             float* src_corr, float* corr_scores, float* transform, int32_t* counts, void* ws, size_t ws_bytes,
             void* stream);
 
+/* ---- native orchestration: one call per scan pair ----------------------------------------------
+ * rdm_engine_run = the collate of geotransformer/utils/data.py:13-77 + RDMNet.forward of
+ * experiments/model_infer.py:109-354 as a fixed sequence of the kernels above on one stream, with
+ * activations in an engine-owned device arena (the ~700 launches of a pair cost ~2 us each from
+ * native code instead of ~15 us each from Python).  Parameters are handed over by their reference
+ * state-dict names (weights/rdmnet.pth.tar -> state['model'], engine/base_tester.py:97-107).
+ * An engine is bound to the device that is current when it is created and must be used by one host
+ * thread at a time; create one engine per in-flight pair.                                        */
+typedef struct rdm_engine rdm_engine;
+
+typedef struct rdm_engine_config {
+  int num_stages;             /* 5 */
+  int kernel_size;            /* 15 */
+  int group_norm;             /* 32 */
+  float init_voxel_size;      /* 0.3 */
+  float init_radius;          /* 4.25 * 0.3 */
+  float init_sigma;           /* 2.0 * 0.3 */
+  int neighbor_limits[5];
+  int out_dim;                /* 256 */
+  int num_heads;              /* 4 */
+  int num_layers;             /* 4 (self,cross) pairs, transformer #1 */
+  int num_layers2;            /* 4, transformer #2 */
+  int vote_mlp_layers;        /* 2 */
+  float vote_limit[3];        /* 3.0 m */
+  float nms_radius;           /* 2.4 m */
+  int points_in_patch;        /* 128 */
+  int num_correspondences;    /* 256 */
+  int dual_normalization;     /* 1 */
+  int sinkhorn_iterations;    /* 100 */
+  float acceptance_radius;    /* 0.6 m */
+  int correspondence_threshold; /* 3 */
+  int num_refinement_steps;   /* 5 */
+  size_t arena_bytes;         /* 0 = default (3 GiB) */
+} rdm_engine_config;
+
+typedef struct rdm_engine_result {
+  float transform[16];        /* estimated_transform, row-major 4x4, src -> ref (host copy) */
+  int32_t n_correspondences, n_hypotheses, best_hypothesis;
+  int64_t n_ref_nodes, n_src_nodes, n_node_correspondences;
+  int64_t level_sizes[5];
+  const float* ref_corr_points;  /* device, [n_correspondences, 3]; valid until the next run */
+  const float* src_corr_points;
+  const float* corr_scores;
+  const float* transform_dev;
+  size_t arena_used;
+} rdm_engine_result;
+
+typedef struct rdm_tensor_view {
+  void* data;                 /* device pointer into the engine arena (valid until the next run) */
+  int64_t rows, cols, ld;     /* ld in elements */
+  int dtype;                  /* 0 = f32, 1 = i64, 2 = u8 */
+} rdm_tensor_view;
+
+int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out);
+void rdm_engine_destroy(rdm_engine* e);
+int rdm_engine_set_param(rdm_engine* e, const char* name, const float* data_host, const int64_t* shape_host, int ndim);
+int rdm_engine_finalize(rdm_engine* e);
+/* ref/src points: device f32 [n,3].  Synchronises `stream` (4 small read-backs of data-dependent sizes). */
+int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
+                   rdm_engine_result* result_host, void* stream);
+/* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
+int rdm_engine_keep_taps(rdm_engine* e, int enable);
+int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor_view* out);
+/* Plain device-to-device copy on `stream` (lets a host without a HIP binding read arena tensors). */
+int rdm_copy_device(void* dst, const void* src, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,816 @@
+// Native orchestration of the whole path: one call per scan pair.
+//
+// rdm_engine_run = collate (geotransformer/utils/data.py:13-77) + RDMNet.forward
+// (experiments/model_infer.py:109-354) expressed as a sequence of this library's own C-ABI kernels
+// on one HIP stream, with activations bump-allocated from an engine-owned device arena.  It exists
+// because the path is ~700 short launches per pair: issued from Python they cost ~15 us each, issued
+// from here ~2 us.  The op sequence is identical to rdmnet_amd/model.py (the per-op mirror used by
+// the stage tests), so both produce bit-identical results.
+//
+// Host synchronisations per pair (data-dependent sizes): subsampled level sizes, NMS survivor
+// counts, number of patch correspondences, number of point correspondences.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+
+namespace {
+
+using namespace rdm;
+
+struct Mat {  // row-major view
+  float* p = nullptr;
+  int64_t rows = 0, cols = 0, ld = 0;
+  Mat cols_from(int64_t c0, int64_t n) const { return Mat{p + c0, rows, n, ld}; }
+  Mat rows_from(int64_t r0, int64_t n) const { return Mat{p + r0 * ld, n, cols, ld}; }
+};
+
+struct HostParam {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+struct Linear {  // B operand [K_pad, N_pad] + bias
+  float* b = nullptr;
+  float* bias = nullptr;
+  int64_t in = 0, out = 0, kpad = 0, ldb = 0;
+};
+
+inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
+
+}  // namespace
+
+struct rdm_engine {
+  rdm_engine_config cfg;
+  std::map<std::string, HostParam> host;
+  std::map<std::string, Linear> lin;
+  std::map<std::string, float*> vec;
+  std::vector<void*> owned;   // device allocations of parameters
+  char* arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
+  void* pinned = nullptr;     // small host staging buffer for the size read-backs
+  bool finalized = false;
+  std::map<std::string, rdm_tensor_view> taps;
+  bool keep_taps = false;
+
+  template <typename T>
+  T* alloc(size_t count) {
+    size_t bytes = align_up(count * sizeof(T) + 16);
+    if (arena_off + bytes > arena_cap) return nullptr;
+    T* r = reinterpret_cast<T*>(arena + arena_off);
+    arena_off += bytes;
+    return r;
+  }
+  Mat mat(int64_t rows, int64_t cols) {
+    Mat m;
+    m.rows = rows; m.cols = cols; m.ld = pad4(cols);
+    m.p = alloc<float>(static_cast<size_t>(rows > 0 ? rows : 1) * m.ld);
+    return m;
+  }
+};
+
+namespace {
+
+#define ENG_CHECK(call)            \
+  do {                             \
+    int _rc = (call);              \
+    if (_rc != 0) return _rc;      \
+  } while (0)
+#define ENG_ALLOC(ptr)                                             \
+  do {                                                             \
+    if ((ptr) == nullptr) {                                        \
+      set_error("rdm_engine: activation arena exhausted (%zu B)", e->arena_cap); \
+      return RDM_ERR_WORKSPACE;                                    \
+    }                                                              \
+  } while (0)
+
+struct Run {  // per-call context
+  rdm_engine* e;
+  hipStream_t st;
+  void* ws;
+  size_t ws_bytes;
+  int groups;
+};
+
+void tap(Run& r, const char* name, const void* p, int64_t rows, int64_t cols, int64_t ld, int dtype) {
+  if (!r.e->keep_taps) return;
+  rdm_tensor_view v;
+  v.data = const_cast<void*>(p); v.rows = rows; v.cols = cols; v.ld = ld; v.dtype = dtype;
+  r.e->taps[name] = v;
+}
+void tap(Run& r, const char* name, const Mat& m) { tap(r, name, m.p, m.rows, m.cols, m.ld, 0); }
+
+int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, bool alloc_out = true) {
+  rdm_engine* e = r.e;
+  auto it = e->lin.find(name);
+  if (it == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s", name.c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear& L = it->second;
+  if (alloc_out) {
+    y = e->mat(x.rows, L.out);
+    ENG_ALLOC(y.p);
+  }
+  return rdm_gemm(x.p, x.ld, 0, L.b, L.ldb, 0, 0, y.p, y.ld, 0, x.rows, L.out, L.kpad, 1, L.bias, nullptr, act, r.ws,
+                  r.ws_bytes, r.st);
+}
+
+float* vecp(Run& r, const std::string& name) {
+  auto it = r.e->vec.find(name);
+  return it == r.e->vec.end() ? nullptr : it->second;
+}
+
+int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
+  rdm_engine* e = r.e;
+  y = e->mat(x.rows, x.cols);
+  ENG_ALLOC(y.p);
+  float* g = vecp(r, name + ".norm.weight");
+  float* b = vecp(r, name + ".norm.bias");
+  if (!g || !b) {
+    set_error("rdm_engine: missing parameter %s.norm.*", name.c_str());
+    return RDM_ERR_ARG;
+  }
+  return rdm_group_norm(x.p, x.rows, x.cols, x.ld, r.groups, g, b, 1e-5f, res ? res->p : nullptr, res ? res->ld : 0, act,
+                        y.p, y.ld, positive, r.ws, r.ws_bytes, r.st);
+}
+
+int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
+  Mat t;
+  ENG_CHECK(linear(r, name + ".mlp", x, t));
+  return group_norm(r, name + ".norm", t, y, act, res, positive);
+}
+
+int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, int act, Mat& y, bool alloc_out = true) {
+  rdm_engine* e = r.e;
+  if (alloc_out) {
+    y = e->mat(x.rows, x.cols);
+    ENG_ALLOC(y.p);
+  }
+  return rdm_layer_norm(x.p, x.rows, x.cols, x.ld, res ? res->p : nullptr, res ? res->ld : 0, vecp(r, name + ".weight"),
+                        vecp(r, name + ".bias"), 1e-5f, act, y.p, y.ld, r.st);
+}
+
+struct Level {
+  float* pts = nullptr;
+  int64_t n = 0;
+  int64_t* lengths = nullptr;  // device [2]
+  int64_t n_ref = 0;
+};
+struct Table {
+  int64_t* idx = nullptr;
+  int64_t rows = 0, width = 0;
+  int32_t* flags = nullptr;  // device [2]: max_count, status
+};
+
+int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
+           const Table& t, float sigma, Mat& y) {
+  rdm_engine* e = r.e;
+  auto it = e->lin.find(name + ".weights");
+  if (it == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s.weights", name.c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear& W = it->second;
+  const int64_t cin = x.cols, kdim = cin == 1 ? 16 : 15 * cin;
+  Mat wf = e->mat(q.n, kdim);
+  ENG_ALLOC(wf.p);
+  float* nn = e->alloc<float>(q.n > 0 ? q.n : 1);
+  ENG_ALLOC(nn);
+  ENG_CHECK(rdm_kpconv_gather(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
+                              vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, r.st));
+  y = e->mat(q.n, W.out);
+  ENG_ALLOC(y.p);
+  return rdm_gemm(wf.p, wf.ld, 0, W.b, W.ldb, 0, 0, y.p, y.ld, 0, q.n, W.out, W.kpad, 1, W.bias, nn, 0, r.ws, r.ws_bytes,
+                  r.st);
+}
+
+int attention_layer(Run& r, const std::string& p, const Mat& x, const Mat& mem, const Mat* emb, Mat& out) {
+  rdm_engine* e = r.e;
+  const int64_t d = x.cols;
+  const int heads = e->cfg.num_heads;
+  Mat q, k, v;
+  if (mem.p == x.p) {
+    Mat qkv;
+    ENG_CHECK(linear(r, p + ".qkv", x, qkv));
+    q = qkv.cols_from(0, d); k = qkv.cols_from(d, d); v = qkv.cols_from(2 * d, d);
+  } else {
+    ENG_CHECK(linear(r, p + ".q", x, q));
+    Mat kv;
+    ENG_CHECK(linear(r, p + ".kv", mem, kv));
+    k = kv.cols_from(0, d); v = kv.cols_from(d, d);
+  }
+  if (emb) ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb->p, emb->ld, q.rows, d, r.st));
+  Mat hid = e->mat(x.rows, d);
+  ENG_ALLOC(hid.p);
+  ENG_CHECK(rdm_attention(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, x.rows, mem.rows, heads, static_cast<int>(d / heads), r.st));
+  Mat h2, y, z1, z2;
+  ENG_CHECK(linear(r, p + ".attention.linear", hid, h2));
+  ENG_CHECK(layer_norm(r, p + ".attention.norm", h2, &x, 0, y));
+  ENG_CHECK(linear(r, p + ".output.expand", y, z1, 1));
+  ENG_CHECK(linear(r, p + ".output.squeeze", z1, z2));
+  return layer_norm(r, p + ".output.norm", z2, &y, 0, out);
+}
+
+int thdroformer(Run& r, const std::string& name, const Mat& ref_p4, const Mat& src_p4, const Mat& ref_x, const Mat& src_x,
+                int num_layers, Mat out_ref, Mat out_src) {
+  Mat e0, e1, f0, f1;
+  ENG_CHECK(linear(r, name + ".embedding.proj", ref_p4, e0));
+  ENG_CHECK(linear(r, name + ".embedding.proj", src_p4, e1));
+  ENG_CHECK(linear(r, name + ".in_proj", ref_x, f0));
+  ENG_CHECK(linear(r, name + ".in_proj", src_x, f1));
+  for (int i = 0; i < 2 * num_layers; ++i) {
+    const std::string p = name + ".transformer.layers." + std::to_string(i);
+    Mat n0, n1;
+    if (i % 2 == 0) {
+      ENG_CHECK(attention_layer(r, p, f0, f0, &e0, n0));
+      ENG_CHECK(attention_layer(r, p, f1, f1, &e1, n1));
+    } else {
+      ENG_CHECK(attention_layer(r, p, f0, f1, nullptr, n0));
+      ENG_CHECK(attention_layer(r, p, f1, n0, nullptr, n1));  // sequential: sees the updated ref features
+    }
+    f0 = n0;
+    f1 = n1;
+  }
+  ENG_CHECK(linear(r, name + ".out_proj", f0, out_ref, 0, false));
+  return linear(r, name + ".out_proj", f1, out_src, 0, false);
+}
+
+// [n,3] -> [n,4] zero padded
+__global__ void pad_points_kernel(const float* p, int64_t n, float* out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  out[4 * i] = p[3 * i];
+  out[4 * i + 1] = p[3 * i + 1];
+  out[4 * i + 2] = p[3 * i + 2];
+  out[4 * i + 3] = 0.f;
+}
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void concat_points_kernel(const float* a, int64_t na, const float* b, int64_t nb, float* out, int64_t* lengths) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i == 0) {
+    lengths[0] = na;
+    lengths[1] = nb;
+  }
+  if (i < 3 * na) out[i] = a[i];
+  else if (i < 3 * (na + nb)) out[i] = b[i - 3 * na];
+}
+__global__ void widen_index_kernel(const int32_t* in, int64_t n, int64_t* out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void pack2_kernel(const float* a, const float* b, int64_t n, float* out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) {
+    out[2 * i] = a[i];
+    out[2 * i + 1] = b[i];
+  }
+}
+
+template <typename K, typename... A>
+int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
+  if (n <= 0) return RDM_OK;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(n, 256))), dim3(256), 0, st, args...);
+  return launch_status(what);
+}
+
+int d2h(Run& r, const void* dev, size_t bytes, void* host_dst) {
+  RDM_HIP_CHECK(hipMemcpyAsync(r.e->pinned, dev, bytes, hipMemcpyDeviceToHost, r.st));
+  RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+  std::memcpy(host_dst, r.e->pinned, bytes);
+  return RDM_OK;
+}
+
+}  // namespace
+
+extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out) {
+  RDM_REQUIRE(cfg && out, "rdm_engine_create: null pointer");
+  RDM_REQUIRE(cfg->num_stages == 5 && cfg->kernel_size == 15, "rdm_engine_create: only 5 stages / 15 kernel points");
+  rdm_engine* e = new rdm_engine();
+  e->cfg = *cfg;
+  e->arena_cap = cfg->arena_bytes ? cfg->arena_bytes : (size_t(3) << 30);
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
+  if (err != hipSuccess) {
+    set_error("rdm_engine_create: hipMalloc(%zu) failed: %s", e->arena_cap, hipGetErrorString(err));
+    delete e;
+    return RDM_ERR_HIP;
+  }
+  err = hipHostMalloc(&e->pinned, 4096, hipHostMallocDefault);
+  if (err != hipSuccess) {
+    set_error("rdm_engine_create: hipHostMalloc failed: %s", hipGetErrorString(err));
+    hipFree(e->arena);
+    delete e;
+    return RDM_ERR_HIP;
+  }
+  *out = e;
+  return RDM_OK;
+}
+
+extern "C" void rdm_engine_destroy(rdm_engine* e) {
+  if (!e) return;
+  for (void* p : e->owned) hipFree(p);
+  if (e->arena) hipFree(e->arena);
+  if (e->pinned) hipHostFree(e->pinned);
+  delete e;
+}
+
+extern "C" int rdm_engine_set_param(rdm_engine* e, const char* name, const float* data_host, const int64_t* shape_host,
+                                    int ndim) {
+  RDM_REQUIRE(e && name && data_host && ndim >= 0 && ndim <= 4, "rdm_engine_set_param: bad arguments");
+  HostParam p;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    p.shape.push_back(shape_host[i]);
+    n *= shape_host[i];
+  }
+  p.data.assign(data_host, data_host + n);
+  e->host[name] = std::move(p);
+  e->finalized = false;
+  return RDM_OK;
+}
+
+namespace {
+int upload(rdm_engine* e, const std::vector<float>& h, float** dev) {
+  void* p = nullptr;
+  RDM_HIP_CHECK(hipMalloc(&p, (h.size() + 4) * sizeof(float)));
+  RDM_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  e->owned.push_back(p);
+  *dev = static_cast<float*>(p);
+  return RDM_OK;
+}
+// nn.Linear [out,in] (+ optional further [out_i,in] blocks stacked along out) -> B [pad4(in), pad4(out)]
+int make_linear(rdm_engine* e, const std::string& key, const std::vector<const HostParam*>& ws,
+                const std::vector<const HostParam*>& bs) {
+  const int64_t in = ws[0]->shape[1];
+  int64_t out = 0;
+  for (auto* w : ws) out += w->shape[0];
+  Linear L;
+  L.in = in; L.out = out; L.kpad = pad4(in); L.ldb = pad4(out);
+  std::vector<float> b(static_cast<size_t>(L.kpad) * L.ldb, 0.f), bias;
+  int64_t o0 = 0;
+  for (auto* w : ws) {
+    for (int64_t o = 0; o < w->shape[0]; ++o)
+      for (int64_t i = 0; i < in; ++i) b[i * L.ldb + o0 + o] = w->data[o * in + i];
+    o0 += w->shape[0];
+  }
+  for (auto* bb : bs) bias.insert(bias.end(), bb->data.begin(), bb->data.end());
+  ENG_CHECK(upload(e, b, &L.b));
+  ENG_CHECK(upload(e, bias, &L.bias));
+  e->lin[key] = L;
+  return RDM_OK;
+}
+bool ends_with(const std::string& s, const char* suf) {
+  const size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+}  // namespace
+
+extern "C" int rdm_engine_finalize(rdm_engine* e) {
+  RDM_REQUIRE(e, "rdm_engine_finalize: null engine");
+  for (void* p : e->owned) hipFree(p);
+  e->owned.clear();
+  e->lin.clear();
+  e->vec.clear();
+  for (auto& kv : e->host) {
+    const std::string& name = kv.first;
+    const HostParam& p = kv.second;
+    if (ends_with(name, "KPConv.weights")) {
+      const int64_t k = p.shape[0], cin = p.shape[1], cout = p.shape[2];
+      Linear L;
+      L.in = k * cin; L.out = cout; L.kpad = pad4(cin == 1 ? 16 : k * cin); L.ldb = pad4(cout);
+      std::vector<float> b(static_cast<size_t>(L.kpad) * L.ldb, 0.f);
+      for (int64_t r = 0; r < k * cin; ++r)
+        for (int64_t c = 0; c < cout; ++c) b[r * L.ldb + c] = p.data[r * cout + c];
+      ENG_CHECK(upload(e, b, &L.b));
+      auto bi = e->host.find(name.substr(0, name.size() - 8) + ".bias");
+      RDM_REQUIRE(bi != e->host.end(), "rdm_engine_finalize: %s has no bias", name.c_str());
+      ENG_CHECK(upload(e, bi->second.data, &L.bias));
+      e->lin[name] = L;
+    } else if (ends_with(name, ".weight") && p.shape.size() == 2) {
+      const std::string base = name.substr(0, name.size() - 7);
+      auto bi = e->host.find(base + ".bias");
+      RDM_REQUIRE(bi != e->host.end(), "rdm_engine_finalize: %s has no bias", name.c_str());
+      ENG_CHECK(make_linear(e, base, {&p}, {&bi->second}));
+      if (ends_with(base, ".attention.attention.proj_q")) {  // fused q|k|v and k|v projections
+        const std::string a = base.substr(0, base.size() - 7);                    // ...attention.attention
+        const std::string layer = a.substr(0, a.size() - std::strlen(".attention.attention"));
+        auto W = [&](const char* n) { return &e->host.at(a + "." + n + ".weight"); };
+        auto B = [&](const char* n) { return &e->host.at(a + "." + n + ".bias"); };
+        ENG_CHECK(make_linear(e, layer + ".qkv", {W("proj_q"), W("proj_k"), W("proj_v")}, {B("proj_q"), B("proj_k"), B("proj_v")}));
+        ENG_CHECK(make_linear(e, layer + ".q", {W("proj_q")}, {B("proj_q")}));
+        ENG_CHECK(make_linear(e, layer + ".kv", {W("proj_k"), W("proj_v")}, {B("proj_k"), B("proj_v")}));
+      }
+    } else if (!(ends_with(name, ".bias") && e->host.count(name.substr(0, name.size() - 5) + ".weight") &&
+                 e->host.at(name.substr(0, name.size() - 5) + ".weight").shape.size() == 2)) {
+      float* d = nullptr;
+      ENG_CHECK(upload(e, p.data, &d));
+      e->vec[name] = d;
+    }
+  }
+  e->finalized = true;
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_keep_taps(rdm_engine* e, int enable) {
+  RDM_REQUIRE(e, "rdm_engine_keep_taps: null engine");
+  e->keep_taps = enable != 0;
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor_view* out) {
+  RDM_REQUIRE(e && name && out, "rdm_engine_get_tensor: null pointer");
+  auto it = e->taps.find(name);
+  if (it == e->taps.end()) {
+    set_error("rdm_engine_get_tensor: no tensor named %s (call rdm_engine_keep_taps first)", name);
+    return RDM_ERR_ARG;
+  }
+  *out = it->second;
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
+                              int64_t n_src, rdm_engine_result* res, void* stream) {
+  RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_run: null pointer");
+  RDM_REQUIRE(e->finalized, "rdm_engine_run: call rdm_engine_finalize first");
+  RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_run: empty cloud");
+  const rdm_engine_config& c = e->cfg;
+  e->arena_off = 0;
+  e->taps.clear();
+  Run r;
+  r.e = e; r.st = static_cast<hipStream_t>(stream); r.groups = c.group_norm;
+  const int64_t n0 = n_ref + n_src;
+  // kernel scratch: the largest consumers are the grid-subsample tables and split-K partials
+  r.ws_bytes = std::max<size_t>(rdm_grid_subsample_workspace_bytes(n0, 2),
+                                std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(64) << 20));
+  r.ws = e->alloc<char>(r.ws_bytes);
+  ENG_ALLOC(r.ws);
+  std::memset(res, 0, sizeof(*res));
+
+  // ---------------------------------------------------------------- collate (data.py:13-77)
+  Level lv[5];
+  lv[0].n = n0; lv[0].n_ref = n_ref;
+  lv[0].pts = e->alloc<float>(3 * n0);
+  lv[0].lengths = e->alloc<int64_t>(2);
+  ENG_ALLOC(lv[0].pts); ENG_ALLOC(lv[0].lengths);
+  ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, r.st, ref_points, n_ref, src_points, n_src, lv[0].pts,
+                     lv[0].lengths));
+  int64_t* all_len = e->alloc<int64_t>(8);  // device lengths of levels 1..4, contiguous for one read-back
+  ENG_ALLOC(all_len);
+  float voxel = c.init_voxel_size;
+  int64_t cap = n0;
+  for (int i = 1; i < 5; ++i) {
+    voxel *= 2.f;  // data.py:23-28
+    lv[i].pts = e->alloc<float>(3 * cap);
+    lv[i].lengths = all_len + 2 * (i - 1);
+    ENG_ALLOC(lv[i].pts);
+    ENG_CHECK(rdm_grid_subsample(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
+                                 r.st));
+    // capacity of the next level is unknown on the host until the read-back; run it at full capacity
+  }
+  int64_t host_len[8];
+  // NOTE: each level was subsampled with n_points = cap (capacity): rows beyond the true count are
+  // never read because the kernels walk `lengths`.
+  ENG_CHECK(d2h(r, all_len, sizeof(host_len), host_len));
+  for (int i = 1; i < 5; ++i) {
+    lv[i].n_ref = host_len[2 * (i - 1)];
+    lv[i].n = host_len[2 * (i - 1)] + host_len[2 * (i - 1) + 1];
+    res->level_sizes[i] = lv[i].n;
+  }
+  res->level_sizes[0] = n0;
+
+  int32_t* flags = e->alloc<int32_t>(64);
+  ENG_ALLOC(flags);
+  RDM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(int32_t), r.st));
+  Table nb[5], sub[4], up[4];
+  float radius = c.init_radius;
+  int call = 0;
+  auto search = [&](const Level& q, const Level& s, float rad, int limit, Table& t) -> int {
+    t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
+    t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
+    ENG_ALLOC(t.idx);
+    return rdm_radius_neighbors(q.pts, q.n, s.pts, s.n, q.lengths, s.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
+                                t.flags + 1, r.ws, r.ws_bytes, r.st);
+  };
+  for (int i = 0; i < 5; ++i) {
+    ENG_CHECK(search(lv[i], lv[i], radius, c.neighbor_limits[i], nb[i]));
+    if (i < 4) {
+      ENG_CHECK(search(lv[i + 1], lv[i], radius, c.neighbor_limits[i], sub[i]));
+      ENG_CHECK(search(lv[i], lv[i + 1], radius * 2.f, c.neighbor_limits[i + 1], up[i]));
+    }
+    radius *= 2.f;
+  }
+  for (int i = 0; i < 5; ++i) {
+    tap(r, ("points" + std::to_string(i)).c_str(), lv[i].pts, lv[i].n, 3, 3, 0);
+    tap(r, ("neighbors" + std::to_string(i)).c_str(), nb[i].idx, nb[i].rows, nb[i].width, nb[i].width, 1);
+    if (i < 4) {
+      tap(r, ("subsampling" + std::to_string(i)).c_str(), sub[i].idx, sub[i].rows, sub[i].width, sub[i].width, 1);
+      tap(r, ("upsampling" + std::to_string(i)).c_str(), up[i].idx, up[i].rows, up[i].width, up[i].width, 1);
+    }
+  }
+
+  // ---------------------------------------------------------------- encoder (backbone.py:72-107)
+  Mat x = e->mat(n0, 1);
+  ENG_ALLOC(x.p);
+  ENG_CHECK(launch1d("fill", fill_kernel, n0 * x.ld, r.st, x.p, n0 * x.ld, 1.0f));  // features = 1 (dataset.py:187-188)
+  uint8_t* x_pos = e->alloc<uint8_t>(n0);
+  ENG_ALLOC(x_pos);
+  ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, r.st));
+  Mat feats[5];
+  {
+    const char* names[14] = {"encoder1_1", "encoder1_2", "encoder2_1", "encoder2_2", "encoder2_3", "encoder3_1", "encoder3_2",
+                             "encoder3_3", "encoder4_1", "encoder4_2", "encoder4_3", "encoder5_1", "encoder5_2", "encoder5_3"};
+    const int level[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
+    const bool strided[14] = {false, false, true, false, false, true, false, false, true, false, false, true, false, false};
+    int fi = 0;
+    for (int b = 0; b < 14; ++b) {
+      const std::string name = std::string("encoder.") + names[b];
+      const int lvl = level[b];
+      const Level& s = lv[lvl];
+      const Level& q = strided[b] ? lv[lvl + 1] : lv[lvl];
+      const Table& t = strided[b] ? sub[lvl] : nb[lvl];
+      const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
+      Mat y;
+      if (b == 0) {
+        Mat conv;
+        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, conv));
+        ENG_CHECK(group_norm(r, name + ".norm", conv, y, 2, nullptr, nullptr));
+      } else {
+        Mat h = x;
+        uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
+        ENG_ALLOC(h_pos);
+        if (e->lin.count(name + ".unary1.mlp")) {
+          ENG_CHECK(unary(r, name + ".unary1", x, h, 2, nullptr, h_pos));
+        } else {
+          ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
+        }
+        Mat conv, cn;
+        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv));
+        ENG_CHECK(group_norm(r, name + ".norm_conv", conv, cn, 2, nullptr, nullptr));
+        Mat sc = x;
+        if (strided[b]) {
+          sc = e->mat(q.n, x.cols);
+          ENG_ALLOC(sc.p);
+          ENG_CHECK(rdm_gather_max(x.p, x.rows, x.cols, x.ld, t.idx, q.n, t.width, t.width, t.flags, sc.p, sc.ld, r.st));
+        }
+        if (e->lin.count(name + ".unary_shortcut.mlp")) {
+          Mat s2;
+          ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));
+          sc = s2;
+        }
+        ENG_CHECK(unary(r, name + ".unary2", cn, y, 2, &sc, nullptr));
+      }
+      x = y;
+      tap(r, name.c_str(), x);
+      if (b == 1 || b == 4 || b == 7 || b == 10 || b == 13) feats[fi++] = x;
+    }
+  }
+  const int64_t Nc = lv[4].n, nc_ref = lv[4].n_ref, Nf = lv[1].n, nf_ref = lv[1].n_ref;
+  const int64_t D = c.out_dim;  // 256
+  tap(r, "feats_c_enc", feats[4]);
+
+  // ---------------------------------------------------------------- transformer #1 + heads
+  Mat pts_c4{e->alloc<float>(4 * (Nc > 0 ? Nc : 1)), Nc, 4, 4};
+  ENG_ALLOC(pts_c4.p);
+  ENG_CHECK(launch1d("pad_points", pad_points_kernel, Nc, r.st, lv[4].pts, Nc, pts_c4.p));
+  Mat buf_c = e->mat(Nc, D + 1);
+  ENG_ALLOC(buf_c.p);
+  Mat x_c = buf_c.cols_from(0, D);
+  ENG_CHECK(thdroformer(r, "transformer", pts_c4.rows_from(0, nc_ref), pts_c4.rows_from(nc_ref, Nc - nc_ref),
+                        feats[4].rows_from(0, nc_ref), feats[4].rows_from(nc_ref, Nc - nc_ref), c.num_layers,
+                        x_c.rows_from(0, nc_ref), x_c.rows_from(nc_ref, Nc - nc_ref)));
+  tap(r, "t1", x_c);
+  Mat n2p_logit = buf_c.cols_from(D, 1);
+  ENG_CHECK(linear(r, "proj_n2p_score", x_c, n2p_logit, 0, false));
+  float* n2p = e->alloc<float>(Nc);
+  ENG_ALLOC(n2p);
+  ENG_CHECK(rdm_sigmoid_column(n2p_logit.p, n2p_logit.ld, Nc, n2p, r.st));
+
+  // ---------------------------------------------------------------- decoder (backbone.py:118-151)
+  Mat dec;
+  {
+    Mat c4 = e->mat(lv[3].n, buf_c.cols + feats[3].cols);
+    ENG_ALLOC(c4.p);
+    ENG_CHECK(rdm_upsample_concat(buf_c.p, Nc, buf_c.cols, buf_c.ld, up[3].idx, up[3].width, feats[3].p, feats[3].cols,
+                                  feats[3].ld, lv[3].n, c4.p, c4.ld, r.st));
+    Mat l4;
+    ENG_CHECK(unary(r, "decoder.decoder4", c4, l4, 2, nullptr, nullptr));
+    Mat c3 = e->mat(lv[2].n, l4.cols + feats[2].cols);
+    ENG_ALLOC(c3.p);
+    ENG_CHECK(rdm_upsample_concat(l4.p, l4.rows, l4.cols, l4.ld, up[2].idx, up[2].width, feats[2].p, feats[2].cols,
+                                  feats[2].ld, lv[2].n, c3.p, c3.ld, r.st));
+    Mat l3;
+    ENG_CHECK(unary(r, "decoder.decoder3", c3, l3, 2, nullptr, nullptr));
+    Mat c2 = e->mat(lv[1].n, l3.cols + feats[1].cols);
+    ENG_ALLOC(c2.p);
+    ENG_CHECK(rdm_upsample_concat(l3.p, l3.rows, l3.cols, l3.ld, up[1].idx, up[1].width, feats[1].p, feats[1].cols,
+                                  feats[1].ld, lv[1].n, c2.p, c2.ld, r.st));
+    ENG_CHECK(linear(r, "decoder.decoder2.mlp", c2, dec));
+  }
+  tap(r, "decoder", dec);
+  Mat feats_f = dec.cols_from(0, D);
+  float* p2p = e->alloc<float>(Nf);
+  ENG_ALLOC(p2p);
+  ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, r.st));
+  tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
+
+  // ---------------------------------------------------------------- vote (vote.py:83-117)
+  Mat h = x_c;
+  for (int i = 0; i < c.vote_mlp_layers; ++i) {
+    Mat t1, t2;
+    ENG_CHECK(linear(r, "vote.mlp_modules." + std::to_string(3 * i), h, t1));
+    ENG_CHECK(layer_norm(r, "vote.mlp_modules." + std::to_string(3 * i + 1), t1, nullptr, 1, t2));
+    h = t2;
+  }
+  Mat off;
+  ENG_CHECK(linear(r, "vote.ctr_reg", h, off));
+  float* shifted = e->alloc<float>(3 * (Nc > 0 ? Nc : 1));
+  ENG_ALLOC(shifted);
+  ENG_CHECK(rdm_vote_shift(lv[4].pts, off.p, off.ld, Nc, c.vote_limit[0], c.vote_limit[1], c.vote_limit[2], shifted, r.st));
+  Mat off_f = off.cols_from(3, D), vfeats;
+  ENG_CHECK(layer_norm(r, "vote.out_proj.0", x_c, &off_f, 0, vfeats));
+  tap(r, "vote_xyz", shifted, Nc, 3, 3, 0);
+  tap(r, "vote_feats", vfeats);
+  Mat n2n_logit;
+  ENG_CHECK(linear(r, "proj_n2n_score", vfeats, n2n_logit));
+  float* n2n = e->alloc<float>(Nc);
+  ENG_ALLOC(n2n);
+  ENG_CHECK(rdm_sigmoid_column(n2n_logit.p, n2n_logit.ld, Nc, n2n, r.st));
+
+  // ---------------------------------------------------------------- NMS (vote.py:13-40)
+  Level nodes_all;
+  nodes_all.pts = shifted; nodes_all.n = Nc; nodes_all.lengths = lv[4].lengths; nodes_all.n_ref = nc_ref;
+  Table nms_t;
+  ENG_CHECK(search(nodes_all, nodes_all, c.nms_radius, c.neighbor_limits[4], nms_t));
+  uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);
+  ENG_ALLOC(keep);
+  ENG_CHECK(rdm_nms(nms_t.idx, Nc, nms_t.width, nms_t.width, nms_t.flags, keep, r.st));
+  tap(r, "nms_mask", keep, Nc, 1, 1, 2);
+  int32_t* order = e->alloc<int32_t>(Nc > 0 ? Nc : 1);
+  int32_t* kept = flags + 60;  // [2]
+  ENG_ALLOC(order);
+  ENG_CHECK(rdm_compact_indices(keep, 0, nc_ref, order, kept, r.st));
+  ENG_CHECK(rdm_compact_indices(keep, nc_ref, Nc, order + nc_ref, kept + 1, r.st));
+  int32_t host_flags[64];
+  ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
+  for (int i = 0; i < 2 * call; i += 2)
+    if (host_flags[i + 1] != 0) {
+      set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours");
+      return RDM_ERR_CAPACITY;
+    }
+  const int64_t m_r = host_flags[60], m_s = host_flags[61], Mn = m_r + m_s;
+  RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
+  int64_t* sel = e->alloc<int64_t>(Mn);
+  ENG_ALLOC(sel);
+  ENG_CHECK(launch1d("widen", widen_index_kernel, m_r, r.st, order, m_r, sel));
+  ENG_CHECK(launch1d("widen", widen_index_kernel, m_s, r.st, order + nc_ref, m_s, sel + m_r));
+  float* nodes = e->alloc<float>(3 * Mn);
+  ENG_ALLOC(nodes);
+  ENG_CHECK(rdm_gather_rows(shifted, Nc, 3, 3, sel, Mn, nodes, 3, r.st));
+  Mat sel_feats = e->mat(Mn, D);
+  ENG_ALLOC(sel_feats.p);
+  ENG_CHECK(rdm_gather_rows(vfeats.p, Nc, D, vfeats.ld, sel, Mn, sel_feats.p, sel_feats.ld, r.st));
+  float* packed = e->alloc<float>(2 * Nc);
+  float* sel_scores = e->alloc<float>(2 * Mn);
+  ENG_ALLOC(packed); ENG_ALLOC(sel_scores);
+  ENG_CHECK(launch1d("pack2", pack2_kernel, Nc, r.st, n2p, n2n, Nc, packed));
+  ENG_CHECK(rdm_gather_rows(packed, Nc, 2, 2, sel, Mn, sel_scores, 2, r.st));
+  tap(r, "nodes", nodes, Mn, 3, 3, 0);
+  tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
+
+  // ---------------------------------------------------------------- transformer #2, normalise
+  Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
+  ENG_ALLOC(nodes4.p);
+  ENG_CHECK(launch1d("pad_points", pad_points_kernel, Mn, r.st, nodes, Mn, nodes4.p));
+  Mat buf2 = e->mat(Mn, D);
+  ENG_ALLOC(buf2.p);
+  ENG_CHECK(thdroformer(r, "transformer2", nodes4.rows_from(0, m_r), nodes4.rows_from(m_r, m_s), sel_feats.rows_from(0, m_r),
+                        sel_feats.rows_from(m_r, m_s), c.num_layers2, buf2.rows_from(0, m_r), buf2.rows_from(m_r, m_s)));
+  tap(r, "t2", buf2);
+  Mat fn = e->mat(Mn, D);
+  ENG_ALLOC(fn.p);
+  ENG_CHECK(rdm_l2_normalize(buf2.p, buf2.ld, Mn, D, fn.p, fn.ld, r.st));
+  tap(r, "feats_c", fn);
+
+  // ---------------------------------------------------------------- grouping + coarse matching
+  const int K = c.points_in_patch;
+  const float* pf_ref = lv[1].pts;
+  const float* pf_src = lv[1].pts + 3 * nf_ref;
+  const int64_t nf_src = Nf - nf_ref;
+  int64_t* r_knn = e->alloc<int64_t>(m_r * K);
+  int64_t* s_knn = e->alloc<int64_t>(m_s * K);
+  uint8_t* r_km = e->alloc<uint8_t>(m_r * K);
+  uint8_t* s_km = e->alloc<uint8_t>(m_s * K);
+  uint8_t* r_nm = e->alloc<uint8_t>(m_r);
+  uint8_t* s_nm = e->alloc<uint8_t>(m_s);
+  ENG_ALLOC(r_knn); ENG_ALLOC(s_knn); ENG_ALLOC(r_km); ENG_ALLOC(s_km); ENG_ALLOC(r_nm); ENG_ALLOC(s_nm);
+  int32_t* p2n_status = flags + 62;
+  ENG_CHECK(rdm_point_to_node(pf_ref, nf_ref, nodes, m_r, K, r_knn, r_km, r_nm, p2n_status, r.ws, r.ws_bytes, r.st));
+  ENG_CHECK(rdm_point_to_node(pf_src, nf_src, nodes + 3 * m_r, m_s, K, s_knn, s_km, s_nm, p2n_status, r.ws, r.ws_bytes, r.st));
+  Mat sim = e->mat(m_r, m_s);
+  ENG_ALLOC(sim.p);
+  ENG_CHECK(rdm_gemm(fn.p, fn.ld, 0, fn.p + m_r * fn.ld, fn.ld, 0, 1, sim.p, sim.ld, 0, m_r, m_s, D, 1, nullptr, nullptr, 0,
+                     r.ws, r.ws_bytes, r.st));
+  const int kc = c.num_correspondences;
+  int64_t* r_sel = e->alloc<int64_t>(kc);
+  int64_t* s_sel = e->alloc<int64_t>(kc);
+  float* node_sc = e->alloc<float>(kc);
+  int32_t* n_sel = flags + 63;
+  ENG_ALLOC(r_sel); ENG_ALLOC(s_sel); ENG_ALLOC(node_sc);
+  ENG_CHECK(rdm_coarse_matching(sim.p, m_r, m_s, sim.ld, r_nm, s_nm, c.dual_normalization, kc, r_sel, s_sel, node_sc, n_sel,
+                                r.ws, r.ws_bytes, r.st));
+  int32_t tail[2];
+  ENG_CHECK(d2h(r, flags + 62, sizeof(tail), tail));
+  if (tail[0] != 0) {
+    set_error("rdm_engine_run: a superpoint owns more than 4096 points");
+    return RDM_ERR_CAPACITY;
+  }
+  const int64_t B = tail[1];
+  RDM_REQUIRE(B > 0, "rdm_engine_run: no superpoint correspondences");
+  tap(r, "ref_node_corr_indices", r_sel, B, 1, 1, 1);
+  tap(r, "src_node_corr_indices", s_sel, B, 1, 1, 1);
+  tap(r, "node_corr_scores", node_sc, B, 1, 1, 0);
+
+  // ---------------------------------------------------------------- patches, Sinkhorn, LGR
+  int64_t* r_idx = e->alloc<int64_t>(B * K);
+  int64_t* s_idx = e->alloc<int64_t>(B * K);
+  uint8_t* r_pm = e->alloc<uint8_t>(B * K);
+  uint8_t* s_pm = e->alloc<uint8_t>(B * K);
+  float* r_pts = e->alloc<float>(B * K * 3);
+  float* s_pts = e->alloc<float>(B * K * 3);
+  float* r_pf = e->alloc<float>(B * K * D);
+  float* s_pf = e->alloc<float>(B * K * D);
+  ENG_ALLOC(r_idx); ENG_ALLOC(s_idx); ENG_ALLOC(r_pm); ENG_ALLOC(s_pm); ENG_ALLOC(r_pts); ENG_ALLOC(s_pts);
+  ENG_ALLOC(r_pf); ENG_ALLOC(s_pf);
+  ENG_CHECK(rdm_gather_rows(r_knn, m_r, 2 * K, 2 * K, r_sel, B, r_idx, 2 * K, r.st));
+  ENG_CHECK(rdm_gather_rows(s_knn, m_s, 2 * K, 2 * K, s_sel, B, s_idx, 2 * K, r.st));
+  ENG_CHECK(rdm_gather_rows(r_km, m_r, K / 4, K / 4, r_sel, B, r_pm, K / 4, r.st));
+  ENG_CHECK(rdm_gather_rows(s_km, m_s, K / 4, K / 4, s_sel, B, s_pm, K / 4, r.st));
+  ENG_CHECK(rdm_gather_rows(pf_ref, nf_ref, 3, 3, r_idx, B * K, r_pts, 3, r.st));
+  ENG_CHECK(rdm_gather_rows(pf_src, nf_src, 3, 3, s_idx, B * K, s_pts, 3, r.st));
+  ENG_CHECK(rdm_gather_rows(feats_f.p, nf_ref, D, feats_f.ld, r_idx, B * K, r_pf, D, r.st));
+  ENG_CHECK(rdm_gather_rows(feats_f.p + nf_ref * feats_f.ld, nf_src, D, feats_f.ld, s_idx, B * K, s_pf, D, r.st));
+  float* sqrt_c = e->alloc<float>(K);
+  float* scores = e->alloc<float>(B * K * K);
+  float* ms = e->alloc<float>(B * (K + 1) * (K + 1));
+  ENG_ALLOC(sqrt_c); ENG_ALLOC(scores); ENG_ALLOC(ms);
+  ENG_CHECK(launch1d("fill", fill_kernel, K, r.st, sqrt_c, static_cast<int64_t>(K), std::sqrt(static_cast<float>(D))));
+  ENG_CHECK(rdm_gemm(r_pf, D, K * D, s_pf, D, K * D, 1, scores, K, static_cast<int64_t>(K) * K, K, K, D, static_cast<int>(B),
+                     nullptr, sqrt_c, 0, nullptr, 0, r.st));
+  ENG_CHECK(rdm_sinkhorn(scores, B, K, K, r_pm, s_pm, vecp(r, "optimal_transport.alpha"), c.sinkhorn_iterations, ms, r.st));
+  tap(r, "patch_scores", scores, B * K, K, K, 0);
+  tap(r, "matching_scores", ms, B * (K + 1), K + 1, K + 1, 0);
+  tap(r, "ref_node_corr_knn_points", r_pts, B * K, 3, 3, 0);
+  tap(r, "src_node_corr_knn_points", s_pts, B * K, 3, 3, 0);
+  tap(r, "ref_node_corr_knn_masks", r_pm, B, K, K, 2);
+  tap(r, "src_node_corr_knn_masks", s_pm, B, K, K, 2);
+
+  const int64_t ccap = B * 2 * K;
+  float* rc = e->alloc<float>(3 * ccap);
+  float* sc = e->alloc<float>(3 * ccap);
+  float* cs = e->alloc<float>(ccap);
+  float* T = e->alloc<float>(16);
+  int32_t* counts = e->alloc<int32_t>(4);
+  ENG_ALLOC(rc); ENG_ALLOC(sc); ENG_ALLOC(cs); ENG_ALLOC(T); ENG_ALLOC(counts);
+  ENG_CHECK(rdm_lgr(ms, r_pts, s_pts, r_pm, s_pm, B, K, c.acceptance_radius, c.correspondence_threshold,
+                    c.num_refinement_steps, rc, sc, cs, T, counts, r.ws, r.ws_bytes, r.st));
+  struct {
+    float T[16];
+    int32_t counts[4];
+  } tailbuf;
+  RDM_HIP_CHECK(hipMemcpyAsync(r.e->pinned, T, 16 * sizeof(float), hipMemcpyDeviceToHost, r.st));
+  RDM_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(r.e->pinned) + 64, counts, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, r.st));
+  RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+  std::memcpy(tailbuf.T, r.e->pinned, 64);
+  std::memcpy(tailbuf.counts, static_cast<char*>(r.e->pinned) + 64, 12);
+  std::memcpy(res->transform, tailbuf.T, 64);
+  res->n_correspondences = tailbuf.counts[0];
+  res->n_hypotheses = tailbuf.counts[1];
+  res->best_hypothesis = tailbuf.counts[2];
+  res->n_ref_nodes = m_r;
+  res->n_src_nodes = m_s;
+  res->n_node_correspondences = B;
+  res->ref_corr_points = rc;
+  res->src_corr_points = sc;
+  res->corr_scores = cs;
+  res->transform_dev = T;
+  res->arena_used = e->arena_off;
+  tap(r, "ref_corr_points", rc, res->n_correspondences, 3, 3, 0);
+  tap(r, "src_corr_points", sc, res->n_correspondences, 3, 3, 0);
+  tap(r, "corr_scores", cs, res->n_correspondences, 1, 1, 0);
+  tap(r, "estimated_transform", T, 4, 4, 4, 0);
+  return RDM_OK;
+}
+
+extern "C" int rdm_copy_device(void* dst, const void* src, size_t bytes, void* stream) {
+  RDM_REQUIRE(dst && src, "rdm_copy_device: null pointer");
+  RDM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return rdm::RDM_OK;
+}

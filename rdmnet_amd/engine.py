@@ -1,0 +1,124 @@
+"""ctypes front-end of the native engine (rdm_engine_*): one call per scan pair."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, weights
+
+
+class EngineConfig(ctypes.Structure):
+    _fields_ = [('num_stages', ctypes.c_int), ('kernel_size', ctypes.c_int), ('group_norm', ctypes.c_int),
+                ('init_voxel_size', ctypes.c_float), ('init_radius', ctypes.c_float), ('init_sigma', ctypes.c_float),
+                ('neighbor_limits', ctypes.c_int * 5), ('out_dim', ctypes.c_int), ('num_heads', ctypes.c_int),
+                ('num_layers', ctypes.c_int), ('num_layers2', ctypes.c_int), ('vote_mlp_layers', ctypes.c_int),
+                ('vote_limit', ctypes.c_float * 3), ('nms_radius', ctypes.c_float), ('points_in_patch', ctypes.c_int),
+                ('num_correspondences', ctypes.c_int), ('dual_normalization', ctypes.c_int),
+                ('sinkhorn_iterations', ctypes.c_int), ('acceptance_radius', ctypes.c_float),
+                ('correspondence_threshold', ctypes.c_int), ('num_refinement_steps', ctypes.c_int),
+                ('arena_bytes', ctypes.c_size_t)]
+
+
+class EngineResult(ctypes.Structure):
+    _fields_ = [('transform', ctypes.c_float * 16), ('n_correspondences', ctypes.c_int32),
+                ('n_hypotheses', ctypes.c_int32), ('best_hypothesis', ctypes.c_int32),
+                ('n_ref_nodes', ctypes.c_int64), ('n_src_nodes', ctypes.c_int64),
+                ('n_node_correspondences', ctypes.c_int64), ('level_sizes', ctypes.c_int64 * 5),
+                ('ref_corr_points', ctypes.c_void_p), ('src_corr_points', ctypes.c_void_p),
+                ('corr_scores', ctypes.c_void_p), ('transform_dev', ctypes.c_void_p), ('arena_used', ctypes.c_size_t)]
+
+
+class TensorView(ctypes.Structure):
+    _fields_ = [('data', ctypes.c_void_p), ('rows', ctypes.c_int64), ('cols', ctypes.c_int64), ('ld', ctypes.c_int64),
+                ('dtype', ctypes.c_int)]
+
+
+_DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
+
+
+def make_config(cfg, arena_bytes=0):
+    c = EngineConfig()
+    b, t, fm = cfg.backbone, cfg.thdroformer, cfg.fine_matching
+    c.num_stages, c.kernel_size, c.group_norm = b.num_stages, b.kernel_size, b.group_norm
+    c.init_voxel_size, c.init_radius, c.init_sigma = b.init_voxel_size, b.init_radius, b.init_sigma
+    c.neighbor_limits = (ctypes.c_int * 5)(*[int(x) for x in cfg.neighbor_limits])
+    c.out_dim, c.num_heads, c.num_layers, c.num_layers2 = t.output_dim, t.num_heads, t.num_layers, t.num_layers2
+    c.vote_mlp_layers = len(cfg.Vote.MLPS)
+    c.vote_limit = (ctypes.c_float * 3)(*[float(x) for x in cfg.Vote.MAX_TRANSLATE_RANGE])
+    c.nms_radius = cfg.Vote.NMS_radius
+    c.points_in_patch = cfg.model.num_points_in_patch
+    c.num_correspondences = cfg.coarse_matching.num_correspondences
+    c.dual_normalization = int(cfg.coarse_matching.dual_normalization)
+    c.sinkhorn_iterations = cfg.model.num_sinkhorn_iterations
+    c.acceptance_radius, c.correspondence_threshold = fm.acceptance_radius, fm.correspondence_threshold
+    c.num_refinement_steps = fm.num_refinement_steps
+    c.arena_bytes = arena_bytes
+    return c
+
+
+class Engine:
+    """Owns a native engine bound to the current device.  Not thread-safe: one engine per in-flight pair."""
+
+    def __init__(self, cfg, state, device=None, arena_bytes=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError('rdmnet_amd.engine needs a GPU (no CPU fallback)')
+        self.L = _lib.lib()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = cfg
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            c = make_config(cfg, arena_bytes)
+            _lib.check(self.L.rdm_engine_create(ctypes.byref(c), ctypes.byref(self._h)), 'rdm_engine_create')
+            for name, shape in weights.schema(cfg).items():
+                v = state[name]
+                v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+                v = np.ascontiguousarray(v, dtype=np.float32)
+                if tuple(v.shape) != tuple(shape):
+                    raise RuntimeError(f'size mismatch for {name}: {tuple(v.shape)} vs {tuple(shape)}')
+                shp = (ctypes.c_int64 * max(len(shape), 1))(*shape)
+                _lib.check(self.L.rdm_engine_set_param(self._h, name.encode(), v.ctypes.data, ctypes.addressof(shp),
+                                                       len(shape)), 'rdm_engine_set_param')
+            _lib.check(self.L.rdm_engine_finalize(self._h), 'rdm_engine_finalize')
+        self.result = EngineResult()
+
+    def __del__(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self.L.rdm_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def keep_taps(self, enable=True):
+        _lib.check(self.L.rdm_engine_keep_taps(self._h, int(enable)), 'rdm_engine_keep_taps')
+
+    def run(self, ref_points, src_points):
+        """ref/src: float32 CUDA tensors [n,3] on this engine's device.  Returns the EngineResult (host)."""
+        assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
+        assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
+        _lib.check(self.L.rdm_engine_run(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
+                                         src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()),
+                   'rdm_engine_run')
+        return self.result
+
+    def transform(self):
+        return np.ctypeslib.as_array(self.result.transform).reshape(4, 4).copy()
+
+    def tensor(self, name):
+        """Copy of a stage tensor of the last run (requires keep_taps before the run)."""
+        v = TensorView()
+        _lib.check(self.L.rdm_engine_get_tensor(self._h, name.encode(), ctypes.byref(v)), 'rdm_engine_get_tensor')
+        dt = _DTYPES[v.dtype]
+        out = torch.empty((v.rows, v.ld), dtype=dt, device=self.device)
+        if v.rows > 0:
+            _lib.check(self.L.rdm_copy_device(out.data_ptr(), v.data, out.numel() * out.element_size(), _lib.stream_ptr()),
+                       'rdm_copy_device')
+        return out[:, :v.cols]
+
+    def corr(self):
+        """(ref_corr_points, src_corr_points, corr_scores) of the last run as fresh tensors."""
+        n = self.result.n_correspondences
+        outs = []
+        for ptr, cols in ((self.result.ref_corr_points, 3), (self.result.src_corr_points, 3), (self.result.corr_scores, 1)):
+            t = torch.empty((n, cols), dtype=torch.float32, device=self.device)
+            if n > 0:
+                _lib.check(self.L.rdm_copy_device(t.data_ptr(), ptr, t.numel() * 4, _lib.stream_ptr()), 'rdm_copy_device')
+            outs.append(t)
+        return outs[0], outs[1], outs[2][:, 0]
