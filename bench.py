@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=1, help='pairs in flight per GPU (host threads, one HIP stream each)')
+    ap.add_argument('--path', choices=['engine', 'python'], default='engine',
+                    help='engine: one native call per pair (rdm_engine_run); python: per-op mirror (rdmnet_amd.model)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -119,12 +121,14 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from rdmnet_amd import collate, config, model, sharding, weights
+    from rdmnet_amd import collate, config, engine, model, sharding, weights
     cfg = config.make_cfg()
     state = weights.synthetic_state_dict(cfg, seed=0)
-    net = model.create_model(cfg).cuda(local_rank)
-    net.load_state_dict(state)
-    net._prepare()
+    net = None
+    if args.path == 'python':
+        net = model.create_model(cfg).cuda(local_rank)
+        net.load_state_dict(state)
+        net._prepare()
 
     if rank == 0:
         pairs = make_pairs(args.pairs, args.cache)
@@ -136,7 +140,7 @@ def main():
     dev_pairs = [(torch.from_numpy(r).to(dev), torch.from_numpy(s).to(dev)) for r, s, _ in pairs]
     n_points = float(np.mean([len(r) + len(s) for r, s, _ in pairs]))
 
-    def step(i):
+    def step(i):  # per-op Python mirror
         r, s = dev_pairs[(rank + i * world) % len(dev_pairs)]  # rank-strided sharding of the pair stream
         item = {'ref_points': r, 'src_points': s, 'ref_feats': torch.ones((r.shape[0], 1), device=dev),
                 'src_feats': torch.ones((s.shape[0], 1), device=dev)}
@@ -144,7 +148,7 @@ def main():
                                                           cfg.backbone.init_radius, cfg.neighbor_limits, device=dev)
         data['testing'] = True
         out = net(data)
-        return out
+        return out['estimated_transform'].cpu().numpy(), out['corr_scores'].shape[0]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -155,23 +159,37 @@ def main():
     import threading
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
 
-    def run_range(indices, stream, rec, lat_out, prof_out):
+    engines = []
+    if args.path == 'engine':
+        for _ in range(args.streams):
+            eng = engine.Engine(cfg, state, device=dev)
+            eng.enable_profile(True)
+            engines.append(eng)
+
+    def run_range(indices, stream, rec, lat_out, prof_out, eng):
         ctx = torch.cuda.stream(stream) if stream is not None else None
         if ctx is not None:
             ctx.__enter__()
         try:
-            net.set_thread_profile(prof_out)
+            if net is not None:
+                net.set_thread_profile(prof_out)
             for slot, i in indices:
                 ts = time.perf_counter()
-                out = step(i)
-                T = out['estimated_transform']  # forward's final sync already happened (correspondence count)
+                pid = (rank + i * world) % len(dev_pairs)
+                if eng is not None:
+                    res = eng.run(*dev_pairs[pid])  # returns after the pose has been read back
+                    T, n_corr = eng.transform(), res.n_correspondences
+                    if prof_out is not None:
+                        prof_out.extend(eng.kpconv_profile())
+                else:
+                    T, n_corr = step(i)
                 if rec is not None:
-                    pid = (rank + i * world) % len(dev_pairs)
-                    rre, rte = pose_error(T.cpu().numpy(), pairs[pid][2])
-                    rec[slot] = torch.tensor([pid, rre, rte, out['corr_scores'].shape[0]])
+                    rre, rte = pose_error(T, pairs[pid][2])
+                    rec[slot] = torch.tensor([pid, rre, rte, n_corr])
                     lat_out.append((time.perf_counter() - ts) * 1e3)
         finally:
-            net.set_thread_profile(None)
+            if net is not None:
+                net.set_thread_profile(None)
             if ctx is not None:
                 ctx.__exit__(None, None, None)
 
@@ -180,9 +198,10 @@ def main():
         for slot in range(count):
             jobs[slot % len(streams)].append((slot, first + slot))
         if len(streams) == 1:
-            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0])
+            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0], engines[0] if engines else None)
             return
-        threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k]))
+        threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k],
+                                                            engines[k] if engines else None))
                    for k in range(len(streams))]
         for t in threads:
             t.start()
@@ -214,14 +233,18 @@ def main():
     t_total = t_gather = b_total = b_gather = 0.0
     per_layer = {}
     for rec in prof:
-        e0, e1, e2 = rec['events']
-        tg, tt = e0.elapsed_time(e1) * 1e-3, e0.elapsed_time(e2) * 1e-3
+        if 'events' in rec:
+            e0, e1, e2 = rec['events']
+            tg, tt = e0.elapsed_time(e1) * 1e-3, e0.elapsed_time(e2) * 1e-3
+        else:
+            tg, tt = rec['gather_ms'] * 1e-3, rec['total_ms'] * 1e-3
         t_total += tt
         t_gather += tg
         b_total += rec['bytes']
         b_gather += rec['gather_bytes']
-        d = per_layer.setdefault(rec['name'], {'t': 0.0, 'tg': 0.0, 'bytes': rec['bytes'], 'n': 0, 'm': rec['m'],
-                                               'h': rec['h'], 'cin': rec['cin'], 'cout': rec['cout']})
+        key = rec.get('name') or f"kpconv M={rec['m']} H={rec['h']} C={rec['cin']}->{rec['cout']}"
+        d = per_layer.setdefault(key, {'t': 0.0, 'tg': 0.0, 'bytes': rec['bytes'], 'n': 0, 'm': rec['m'],
+                                       'h': rec['h'], 'cin': rec['cin'], 'cout': rec['cout']})
         d['t'] += tt
         d['tg'] += tg
         d['n'] += 1
@@ -242,7 +265,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'points_per_pair': n_points,
-                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams,
+                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},

@@ -247,6 +247,12 @@ typedef struct rdm_tensor_view {
   int dtype;                  /* 0 = f32, 1 = i64, 2 = u8 */
 } rdm_tensor_view;
 
+typedef struct rdm_kpconv_profile {   /* one KPConv layer of the last run (HIP events on the run's stream) */
+  int64_t m, h, c_in, c_out, pooled_channels;
+  float gather_ms;            /* rdm_kpconv_gather alone */
+  float total_ms;             /* gather + weight GEMM */
+} rdm_kpconv_profile;
+
 int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out);
 void rdm_engine_destroy(rdm_engine* e);
 int rdm_engine_set_param(rdm_engine* e, const char* name, const float* data_host, const int64_t* shape_host, int ndim);
@@ -255,6 +261,9 @@ int rdm_engine_finalize(rdm_engine* e);
 int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
                    rdm_engine_result* result_host, void* stream);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
+/* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
+int rdm_engine_enable_profile(rdm_engine* e, int enable);
+int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);
 int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor_view* out);
 /* Plain device-to-device copy on `stream` (lets a host without a HIP binding read arena tensors). */

@@ -57,6 +57,10 @@ struct rdm_engine {
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
   bool keep_taps = false;
+  bool profile = false;
+  std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
+  std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
+  int prof_layers = 0;
 
   template <typename T>
   T* alloc(size_t count) {
@@ -169,7 +173,7 @@ struct Table {
 };
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
-           const Table& t, float sigma, Mat& y) {
+           const Table& t, float sigma, Mat& y, int64_t pooled_channels = 0) {
   rdm_engine* e = r.e;
   auto it = e->lin.find(name + ".weights");
   if (it == e->lin.end()) {
@@ -182,12 +186,25 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   ENG_ALLOC(wf.p);
   float* nn = e->alloc<float>(q.n > 0 ? q.n : 1);
   ENG_ALLOC(nn);
+  const int li = e->prof_layers;
+  const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
+  if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
   ENG_CHECK(rdm_kpconv_gather(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
                               vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, r.st));
+  if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
   y = e->mat(q.n, W.out);
   ENG_ALLOC(y.p);
-  return rdm_gemm(wf.p, wf.ld, 0, W.b, W.ldb, 0, 0, y.p, y.ld, 0, q.n, W.out, W.kpad, 1, W.bias, nn, 0, r.ws, r.ws_bytes,
-                  r.st);
+  ENG_CHECK(rdm_gemm(wf.p, wf.ld, 0, W.b, W.ldb, 0, 0, y.p, y.ld, 0, q.n, W.out, W.kpad, 1, W.bias, nn, 0, r.ws, r.ws_bytes,
+                     r.st));
+  if (prof) {
+    RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
+    rdm_kpconv_profile p;
+    p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pooled_channels;
+    p.gather_ms = p.total_ms = 0.f;
+    e->prof.push_back(p);
+    e->prof_layers++;
+  }
+  return RDM_OK;
 }
 
 int attention_layer(Run& r, const std::string& p, const Mat& x, const Mat& mem, const Mat* emb, Mat& out) {
@@ -317,6 +334,7 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
 extern "C" void rdm_engine_destroy(rdm_engine* e) {
   if (!e) return;
   for (void* p : e->owned) hipFree(p);
+  for (auto& ev : e->events) hipEventDestroy(ev);
   if (e->arena) hipFree(e->arena);
   if (e->pinned) hipHostFree(e->pinned);
   delete e;
@@ -419,6 +437,23 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
   return RDM_OK;
 }
 
+extern "C" int rdm_engine_enable_profile(rdm_engine* e, int enable) {
+  RDM_REQUIRE(e, "rdm_engine_enable_profile: null engine");
+  e->profile = enable != 0;
+  if (e->profile && e->events.empty()) {
+    e->events.resize(3 * 16);
+    for (auto& ev : e->events) RDM_HIP_CHECK(hipEventCreate(&ev));
+  }
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap) {
+  RDM_REQUIRE(e && out && cap >= 0, "rdm_engine_get_profile: bad arguments");
+  const int n = std::min<int>(cap, static_cast<int>(e->prof.size()));
+  for (int i = 0; i < n; ++i) out[i] = e->prof[i];
+  return static_cast<int>(e->prof.size());
+}
+
 extern "C" int rdm_engine_keep_taps(rdm_engine* e, int enable) {
   RDM_REQUIRE(e, "rdm_engine_keep_taps: null engine");
   e->keep_taps = enable != 0;
@@ -444,6 +479,8 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   const rdm_engine_config& c = e->cfg;
   e->arena_off = 0;
   e->taps.clear();
+  e->prof.clear();
+  e->prof_layers = 0;
   Run r;
   r.e = e; r.st = static_cast<hipStream_t>(stream); r.groups = c.group_norm;
   const int64_t n0 = n_ref + n_src;
@@ -552,7 +589,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
           ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
         }
         Mat conv, cn;
-        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv));
+        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv, strided[b] ? x.cols : 0));
         ENG_CHECK(group_norm(r, name + ".norm_conv", conv, cn, 2, nullptr, nullptr));
         Mat sc = x;
         if (strided[b]) {
@@ -802,6 +839,10 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   res->corr_scores = cs;
   res->transform_dev = T;
   res->arena_used = e->arena_off;
+  for (int i = 0; i < e->prof_layers; ++i) {  // the stream is idle here (read-back above synchronised it)
+    RDM_HIP_CHECK(hipEventElapsedTime(&e->prof[i].gather_ms, e->events[3 * i], e->events[3 * i + 1]));
+    RDM_HIP_CHECK(hipEventElapsedTime(&e->prof[i].total_ms, e->events[3 * i], e->events[3 * i + 2]));
+  }
   tap(r, "ref_corr_points", rc, res->n_correspondences, 3, 3, 0);
   tap(r, "src_corr_points", sc, res->n_correspondences, 3, 3, 0);
   tap(r, "corr_scores", cs, res->n_correspondences, 1, 1, 0);

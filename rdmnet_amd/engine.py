@@ -33,6 +33,11 @@ class TensorView(ctypes.Structure):
                 ('dtype', ctypes.c_int)]
 
 
+class KpconvProfile(ctypes.Structure):
+    _fields_ = [('m', ctypes.c_int64), ('h', ctypes.c_int64), ('c_in', ctypes.c_int64), ('c_out', ctypes.c_int64),
+                ('pooled_channels', ctypes.c_int64), ('gather_ms', ctypes.c_float), ('total_ms', ctypes.c_float)]
+
+
 _DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
 
 
@@ -72,9 +77,9 @@ class Engine:
             for name, shape in weights.schema(cfg).items():
                 v = state[name]
                 v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-                v = np.ascontiguousarray(v, dtype=np.float32)
                 if tuple(v.shape) != tuple(shape):
                     raise RuntimeError(f'size mismatch for {name}: {tuple(v.shape)} vs {tuple(shape)}')
+                v = np.ascontiguousarray(v, dtype=np.float32)  # (0-d becomes 1-d here, hence the check above)
                 shp = (ctypes.c_int64 * max(len(shape), 1))(*shape)
                 _lib.check(self.L.rdm_engine_set_param(self._h, name.encode(), v.ctypes.data, ctypes.addressof(shp),
                                                        len(shape)), 'rdm_engine_set_param')
@@ -85,6 +90,21 @@ class Engine:
         if getattr(self, '_h', None) and self._h.value:
             self.L.rdm_engine_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def enable_profile(self, enable=True):
+        _lib.check(self.L.rdm_engine_enable_profile(self._h, int(enable)), 'rdm_engine_enable_profile')
+
+    def kpconv_profile(self):
+        """Per-KPConv-layer records of the last run: dicts with sizes, SURVEY §8d algorithmic bytes and ms."""
+        buf = (KpconvProfile * 16)()
+        n = self.L.rdm_engine_get_profile(self._h, ctypes.addressof(buf), 16)
+        out = []
+        for p in buf[:max(n, 0)]:
+            gather = p.m * p.h * (8 + 12 + 4 * p.c_in)
+            total = gather + 4 * p.m * p.c_out + (p.m * p.h * (8 + 4 * p.pooled_channels) if p.pooled_channels else 0)
+            out.append({'m': p.m, 'h': p.h, 'cin': p.c_in, 'cout': p.c_out, 'bytes': total, 'gather_bytes': gather,
+                        'gather_ms': p.gather_ms, 'total_ms': p.total_ms})
+        return out
 
     def keep_taps(self, enable=True):
         _lib.check(self.L.rdm_engine_keep_taps(self._h, int(enable)), 'rdm_engine_keep_taps')
