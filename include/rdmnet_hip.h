@@ -250,7 +250,7 @@ typedef struct rdm_tensor_view {
 typedef struct rdm_kpconv_profile {   /* one KPConv layer of the last run (HIP events on the run's stream) */
   int64_t m, h, c_in, c_out, pooled_channels;
   float gather_ms;            /* rdm_kpconv_gather alone */
-  float total_ms;             /* gather + weight GEMM */
+  float total_ms;             /* gather + weight GEMM (+ the shortcut max-pool of strided blocks) */
 } rdm_kpconv_profile;
 
 int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out);

@@ -173,7 +173,7 @@ struct Table {
 };
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
-           const Table& t, float sigma, Mat& y, int64_t pooled_channels = 0) {
+           const Table& t, float sigma, Mat& y, const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
   rdm_engine* e = r.e;
   auto it = e->lin.find(name + ".weights");
   if (it == e->lin.end()) {
@@ -196,10 +196,16 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   ENG_ALLOC(y.p);
   ENG_CHECK(rdm_gemm(wf.p, wf.ld, 0, W.b, W.ldb, 0, 0, y.p, y.ld, 0, q.n, W.out, W.kpad, 1, W.bias, nn, 0, r.ws, r.ws_bytes,
                      r.st));
+  if (pool_src) {  // strided block: the shortcut max-pool over the same neighbour table (functional.py:54-67)
+    *pool_out = e->mat(q.n, pool_src->cols);
+    ENG_ALLOC(pool_out->p);
+    ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.width,
+                             t.flags, pool_out->p, pool_out->ld, r.st));
+  }
   if (prof) {
     RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
     rdm_kpconv_profile p;
-    p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pooled_channels;
+    p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
     p.gather_ms = p.total_ms = 0.f;
     e->prof.push_back(p);
     e->prof_layers++;
@@ -589,14 +595,9 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
           ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
         }
         Mat conv, cn;
-        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv, strided[b] ? x.cols : 0));
-        ENG_CHECK(group_norm(r, name + ".norm_conv", conv, cn, 2, nullptr, nullptr));
         Mat sc = x;
-        if (strided[b]) {
-          sc = e->mat(q.n, x.cols);
-          ENG_ALLOC(sc.p);
-          ENG_CHECK(rdm_gather_max(x.p, x.rows, x.cols, x.ld, t.idx, q.n, t.width, t.width, t.flags, sc.p, sc.ld, r.st));
-        }
+        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv, strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
+        ENG_CHECK(group_norm(r, name + ".norm_conv", conv, cn, 2, nullptr, nullptr));
         if (e->lin.count(name + ".unary_shortcut.mlp")) {
           Mat s2;
           ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));

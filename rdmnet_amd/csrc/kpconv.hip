@@ -43,15 +43,20 @@ struct KpArgs {
   float sigma;
 };
 
-template <int VEC, int U>
+// VEC x U x 16 channels per wavefront; SPLIT wavefronts share one query (channel slices) so that the
+// coarse levels (few hundred queries, 256-512 channels) still fill the chip; PF neighbour groups of
+// four are fetched before the first is consumed (the gather -> MFMA chain is latency-bound otherwise).
+template <int VEC, int U, int SPLIT, int PF>
 __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = bit pattern of the support row (or -1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * kWaves + wave;
+  const int unit = blockIdx.x * kWaves + wave;
+  const int m = unit / SPLIT, slice = unit % SPLIT;
   if (m >= a.M) return;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const int g = lane >> 4, j = lane & 15;
+  const int c_base = slice * (16 * VEC * U);  // first channel of this wavefront's slice
 
   // ---- phase 1: neighbour rows, relative positions, positive-row count
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
@@ -83,45 +88,53 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
 #pragma unroll
   for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- phase 2: four neighbours per step
-  for (int h0 = 0; h0 < H; h0 += 4) {
-    const int h = h0 + g;
-    float w = 0.f;
-    int id = -1;
-    if (h < H) {
-      const float4 v = nb[wave][h];
-      id = __float_as_int(v.w);
-      const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      w = fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma);
-      if (j >= kKP || id < 0) w = 0.f;
-    }
-    const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
+  // ---- phase 2: PF groups of four neighbours per trip
+  for (int h0 = 0; h0 < H; h0 += 4 * PF) {
+    float w[PF];
+    float f[PF][U][VEC];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float f[VEC];
-      if (id >= 0) {
-        if (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(row + 16 * VEC * u);
-          f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
-        } else if (VEC == 2) {
-          const float2 t = *reinterpret_cast<const float2*>(row + 16 * VEC * u);
-          f[0] = t.x; f[1] = t.y;
-        } else {
-          f[0] = row[16 * VEC * u];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+    for (int p = 0; p < PF; ++p) {
+      const int h = h0 + 4 * p + g;
+      int id = -1;
+      w[p] = 0.f;
+      if (h < H) {
+        const float4 v = nb[wave][h];
+        id = __float_as_int(v.w);
+        const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        w[p] = fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma);
+        if (j >= kKP || id < 0) w[p] = 0.f;
       }
+      const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + c_base + VEC * j;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        acc[u * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, f[e], acc[u * VEC + e], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        if (id >= 0) {
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(row + 16 * VEC * u);
+            f[p][u][0] = t.x; f[p][u][1] = t.y; f[p][u][2] = t.z; f[p][u][VEC - 1] = t.w;
+          } else if (VEC == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(row + 16 * VEC * u);
+            f[p][u][0] = t.x; f[p][u][VEC - 1] = t.y;
+          } else {
+            f[p][u][0] = row[16 * VEC * u];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) f[p][u][e] = 0.f;
+        }
+      }
     }
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          acc[u * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][u][e], acc[u * VEC + e], 0, 0, 0);
   }
 
   // ---- store WF[m, k, c]: accumulator row = 4*g + r = kernel point, column j
-  float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
+  float* out = a.wf + static_cast<int64_t>(m) * a.ldw + c_base;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int k = 4 * g + r;
@@ -139,44 +152,36 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
       }
     }
   }
-  if (lane == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+  if (lane == 0 && slice == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
 }
 
 // First layer (C_in = 1, features == 1 for every real point, reference dataset.py:187-188 and
 // model_infer.py:113): WF[m,k] = sum_h w[h,k] * f[idx], no matrix core needed.
-__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * kWaves + wave;
+__global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(KpArgs a) {
+  // 16 lanes per query: lane j < 15 owns kernel point j and walks all neighbours (no reductions)
+  const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
   if (m >= a.M) return;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
-  float acc[kKP];
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) acc[k] = 0.f;
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
+              kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  float acc = 0.f;
   int positives = 0;
-  for (int h = lane; h < H; h += 64) {
-    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+  const int64_t* row = a.idx + static_cast<int64_t>(m) * a.ldi;
+  for (int h = 0; h < H; ++h) {
+    const int64_t id = row[h];
     if (id < 0 || id >= a.Ns) continue;
     const float f = a.s_feats[id * a.ldf];
     positives += a.s_pos[id];
-    const float rx = a.s_points[3 * id] - qx, ry = a.s_points[3 * id + 1] - qy,
-                rz = a.s_points[3 * id + 2] - qz;
-#pragma unroll
-    for (int k = 0; k < kKP; ++k) {
-      const float dx = rx - a.kp[3 * k], dy = ry - a.kp[3 * k + 1], dz = rz - a.kp[3 * k + 2];
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      acc[k] += fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma) * f;
-    }
+    const float dx = (a.s_points[3 * id] - qx) - kx, dy = (a.s_points[3 * id + 1] - qy) - ky,
+                dz = (a.s_points[3 * id + 2] - qz) - kz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    acc += fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma) * f;
   }
-  positives = wave_sum_i(positives);
   float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) {
-    const float s = wave_sum(acc[k]);
-    if (lane == 0) out[k] = s;
-  }
-  if (lane == 0) {
+  if (j < kKP) out[j] = acc;
+  else {
     for (int k = kKP; k < a.ldw; ++k) out[k] = 0.f;
     a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
   }
@@ -228,14 +233,25 @@ extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* 
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
   a.ldw = static_cast<int>(ldw); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(ceil_div<int64_t>(m, kWaves)), block(64 * kWaves);
+  const dim3 block(64 * kWaves);
+  auto grid = [&](int split) { return dim3(static_cast<unsigned>(ceil_div<int64_t>(m * split, kWaves))); };
+  const bool small = m < 4096;  // coarse levels: slice the channels over several wavefronts per query
   switch (c) {
-    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, grid, block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1>), grid, block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1>), grid, block, 0, st, a); break;
-    case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 2>), grid, block, 0, st, a); break;
-    case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 4>), grid, block, 0, st, a); break;
-    case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 8>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, 16)), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 4>), grid(1), block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 1, 4>), grid(1), block, 0, st, a); break;
+    case 128:
+      if (small) hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 4>), grid(2), block, 0, st, a);
+      else hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 1, 2>), grid(1), block, 0, st, a);
+      break;
+    case 256:
+      if (small) hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 4, 4>), grid(4), block, 0, st, a);
+      else hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 2, 2>), grid(2), block, 0, st, a);
+      break;
+    case 512:
+      if (small) hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 4, 2>), grid(4), block, 0, st, a);
+      else hipLaunchKernelGGL((kpconv_gather_kernel<4, 4, 2, 1>), grid(2), block, 0, st, a);
+      break;
     default:
       set_error("rdm_kpconv_gather: channel count %lld has no kernel instance", (long long)c);
       return RDM_ERR_ARG;

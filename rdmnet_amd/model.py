@@ -121,7 +121,7 @@ class RDMNet:
         return ops.group_norm(x, self._w[name + '.norm.weight'], self._w[name + '.norm.bias'],
                               self.cfg.backbone.group_norm, act=act, residual=residual, want_positive=want_positive)
 
-    def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None, pooled_channels=0):
+    def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None, pool_src=None):
         b, cin, cout = self._w[name + '.weights']
         prof = getattr(self._tls, 'profile', None)
         if prof is not None:
@@ -131,15 +131,17 @@ class RDMNet:
         if prof is not None:
             e1.record()
         y = ops.gemm(wf, b, b.shape[0], cout, bias=self._w[name + '.bias'], rowdiv=nn)
+        pooled = ops.gather_max(pool_src, idx, width) if pool_src is not None else None
         if prof is not None:
             e2.record()
             m, h = idx.shape
             # SURVEY.md §8d algorithmic bytes of one KPConv layer (padded slots counted, int64 indices, fp32):
             #   M*H*(8 + 12 + 4*C_in) + 4*M*C_out   (+ M*H*(8 + 4*C_block_in) for the strided shortcut pool)
+            pooled_channels = pool_src.shape[1] if pool_src is not None else 0
             nbytes = m * h * (8 + 12 + 4 * cin) + 4 * m * cout + (m * h * (8 + 4 * pooled_channels) if pooled_channels else 0)
             prof.append({'name': name, 'm': m, 'h': h, 'cin': cin, 'cout': cout, 'bytes': nbytes,
                          'gather_bytes': m * h * (8 + 12 + 4 * cin), 'events': (e0, e1, e2)})
-        return y
+        return (y, pooled) if pool_src is not None else y
 
     def _unary(self, name, x, act=ACT_LEAKY, residual=None, want_positive=False):
         return self._gn(name + '.norm', self._linear(name + '.mlp', x), act=act, residual=residual,
@@ -155,9 +157,11 @@ class RDMNet:
             y, y_pos = self._unary(name + '.unary1', x, want_positive=True)
         else:
             y, y_pos = x, (x_pos if x_pos is not None else ops.row_positive(x))
-        y = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width, pooled_channels=x.shape[1] if strided else 0)
+        if strided:
+            y, sc = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width, pool_src=x)
+        else:
+            y, sc = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width), x
         y = self._gn(name + '.norm_conv', y, act=ACT_LEAKY)
-        sc = ops.gather_max(x, idx, width) if strided else x
         if (name + '.unary_shortcut.mlp') in W:
             sc = self._unary(name + '.unary_shortcut', sc, act=ACT_NONE)
         # leaky_relu(unary2(y) + shortcut): the add and the activation ride on unary2's GroupNorm apply
