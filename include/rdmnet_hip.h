@@ -110,6 +110,16 @@ size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c);
 int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx, int groups, const float* gamma,
                    const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y,
                    int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
+/* rdm_linear_group_norm: y = act(GroupNorm(x W + bias [/ rowdiv]) [+ residual]) -- UnaryBlock / the
+ * KPConv weight contraction + norm_conv (modules/kpconv/modules.py:53-83, 196-207): the GEMM epilogue
+ * emits the GroupNorm statistics, saving a pass over the activations.  lin_out [m, n] is scratch for
+ * the pre-norm activations.  Same operand rules as rdm_gemm (trans_b = 0).                       */
+size_t rdm_linear_group_norm_workspace_bytes(int64_t m, int64_t n);
+int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                          const float* rowdiv, int64_t m, int64_t n, int64_t k, int groups, const float* gamma,
+                          const float* beta, float eps, const float* residual, int64_t ldr, int act, float* lin_out,
+                          int64_t ld_lin, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
+                          void* stream);
 int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
                    int64_t ldr, const float* gamma, const float* beta, float eps, int act, float* y,
                    int64_t ldy, void* stream);

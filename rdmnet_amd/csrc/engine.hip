@@ -18,6 +18,7 @@
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -144,10 +145,27 @@ int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, c
                         y.p, y.ld, positive, r.ws, r.ws_bytes, r.st);
 }
 
+// Linear + GroupNorm (+ residual, activation): statistics come out of the GEMM epilogue
 int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
-  Mat t;
-  ENG_CHECK(linear(r, name + ".mlp", x, t));
-  return group_norm(r, name + ".norm", t, y, act, res, positive);
+  rdm_engine* e = r.e;
+  auto it = e->lin.find(name + ".mlp");
+  if (it == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s.mlp", name.c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear& L = it->second;
+  Mat t = e->mat(x.rows, L.out);
+  y = e->mat(x.rows, L.out);
+  ENG_ALLOC(t.p); ENG_ALLOC(y.p);
+  float* g = vecp(r, name + ".norm.norm.weight");
+  float* b = vecp(r, name + ".norm.norm.bias");
+  if (!g || !b) {
+    set_error("rdm_engine: missing parameter %s.norm.norm.*", name.c_str());
+    return RDM_ERR_ARG;
+  }
+  return rdm_linear_group_norm(x.p, x.ld, L.b, L.ldb, L.bias, nullptr, x.rows, L.out, L.kpad, r.groups, g, b, 1e-5f,
+                               res ? res->p : nullptr, res ? res->ld : 0, act, t.p, t.ld, y.p, y.ld, positive, r.ws,
+                               r.ws_bytes, r.st);
 }
 
 int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, int act, Mat& y, bool alloc_out = true) {
@@ -173,7 +191,8 @@ struct Table {
 };
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
-           const Table& t, float sigma, Mat& y, const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
+           const Table& t, float sigma, const std::string& norm_name, Mat& y, const Mat* pool_src = nullptr,
+           Mat* pool_out = nullptr) {
   rdm_engine* e = r.e;
   auto it = e->lin.find(name + ".weights");
   if (it == e->lin.end()) {
@@ -192,10 +211,16 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   ENG_CHECK(rdm_kpconv_gather(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
                               vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, r.st));
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
-  y = e->mat(q.n, W.out);
-  ENG_ALLOC(y.p);
-  ENG_CHECK(rdm_gemm(wf.p, wf.ld, 0, W.b, W.ldb, 0, 0, y.p, y.ld, 0, q.n, W.out, W.kpad, 1, W.bias, nn, 0, r.ws, r.ws_bytes,
-                     r.st));
+  Mat conv = e->mat(q.n, W.out);
+  ENG_ALLOC(conv.p);
+  // scratch split: [GEMM split-K partials | GroupNorm partials | GroupNorm finish]
+  const size_t gemm_ws = rdm_gemm_workspace_bytes(q.n, W.out, 1);
+  const size_t stat_bytes = align_up(static_cast<size_t>(gemm_stats_max_blocks(q.n)) * 2 * W.out * sizeof(double));
+  RDM_REQUIRE(gemm_ws + stat_bytes + rdm_group_norm_workspace_bytes(q.n, W.out) <= r.ws_bytes, "rdm_engine: scratch too small");
+  double* gn_partial = reinterpret_cast<double*>(static_cast<char*>(r.ws) + gemm_ws);
+  int gn_blocks = 0;
+  ENG_CHECK(gemm_with_stats(wf.p, wf.ld, W.b, W.ldb, conv.p, conv.ld, q.n, W.out, W.kpad, W.bias, nn, r.ws, gemm_ws,
+                            gn_partial, &gn_blocks, r.st));
   if (pool_src) {  // strided block: the shortcut max-pool over the same neighbour table (functional.py:54-67)
     *pool_out = e->mat(q.n, pool_src->cols);
     ENG_ALLOC(pool_out->p);
@@ -210,7 +235,18 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     e->prof.push_back(p);
     e->prof_layers++;
   }
-  return RDM_OK;
+  // GroupNorm + LeakyReLU of the convolution output (modules.py:141-145, 205-207)
+  y = e->mat(q.n, W.out);
+  ENG_ALLOC(y.p);
+  float* gam = vecp(r, norm_name + ".norm.weight");
+  float* bet = vecp(r, norm_name + ".norm.bias");
+  if (!gam || !bet) {
+    set_error("rdm_engine: missing parameter %s.norm.*", norm_name.c_str());
+    return RDM_ERR_ARG;
+  }
+  return group_norm_finish(gn_partial, gn_blocks, conv.p, q.n, W.out, conv.ld, r.groups, gam, bet, 1e-5f, nullptr, 0, 2, y.p,
+                           y.ld, nullptr, static_cast<char*>(r.ws) + gemm_ws + stat_bytes, r.ws_bytes - gemm_ws - stat_bytes,
+                           r.st);
 }
 
 int attention_layer(Run& r, const std::string& p, const Mat& x, const Mat& mem, const Mat* emb, Mat& out) {
@@ -582,9 +618,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
       const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
       Mat y;
       if (b == 0) {
-        Mat conv;
-        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, conv));
-        ENG_CHECK(group_norm(r, name + ".norm", conv, y, 2, nullptr, nullptr));
+        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y));
       } else {
         Mat h = x;
         uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
@@ -594,10 +628,10 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
         } else {
           ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
         }
-        Mat conv, cn;
+        Mat cn;
         Mat sc = x;
-        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, conv, strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
-        ENG_CHECK(group_norm(r, name + ".norm_conv", conv, cn, 2, nullptr, nullptr));
+        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, strided[b] ? &x : nullptr,
+                         strided[b] ? &sc : nullptr));
         if (e->lin.count(name + ".unary_shortcut.mlp")) {
           Mat s2;
           ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));

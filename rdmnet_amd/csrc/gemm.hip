@@ -15,6 +15,7 @@
 // Requirements: lda, ldb, K multiples of 4 and 16-byte aligned bases (callers pad with zeros).
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -34,6 +35,7 @@ struct GemmArgs {
   int act;               // 0 none, 1 relu, 2 leaky-relu(0.1)
   int splits;            // split-K factor (partials go to `part`)
   float* part;           // [batch*splits, M, N] when splits > 1
+  double* stats;         // optional GroupNorm partials [grid.y][2][N] (non split-K only)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
   __shared__ float As[2][BK][LDA_S];
   __shared__ float Bs[2][BK][LDB_S];
+  __shared__ double stat_red[WM][BN][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -173,27 +176,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   // epilogue
   const bool partial = g.splits > 1;
+  const bool stats = g.stats != nullptr && !partial;
   float* C = partial ? g.part + static_cast<long long>(blockIdx.z) * g.M * g.N : g.C + batch * g.sc;
   const int ldc = partial ? g.N : g.ldc;
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+  for (int j = 0; j < FN; ++j) {
+    const int col = n0 + wn * TN + j * 32 + li;
+    const float bv = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
+    double cs = 0.0, css = 0.0;
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * TN + j * 32 + li;
-      if (col >= g.N) continue;
-      const float bv = (!partial && g.bias) ? g.bias[col] : 0.f;
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M) continue;
+        if (row >= g.M || col >= g.N) continue;
         float v = acc[i][j][r];
         if (!partial) {
           if (g.rowdiv) v = v / g.rowdiv[row];
           v = apply_act(v + bv, g.act);
         }
         C[static_cast<long long>(row) * ldc + col] = v;
+        cs += v;
+        css += static_cast<double>(v) * v;
       }
     }
+    if (stats) {  // GroupNorm statistics of this block's rows, fixed combination order
+      cs += __shfl_xor(cs, 32, 64);
+      css += __shfl_xor(css, 32, 64);
+      if (lk == 0) {
+        stat_red[wm][wn * TN + j * 32 + li][0] = cs;
+        stat_red[wm][wn * TN + j * 32 + li][1] = css;
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += 256) {
+      const int col = n0 + cl;
+      if (col >= g.N) continue;
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        a += stat_red[w][cl][0];
+        b += stat_red[w][cl][1];
+      }
+      g.stats[(static_cast<long long>(blockIdx.y) * 2 + 0) * g.N + col] = a;
+      g.stats[(static_cast<long long>(blockIdx.y) * 2 + 1) * g.N + col] = b;
+    }
+  }
 }
 
 __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
@@ -230,6 +260,58 @@ extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
                   static_cast<size_t>(batches > 0 ? batches : 1));
 }
 
+namespace {
+
+int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
+  const long long m = g.M, n = g.N, k = g.K;
+  enum { T128, T64, T128x32 } tile;
+  if (n <= 32) tile = T128x32;
+  else if (m >= 2048 && n >= 128) tile = T128;
+  else tile = T64;
+  const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
+  const long long tiles = ceil_div<long long>(m, bm) * ceil_div<long long>(n, bn) * batches;
+  const int ktiles = static_cast<int>(ceil_div<long long>(k, BK));
+  if (tiles < 256 && ktiles >= 32) {
+    int s = static_cast<int>(ceil_div<long long>(512, tiles));
+    if (s > 16) s = 16;
+    if (s > ktiles / 8) s = ktiles / 8;
+    const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
+    if (s > 1 && ws && ws_bytes >= need) {
+      g.splits = s;
+      g.part = static_cast<float*>(ws);
+    }
+  }
+  if (g.splits > 1) g.stats = nullptr;
+  if (stat_blocks) *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm)) : 0;
+  switch (tile) {
+    case T128: launch<128, 128, 2, 2>(g, batches, trans_b, st); break;
+    case T64: launch<64, 64, 2, 2>(g, batches, trans_b, st); break;
+    case T128x32: launch<128, 32, 4, 1>(g, batches, trans_b, st); break;
+  }
+  if (int e = launch_status("gemm_kernel")) return e;
+  if (g.splits > 1) {
+    const long long total = static_cast<long long>(batches) * m * n;
+    const int blocks = static_cast<int>(std::min<long long>(ceil_div<long long>(total, 256), 2048));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, batches);
+    return launch_status("splitk_reduce_kernel");
+  }
+  return RDM_OK;
+}
+
+}  // namespace
+
+int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t m,
+                         int64_t n, int64_t k, const float* bias, const float* rowdiv, void* ws, size_t ws_bytes,
+                         double* gn_partial, int* gn_blocks, void* stream) {
+  GemmArgs g;
+  g.A = a; g.B = b; g.C = c; g.bias = bias; g.rowdiv = rowdiv;
+  g.M = static_cast<int>(m); g.N = static_cast<int>(n); g.K = static_cast<int>(k);
+  g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
+  g.sa = g.sb = g.sc = 0;
+  g.act = 0; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
+  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,
                         int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c,
                         int64_t m, int64_t n, int64_t k, int batches, const float* bias,
@@ -244,43 +326,45 @@ extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const flo
   RDM_REQUIRE((reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0,
               "rdm_gemm: A and B must be 16-byte aligned");
   RDM_REQUIRE(act >= 0 && act <= 2, "rdm_gemm: unknown activation %d", act);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   GemmArgs g;
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.rowdiv = rowdiv;
   g.M = static_cast<int>(m); g.N = static_cast<int>(n); g.K = static_cast<int>(k);
   g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
   g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
-  g.act = act; g.splits = 1; g.part = nullptr;
+  g.act = act; g.splits = 1; g.part = nullptr; g.stats = nullptr;
+  return gemm_dispatch(g, batches, trans_b != 0, ws, ws_bytes, nullptr, static_cast<hipStream_t>(stream));
+}
 
-  // tile choice
-  enum { T128, T64, T128x32 } tile;
-  if (n <= 32) tile = T128x32;
-  else if (m >= 2048 && n >= 128) tile = T128;
-  else tile = T64;
-  const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
-  const long long tiles = static_cast<long long>(ceil_div<int64_t>(m, bm)) * ceil_div<int64_t>(n, bn) * batches;
-  const int ktiles = static_cast<int>(ceil_div<int64_t>(k, BK));
-  if (tiles < 256 && ktiles >= 32) {
-    int s = static_cast<int>(ceil_div<long long>(512, tiles));
-    if (s > 16) s = 16;
-    if (s > ktiles / 8) s = ktiles / 8;
-    const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
-    if (s > 1 && ws && ws_bytes >= need) {
-      g.splits = s;
-      g.part = static_cast<float*>(ws);
-    }
+// y = act(GroupNorm(x W + b [/ rowdiv]) [+ residual]): the Linear/KPConv-weight GEMM writes its
+// GroupNorm statistics from its own epilogue, so the normalisation costs one tiny finalize launch and
+// one fused apply pass.  lin_out [m, n] receives the pre-norm activations (scratch for the caller).
+extern "C" size_t rdm_linear_group_norm_workspace_bytes(int64_t m, int64_t n) {
+  return rdm_gemm_workspace_bytes(m, n, 1) + rdm::align_up(static_cast<size_t>(rdm::gemm_stats_max_blocks(m)) * 2 * n * sizeof(double)) +
+         rdm_group_norm_workspace_bytes(m, n) + 1024;
+}
+
+extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                     const float* rowdiv, int64_t m, int64_t n, int64_t k, int groups,
+                                     const float* gamma, const float* beta, float eps, const float* residual,
+                                     int64_t ldr, int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy,
+                                     uint8_t* positive, void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && w && gamma && beta && lin_out && y, "rdm_linear_group_norm: null pointer");
+  RDM_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "rdm_linear_group_norm: K, ldx, ldw must be multiples of 4");
+  if (m == 0) return RDM_OK;
+  Arena ar(ws, ws_bytes);
+  const size_t gemm_ws = rdm_gemm_workspace_bytes(m, n, 1);
+  char* gws = ar.take<char>(gemm_ws);
+  double* partial = ar.take<double>(static_cast<size_t>(gemm_stats_max_blocks(m)) * 2 * n);
+  const size_t gn_ws = rdm_group_norm_workspace_bytes(m, n);
+  char* nws = ar.take<char>(gn_ws);
+  if (!ar.ok) {
+    set_error("rdm_linear_group_norm: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
   }
-  switch (tile) {
-    case T128: launch<128, 128, 2, 2>(g, batches, trans_b != 0, st); break;
-    case T64: launch<64, 64, 2, 2>(g, batches, trans_b != 0, st); break;
-    case T128x32: launch<128, 32, 4, 1>(g, batches, trans_b != 0, st); break;
-  }
-  if (int e = launch_status("gemm_kernel")) return e;
-  if (g.splits > 1) {
-    const long long total = static_cast<long long>(batches) * m * n;
-    const int blocks = static_cast<int>(std::min<long long>(ceil_div<long long>(total, 256), 2048));
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, batches);
-    return launch_status("splitk_reduce_kernel");
-  }
-  return RDM_OK;
+  int nblk = 0;
+  if (int e = gemm_with_stats(x, ldx, w, ldw, lin_out, ld_lin, m, n, k, bias, rowdiv, gws, gemm_ws, partial, &nblk, stream))
+    return e;
+  return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, residual, ldr, act, y, ldy,
+                           positive, nws, gn_ws, stream);
 }

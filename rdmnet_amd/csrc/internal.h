@@ -1,0 +1,24 @@
+// Cross-translation-unit helpers of librdmnet_hip.so (not part of the C-ABI).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace rdm {
+
+// GEMM with an optional GroupNorm-statistics epilogue.  When `gn_partial` is non-null and the GEMM
+// does not run split-K, every block row writes per-column (sum, sum of squares) of ITS output rows to
+// gn_partial[(block_row*2 + {0,1}) * n + col] (fp64) and *gn_blocks receives the number of block rows;
+// otherwise *gn_blocks = 0 and the caller must compute the statistics itself.
+int gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t m,
+                    int64_t n, int64_t k, const float* bias, const float* rowdiv, void* ws, size_t ws_bytes,
+                    double* gn_partial, int* gn_blocks, void* stream);
+
+// Upper bound of block rows gemm_with_stats can produce for m rows.
+inline int64_t gemm_stats_max_blocks(int64_t m) { return (m + 63) / 64 + 1; }
+
+// GroupNorm given (optional) precomputed partials: nblk > 0 uses them, nblk == 0 computes them.
+int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
+                      const float* gamma, const float* beta, float eps, const float* residual, int64_t ldr, int act,
+                      float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
+
+}  // namespace rdm

@@ -10,6 +10,7 @@
 //     (functional.py:6-22, experiments/backbone.py:131-143).
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -227,6 +228,34 @@ extern "C" size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c) {
   return rdm::align_up(nblk * 2 * c * sizeof(double)) + rdm::align_up(2 * c * sizeof(float));
 }
 
+int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx,
+                           int groups, const float* gamma, const float* beta, float eps, const float* residual,
+                           int64_t ldr, int act, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
+                           void* stream) {
+  Arena ar(ws, ws_bytes);
+  const int own_blk = static_cast<int>(ceil_div<int64_t>(n, kGnRowsPerBlock));
+  double* partial = ar.take<double>(static_cast<size_t>(own_blk) * 2 * c);
+  float* ss = ar.take<float>(2 * c);
+  if (!ar.ok) {
+    set_error("rdm_group_norm: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double* use = partial_in;
+  if (nblk <= 0) {
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(own_blk, ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x,
+                       static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), partial);
+    use = partial;
+    nblk = own_blk;
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(256), 0, st, use, nblk,
+                     static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
+                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
+                     static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
+  return launch_status("group_norm kernels");
+}
+
 extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
                               const float* gamma, const float* beta, float eps, const float* residual,
                               int64_t ldr, int act, float* y, int64_t ldy, uint8_t* positive, void* ws,
@@ -236,23 +265,8 @@ extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
   RDM_REQUIRE(n >= 0 && c > 0 && groups > 0 && c % groups == 0 && c <= 4096 && 64 % (c / groups) == 0,
               "rdm_group_norm: bad sizes (n=%lld c=%lld groups=%d)", (long long)n, (long long)c, groups);
   if (n == 0) return RDM_OK;
-  const int nblk = static_cast<int>(ceil_div<int64_t>(n, kGnRowsPerBlock));
-  Arena ar(ws, ws_bytes);
-  double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c);
-  float* ss = ar.take<float>(2 * c);
-  if (!ar.ok) {
-    set_error("rdm_group_norm: workspace too small (%zu < %zu)", ws_bytes, ar.off);
-    return RDM_ERR_WORKSPACE;
-  }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x,
-                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(256), 0, st, partial, nblk,
-                     static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
-                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
-                     static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
-  return launch_status("group_norm kernels");
+  return group_norm_finish(nullptr, 0, x, n, c, ldx, groups, gamma, beta, eps, residual, ldr, act, y, ldy, positive, ws,
+                           ws_bytes, stream);
 }
 
 extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,

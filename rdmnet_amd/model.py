@@ -121,7 +121,9 @@ class RDMNet:
         return ops.group_norm(x, self._w[name + '.norm.weight'], self._w[name + '.norm.bias'],
                               self.cfg.backbone.group_norm, act=act, residual=residual, want_positive=want_positive)
 
-    def _kpconv(self, name, x, x_pos, q, s, idx, sigma, width=None, pool_src=None):
+    def _kpconv(self, name, norm, x, x_pos, q, s, idx, sigma, width=None, pool_src=None):
+        """KPConv + its GroupNorm + LeakyReLU (gather kernel, then the weight GEMM whose epilogue emits the
+        GroupNorm statistics).  `norm` = parameter prefix of the GroupNorm that follows the convolution."""
         b, cin, cout = self._w[name + '.weights']
         prof = getattr(self._tls, 'profile', None)
         if prof is not None:
@@ -130,7 +132,8 @@ class RDMNet:
         wf, nn = ops.kpconv_gather(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, width)
         if prof is not None:
             e1.record()
-        y = ops.gemm(wf, b, b.shape[0], cout, bias=self._w[name + '.bias'], rowdiv=nn)
+        y = ops.linear_group_norm(wf, b, b.shape[0], cout, self._w[name + '.bias'], self._w[norm + '.norm.weight'],
+                                  self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, rowdiv=nn, act=ACT_LEAKY)
         pooled = ops.gather_max(pool_src, idx, width) if pool_src is not None else None
         if prof is not None:
             e2.record()
@@ -144,12 +147,13 @@ class RDMNet:
         return (y, pooled) if pool_src is not None else y
 
     def _unary(self, name, x, act=ACT_LEAKY, residual=None, want_positive=False):
-        return self._gn(name + '.norm', self._linear(name + '.mlp', x), act=act, residual=residual,
-                        want_positive=want_positive)
+        b, bias, in_f, out_f = self._w[name + '.mlp']
+        return ops.linear_group_norm(x, b, pad4(in_f), out_f, bias, self._w[name + '.norm.norm.weight'],
+                                     self._w[name + '.norm.norm.bias'], self.cfg.backbone.group_norm, act=act,
+                                     residual=residual, want_positive=want_positive)
 
     def _conv_block(self, name, x, x_pos, q, s, idx, sigma, width):
-        y = self._kpconv(name + '.KPConv', x, x_pos, q, s, idx, sigma, width)
-        return self._gn(name + '.norm', y, act=ACT_LEAKY)
+        return self._kpconv(name + '.KPConv', name + '.norm', x, x_pos, q, s, idx, sigma, width)
 
     def _residual_block(self, name, x, x_pos, q, s, idx, sigma, strided, width):
         W = self._w
@@ -158,10 +162,9 @@ class RDMNet:
         else:
             y, y_pos = x, (x_pos if x_pos is not None else ops.row_positive(x))
         if strided:
-            y, sc = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width, pool_src=x)
+            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width, pool_src=x)
         else:
-            y, sc = self._kpconv(name + '.KPConv', y, y_pos, q, s, idx, sigma, width), x
-        y = self._gn(name + '.norm_conv', y, act=ACT_LEAKY)
+            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width), x
         if (name + '.unary_shortcut.mlp') in W:
             sc = self._unary(name + '.unary_shortcut', sc, act=ACT_NONE)
         # leaky_relu(unary2(y) + shortcut): the add and the activation ride on unary2's GroupNorm apply

@@ -114,6 +114,23 @@ def group_norm(x, gamma, beta, groups, *, act=ACT_NONE, residual=None, want_posi
     return (y, pos) if want_positive else y
 
 
+def linear_group_norm(x, b, k, n, bias, gamma, beta, groups, *, rowdiv=None, act=ACT_NONE, residual=None,
+                      want_positive=False, eps=1e-5):
+    """act(GroupNorm(x[:, :k] @ b + bias [/ rowdiv]) [+ residual]); statistics from the GEMM epilogue."""
+    L = _lib.lib()
+    m = x.shape[0]
+    lin = feat_empty(m, n, x.device)
+    y = feat_empty(m, n, x.device)
+    pos = torch.empty((max(m, 1),), dtype=torch.uint8, device=x.device) if want_positive else None
+    ws = scratch(x.device, L.rdm_linear_group_norm_workspace_bytes(m, n))
+    _lib.check(L.rdm_linear_group_norm(x.data_ptr(), _ld(x), b.data_ptr(), _ld(b), _lib.ptr(bias), _lib.ptr(rowdiv), m, n, k,
+                                       groups, gamma.data_ptr(), beta.data_ptr(), eps, _lib.ptr(residual),
+                                       _ld(residual) if residual is not None else 0, act, lin.data_ptr(), _ld(lin),
+                                       y.data_ptr(), _ld(y), _lib.ptr(pos), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_linear_group_norm')
+    return (y, pos) if want_positive else y
+
+
 def layer_norm(x, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=None):
     L = _lib.lib()
     n, c = x.shape
