@@ -187,11 +187,15 @@ def main():
                     rre, rte = pose_error(T, pairs[pid][2])
                     rec[slot] = torch.tensor([pid, rre, rte, n_corr])
                     lat_out.append((time.perf_counter() - ts) * 1e3)
+        except BaseException as exc:  # surfaced by run_all (a worker thread must not fail silently)
+            errors.append(exc)
         finally:
             if net is not None:
                 net.set_thread_profile(None)
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+
+    errors = []
 
     def run_all(first, count, rec, lat_out, prof_lists):
         jobs = [[] for _ in streams]
@@ -199,6 +203,8 @@ def main():
             jobs[slot % len(streams)].append((slot, first + slot))
         if len(streams) == 1:
             run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0], engines[0] if engines else None)
+            if errors:
+                raise errors[0]
             return
         threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k],
                                                             engines[k] if engines else None))
@@ -207,6 +213,8 @@ def main():
             t.start()
         for t in threads:
             t.join()
+        if errors:
+            raise errors[0]
 
     run_all(0, args.warmup, None, [], [None] * len(streams))
     lat = []

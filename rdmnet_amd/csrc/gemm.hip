@@ -255,9 +255,11 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
-  // worst case split factor is 16
-  return align_up(static_cast<size_t>(m) * static_cast<size_t>(n) * 16 * sizeof(float) *
-                  static_cast<size_t>(batches > 0 ? batches : 1));
+  // split-K is only chosen while fewer than 256 tiles exist and targets ~512 blocks, so the partials
+  // never exceed (512 + 256) tiles of 128 x 128 floats; tiny problems need at most 16 copies.
+  const size_t by_shape = static_cast<size_t>(m) * static_cast<size_t>(n) * 16;
+  const size_t by_tiles = static_cast<size_t>(768) * 128 * 128;
+  return align_up(std::min(by_shape, by_tiles) * sizeof(float) * static_cast<size_t>(batches > 0 ? batches : 1));
 }
 
 namespace {

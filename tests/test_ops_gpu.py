@@ -125,3 +125,16 @@ def test_pooling_ops_are_exact(ops):
     cp = torch.cat([coarse, torch.zeros(1, 257)])
     assert torch.equal(y.cpu(), torch.cat([cp[idx[:, 0]], skip], 1))
     assert y.stride(0) == 1284 and torch.count_nonzero(torch.as_strided(y, (m, 3), (1284, 1), 1281)) == 0
+
+
+@pytest.mark.parametrize('m,k,n', [(5000, 64, 32), (13795, 128, 256), (700, 1024, 512), (77, 36, 64)])
+def test_linear_group_norm_fused_matches_torch(ops, m, k, n):
+    g = torch.Generator().manual_seed(m + n)
+    x, w, bias = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    gamma, beta, res = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g), torch.randn(m, n, generator=g)
+    rowdiv = torch.randint(1, 5, (m,), generator=g).float()
+    lin = (x.double() @ w.double()) / rowdiv.double()[:, None] + bias.double()
+    ref = F.leaky_relu(F.group_norm(lin.t()[None], 32, gamma.double(), beta.double(), 1e-5)[0].t() + res.double(), 0.1)
+    y = ops.linear_group_norm(padded(x), padded(w), k, n, bias.cuda(), gamma.cuda(), beta.cuda(), 32, rowdiv=rowdiv.cuda(),
+                              act=ops.ACT_LEAKY, residual=padded(res))
+    assert (y.cpu().double() - ref).abs().max().item() <= 5e-5
