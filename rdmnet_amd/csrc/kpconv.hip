@@ -235,16 +235,16 @@ extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(64 * kWaves);
   auto grid = [&](int split) { return dim3(static_cast<unsigned>(ceil_div<int64_t>(m * split, kWaves))); };
-  // Every instance keeps 64 channels (32 for C = 32) per wavefront and fetches the feature rows of up
-  // to 24 neighbour groups (96 neighbours) before the first MFMA: the kernel is bound by dependent
-  // L2/HBM round trips, not by bytes, so memory-level parallelism per wavefront is what pays.
+  // 64 channels (32 for C = 32) per wavefront, four neighbour groups prefetched per trip.  Measured on
+  // MI355X: deeper prefetch (24 groups, 3 waves/SIMD) is SLOWER -- the kernel is bound by 128-B line
+  // fills from L2 (feature row + point + flag per neighbour), not by the dependent-load chain.
   switch (c) {
     case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, 16)), dim3(256), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 24>), grid(1), block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 1, 24>), grid(1), block, 0, st, a); break;
-    case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 24>), grid(2), block, 0, st, a); break;
-    case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 4, 24>), grid(4), block, 0, st, a); break;
-    case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 8, 24>), grid(8), block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 4>), grid(1), block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 1, 4>), grid(1), block, 0, st, a); break;
+    case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 4>), grid(2), block, 0, st, a); break;
+    case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 4, 4>), grid(4), block, 0, st, a); break;
+    case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 4, 2>), grid(4), block, 0, st, a); break;
     default:
       set_error("rdm_kpconv_gather: channel count %lld has no kernel instance", (long long)c);
       return RDM_ERR_ARG;

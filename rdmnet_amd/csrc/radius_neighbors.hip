@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   int64_t begin;
   const int b = cloud_of(q_lengths, batch, qi, begin);
 
-  volatile unsigned long long* K = keys[wave];
+  unsigned long long* K = keys[wave];
   int count = 0;
   if (b < batch) {
     int cx, cy, cz;
@@ -242,17 +242,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // bitonic sort of p2 keys by one wavefront (LDS, lock-step)
+  // bitonic sort of p2 keys by one wavefront: every stage reads all of its pairs, then writes them
+  // (plain LDS accesses batched by the compiler; wavefront-scope fences order the stages)
   for (int k = 2; k <= p2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = lane; i < p2; i += 64) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = K[i], c = K[ixj];
+      unsigned long long lo[8], hi[8];
+      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = 2 * j * (t / j) + (t % j);
+          lo[u] = K[i];
+          hi[u] = K[i + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = 2 * j * (t / j) + (t % j);
           const bool up = (i & k) == 0;
-          if ((a > c) == up) {
-            K[i] = c;
-            K[ixj] = a;
+          if ((lo[u] > hi[u]) == up) {
+            K[i] = hi[u];
+            K[i + j] = lo[u];
           }
         }
       }
