@@ -247,12 +247,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   for (int k = 2; k <= p2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       unsigned long long lo[8], hi[8];
-      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j
+      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j (bit form below)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int t = lane + 64 * u;
         if (t < pairs) {
-          const int i = 2 * j * (t / j) + (t % j);
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
           lo[u] = K[i];
           hi[u] = K[i + j];
         }
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
       for (int u = 0; u < 8; ++u) {
         const int t = lane + 64 * u;
         if (t < pairs) {
-          const int i = 2 * j * (t / j) + (t % j);
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const bool up = (i & k) == 0;
           if ((lo[u] > hi[u]) == up) {
             K[i] = hi[u];
