@@ -156,7 +156,8 @@ template <int CAP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
     const float* q, int64_t nq, int64_t ns, const int64_t* q_lengths, int batch, float radius,
     const GridMeta* meta, const int* cell_count, const int* cell_start, const float4* sorted,
-    int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status) {
+    int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo,
+    int only_redo) {
   __shared__ unsigned long long keys[kWavesPerBlock][CAP];
   __shared__ int seg_start[kWavesPerBlock][28];
   __shared__ int seg_pref[kWavesPerBlock][28];
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
   if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  if (only_redo && !redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
   const GridMeta g = *meta;
   const float r2 = radius * radius;
   const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
@@ -227,12 +229,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
       count += __popcll(m);
     }
   }
-  if (count > CAP) {
-    if (lane == 0) atomicExch(status, 1);
-  }
   if (lane == 0) {
     if (out_counts) out_counts[qi] = count;
-    if (out_max) atomicMax(out_max, count);
+    // one address for all queries: same-address atomics cost ~12 ns each, so only raise it when needed
+    if (out_max && count > ld_agent(out_max)) atomicMax(out_max, count);
+  }
+  if (count > CAP) {  // the sorted prefix cannot be produced from a truncated buffer
+    if (lane == 0) {
+      if (only_redo || !redo) atomicExch(status, 1);
+      else redo[qi] = 1;
+    }
+    if (width > 0 && !only_redo && redo) return;  // the large-buffer pass writes this row
+  } else if (lane == 0 && redo && !only_redo) {
+    redo[qi] = 0;
   }
   if (width <= 0) return;
 
@@ -281,7 +290,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
 }  // namespace
 
 extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch) {
-  (void)n_q;
   (void)batch;
   rdm::Arena a(nullptr, 0);
   const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
@@ -291,6 +299,7 @@ extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s,
   a.take<int>(ns);
   a.take<int>(ns);
   a.take<float4>(ns);
+  a.take<unsigned char>(static_cast<size_t>(n_q > 0 ? n_q : 1));
   return a.off;
 }
 
@@ -317,6 +326,7 @@ extern "C" int rdm_radius_neighbors(const float* q_points, int64_t n_q, const fl
   int* pt_cell = ar.take<int>(ns);
   int* pt_slot = ar.take<int>(ns);
   float4* sorted = ar.take<float4>(ns);
+  unsigned char* redo = ar.take<unsigned char>(static_cast<size_t>(n_q));
   if (!ar.ok) {
     set_error("rdm_radius_neighbors: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
     return RDM_ERR_WORKSPACE;
@@ -333,8 +343,14 @@ extern "C" int rdm_radius_neighbors(const float* q_points, int64_t n_q, const fl
                        pt_slot, cell_start, sorted);
   }
   const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
-  hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
+  // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
+  // neighbours is redone by the large-buffer instance (which exits at once for all other queries)
+  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
                      q_points, n_q, n_s, q_lengths, batch, radius, meta, cell_count, cell_start,
-                     sorted, width, out_idx, out_counts, out_max, status);
+                     sorted, width, out_idx, out_counts, out_max, status, redo, 0);
+  if (width > 0)
+    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
+                       q_points, n_q, n_s, q_lengths, batch, radius, meta, cell_count, cell_start,
+                       sorted, width, out_idx, out_counts, out_max, status, redo, 1);
   return launch_status("rn_query_kernel");
 }
