@@ -9,7 +9,7 @@
 // contraction of KPConv (modules/kpconv/kpconv.py:107-110), transformer projections / FFN, the vote
 // MLP, coarse-matching similarities and the batched patch score einsum (model_infer.py:310-311).
 //
-// Tiling: 256 threads = 4 wavefronts; block tile BM x BN x 16, LDS double-buffered, operands stored
+// Tiling: 256 threads = 4 wavefronts; block tile BM x BN x BK (BK = 16/32/64), LDS double-buffered, operands stored
 // k-major in LDS so a 32x32x2 fragment read is two conflict-free 128-B rows.  Split-K (partials +
 // fixed-order reduce, no atomics => deterministic) keeps the small-M / huge-K coarse levels busy.
 // Requirements: lda, ldb, K multiples of 4 and 16-byte aligned bases (callers pad with zeros).
@@ -44,13 +44,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-constexpr int BK = 16;
-
-template <int BM, int BN, int WM, int WN, bool TRANS_B>
+template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
-  constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+  // transposed-staged tiles use an odd row stride (scalar LDS writes of one k-column hit distinct
+  // banks); the row-major B tile is written as float4 and keeps a 16-byte-aligned stride
+  constexpr int LDA_S = BM + 1, LDB_S = TRANS_B ? BN + 1 : BN + 4;
   __shared__ float As[2][BK][LDA_S];
   __shared__ float Bs[2][BK][LDB_S];
   __shared__ double stat_red[WM][BN][2];
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int per = (ktiles + g.splits - 1) / g.splits;
   const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
 
-  constexpr int A_V = BM / 64;                      // float4 per thread for the A tile
+  constexpr int A_N4 = BM * BK / 4;                 // float4 in the A tile
+  constexpr int A_V = (A_N4 + 255) / 256;           // float4 per thread for the A tile
+  constexpr int KC4 = BK / 4;                       // float4 per tile row
   constexpr int B_N4 = BK * BN / 4;                 // float4 in the B tile
   constexpr int B_V = (B_N4 + 255) / 256;           // float4 per thread for the B tile
   float4 ra[A_V], rb[B_V];
@@ -76,18 +78,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
-      const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, kc = (idx % KC4) * 4;
       const int gm = m0 + row, gk = k0 + kc;
-      ra[i] = (gm < g.M && gk < g.K)
+      ra[i] = (idx < A_N4 && gm < g.M && gk < g.K)
                   ? *reinterpret_cast<const float4*>(A + static_cast<long long>(gm) * g.lda + gk)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (TRANS_B) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
-        const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+        const int idx = tid + i * 256;
+        const int row = idx / KC4, kc = (idx % KC4) * 4;
         const int gn = n0 + row, gk = k0 + kc;
-        rb[i] = (row < BN && gn < g.N && gk < g.K)
+        rb[i] = (idx < B_N4 && gn < g.N && gk < g.K)
                     ? *reinterpret_cast<const float4*>(B + static_cast<long long>(gn) * g.ldb + gk)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
-      const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
+      const int idx = tid + i * 256;
+      const int row = idx / KC4, kc = (idx % KC4) * 4;
+      if (idx >= A_N4) continue;
       As[buf][kc + 0][row] = ra[i].x;
       As[buf][kc + 1][row] = ra[i].y;
       As[buf][kc + 2][row] = ra[i].z;
@@ -123,8 +129,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (TRANS_B) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
-        const int row = (tid >> 2) + i * 64, kc = (tid & 3) * 4;
-        if (row >= BN) continue;
+        const int idx = tid + i * 256;
+        const int row = idx / KC4, kc = (idx % KC4) * 4;
+        if (idx >= B_N4) continue;
         Bs[buf][kc + 0][row] = rb[i].x;
         Bs[buf][kc + 1][row] = rb[i].y;
         Bs[buf][kc + 2][row] = rb[i].z;
@@ -243,13 +250,13 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
   if (trans_b)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true>), grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false>), grid, dim3(256), 0, st, g);
 }
 
 }  // namespace
@@ -272,11 +279,12 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   else tile = T64;
   const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   const long long tiles = ceil_div<long long>(m, bm) * ceil_div<long long>(n, bn) * batches;
-  const int ktiles = static_cast<int>(ceil_div<long long>(k, BK));
-  if (tiles < 256 && ktiles >= 32) {
+  // deterministic split-K for the coarse levels (few tiles, K in the thousands): target ~512 blocks,
+  // at least 128 of K per split
+  if (tiles < 256 && k >= 512) {
     int s = static_cast<int>(ceil_div<long long>(512, tiles));
     if (s > 16) s = 16;
-    if (s > ktiles / 8) s = ktiles / 8;
+    if (s > k / 128) s = static_cast<int>(k / 128);
     const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
     if (s > 1 && ws && ws_bytes >= need) {
       g.splits = s;
@@ -285,10 +293,18 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   }
   if (g.splits > 1) g.stats = nullptr;
   if (stat_blocks) *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm)) : 0;
+  // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
+  // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   switch (tile) {
-    case T128: launch<128, 128, 2, 2>(g, batches, trans_b, st); break;
-    case T64: launch<64, 64, 2, 2>(g, batches, trans_b, st); break;
-    case T128x32: launch<128, 32, 4, 1>(g, batches, trans_b, st); break;
+    case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;
+    case T64:
+      if (k >= 48) launch<64, 64, 2, 2, 64>(g, batches, trans_b, st);
+      else launch<64, 64, 2, 2, 16>(g, batches, trans_b, st);
+      break;
+    case T128x32:
+      if (k >= 32) launch<128, 32, 4, 1, 32>(g, batches, trans_b, st);
+      else launch<128, 32, 4, 1, 16>(g, batches, trans_b, st);
+      break;
   }
   if (int e = launch_status("gemm_kernel")) return e;
   if (g.splits > 1) {
