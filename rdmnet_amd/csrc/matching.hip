@@ -265,15 +265,28 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n
       if ((u & mask_hi) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned acc = 0;
-      int b = nb - 1;
-      for (; b > 0; --b) {
-        if (acc + hist[b] >= need) break;
-        acc += hist[b];
+    // find the bin holding the need-th largest value: wavefront 0 scans from the top, 64 bins per lane
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x, per = nb / 64;  // nb is 4096 or 256
+      const int hi = nb - 1 - lane * per;           // this lane owns bins hi, hi-1, ..., hi-per+1
+      unsigned mine = 0;
+      for (int q = 0; q < per; ++q) mine += hist[hi - q];
+      unsigned incl = mine;                          // inclusive prefix over lanes (higher bins first)
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
       }
-      sh_prefix = prefix | (static_cast<unsigned>(b) << shifts[pass]);
-      sh_need = need - acc;
+      const unsigned before = incl - mine;
+      if (before < need && incl >= need) {           // exactly one lane
+        unsigned acc = before;
+        int b = hi;
+        for (; b > hi - per + 1; --b) {
+          if (acc + hist[b] >= need) break;
+          acc += hist[b];
+        }
+        sh_prefix = prefix | (static_cast<unsigned>(b) << shifts[pass]);
+        sh_need = need - acc;
+      }
     }
     __syncthreads();
     prefix = sh_prefix;

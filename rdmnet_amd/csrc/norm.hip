@@ -52,18 +52,18 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, 
   }
 }
 
-// One block per 64 columns (whole groups: C/groups divides 64): 4 lanes per column add the row-block
+// One block per 64 columns (whole groups: C/groups divides 64): 16 lanes per column add the row-block
 // partials in a fixed order, then scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partial, int nblk, int n,
-                                                           int c, int groups, const float* gamma,
-                                                           const float* beta, float eps, float* scale,
-                                                           float* shift) {
-  __shared__ double sh[2][4][64];
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+                                                            int c, int groups, const float* gamma,
+                                                            const float* beta, float eps, float* scale,
+                                                            float* shift) {
+  __shared__ double sh[2][16][64];
   const int ci = threadIdx.x & 63, lane = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + ci;
   double s = 0.0, ss = 0.0;
   if (col < c)
-    for (int b = lane; b < nblk; b += 4) {
+    for (int b = lane; b < nblk; b += 16) {
       s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + col];
       ss += partial[(static_cast<int64_t>(b) * 2 + 1) * c + col];
     }
@@ -71,8 +71,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partial,
   sh[1][lane][ci] = ss;
   __syncthreads();
   if (lane == 0) {
-    sh[0][0][ci] = ((sh[0][0][ci] + sh[0][1][ci]) + sh[0][2][ci]) + sh[0][3][ci];
-    sh[1][0][ci] = ((sh[1][0][ci] + sh[1][1][ci]) + sh[1][2][ci]) + sh[1][3][ci];
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < 16; ++k) {
+      a += sh[0][k][ci];
+      b += sh[1][k][ci];
+    }
+    sh[0][0][ci] = a;
+    sh[1][0][ci] = b;
   }
   __syncthreads();
   if (lane == 0 && col < c) {
@@ -248,7 +253,7 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     use = partial;
     nblk = own_blk;
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(256), 0, st, use, nblk,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
                      static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
                      static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
