@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=1, help='pairs in flight per GPU (host threads, one HIP stream each)')
+    ap.add_argument('--streams', type=int, default=3, help='pairs in flight per GPU (host threads, one HIP stream each)')
     ap.add_argument('--path', choices=['engine', 'python'], default='engine',
                     help='engine: one native call per pair (rdm_engine_run); python: per-op mirror (rdmnet_amd.model)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
