@@ -265,9 +265,14 @@ def main():
         d['tg'] += tg
         d['n'] += 1
     n_layers = max(len(prof), 1)
+    traffic, traffic_note = None, None
+    pmc_file = os.path.join(ROOT, 'profiles', 'r01_pmc_kpconv_gather.json')
+    if os.path.exists(pmc_file):  # HBM bytes per gather dispatch from the committed rocprofv3 --pmc passes
+        pmc = json.load(open(pmc_file))
+        traffic, traffic_note = pmc['traffic_bytes_per_dispatch'], pmc['kernel'] + '; ' + pmc['source']
     achieved = b_total / t_total / 1e9 if t_total > 0 else 0.0
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': traffic, 'traffic_scope': traffic_note,
                 'kernel': 'KPConv layer = kpconv_gather_kernel + its gemm_kernel (14 layers/pair)',
                 'bytes_per_launch': b_total / n_layers, 'us_per_launch': t_total / n_layers * 1e6,
                 'gather_only': {'kernel': 'kpconv_gather_kernel', 'achieved': b_gather / t_gather / 1e9 if t_gather > 0 else 0.0,
