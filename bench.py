@@ -98,6 +98,17 @@ def cpu_baseline(cache_dir, n_pairs, timeout_s=150):
                 'sample': f'did not finish one pair within {timeout_s} s'}
 
 
+def _no_nan(x):
+    """Strict JSON: NaN/inf -> null."""
+    if isinstance(x, dict):
+        return {k: _no_nan(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_no_nan(v) for v in x]
+    if isinstance(x, float) and not np.isfinite(x):
+        return None
+    return x
+
+
 def pose_error(T_est, T_gt):
     R = T_gt[:3, :3].T @ T_est[:3, :3].astype(np.float64)
     ang = 2.0 * np.arcsin(min(1.0, np.linalg.norm(R - np.eye(3)) / (2.0 * np.sqrt(2.0))))
@@ -300,7 +311,7 @@ def main():
         with open(os.path.join(ROOT, 'gpurun_out', 'bench_layers.json'), 'w') as f:
             json.dump({k: {**v, 'us': v['t'] / v['n'] * 1e6, 'gather_us': v['tg'] / v['n'] * 1e6,
                            'GBps': v['bytes'] * v['n'] / v['t'] / 1e9} for k, v in per_layer.items()}, f, indent=1)
-        print(json.dumps(result))
+        print(json.dumps(_no_nan(result)))
     if dist is not None:
         dist.destroy_process_group()
 

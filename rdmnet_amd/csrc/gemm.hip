@@ -275,7 +275,9 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   const long long m = g.M, n = g.N, k = g.K;
   enum { T128, T64, T128x32 } tile;
   if (n <= 32) tile = T128x32;
-  else if (m >= 2048 && n >= 128) tile = T128;
+  // 128x128 tiles halve the L2->LDS traffic per flop; they pay off for large M, and for the coarse-level
+  // KPConv contractions (M in the hundreds, K in the thousands) where split-K supplies the parallelism
+  else if (n >= 128 && (m >= 2048 || (m >= 256 && k >= 3072))) tile = T128;
   else tile = T64;
   const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   const long long tiles = ceil_div<long long>(m, bm) * ceil_div<long long>(n, bn) * batches;
@@ -296,7 +298,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   switch (tile) {
-    case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;
+    case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;  // 32-deep measured slower (LDS halves residency)
     case T64:
       if (k >= 48) launch<64, 64, 2, 2, 64>(g, batches, trans_b, st);
       else launch<64, 64, 2, 2, 16>(g, batches, trans_b, st);
