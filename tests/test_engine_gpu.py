@@ -63,3 +63,38 @@ def test_engine_matches_oracle_and_is_deterministic(ctx):
     assert rre < 0.05 and rte < 5e-4, (rre, rte)
     r2 = eng.run(torch.from_numpy(rp).cuda(), torch.from_numpy(sp).cuda())
     assert np.array_equal(eng.transform(), T1) and r2.n_correspondences == n1  # run-to-run bit-reproducible
+
+
+def test_full_size_pair_properties(ctx, golden_dir):
+    """BASELINE-size workload (2 x 16k points): the engine equals the per-op mirror bit for bit, the pose
+    is a proper rigid transform, correspondences are points of the fine level, neighbour tables are
+    distance-sorted, and a second run reproduces everything exactly."""
+    cfg, net, eng = ctx['cfg'], ctx['net'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    ref, src = z['ref0'], z['src0']
+    rp, sp = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+    res = eng.run(rp, sp)
+    T = eng.transform()
+    R = T[:3, :3].astype(np.float64)
+    assert np.abs(R.T @ R - np.eye(3)).max() < 1e-5 and abs(np.linalg.det(R) - 1.0) < 1e-5
+    assert np.array_equal(T[3], np.array([0, 0, 0, 1], np.float32))
+    assert res.level_sizes[0] == len(ref) + len(src) and all(res.level_sizes[i] > res.level_sizes[i + 1] for i in range(4))
+    rc, sc, cs = eng.corr()
+    assert rc.shape[0] == res.n_correspondences > 0 and bool((cs > 0).all()) and bool((cs <= 1.0 + 1e-6).all())
+    pts_f = eng.tensor('points1')
+    n_ref_f = int(res.level_sizes[1])  # both clouds stacked; correspondences must be rows of it
+    fine = {tuple(p) for p in pts_f.cpu().numpy().round(6).tolist()}
+    assert all(tuple(p) in fine for p in rc.cpu().numpy().round(6).tolist()[:200])
+    nb, p0 = eng.tensor('neighbors1').cpu(), pts_f.cpu()
+    pad = torch.cat([p0, torch.full((1, 3), 1e6)])
+    d = ((pad[nb] - p0[:, None]) ** 2).sum(-1)
+    valid = nb < p0.shape[0]
+    both = valid[:, 1:] & valid[:, :-1]
+    assert bool((d[:, 1:][both] >= d[:, :-1][both]).all()) and bool((nb[:, 0] == torch.arange(p0.shape[0])).all())
+    # per-op mirror, same inputs
+    out = net(ctx['collate'].collate_pair(ref, src, cfg))
+    assert np.array_equal(T, out['estimated_transform'].cpu().numpy())
+    assert torch.equal(rc, out['ref_corr_points']) and torch.equal(cs, out['corr_scores'])
+    # run-to-run
+    res2 = eng.run(rp, sp)
+    assert np.array_equal(eng.transform(), T) and res2.n_correspondences == rc.shape[0]
