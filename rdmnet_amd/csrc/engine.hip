@@ -249,55 +249,58 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
                            r.st);
 }
 
-int attention_layer(Run& r, const std::string& p, const Mat& x, const Mat& mem, const Mat* emb, Mat& out) {
-  rdm_engine* e = r.e;
-  const int64_t d = x.cols;
-  const int heads = e->cfg.num_heads;
-  Mat q, k, v;
-  if (mem.p == x.p) {
-    Mat qkv;
-    ENG_CHECK(linear(r, p + ".qkv", x, qkv));
-    q = qkv.cols_from(0, d); k = qkv.cols_from(d, d); v = qkv.cols_from(2 * d, d);
-  } else {
-    ENG_CHECK(linear(r, p + ".q", x, q));
-    Mat kv;
-    ENG_CHECK(linear(r, p + ".kv", mem, kv));
-    k = kv.cols_from(0, d); v = kv.cols_from(d, d);
-  }
-  if (emb) ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb->p, emb->ld, q.rows, d, r.st));
-  Mat hid = e->mat(x.rows, d);
-  ENG_ALLOC(hid.p);
-  ENG_CHECK(rdm_attention(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, x.rows, mem.rows, heads, static_cast<int>(d / heads), r.st));
+// Everything of an attention layer after softmax(QK^T)V: output projection, residual LayerNorm, FFN,
+// residual LayerNorm (thdroformer.py:142-173 / vanilla_transformer.py:69-103, output_layer.py:6-21).
+// `out` is a pre-allocated view (rows of the stacked [ref; src] state).
+int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
   Mat h2, y, z1, z2;
   ENG_CHECK(linear(r, p + ".attention.linear", hid, h2));
   ENG_CHECK(layer_norm(r, p + ".attention.norm", h2, &x, 0, y));
   ENG_CHECK(linear(r, p + ".output.expand", y, z1, 1));
   ENG_CHECK(linear(r, p + ".output.squeeze", z1, z2));
-  return layer_norm(r, p + ".output.norm", z2, &y, 0, out);
+  return layer_norm(r, p + ".output.norm", z2, &y, 0, out, false);
 }
 
-int thdroformer(Run& r, const std::string& name, const Mat& ref_p4, const Mat& src_p4, const Mat& ref_x, const Mat& src_x,
-                int num_layers, Mat out_ref, Mat out_src) {
-  Mat e0, e1, f0, f1;
-  ENG_CHECK(linear(r, name + ".embedding.proj", ref_p4, e0));
-  ENG_CHECK(linear(r, name + ".embedding.proj", src_p4, e1));
-  ENG_CHECK(linear(r, name + ".in_proj", ref_x, f0));
-  ENG_CHECK(linear(r, name + ".in_proj", src_x, f1));
+// rdmnet/thdroformer/thdroformer.py:266-347 on the STACKED [ref; src] rows: every op whose weights
+// are shared by both clouds (embedding, in/out projections, and in self layers the q|k|v projection,
+// rotary embedding and the whole tail) runs once on all rows; only the attention itself is per cloud.
+// Cross layers keep the reference's order: src attends to the UPDATED ref features (:244-245).
+int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
+  rdm_engine* e = r.e;
+  const int heads = e->cfg.num_heads;
+  const int64_t N = x.rows, n1 = N - n0;
+  Mat emb, f;
+  ENG_CHECK(linear(r, name + ".embedding.proj", pts4, emb));
+  ENG_CHECK(linear(r, name + ".in_proj", x, f));
+  const int64_t d = f.cols;
+  const int hd = static_cast<int>(d / heads);
   for (int i = 0; i < 2 * num_layers; ++i) {
     const std::string p = name + ".transformer.layers." + std::to_string(i);
-    Mat n0, n1;
+    Mat fnew = e->mat(N, d), hid = e->mat(N, d);
+    ENG_ALLOC(fnew.p); ENG_ALLOC(hid.p);
     if (i % 2 == 0) {
-      ENG_CHECK(attention_layer(r, p, f0, f0, &e0, n0));
-      ENG_CHECK(attention_layer(r, p, f1, f1, &e1, n1));
+      Mat qkv;
+      ENG_CHECK(linear(r, p + ".qkv", f, qkv));
+      Mat q = qkv.cols_from(0, d), k = qkv.cols_from(d, d), v = qkv.cols_from(2 * d, d);
+      ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb.p, emb.ld, N, d, r.st));
+      ENG_CHECK(rdm_attention(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n0, heads, hd, r.st));
+      ENG_CHECK(rdm_attention(q.p + n0 * q.ld, q.ld, k.p + n0 * k.ld, k.ld, v.p + n0 * v.ld, v.ld, hid.p + n0 * hid.ld, hid.ld,
+                              n1, n1, heads, hd, r.st));
+      ENG_CHECK(attention_tail(r, p, hid, f, fnew));
     } else {
-      ENG_CHECK(attention_layer(r, p, f0, f1, nullptr, n0));
-      ENG_CHECK(attention_layer(r, p, f1, n0, nullptr, n1));  // sequential: sees the updated ref features
+      Mat q, kv1, kv0;
+      ENG_CHECK(linear(r, p + ".q", f, q));
+      ENG_CHECK(linear(r, p + ".kv", f.rows_from(n0, n1), kv1));
+      ENG_CHECK(rdm_attention(q.p, q.ld, kv1.p, kv1.ld, kv1.p + d, kv1.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
+      ENG_CHECK(attention_tail(r, p, hid.rows_from(0, n0), f.rows_from(0, n0), fnew.rows_from(0, n0)));
+      ENG_CHECK(linear(r, p + ".kv", fnew.rows_from(0, n0), kv0));
+      ENG_CHECK(rdm_attention(q.p + n0 * q.ld, q.ld, kv0.p, kv0.ld, kv0.p + d, kv0.ld, hid.p + n0 * hid.ld, hid.ld, n1, n0, heads,
+                              hd, r.st));
+      ENG_CHECK(attention_tail(r, p, hid.rows_from(n0, n1), f.rows_from(n0, n1), fnew.rows_from(n0, n1)));
     }
-    f0 = n0;
-    f1 = n1;
+    f = fnew;
   }
-  ENG_CHECK(linear(r, name + ".out_proj", f0, out_ref, 0, false));
-  return linear(r, name + ".out_proj", f1, out_src, 0, false);
+  return linear(r, name + ".out_proj", f, out, 0, false);
 }
 
 // [n,3] -> [n,4] zero padded
@@ -655,9 +658,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   Mat buf_c = e->mat(Nc, D + 1);
   ENG_ALLOC(buf_c.p);
   Mat x_c = buf_c.cols_from(0, D);
-  ENG_CHECK(thdroformer(r, "transformer", pts_c4.rows_from(0, nc_ref), pts_c4.rows_from(nc_ref, Nc - nc_ref),
-                        feats[4].rows_from(0, nc_ref), feats[4].rows_from(nc_ref, Nc - nc_ref), c.num_layers,
-                        x_c.rows_from(0, nc_ref), x_c.rows_from(nc_ref, Nc - nc_ref)));
+  ENG_CHECK(thdroformer(r, "transformer", pts_c4, feats[4], nc_ref, c.num_layers, x_c));
   tap(r, "t1", x_c);
   Mat n2p_logit = buf_c.cols_from(D, 1);
   ENG_CHECK(linear(r, "proj_n2p_score", x_c, n2p_logit, 0, false));
@@ -763,8 +764,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   ENG_CHECK(launch1d("pad_points", pad_points_kernel, Mn, r.st, nodes, Mn, nodes4.p));
   Mat buf2 = e->mat(Mn, D);
   ENG_ALLOC(buf2.p);
-  ENG_CHECK(thdroformer(r, "transformer2", nodes4.rows_from(0, m_r), nodes4.rows_from(m_r, m_s), sel_feats.rows_from(0, m_r),
-                        sel_feats.rows_from(m_r, m_s), c.num_layers2, buf2.rows_from(0, m_r), buf2.rows_from(m_r, m_s)));
+  ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2));
   tap(r, "t2", buf2);
   Mat fn = e->mat(Mn, D);
   ENG_ALLOC(fn.p);

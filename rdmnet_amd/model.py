@@ -201,43 +201,46 @@ class RDMNet:
         return self._linear('decoder.decoder2.mlp', ops.upsample_concat(l3, up[1], feats[1]))
 
     # ------------------------------------------------------------------ 3DRoFormer
-    def _attention_layer(self, p, x, mem, emb, heads):
-        """RPEAttentionLayer / AttentionLayer + AttentionOutput (thdroformer.py:142-202,
-        vanilla_transformer.py:69-129, output_layer.py:6-21)."""
-        W, d = self._w, x.shape[1]
-        if mem is x:  # self attention: one fused q|k|v projection
-            qkv = ops.gemm(x, W[p + '.qkv'][0], d, 3 * d, bias=W[p + '.qkv'][1])
-            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        else:
-            q = ops.gemm(x, W[p + '.q'][0], d, d, bias=W[p + '.q'][1])
-            kv = ops.gemm(mem, W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
-            k, v = kv[:, :d], kv[:, d:]
-        if emb is not None:
-            ops.rope(q, k, emb)
-        hid = ops.attention(q, k, v, heads)
-        hid = self._linear(p + '.attention.linear', hid)
-        y = ops.layer_norm(hid, W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], residual=x)
+    def _attention_tail(self, p, hid, x, out):
+        """Output projection, residual LayerNorm, FFN, residual LayerNorm (thdroformer.py:142-173,
+        vanilla_transformer.py:69-103, output_layer.py:6-21); `out` = rows of the stacked state."""
+        W = self._w
+        h2 = self._linear(p + '.attention.linear', hid)
+        y = ops.layer_norm(h2, W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], residual=x)
         z = self._linear(p + '.output.expand', y, act=ACT_RELU)
         z = self._linear(p + '.output.squeeze', z)
-        return ops.layer_norm(z, W[p + '.output.norm.weight'], W[p + '.output.norm.bias'], residual=y)
+        return ops.layer_norm(z, W[p + '.output.norm.weight'], W[p + '.output.norm.bias'], residual=y, out=out)
 
-    def _thdroformer(self, name, ref_pts4, src_pts4, ref_x, src_x, num_layers, out_ref, out_src):
-        """rdmnet/thdroformer/thdroformer.py:266-347 (+ RPEConditionalTransformer.forward :227-251)."""
-        heads = self.cfg.thdroformer.num_heads
-        e0 = self._linear(name + '.embedding.proj', ref_pts4)
-        e1 = self._linear(name + '.embedding.proj', src_pts4)
-        f0 = self._linear(name + '.in_proj', ref_x)
-        f1 = self._linear(name + '.in_proj', src_x)
+    def _thdroformer(self, name, pts4, x, n0, num_layers, out):
+        """rdmnet/thdroformer/thdroformer.py:266-347 on the STACKED [ref; src] rows (same op sequence as
+        the native engine): shared-weight ops run once on all rows, attention per cloud; cross layers are
+        sequential -- src attends to the UPDATED ref features (:244-245)."""
+        W, heads = self._w, self.cfg.thdroformer.num_heads
+        N = x.shape[0]
+        n1 = N - n0
+        emb = self._linear(name + '.embedding.proj', pts4)
+        f = self._linear(name + '.in_proj', x)
+        d = f.shape[1]
         for i in range(2 * num_layers):
             p = f'{name}.transformer.layers.{i}'
+            fnew, hid = ops.feat_empty(N, d, x.device), ops.feat_empty(N, d, x.device)
             if i % 2 == 0:
-                f0 = self._attention_layer(p, f0, f0, e0, heads)
-                f1 = self._attention_layer(p, f1, f1, e1, heads)
+                qkv = ops.gemm(f, W[p + '.qkv'][0], d, 3 * d, bias=W[p + '.qkv'][1])
+                q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+                ops.rope(q, k, emb)
+                ops.attention(q[:n0], k[:n0], v[:n0], heads, out=hid[:n0])
+                ops.attention(q[n0:], k[n0:], v[n0:], heads, out=hid[n0:])
+                self._attention_tail(p, hid, f, fnew)
             else:
-                f0 = self._attention_layer(p, f0, f1, None, heads)
-                f1 = self._attention_layer(p, f1, f0, None, heads)  # sequential: sees the updated f0
-        self._linear(name + '.out_proj', f0, out=out_ref)
-        self._linear(name + '.out_proj', f1, out=out_src)
+                q = ops.gemm(f, W[p + '.q'][0], d, d, bias=W[p + '.q'][1])
+                kv1 = ops.gemm(f[n0:], W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
+                ops.attention(q[:n0], kv1[:, :d], kv1[:, d:], heads, out=hid[:n0])
+                self._attention_tail(p, hid[:n0], f[:n0], fnew[:n0])
+                kv0 = ops.gemm(fnew[:n0], W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
+                ops.attention(q[n0:], kv0[:, :d], kv0[:, d:], heads, out=hid[n0:])
+                self._attention_tail(p, hid[n0:], f[n0:], fnew[n0:])
+            f = fnew
+        self._linear(name + '.out_proj', f, out=out)
 
     @staticmethod
     def _pts4(pts):
@@ -273,8 +276,7 @@ class RDMNet:
         # transformer #1 -> stacked [ref; src] (256 features + n2p logit in column 256)
         buf_c = ops.feat_empty(N_c, t.output_dim + 1, dev)
         pts_c4 = self._pts4(pts_c)
-        self._thdroformer('transformer', pts_c4[:n_c], pts_c4[n_c:], f_c[:n_c], f_c[n_c:], t.num_layers,
-                          buf_c[:n_c, :t.output_dim], buf_c[n_c:, :t.output_dim])
+        self._thdroformer('transformer', pts_c4, f_c, n_c, t.num_layers, buf_c[:, :t.output_dim])
         x_c = buf_c[:, :t.output_dim]
         taps['t1_ref'], taps['t1_src'] = x_c[:n_c], x_c[n_c:]
         self._linear('proj_n2p_score', x_c, out=buf_c[:, t.output_dim:])
@@ -325,8 +327,7 @@ class RDMNet:
         # transformer #2 on the surviving nodes
         buf2 = ops.feat_empty(m_r + m_s, t.output_dim, dev)
         nodes4 = self._pts4(nodes)
-        self._thdroformer('transformer2', nodes4[:m_r], nodes4[m_r:], sel_feats[:m_r], sel_feats[m_r:],
-                          t.num_layers2, buf2[:m_r], buf2[m_r:])
+        self._thdroformer('transformer2', nodes4, sel_feats, m_r, t.num_layers2, buf2)
         taps['t2_ref'], taps['t2_src'] = buf2[:m_r], buf2[m_r:]
         fn = ops.l2_normalize(buf2)
         rfn, sfn = fn[:m_r], fn[m_r:]

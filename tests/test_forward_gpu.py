@@ -57,7 +57,7 @@ def test_transformer_stage(ctx):
     fc = o['feats_c_enc'].contiguous().cuda()
     buf = ops.feat_empty(pts.shape[0], 256, 'cuda')
     p4 = net._pts4(pts)
-    net._thdroformer('transformer', p4[:n_c], p4[n_c:], fc[:n_c], fc[n_c:], 4, buf[:n_c], buf[n_c:])
+    net._thdroformer('transformer', p4, fc, n_c, 4, buf)
     assert rel_err(buf[:n_c], o['t1_ref']) <= 2e-5 and rel_err(buf[n_c:], o['t1_src']) <= 2e-5
 
 
