@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')  # several pairs in flight per GPU: one hardware queue per stream
+
 import numpy as np
 import torch
 
@@ -118,13 +120,15 @@ def pose_error(T_est, T_gt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=3, help='pairs in flight per GPU (host threads, one HIP stream each)')
     ap.add_argument('--path', choices=['engine', 'python'], default='engine',
                     help='engine: one native call per pair (rdm_engine_run); python: per-op mirror (rdmnet_amd.model)')
+    ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) in production; gloo only to exercise the\n'
+                    'multi-process logic on a single GPU (with RDM_BENCH_SHARE_DEVICE=1)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -132,13 +136,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if os.environ.get('RDM_BENCH_SHARE_DEVICE') == '1':
+        local_rank = 0  # test hook: all ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from rdmnet_amd import collate, config, engine, model, sharding, weights
     cfg = config.make_cfg()
@@ -243,14 +252,15 @@ def main():
     t0 = time.perf_counter()
     run_all(args.warmup, args.steps, records, lat, prof_lists)
     # the path's only collective: one gather of per-pair result records (RCCL)
-    gathered = sharding.gather_records(records.to(dev), world, dist)
+    comm_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')  # gloo gathers CPU tensors
+    gathered = sharding.gather_records(records.to(comm_dev), world, dist)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        lat_t = torch.tensor(lat, dtype=torch.float32, device=dev)
+        lat_t = torch.tensor(lat, dtype=torch.float32, device=comm_dev)
         all_lat = [torch.empty_like(lat_t) for _ in range(world)]
         dist.all_gather(all_lat, lat_t)
         lat = torch.cat(all_lat).cpu().tolist()
