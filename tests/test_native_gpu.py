@@ -100,3 +100,20 @@ def test_synthetic_full_size_properties(ext):
     assert all((c, r) in allp for r, c in fwd)
     # clouds never mix
     assert (cols[rows < l1[0]] < l1[0]).all() and (cols[rows >= l1[0]] >= l1[0]).all()
+
+
+def test_dense_neighbourhoods_use_the_large_buffer_pass(ext, oracle_native):
+    """More than 256 neighbours per query: the second (1024-slot) pass must produce the same rows as the
+    oracle; more than 1024 must be reported, not silently truncated."""
+    o = oracle_native.restatement()
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.0, 1.0, size=(3000, 3)).astype(np.float32)
+    lens = np.array([1800, 1200], dtype=np.int64)
+    for radius in (0.5, 0.8):  # ~120-600 neighbours: rows on both sides of the 256 boundary
+        io = o.radius_neighbors(pts, pts, lens, lens, np.float32(radius))
+        ig = gpu_radius(ext, pts, pts, lens, lens, radius)
+        assert io.shape[1] > 256
+        assert np.array_equal(io, ig), radius
+        assert np.array_equal(gpu_radius(ext, pts, pts, lens, lens, radius, width=70), io[:, :70])
+    with pytest.raises(RuntimeError):
+        gpu_radius(ext, pts, pts, lens, lens, 3.0)  # every point of a cloud is a neighbour (> 1024)
