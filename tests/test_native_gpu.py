@@ -109,7 +109,7 @@ def test_dense_neighbourhoods_use_the_large_buffer_pass(ext, oracle_native):
     rng = np.random.default_rng(7)
     pts = rng.uniform(-1.0, 1.0, size=(3000, 3)).astype(np.float32)
     lens = np.array([1800, 1200], dtype=np.int64)
-    for radius in (0.5, 0.8):  # ~120-600 neighbours: rows on both sides of the 256 boundary
+    for radius in (0.7, 0.9):  # ~100-700 neighbours: rows on both sides of the 256 boundary
         io = o.radius_neighbors(pts, pts, lens, lens, np.float32(radius))
         ig = gpu_radius(ext, pts, pts, lens, lens, radius)
         assert io.shape[1] > 256
