@@ -70,6 +70,17 @@ int rdm_radius_neighbors(const float* q_points, int64_t n_q, const float* s_poin
                          int32_t* out_max, int32_t* status, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* The same search in two steps, so that several query sets share one grid over a support cloud (the
+ * collate searches every level three times with the same radius: self, from the coarser and from the
+ * finer level).  `radius` of a query must not exceed the radius the grid was built with (status = 2). */
+size_t rdm_radius_grid_workspace_bytes(int64_t n_s);
+int rdm_radius_grid_build(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch, float radius,
+                          void* grid_ws, size_t grid_ws_bytes, void* stream);
+int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
+                          const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
+                          int32_t* out_counts, int32_t* out_max, int32_t* status, void* ws, size_t ws_bytes,
+                          void* stream);
+
 /* ---- dense contraction ---------------------------------------------------------------------
  * C[b] = act((A[b] (m x k) * op(B[b])) / rowdiv[row] + bias[col]) in fp32 on the f32 MFMA.
  * trans_b = 0: B is [k, n] row-major (pre-transposed nn.Linear weights, KPConv weights viewed

@@ -23,6 +23,10 @@ SIGNATURES = {
     'rdm_radius_neighbors_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_radius_neighbors': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_int, c_f32, c_int,
                                      c_void, c_void, c_void, c_void, c_void, c_size, c_void]),
+    'rdm_radius_grid_workspace_bytes': (c_size, [c_i64]),
+    'rdm_radius_grid_build': (c_int, [c_void, c_i64, c_void, c_int, c_f32, c_void, c_size, c_void]),
+    'rdm_radius_grid_query': (c_int, [c_void, c_size, c_i64, c_void, c_i64, c_void, c_int, c_f32, c_int, c_void, c_void,
+                                      c_void, c_void, c_void, c_size, c_void]),
     'rdm_gemm_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_gemm': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_i64, c_i64, c_i64, c_i64,
                          c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_void]),

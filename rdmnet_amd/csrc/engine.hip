@@ -574,19 +574,29 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   Table nb[5], sub[4], up[4];
   float radius = c.init_radius;
   int call = 0;
-  auto search = [&](const Level& q, const Level& s, float rad, int limit, Table& t) -> int {
+  // every level is searched three times with the same radius r_i (self, from level i+1, from level
+  // i-1 with 2*r_{i-1} = r_i): one grid per level serves all three (data.py:35-67)
+  struct Grid { void* ws; size_t bytes; int64_t n_s; };
+  auto build_grid = [&](const Level& s, float rad, Grid& g) -> int {
+    g.n_s = s.n;
+    g.bytes = rdm_radius_grid_workspace_bytes(s.n);
+    g.ws = e->alloc<char>(g.bytes);
+    ENG_ALLOC(g.ws);
+    return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
+  };
+  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t) -> int {
     t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
     t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
     ENG_ALLOC(t.idx);
-    return rdm_radius_neighbors(q.pts, q.n, s.pts, s.n, q.lengths, s.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
-                                t.flags + 1, r.ws, r.ws_bytes, r.st);
+    return rdm_radius_grid_query(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
+                                 t.flags + 1, r.ws, r.ws_bytes, r.st);
   };
+  Grid grids[5];
   for (int i = 0; i < 5; ++i) {
-    ENG_CHECK(search(lv[i], lv[i], radius, c.neighbor_limits[i], nb[i]));
-    if (i < 4) {
-      ENG_CHECK(search(lv[i + 1], lv[i], radius, c.neighbor_limits[i], sub[i]));
-      ENG_CHECK(search(lv[i], lv[i + 1], radius * 2.f, c.neighbor_limits[i + 1], up[i]));
-    }
+    ENG_CHECK(build_grid(lv[i], radius, grids[i]));
+    ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i]));
+    if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i]));
+    if (i > 0) ENG_CHECK(search(lv[i - 1], grids[i], radius, c.neighbor_limits[i], up[i - 1]));
     radius *= 2.f;
   }
   for (int i = 0; i < 5; ++i) {
@@ -721,7 +731,9 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   Level nodes_all;
   nodes_all.pts = shifted; nodes_all.n = Nc; nodes_all.lengths = lv[4].lengths; nodes_all.n_ref = nc_ref;
   Table nms_t;
-  ENG_CHECK(search(nodes_all, nodes_all, c.nms_radius, c.neighbor_limits[4], nms_t));
+  Grid nms_grid;
+  ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
+  ENG_CHECK(search(nodes_all, nms_grid, c.nms_radius, c.neighbor_limits[4], nms_t));
   uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);
   ENG_ALLOC(keep);
   ENG_CHECK(rdm_nms(nms_t.idx, Nc, nms_t.width, nms_t.width, nms_t.flags, keep, r.st));
@@ -735,7 +747,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
   for (int i = 0; i < 2 * call; i += 2)
     if (host_flags[i + 1] != 0) {
-      set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours");
+      set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
       return RDM_ERR_CAPACITY;
     }
   const int64_t m_r = host_flags[60], m_s = host_flags[61], Mn = m_r + m_s;

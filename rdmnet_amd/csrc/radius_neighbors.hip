@@ -167,6 +167,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
   if (only_redo && !redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
   const GridMeta g = *meta;
+  if (radius * g.inv_cell > 1.0f) {  // the grid was built for a smaller radius: 27 cells would miss neighbours
+    if (lane == 0) atomicExch(status, 2);
+    return;
+  }
   const float r2 = radius * radius;
   const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
   int64_t begin;
@@ -289,18 +293,97 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
 
 }  // namespace
 
+namespace {
+struct GridViews {
+  GridMeta* meta;
+  int* cell_count;
+  int* cell_start;
+  int* pt_cell;
+  int* pt_slot;
+  float4* sorted;
+};
+bool carve_grid(rdm::Arena& ar, int64_t n_s, GridViews* g) {
+  const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
+  g->meta = ar.take<GridMeta>(1);
+  g->cell_count = ar.take<int>(kMaxCells);
+  g->cell_start = ar.take<int>(kMaxCells);
+  g->pt_cell = ar.take<int>(ns);
+  g->pt_slot = ar.take<int>(ns);
+  g->sorted = ar.take<float4>(ns);
+  return ar.ok;
+}
+}  // namespace
+
+extern "C" size_t rdm_radius_grid_workspace_bytes(int64_t n_s) {
+  rdm::Arena a(nullptr, 0);
+  GridViews g;
+  carve_grid(a, n_s, &g);
+  return a.off;
+}
+
+extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch,
+                                     float radius, void* grid_ws, size_t grid_ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(s_lengths && grid_ws, "rdm_radius_grid_build: null pointer");
+  RDM_REQUIRE(n_s >= 0 && n_s < (1ll << 31) && batch > 0 && batch <= kMaxBatch && radius > 0.f,
+              "rdm_radius_grid_build: bad arguments (n_s=%lld batch=%d)", (long long)n_s, batch);
+  RDM_REQUIRE(n_s == 0 || s_points, "rdm_radius_grid_build: null points");
+  Arena ar(grid_ws, grid_ws_bytes);
+  GridViews g;
+  if (!carve_grid(ar, n_s, &g)) {
+    set_error("rdm_radius_grid_build: workspace too small (%zu < %zu bytes)", grid_ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rn_bbox_kernel, dim3(1), dim3(1024), 0, st, s_points, n_s, radius, batch, g.meta);
+  RDM_HIP_CHECK(hipMemsetAsync(g.cell_count, 0, sizeof(int) * kMaxCells, st));
+  if (n_s > 0) {
+    const int blocks = static_cast<int>(ceil_div<int64_t>(n_s, 256));
+    hipLaunchKernelGGL(rn_count_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, s_lengths, batch, g.meta,
+                       g.cell_count, g.pt_cell, g.pt_slot);
+    hipLaunchKernelGGL(rn_alloc_kernel, dim3(1024), dim3(256), 0, st, g.meta, batch, g.cell_count, g.cell_start);
+    hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, g.pt_cell, g.pt_slot,
+                       g.cell_start, g.sorted);
+  }
+  return launch_status("radius grid build");
+}
+
+extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points,
+                                     int64_t n_q, const int64_t* q_lengths, int batch, float radius, int width,
+                                     int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(grid_ws && q_lengths && status, "rdm_radius_grid_query: null pointer");
+  RDM_REQUIRE(n_q >= 0 && batch > 0 && batch <= kMaxBatch && radius > 0.f, "rdm_radius_grid_query: bad arguments");
+  RDM_REQUIRE(width >= 0 && (width == 0 || out_idx), "rdm_radius_grid_query: width/out_idx mismatch");
+  if (n_q == 0) return RDM_OK;
+  RDM_REQUIRE(q_points, "rdm_radius_grid_query: null points");
+  Arena gar(grid_ws, grid_ws_bytes);
+  GridViews g;
+  RDM_REQUIRE(carve_grid(gar, n_s, &g), "rdm_radius_grid_query: grid workspace size does not match n_s");
+  Arena ar(ws, ws_bytes);
+  unsigned char* redo = ar.take<unsigned char>(static_cast<size_t>(n_q));
+  if (!ar.ok) {
+    set_error("rdm_radius_grid_query: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
+  // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
+  // neighbours is redone by the large-buffer instance (which exits at once for all other queries)
+  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, q_points, n_q, n_s,
+                     q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx, out_counts,
+                     out_max, status, redo, 0);
+  if (width > 0)
+    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, q_points, n_q, n_s,
+                       q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx,
+                       out_counts, out_max, status, redo, 1);
+  return launch_status("rn_query_kernel");
+}
+
 extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch) {
   (void)batch;
-  rdm::Arena a(nullptr, 0);
-  const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
-  a.take<GridMeta>(1);
-  a.take<int>(kMaxCells);
-  a.take<int>(kMaxCells);
-  a.take<int>(ns);
-  a.take<int>(ns);
-  a.take<float4>(ns);
-  a.take<unsigned char>(static_cast<size_t>(n_q > 0 ? n_q : 1));
-  return a.off;
+  return rdm_radius_grid_workspace_bytes(n_s) + rdm::align_up(static_cast<size_t>(n_q > 0 ? n_q : 1));
 }
 
 extern "C" int rdm_radius_neighbors(const float* q_points, int64_t n_q, const float* s_points,
@@ -310,47 +393,15 @@ extern "C" int rdm_radius_neighbors(const float* q_points, int64_t n_q, const fl
                                     size_t ws_bytes, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(q_lengths && s_lengths && status, "rdm_radius_neighbors: null pointer");
-  RDM_REQUIRE(n_q >= 0 && n_s >= 0 && n_s < (1ll << 31) && batch > 0 && batch <= kMaxBatch,
-              "rdm_radius_neighbors: bad sizes (n_q=%lld n_s=%lld batch=%d)", (long long)n_q,
-              (long long)n_s, batch);
   RDM_REQUIRE(width >= 0 && (width == 0 || out_idx), "rdm_radius_neighbors: width/out_idx mismatch");
   RDM_REQUIRE(radius > 0.f, "rdm_radius_neighbors: radius must be positive");
   if (n_q == 0) return RDM_OK;
-  RDM_REQUIRE(q_points && (n_s == 0 || s_points), "rdm_radius_neighbors: null points");
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  Arena ar(ws, ws_bytes);
-  const size_t ns = static_cast<size_t>(n_s > 0 ? n_s : 1);
-  GridMeta* meta = ar.take<GridMeta>(1);
-  int* cell_count = ar.take<int>(kMaxCells);
-  int* cell_start = ar.take<int>(kMaxCells);
-  int* pt_cell = ar.take<int>(ns);
-  int* pt_slot = ar.take<int>(ns);
-  float4* sorted = ar.take<float4>(ns);
-  unsigned char* redo = ar.take<unsigned char>(static_cast<size_t>(n_q));
-  if (!ar.ok) {
-    set_error("rdm_radius_neighbors: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
+  const size_t gbytes = rdm_radius_grid_workspace_bytes(n_s);
+  if (ws == nullptr || ws_bytes < gbytes) {
+    set_error("rdm_radius_neighbors: workspace too small (%zu < %zu bytes)", ws_bytes, gbytes);
     return RDM_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL(rn_bbox_kernel, dim3(1), dim3(1024), 0, st, s_points, n_s, radius, batch, meta);
-  RDM_HIP_CHECK(hipMemsetAsync(cell_count, 0, sizeof(int) * kMaxCells, st));
-  if (n_s > 0) {
-    const int blocks = static_cast<int>(ceil_div<int64_t>(n_s, 256));
-    hipLaunchKernelGGL(rn_count_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, s_lengths,
-                       batch, meta, cell_count, pt_cell, pt_slot);
-    hipLaunchKernelGGL(rn_alloc_kernel, dim3(1024), dim3(256), 0, st, meta, batch, cell_count,
-                       cell_start);
-    hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, pt_cell,
-                       pt_slot, cell_start, sorted);
-  }
-  const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
-  // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
-  // neighbours is redone by the large-buffer instance (which exits at once for all other queries)
-  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
-                     q_points, n_q, n_s, q_lengths, batch, radius, meta, cell_count, cell_start,
-                     sorted, width, out_idx, out_counts, out_max, status, redo, 0);
-  if (width > 0)
-    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st,
-                       q_points, n_q, n_s, q_lengths, batch, radius, meta, cell_count, cell_start,
-                       sorted, width, out_idx, out_counts, out_max, status, redo, 1);
-  return launch_status("rn_query_kernel");
+  if (int e = rdm_radius_grid_build(s_points, n_s, s_lengths, batch, radius, ws, gbytes, stream)) return e;
+  return rdm_radius_grid_query(ws, gbytes, n_s, q_points, n_q, q_lengths, batch, radius, width, out_idx, out_counts, out_max,
+                               status, static_cast<char*>(ws) + gbytes, ws_bytes - gbytes, stream);
 }
