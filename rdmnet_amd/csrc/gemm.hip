@@ -233,6 +233,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
+// one workgroup = ONE 32 x 32 output tile, its four wavefronts split K four ways, operands go straight
+// from global memory to the MFMA registers (each lane reads 16 contiguous k of its A row; B rows are
+// 128-B coalesced), and the four partial tiles are added through LDS in a fixed order.  The dependent
+// MFMA chain per wavefront is K/8 instructions instead of K/2, which is what bounds a 350 x 128 x 128
+// projection, not bandwidth.
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int kq = g.K / 4;                 // this wavefront's K range (multiple of 4)
+  const int kbeg = wave * kq;
+  const int row = min(m0 + li, g.M - 1);
+  const int col = n0 + li;
+  const bool col_ok = col < g.ldb;        // pad columns of B are zero
+  const float* arow = g.A + static_cast<long long>(row) * g.lda;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // chunks of 32 k: lane half lk covers k = kbeg + c + lk*16 + t, t = 0..15
+  for (int c = 0; c < kq; c += 32) {
+    float a[16], b[16];
+    const int kb = kbeg + c + lk * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c + lk * 16 + 4 * q < kq) v = *reinterpret_cast<const float4*>(arow + kb + 4 * q);
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      b[t] = (col_ok && c + lk * 16 + t < kq) ? g.B[static_cast<long long>(kb + t) * g.ldb + col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lk][li] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, rr = e >> 5, cc = e & 31;
+    const int orow = m0 + rr, ocol = n0 + cc;
+    if (orow < g.M && ocol < g.N) {
+      float v = ((red[0][rr][cc] + red[1][rr][cc]) + red[2][rr][cc]) + red[3][rr][cc];
+      if (g.bias) v += g.bias[ocol];
+      g.C[static_cast<long long>(orow) * g.ldc + ocol] = apply_act(v, g.act);
+    }
+  }
+}
+
 __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
   const long long total = static_cast<long long>(batches) * g.M * g.N;
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
@@ -273,6 +324,12 @@ namespace {
 
 int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
   const long long m = g.M, n = g.N, k = g.K;
+  if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && m <= 1536 && k % 16 == 0 && k >= 64 &&
+      m * n <= 1536 * 512) {
+    if (stat_blocks) *stat_blocks = 0;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
+    return launch_status("gemm_small_kernel");
+  }
   enum { T128, T64, T128x32 } tile;
   if (n <= 32) tile = T128x32;
   // 128x128 tiles halve the L2->LDS traffic per flop; they pay off for large M, and for the coarse-level
