@@ -81,6 +81,10 @@ int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, cons
                           int32_t* out_counts, int32_t* out_max, int32_t* status, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* The grid's support records in cell order: n_s x {x, y, z, bit pattern of the int32 row index}.  Rows of
+ * one cell are contiguous, which makes the 4th component a spatially coherent processing order. */
+const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_t n_s);
+
 /* ---- dense contraction ---------------------------------------------------------------------
  * C[b] = act((A[b] (m x k) * op(B[b])) / rowdiv[row] + bias[col]) in fp32 on the f32 MFMA.
  * trans_b = 0: B is [k, n] row-major (pre-transposed nn.Linear weights, KPConv weights viewed
@@ -108,6 +112,14 @@ int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, i
                       const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
                       const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
                       void* stream);
+/* Same, visiting the queries in the order given by `order_records` (m x float4 whose 4th component
+ * holds the query row, e.g. rdm_radius_grid_records of the query level): neighbouring queries share
+ * most of their neighbours, so the gathered lines are re-used from the CU's L1.  Results are identical. */
+int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                              const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                              const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                              const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
+                              const float* order_records, void* stream);
 int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld, uint8_t* out, void* stream);
 
 /* ---- a5: block glue --------------------------------------------------------------------------

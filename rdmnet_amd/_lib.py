@@ -32,6 +32,9 @@ SIGNATURES = {
                          c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_void]),
     'rdm_kpconv_gather': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
+    'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
+                                          c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
+    'rdm_radius_grid_records': (c_void, [c_void, c_size, c_i64]),
     'rdm_row_positive': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void]),
     'rdm_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_group_norm': (c_int, [c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_f32, c_void, c_i64, c_int,

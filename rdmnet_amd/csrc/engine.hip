@@ -191,8 +191,8 @@ struct Table {
 };
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
-           const Table& t, float sigma, const std::string& norm_name, Mat& y, const Mat* pool_src = nullptr,
-           Mat* pool_out = nullptr) {
+           const Table& t, float sigma, const std::string& norm_name, Mat& y, const float* order,
+           const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
   rdm_engine* e = r.e;
   auto it = e->lin.find(name + ".weights");
   if (it == e->lin.end()) {
@@ -208,8 +208,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   const int li = e->prof_layers;
   const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
-  ENG_CHECK(rdm_kpconv_gather(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
-                              vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, r.st));
+  ENG_CHECK(rdm_kpconv_gather_ordered(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
+                                      vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, order, r.st));
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
   Mat conv = e->mat(q.n, W.out);
   ENG_ALLOC(conv.p);
@@ -629,9 +629,13 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
       const Level& q = strided[b] ? lv[lvl + 1] : lv[lvl];
       const Table& t = strided[b] ? sub[lvl] : nb[lvl];
       const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
+      // visit the queries in the cell order of their level's search grid: neighbouring queries share most
+      // neighbours, so gathered lines are re-used from L1 (results do not depend on the order)
+      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];
+      const float* order = rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s);
       Mat y;
       if (b == 0) {
-        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y));
+        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y, order));
       } else {
         Mat h = x;
         uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
@@ -643,8 +647,8 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
         }
         Mat cn;
         Mat sc = x;
-        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, strided[b] ? &x : nullptr,
-                         strided[b] ? &sc : nullptr));
+        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, order,
+                         strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
         if (e->lin.count(name + ".unary_shortcut.mlp")) {
           Mat s2;
           ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));

@@ -36,6 +36,8 @@ struct KpArgs {
   const int64_t* idx;      // [M, ldi]
   const float* kp;         // [15,3]
   const int32_t* width;    // optional device int: effective row width (min(limit, max_count))
+  const float4* order;     // optional processing order: query row = int bits of order[unit].w
+  int units_per_block;     // work units (query x channel slice) per workgroup
   float* wf;               // [M, ldw] (>= 15*C)
   float* nn;               // [M]
   int M, Ns, H, C;
@@ -50,12 +52,33 @@ template <int VEC, int U, int SPLIT, int PF>
 __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = bit pattern of the support row (or -1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int unit = blockIdx.x * kWaves + wave;
-  const int m = unit / SPLIT, slice = unit % SPLIT;
-  if (m >= a.M) return;
+  // Work distribution.  Large levels: a workgroup owns `qpb` consecutive work units (= queries in the
+  // processing order, spatially coherent when `order` is given) and its wavefronts interleave over them,
+  // so lines gathered for one query are still in this CU's L1 for its neighbours; workgroups are
+  // re-mapped so that each XCD (own L2) gets a contiguous range of the level.  Small levels: one unit per
+  // wavefront for parallelism.
+  const int total_units = a.M * SPLIT;
+  const int qpb = a.units_per_block;
+  const int nblk = gridDim.x;
+  int blk = blockIdx.x;
+  if (qpb > kWaves && nblk >= 16) {  // bijective XCD remap (8 XCDs, round-robin dispatch)
+    const int q = nblk / 8, rr = nblk % 8, xcd = blk % 8, within = blk / 8;
+    blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + within;
+  }
+  const int g = lane >> 4, j = lane & 15;
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
+              kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  // hardware sqrt and a reciprocal multiply (1 ulp each) instead of the correctly rounded sqrt/divide:
+  // the kernel is VALU-issue bound (15 influences per neighbour), and float outputs are compared with a
+  // tolerance anyway
+  const float inv_sigma = 1.0f / a.sigma;
+  for (int u0 = wave; u0 < qpb; u0 += kWaves) {
+  const int unit = blk * qpb + u0;
+  if (unit >= total_units) break;
+  const int slice = unit % SPLIT;
+  const int m = a.order ? __float_as_int(a.order[unit / SPLIT].w) : unit / SPLIT;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
-  const int g = lane >> 4, j = lane & 15;
   const int c_base = slice * (16 * VEC * U);  // first channel of this wavefront's slice
 
   // ---- phase 1: neighbour rows, relative positions, positive-row count
@@ -82,8 +105,6 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
-              kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   f32x4 acc[VEC * U];
 #pragma unroll
   for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
         id = __float_as_int(v.w);
         const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
         const float d2 = (dx * dx + dy * dy) + dz * dz;
-        w[p] = fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma);
+        w[p] = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma);
         if (j >= kKP || id < 0) w[p] = 0.f;
       }
       const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + c_base + VEC * j;
@@ -153,19 +174,24 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
     }
   }
   if (lane == 0 && slice == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb[wave] is rewritten by the next unit
+  __builtin_amdgcn_wave_barrier();
+  }  // unit loop
 }
 
 // First layer (C_in = 1, features == 1 for every real point, reference dataset.py:187-188 and
 // model_infer.py:113): WF[m,k] = sum_h w[h,k] * f[idx], no matrix core needed.
 __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(KpArgs a) {
   // 16 lanes per query: lane j < 15 owns kernel point j and walks all neighbours (no reductions)
-  const int m = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
-  if (m >= a.M) return;
+  const int mu = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+  if (mu >= a.M) return;
+  const int m = a.order ? __float_as_int(a.order[mu].w) : mu;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
               kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  const float inv_sigma = 1.0f / a.sigma;
   float acc = 0.f;
   int positives = 0;
   const int64_t* row = a.idx + static_cast<int64_t>(m) * a.ldi;
@@ -177,7 +203,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(KpArgs a) {
     const float dx = (a.s_points[3 * id] - qx) - kx, dy = (a.s_points[3 * id + 1] - qy) - ky,
                 dz = (a.s_points[3 * id + 2] - qz) - kz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
-    acc += fmaxf(0.f, 1.f - __fsqrt_rn(d2) / a.sigma) * f;
+    acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * f;
   }
   float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
   if (j < kKP) out[j] = acc;
@@ -211,11 +237,11 @@ extern "C" int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld
   return launch_status("row_positive_kernel");
 }
 
-extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
-                                 const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
-                                 const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
-                                 const float* kernel_points, float sigma, float* wf, int64_t ldw,
-                                 float* nn, void* stream) {
+extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                         const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                         const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                         const float* kernel_points, float sigma, float* wf, int64_t ldw,
+                                         float* nn, const float* order_records, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
               "rdm_kpconv_gather: null pointer");
@@ -229,12 +255,18 @@ extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* 
   KpArgs a;
   a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive;
   a.idx = idx; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
+  a.order = reinterpret_cast<const float4*>(order_records);
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
   a.ldw = static_cast<int>(ldw); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(64 * kWaves);
-  auto grid = [&](int split) { return dim3(static_cast<unsigned>(ceil_div<int64_t>(m * split, kWaves))); };
+  // one work unit per wavefront.  Measured on MI355X: letting a workgroup own 16 or 64 consecutive
+  // (cell-ordered) queries for L1 re-use does not help (64: too few wavefronts per CU, 16: neutral)
+  auto grid = [&](int split) {
+    a.units_per_block = kWaves;
+    return dim3(static_cast<unsigned>(ceil_div<int64_t>(m * split, a.units_per_block)));
+  };
   // 64 channels (32 for C = 32) per wavefront, four neighbour groups prefetched per trip.  Measured on
   // MI355X: deeper prefetch (24 groups, 3 waves/SIMD) is SLOWER -- the kernel is bound by 128-B line
   // fills from L2 (feature row + point + flag per neighbour), not by the dependent-load chain.
@@ -250,4 +282,13 @@ extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* 
       return RDM_ERR_ARG;
   }
   return launch_status("kpconv_gather_kernel");
+}
+
+extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                 const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                 const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                 const float* kernel_points, float sigma, float* wf, int64_t ldw,
+                                 float* nn, void* stream) {
+  return rdm_kpconv_gather_ordered(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points,
+                                   sigma, wf, ldw, nn, nullptr, stream);
 }

@@ -381,6 +381,13 @@ extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_
   return launch_status("rn_query_kernel");
 }
 
+extern "C" const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_t n_s) {
+  rdm::Arena ar(grid_ws, grid_ws_bytes);
+  GridViews g;
+  if (!carve_grid(ar, n_s, &g)) return nullptr;
+  return reinterpret_cast<const float*>(g.sorted);
+}
+
 extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch) {
   (void)batch;
   return rdm_radius_grid_workspace_bytes(n_s) + rdm::align_up(static_cast<size_t>(n_q > 0 ? n_q : 1));
