@@ -181,35 +181,53 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
 
 // First layer (C_in = 1, features == 1 for every real point, reference dataset.py:187-188 and
 // model_infer.py:113): WF[m,k] = sum_h w[h,k] * f[idx], no matrix core needed.
-__global__ __launch_bounds__(256) void kpconv_gather_c1_kernel(KpArgs a) {
-  // 16 lanes per query: lane j < 15 owns kernel point j and walks all neighbours (no reductions)
-  const int mu = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a) {
+  // one wavefront per query: phase 1 stages (relative position, feature) of every neighbour in LDS with
+  // coalesced index reads; phase 2: lane (g, j) walks neighbours g, g+4, ... for kernel point j
+  __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mu = blockIdx.x * kWaves + wave;
   if (mu >= a.M) return;
   const int m = a.order ? __float_as_int(a.order[mu].w) : mu;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+  int positives = 0;
+  for (int h = lane; h < H; h += 64) {
+    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0 && id < a.Ns) {
+      v.x = a.s_points[3 * id] - qx;
+      v.y = a.s_points[3 * id + 1] - qy;
+      v.z = a.s_points[3 * id + 2] - qz;
+      v.w = a.s_feats[id * a.ldf];
+      positives += a.s_pos[id];
+    }
+    nb[wave][h] = v;
+  }
+  positives = wave_sum_i(positives);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int g = lane >> 4, j = lane & 15;
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
               kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
   float acc = 0.f;
-  int positives = 0;
-  const int64_t* row = a.idx + static_cast<int64_t>(m) * a.ldi;
-  for (int h = 0; h < H; ++h) {
-    const int64_t id = row[h];
-    if (id < 0 || id >= a.Ns) continue;
-    const float f = a.s_feats[id * a.ldf];
-    positives += a.s_pos[id];
-    const float dx = (a.s_points[3 * id] - qx) - kx, dy = (a.s_points[3 * id + 1] - qy) - ky,
-                dz = (a.s_points[3 * id + 2] - qz) - kz;
+  for (int h = g; h < H; h += 4) {
+    const float4 v = nb[wave][h];
+    const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
-    acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * f;
+    acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
   }
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
   float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
-  if (j < kKP) out[j] = acc;
-  else {
-    for (int k = kKP; k < a.ldw; ++k) out[k] = 0.f;
-    a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+  if (g == 0) {
+    if (j < kKP) out[j] = acc;
+    else {
+      for (int k = kKP; k < a.ldw; ++k) out[k] = 0.f;
+      a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
+    }
   }
 }
 
@@ -271,7 +289,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   // MI355X: deeper prefetch (24 groups, 3 waves/SIMD) is SLOWER -- the kernel is bound by 128-B line
   // fills from L2 (feature row + point + flag per neighbour), not by the dependent-load chain.
   switch (c) {
-    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, 16)), dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, kWaves)), block, 0, st, a); break;
     case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 4>), grid(1), block, 0, st, a); break;
     case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 1, 4>), grid(1), block, 0, st, a); break;
     case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 4>), grid(2), block, 0, st, a); break;
