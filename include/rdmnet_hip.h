@@ -85,6 +85,11 @@ int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, cons
  * one cell are contiguous, which makes the 4th component a spatially coherent processing order. */
 const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_t n_s);
 
+/* Calibration of the neighbour limits (geotransformer/utils/data.py:195-220): hist[c] += #{i : counts[i] == c}
+ * for c < hist_n, i.e. the reference's np.bincount(counts, minlength=hist_n)[:hist_n] accumulated over calls.
+ * counts = out_counts of a width-0 (count-only) rdm_radius_neighbors call.  hist_n <= 1024. */
+int rdm_neighbor_histogram(const int32_t* counts, int64_t n, int32_t* hist, int hist_n, void* stream);
+
 /* ---- dense contraction ---------------------------------------------------------------------
  * C[b] = act((A[b] (m x k) * op(B[b])) / rowdiv[row] + bias[col]) in fp32 on the f32 MFMA.
  * trans_b = 0: B is [k, n] row-major (pre-transposed nn.Linear weights, KPConv weights viewed
@@ -166,6 +171,11 @@ int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64
 int rdm_rope(float* q, int64_t ldq, float* k, int64_t ldk, const float* emb, int64_t lde, int64_t n,
              int64_t d_model, void* stream);
 int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                  float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads, int head_dim, void* stream);
+/* Same with Q, K, V and the probabilities rounded to bf16 for the two contractions (bf16 MFMA); logits,
+ * softmax and accumulation in fp32 (BASELINE.json configs[3]: "bf16 attention + fp32 SVD").  Tensors in HBM
+ * stay fp32. */
+int rdm_attention_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                   float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads, int head_dim, void* stream);
 
 /* ---- a8/a9 helpers ------------------------------------------------------------------------------
@@ -259,6 +269,9 @@ typedef struct rdm_engine_config {
   float acceptance_radius;    /* 0.6 m */
   int correspondence_threshold; /* 3 */
   int num_refinement_steps;   /* 5 */
+  int use_vote;               /* 1; 0 = infer.py:119-120 (Mulran): superpoints = un-shifted coarse points with the
+                                 first transformer's features (the reference leaves this case undefined) */
+  int attention_bf16;         /* 0 = fp32 QK^T / PV; 1 = bf16 operands, fp32 softmax + accumulation */
   size_t arena_bytes;         /* 0 = default (3 GiB) */
 } rdm_engine_config;
 
@@ -266,7 +279,8 @@ typedef struct rdm_engine_result {
   float transform[16];        /* estimated_transform, row-major 4x4, src -> ref (host copy) */
   int32_t n_correspondences, n_hypotheses, best_hypothesis;
   int64_t n_ref_nodes, n_src_nodes, n_node_correspondences;
-  int64_t level_sizes[5];
+  int64_t level_sizes[5];        /* stacked [ref; src] points per pyramid level */
+  int64_t level_ref_sizes[5];    /* of which ref */
   const float* ref_corr_points;  /* device, [n_correspondences, 3]; valid until the next run */
   const float* src_corr_points;
   const float* corr_scores;

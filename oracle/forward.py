@@ -156,7 +156,18 @@ def _heads(x, h):
     return x.reshape(x.shape[0], h, -1).transpose(0, 1)  # (n, h*c) -> (h, n, c)
 
 
-def attention_layer(W, p, x, mem, heads, emb=None):
+def dense_attention(q, k, v, bf16=False):
+    """softmax(q k^T / sqrt(d)) v per head ([h, n, d] tensors; thdroformer.py:20-40 with k=None).  bf16=True is
+    BASELINE.json configs[3]: operands of both contractions rounded to bf16, softmax and sums in fp32."""
+    if bf16:
+        q, k, v = (t.bfloat16().float() for t in (q, k, v))
+    scores = torch.softmax(torch.einsum('hnd,hmd->hnm', q, k) / q.shape[-1] ** 0.5, dim=-1)
+    if bf16:
+        scores = scores.bfloat16().float()
+    return torch.matmul(scores, v)
+
+
+def attention_layer(W, p, x, mem, heads, emb=None, bf16=False):
     """RPEAttentionLayer (thdroformer.py:88-173) when emb is given, AttentionLayer
     (modules/transformer/vanilla_transformer.py:15-103) otherwise; then AttentionOutput
     (modules/transformer/output_layer.py:6-21)."""
@@ -167,8 +178,7 @@ def attention_layer(W, p, x, mem, heads, emb=None):
     if emb is not None:
         e = _heads(emb, heads)
         q, k = rotary(q, e), rotary(k, e)
-    scores = torch.softmax(torch.einsum('hnd,hmd->hnm', q, k) / q.shape[-1] ** 0.5, dim=-1)
-    hid = torch.matmul(scores, v).transpose(0, 1).reshape(x.shape[0], -1)
+    hid = dense_attention(q, k, v, bf16).transpose(0, 1).reshape(x.shape[0], -1)
     hid = F.linear(hid, W[p + '.attention.linear.weight'], W[p + '.attention.linear.bias'])
     y = F.layer_norm(hid + x, (x.shape[1],), W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'])
     z = F.linear(F.relu(F.linear(y, W[p + '.output.expand.weight'], W[p + '.output.expand.bias'])),
@@ -176,7 +186,7 @@ def attention_layer(W, p, x, mem, heads, emb=None):
     return F.layer_norm(y + z, (x.shape[1],), W[p + '.output.norm.weight'], W[p + '.output.norm.bias'])
 
 
-def thdroformer(W, name, ref_pts, src_pts, ref_x, src_x, num_layers, heads):
+def thdroformer(W, name, ref_pts, src_pts, ref_x, src_x, num_layers, heads, bf16=False):
     """rdmnet/thdroformer/thdroformer.py:266-347; layer order and the sequential cross update
     follow RPEConditionalTransformer.forward :227-251."""
     e0 = F.linear(ref_pts, W[name + '.embedding.proj.weight'], W[name + '.embedding.proj.bias'])
@@ -186,11 +196,11 @@ def thdroformer(W, name, ref_pts, src_pts, ref_x, src_x, num_layers, heads):
     for i in range(2 * num_layers):
         p = f'{name}.transformer.layers.{i}'
         if i % 2 == 0:
-            f0 = attention_layer(W, p, f0, f0, heads, e0)
-            f1 = attention_layer(W, p, f1, f1, heads, e1)
+            f0 = attention_layer(W, p, f0, f0, heads, e0, bf16=bf16)
+            f1 = attention_layer(W, p, f1, f1, heads, e1, bf16=bf16)
         else:
-            f0 = attention_layer(W, p, f0, f1, heads)
-            f1 = attention_layer(W, p, f1, f0, heads)  # sees the UPDATED f0 (:244-245)
+            f0 = attention_layer(W, p, f0, f1, heads, bf16=bf16)
+            f1 = attention_layer(W, p, f1, f0, heads, bf16=bf16)  # sees the UPDATED f0 (:244-245)
     return (F.linear(f0, W[name + '.out_proj.weight'], W[name + '.out_proj.bias']),
             F.linear(f1, W[name + '.out_proj.weight'], W[name + '.out_proj.bias']))
 
@@ -358,7 +368,7 @@ def lgr(ref_knn, src_knn, ref_mask, src_mask, log_scores, cfg):
 # ----------------------------------------------------------------------------- a17: the forward
 @torch.no_grad()
 def forward(W, cfg, data, taps=None, impl=None):
-    """experiments/model_infer.py:109-354 (inference, vote enabled).  Returns the output dict; `taps`
+    """experiments/model_infer.py:109-354 (inference).  Returns the output dict; `taps`
     (optional dict) receives the stage intermediates used by the teacher-forced tests."""
     taps = taps if taps is not None else {}
     out = {}
@@ -371,8 +381,9 @@ def forward(W, cfg, data, taps=None, impl=None):
 
     feats = encoder(W, cfg, data, taps)
     taps['feats_c_enc'] = feats[-1]
+    bf16 = bool(getattr(t, 'attention_bf16', False))
     rf, sf = thdroformer(W, 'transformer', pts_c[:n_c], pts_c[n_c:], feats[-1][:n_c], feats[-1][n_c:],
-                         t.num_layers, t.num_heads)
+                         t.num_layers, t.num_heads, bf16)
     taps['t1_ref'], taps['t1_src'] = rf, sf
     wn, bn = W['proj_n2p_score.weight'], W['proj_n2p_score.bias']
     r_n2p_logit, s_n2p_logit = F.linear(rf, wn, bn), F.linear(sf, wn, bn)
@@ -384,19 +395,27 @@ def forward(W, cfg, data, taps=None, impl=None):
     feats_f, p2p = dec[:, :-1], dec[:, -1]
     out.update(ref_p2p_scores_c=torch.sigmoid(p2p[:n_f]).clamp(0, 1), src_p2p_scores_c=torch.sigmoid(p2p[n_f:]).clamp(0, 1))
 
-    shifted, vfeats = vote(W, cfg, pts_c, torch.cat([rf, sf], 0))
-    taps['vote_xyz'], taps['vote_feats'] = shifted, vfeats
-    out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:])
-    w2, b2 = W['proj_n2n_score.weight'], W['proj_n2n_score.bias']
-    n2n = torch.sigmoid(F.linear(vfeats, w2, b2).view(-1)).clamp(0, 1)
-    keep, nms_idx = nms(shifted, L[-1], cfg.Vote.NMS_radius, cfg.neighbor_limits[-1], impl)
-    taps['nms_mask'], taps['nms_idx'] = keep, nms_idx
-    rk, sk = keep[:n_c], keep[n_c:]
-    ref_c, src_c = shifted[:n_c][rk], shifted[n_c:][sk]
-    out.update(ref_n2p_scores_c=r_n2p[rk], src_n2p_scores_c=s_n2p[sk], ref_n2n_scores_c=n2n[:n_c][rk],
-               src_n2n_scores_c=n2n[n_c:][sk], ref_points_c=ref_c, src_points_c=src_c)
-    rf2, sf2 = thdroformer(W, 'transformer2', ref_c, src_c, vfeats[:n_c][rk], vfeats[n_c:][sk], t.num_layers2, t.num_heads)
-    taps['t2_ref'], taps['t2_src'] = rf2, sf2
+    if cfg.Vote.model_use_vote and cfg.Vote.inference_use_vote:
+        shifted, vfeats = vote(W, cfg, pts_c, torch.cat([rf, sf], 0))
+        taps['vote_xyz'], taps['vote_feats'] = shifted, vfeats
+        out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:])
+        w2, b2 = W['proj_n2n_score.weight'], W['proj_n2n_score.bias']
+        n2n = torch.sigmoid(F.linear(vfeats, w2, b2).view(-1)).clamp(0, 1)
+        keep, nms_idx = nms(shifted, L[-1], cfg.Vote.NMS_radius, cfg.neighbor_limits[-1], impl)
+        taps['nms_mask'], taps['nms_idx'] = keep, nms_idx
+        rk, sk = keep[:n_c], keep[n_c:]
+        ref_c, src_c = shifted[:n_c][rk], shifted[n_c:][sk]
+        out.update(ref_n2p_scores_c=r_n2p[rk], src_n2p_scores_c=s_n2p[sk], ref_n2n_scores_c=n2n[:n_c][rk],
+                   src_n2n_scores_c=n2n[n_c:][sk], ref_points_c=ref_c, src_points_c=src_c)
+        rf2, sf2 = thdroformer(W, 'transformer2', ref_c, src_c, vfeats[:n_c][rk], vfeats[n_c:][sk], t.num_layers2, t.num_heads,
+                               bf16)
+        taps['t2_ref'], taps['t2_src'] = rf2, sf2
+    else:
+        # infer.py:119-120 switches the vote layer off for Mulran, but model_infer.py:179-246 then never
+        # defines ref_points_c (the reference raises).  Defined here as SURVEY.md §7 hard part 7 does:
+        # superpoints = the un-shifted coarse points, features = the first transformer's output.
+        ref_c, src_c, rf2, sf2 = pts_c[:n_c], pts_c[n_c:], rf, sf
+        out.update(ref_n2p_scores_c=r_n2p, src_n2p_scores_c=s_n2p, ref_points_c=ref_c, src_points_c=src_c)
     rfn, sfn = F.normalize(rf2, p=2, dim=1), F.normalize(sf2, p=2, dim=1)
     out.update(ref_feats_c=rfn, src_feats_c=sfn)
 

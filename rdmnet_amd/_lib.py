@@ -34,6 +34,7 @@ SIGNATURES = {
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
     'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
+    'rdm_neighbor_histogram': (c_int, [c_void, c_i64, c_void, c_int, c_void]),
     'rdm_radius_grid_records': (c_void, [c_void, c_size, c_i64]),
     'rdm_row_positive': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void]),
     'rdm_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
@@ -51,6 +52,8 @@ SIGNATURES = {
     'rdm_gather_rows': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_void]),
     'rdm_rope': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void]),
     'rdm_attention': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
+                              c_void]),
+    'rdm_attention_bf16': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
                               c_void]),
     'rdm_vote_shift': (c_int, [c_void, c_void, c_i64, c_i64, c_f32, c_f32, c_f32, c_void, c_void]),
     'rdm_sigmoid_column': (c_int, [c_void, c_i64, c_i64, c_void, c_void]),

@@ -25,7 +25,8 @@ def make_cfg():
                   p2p_score_threshold=0.1)
     c.coarse_matching = Cfg(num_correspondences=256, dual_normalization=True)
     c.thdroformer = Cfg(input_dim=2048, hidden_dim=128, output_dim=256, num_heads=4, num_layers=4,
-                        input_dim2=256, num_layers2=4, k2=None)
+                        input_dim2=256, num_layers2=4, k2=None,
+                        attention_bf16=False)  # True: BASELINE.json configs[3] (bf16 QK^T / PV, fp32 softmax)
     c.Vote = Cfg(model_use_vote=True, inference_use_vote=True, MAX_TRANSLATE_RANGE=[3.0, 3.0, 3.0],
                  MLPS=[512, 256], NMS_radius=2.4)
     c.fine_matching = Cfg(acceptance_radius=0.6, mutual=False, topk=1, confidence_threshold=0,

@@ -57,6 +57,24 @@ struct AttnArgs {
 
 // One workgroup = 16 queries of one head; its 4 wavefronts split the key tiles (tile % 4 == wave)
 // and merge their online-softmax partials (m, l, O) through LDS at the end.
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+
+// fp32 -> bf16 bits, round to nearest even (inputs are finite)
+__device__ __forceinline__ short to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<short>(u >> 16);
+}
+__device__ __forceinline__ bf16x4_t pack_bf16(float a, float b, float c, float d) {
+  bf16x4_t r;
+  r[0] = to_bf16(a); r[1] = to_bf16(b); r[2] = to_bf16(c); r[3] = to_bf16(d);
+  return r;
+}
+
+// BF16 = false: fp32 operands on the 16x16x4 f32 MFMA.  BF16 = true (configuration "bf16 attention"):
+// Q, K, V and the probabilities are rounded to bf16 in registers and contracted on the 16x16x16 bf16 MFMA;
+// logits, softmax statistics and both accumulators stay fp32.  HBM tensors are fp32 either way.
+template <bool BF16>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   __shared__ float sm[4][16], sl[4][16];
   __shared__ float so[4][16][kHeadDim + 1];
@@ -95,8 +113,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       vv[st] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(ki) * a.ldv + hoff + 2 * x);
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16) {
+      // contraction index = 8*kappa + 4*step + i: lane group kappa holds features 8*kappa .. 8*kappa+7
+      s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16(kf[0], kf[1], kf[2], kf[3]),
+                                                    pack_bf16(qf[0], qf[1], qf[2], qf[3]), s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16(kf[4], kf[5], kf[6], kf[7]),
+                                                    pack_bf16(qf[4], qf[5], qf[6], qf[7]), s, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s, 0, 0, 0);
+      for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s, 0, 0, 0);
+    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -126,10 +152,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       o1[r] *= ar;
     }
     // ---- O += P V : step st uses key 4*kappa + st from lane group kappa, i.e. register st of p
+    if constexpr (BF16) {
+      // lane (x, kappa) of A holds P[query x][keys 4*kappa .. 4*kappa+3] = exactly the registers of p
+      const bf16x4_t pa = pack_bf16(p[0], p[1], p[2], p[3]);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pack_bf16(vv[0].x, vv[1].x, vv[2].x, vv[3].x), o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pack_bf16(vv[0].y, vv[1].y, vv[2].y, vv[3].y), o1, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].x, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].y, o1, 0, 0, 0);
+      for (int st = 0; st < 4; ++st) {
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].x, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(p[st], vv[st].y, o1, 0, 0, 0);
+      }
     }
   }
   // ---- merge the four partial softmaxes
@@ -212,9 +245,9 @@ extern "C" int rdm_rope(float* q, int64_t ldq, float* k, int64_t ldk, const floa
   return launch_status("rope_kernel");
 }
 
-extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
-                             int64_t ldv, float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads,
-                             int head_dim, void* stream) {
+static int attention_launch(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads, int head_dim, bool bf16,
+                            void* stream) {
   using namespace rdm;
   RDM_REQUIRE(q && k && v && out, "rdm_attention: null pointer");
   RDM_REQUIRE(head_dim == kHeadDim, "rdm_attention: head_dim must be %d", kHeadDim);
@@ -227,9 +260,24 @@ extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_
   a.ldq = static_cast<int>(ldq); a.ldk = static_cast<int>(ldk); a.ldv = static_cast<int>(ldv);
   a.ldo = static_cast<int>(ldo);
   a.inv_scale = sqrtf(static_cast<float>(head_dim));
-  hipLaunchKernelGGL(attention_kernel, dim3(ceil_div<int64_t>(n_q, 16), heads), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  const dim3 grid(ceil_div<int64_t>(n_q, 16), heads);
+  if (bf16)
+    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return launch_status("attention_kernel");
+}
+
+extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                             int64_t ldv, float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads,
+                             int head_dim, void* stream) {
+  return attention_launch(q, ldq, k, ldk, v, ldv, out, ldo, n_q, n_k, heads, head_dim, false, stream);
+}
+
+extern "C" int rdm_attention_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
+                                  int64_t ldv, float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads,
+                                  int head_dim, void* stream) {
+  return attention_launch(q, ldq, k, ldk, v, ldv, out, ldo, n_q, n_k, heads, head_dim, true, stream);
 }
 
 extern "C" int rdm_vote_shift(const float* xyz, const float* offsets, int64_t ldo, int64_t n, float lx,

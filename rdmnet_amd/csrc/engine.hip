@@ -274,6 +274,7 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
   ENG_CHECK(linear(r, name + ".in_proj", x, f));
   const int64_t d = f.cols;
   const int hd = static_cast<int>(d / heads);
+  const auto attend = e->cfg.attention_bf16 ? rdm_attention_bf16 : rdm_attention;
   for (int i = 0; i < 2 * num_layers; ++i) {
     const std::string p = name + ".transformer.layers." + std::to_string(i);
     Mat fnew = e->mat(N, d), hid = e->mat(N, d);
@@ -283,18 +284,18 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
       ENG_CHECK(linear(r, p + ".qkv", f, qkv));
       Mat q = qkv.cols_from(0, d), k = qkv.cols_from(d, d), v = qkv.cols_from(2 * d, d);
       ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb.p, emb.ld, N, d, r.st));
-      ENG_CHECK(rdm_attention(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n0, heads, hd, r.st));
-      ENG_CHECK(rdm_attention(q.p + n0 * q.ld, q.ld, k.p + n0 * k.ld, k.ld, v.p + n0 * v.ld, v.ld, hid.p + n0 * hid.ld, hid.ld,
+      ENG_CHECK(attend(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n0, heads, hd, r.st));
+      ENG_CHECK(attend(q.p + n0 * q.ld, q.ld, k.p + n0 * k.ld, k.ld, v.p + n0 * v.ld, v.ld, hid.p + n0 * hid.ld, hid.ld,
                               n1, n1, heads, hd, r.st));
       ENG_CHECK(attention_tail(r, p, hid, f, fnew));
     } else {
       Mat q, kv1, kv0;
       ENG_CHECK(linear(r, p + ".q", f, q));
       ENG_CHECK(linear(r, p + ".kv", f.rows_from(n0, n1), kv1));
-      ENG_CHECK(rdm_attention(q.p, q.ld, kv1.p, kv1.ld, kv1.p + d, kv1.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
+      ENG_CHECK(attend(q.p, q.ld, kv1.p, kv1.ld, kv1.p + d, kv1.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
       ENG_CHECK(attention_tail(r, p, hid.rows_from(0, n0), f.rows_from(0, n0), fnew.rows_from(0, n0)));
       ENG_CHECK(linear(r, p + ".kv", fnew.rows_from(0, n0), kv0));
-      ENG_CHECK(rdm_attention(q.p + n0 * q.ld, q.ld, kv0.p, kv0.ld, kv0.p + d, kv0.ld, hid.p + n0 * hid.ld, hid.ld, n1, n0, heads,
+      ENG_CHECK(attend(q.p + n0 * q.ld, q.ld, kv0.p, kv0.ld, kv0.p + d, kv0.ld, hid.p + n0 * hid.ld, hid.ld, n1, n0, heads,
                               hd, r.st));
       ENG_CHECK(attention_tail(r, p, hid.rows_from(n0, n1), f.rows_from(n0, n1), fnew.rows_from(n0, n1)));
     }
@@ -565,8 +566,10 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
     lv[i].n_ref = host_len[2 * (i - 1)];
     lv[i].n = host_len[2 * (i - 1)] + host_len[2 * (i - 1) + 1];
     res->level_sizes[i] = lv[i].n;
+    res->level_ref_sizes[i] = lv[i].n_ref;
   }
   res->level_sizes[0] = n0;
+  res->level_ref_sizes[0] = n_ref;
 
   int32_t* flags = e->alloc<int32_t>(64);
   ENG_ALLOC(flags);
@@ -708,80 +711,100 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, r.st));
   tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
 
-  // ---------------------------------------------------------------- vote (vote.py:83-117)
-  Mat h = x_c;
-  for (int i = 0; i < c.vote_mlp_layers; ++i) {
-    Mat t1, t2;
-    ENG_CHECK(linear(r, "vote.mlp_modules." + std::to_string(3 * i), h, t1));
-    ENG_CHECK(layer_norm(r, "vote.mlp_modules." + std::to_string(3 * i + 1), t1, nullptr, 1, t2));
-    h = t2;
-  }
-  Mat off;
-  ENG_CHECK(linear(r, "vote.ctr_reg", h, off));
-  float* shifted = e->alloc<float>(3 * (Nc > 0 ? Nc : 1));
-  ENG_ALLOC(shifted);
-  ENG_CHECK(rdm_vote_shift(lv[4].pts, off.p, off.ld, Nc, c.vote_limit[0], c.vote_limit[1], c.vote_limit[2], shifted, r.st));
-  Mat off_f = off.cols_from(3, D), vfeats;
-  ENG_CHECK(layer_norm(r, "vote.out_proj.0", x_c, &off_f, 0, vfeats));
-  tap(r, "vote_xyz", shifted, Nc, 3, 3, 0);
-  tap(r, "vote_feats", vfeats);
-  Mat n2n_logit;
-  ENG_CHECK(linear(r, "proj_n2n_score", vfeats, n2n_logit));
-  float* n2n = e->alloc<float>(Nc);
-  ENG_ALLOC(n2n);
-  ENG_CHECK(rdm_sigmoid_column(n2n_logit.p, n2n_logit.ld, Nc, n2n, r.st));
-
-  // ---------------------------------------------------------------- NMS (vote.py:13-40)
-  Level nodes_all;
-  nodes_all.pts = shifted; nodes_all.n = Nc; nodes_all.lengths = lv[4].lengths; nodes_all.n_ref = nc_ref;
-  Table nms_t;
-  Grid nms_grid;
-  ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
-  ENG_CHECK(search(nodes_all, nms_grid, c.nms_radius, c.neighbor_limits[4], nms_t));
-  uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);
-  ENG_ALLOC(keep);
-  ENG_CHECK(rdm_nms(nms_t.idx, Nc, nms_t.width, nms_t.width, nms_t.flags, keep, r.st));
-  tap(r, "nms_mask", keep, Nc, 1, 1, 2);
-  int32_t* order = e->alloc<int32_t>(Nc > 0 ? Nc : 1);
-  int32_t* kept = flags + 60;  // [2]
-  ENG_ALLOC(order);
-  ENG_CHECK(rdm_compact_indices(keep, 0, nc_ref, order, kept, r.st));
-  ENG_CHECK(rdm_compact_indices(keep, nc_ref, Nc, order + nc_ref, kept + 1, r.st));
-  int32_t host_flags[64];
-  ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
-  for (int i = 0; i < 2 * call; i += 2)
-    if (host_flags[i + 1] != 0) {
-      set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
-      return RDM_ERR_CAPACITY;
+  int64_t m_r = 0, m_s = 0, Mn = 0;
+  float* nodes = nullptr;
+  Mat buf2;
+  if (c.use_vote) {
+    // ---------------------------------------------------------------- vote (vote.py:83-117)
+    Mat h = x_c;
+    for (int i = 0; i < c.vote_mlp_layers; ++i) {
+      Mat t1, t2;
+      ENG_CHECK(linear(r, "vote.mlp_modules." + std::to_string(3 * i), h, t1));
+      ENG_CHECK(layer_norm(r, "vote.mlp_modules." + std::to_string(3 * i + 1), t1, nullptr, 1, t2));
+      h = t2;
     }
-  const int64_t m_r = host_flags[60], m_s = host_flags[61], Mn = m_r + m_s;
-  RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
-  int64_t* sel = e->alloc<int64_t>(Mn);
-  ENG_ALLOC(sel);
-  ENG_CHECK(launch1d("widen", widen_index_kernel, m_r, r.st, order, m_r, sel));
-  ENG_CHECK(launch1d("widen", widen_index_kernel, m_s, r.st, order + nc_ref, m_s, sel + m_r));
-  float* nodes = e->alloc<float>(3 * Mn);
-  ENG_ALLOC(nodes);
-  ENG_CHECK(rdm_gather_rows(shifted, Nc, 3, 3, sel, Mn, nodes, 3, r.st));
-  Mat sel_feats = e->mat(Mn, D);
-  ENG_ALLOC(sel_feats.p);
-  ENG_CHECK(rdm_gather_rows(vfeats.p, Nc, D, vfeats.ld, sel, Mn, sel_feats.p, sel_feats.ld, r.st));
-  float* packed = e->alloc<float>(2 * Nc);
-  float* sel_scores = e->alloc<float>(2 * Mn);
-  ENG_ALLOC(packed); ENG_ALLOC(sel_scores);
-  ENG_CHECK(launch1d("pack2", pack2_kernel, Nc, r.st, n2p, n2n, Nc, packed));
-  ENG_CHECK(rdm_gather_rows(packed, Nc, 2, 2, sel, Mn, sel_scores, 2, r.st));
-  tap(r, "nodes", nodes, Mn, 3, 3, 0);
-  tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
+    Mat off;
+    ENG_CHECK(linear(r, "vote.ctr_reg", h, off));
+    float* shifted = e->alloc<float>(3 * (Nc > 0 ? Nc : 1));
+    ENG_ALLOC(shifted);
+    ENG_CHECK(rdm_vote_shift(lv[4].pts, off.p, off.ld, Nc, c.vote_limit[0], c.vote_limit[1], c.vote_limit[2], shifted, r.st));
+    Mat off_f = off.cols_from(3, D), vfeats;
+    ENG_CHECK(layer_norm(r, "vote.out_proj.0", x_c, &off_f, 0, vfeats));
+    tap(r, "vote_xyz", shifted, Nc, 3, 3, 0);
+    tap(r, "vote_feats", vfeats);
+    Mat n2n_logit;
+    ENG_CHECK(linear(r, "proj_n2n_score", vfeats, n2n_logit));
+    float* n2n = e->alloc<float>(Nc);
+    ENG_ALLOC(n2n);
+    ENG_CHECK(rdm_sigmoid_column(n2n_logit.p, n2n_logit.ld, Nc, n2n, r.st));
 
-  // ---------------------------------------------------------------- transformer #2, normalise
-  Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
-  ENG_ALLOC(nodes4.p);
-  ENG_CHECK(launch1d("pad_points", pad_points_kernel, Mn, r.st, nodes, Mn, nodes4.p));
-  Mat buf2 = e->mat(Mn, D);
-  ENG_ALLOC(buf2.p);
-  ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2));
-  tap(r, "t2", buf2);
+    // ---------------------------------------------------------------- NMS (vote.py:13-40)
+    Level nodes_all;
+    nodes_all.pts = shifted; nodes_all.n = Nc; nodes_all.lengths = lv[4].lengths; nodes_all.n_ref = nc_ref;
+    Table nms_t;
+    Grid nms_grid;
+    ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
+    ENG_CHECK(search(nodes_all, nms_grid, c.nms_radius, c.neighbor_limits[4], nms_t));
+    uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);
+    ENG_ALLOC(keep);
+    ENG_CHECK(rdm_nms(nms_t.idx, Nc, nms_t.width, nms_t.width, nms_t.flags, keep, r.st));
+    tap(r, "nms_mask", keep, Nc, 1, 1, 2);
+    int32_t* order = e->alloc<int32_t>(Nc > 0 ? Nc : 1);
+    int32_t* kept = flags + 60;  // [2]
+    ENG_ALLOC(order);
+    ENG_CHECK(rdm_compact_indices(keep, 0, nc_ref, order, kept, r.st));
+    ENG_CHECK(rdm_compact_indices(keep, nc_ref, Nc, order + nc_ref, kept + 1, r.st));
+    int32_t host_flags[64];
+    ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
+    for (int i = 0; i < 2 * call; i += 2)
+      if (host_flags[i + 1] != 0) {
+        set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
+        return RDM_ERR_CAPACITY;
+      }
+    m_r = host_flags[60]; m_s = host_flags[61]; Mn = m_r + m_s;
+    RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
+    int64_t* sel = e->alloc<int64_t>(Mn);
+    ENG_ALLOC(sel);
+    ENG_CHECK(launch1d("widen", widen_index_kernel, m_r, r.st, order, m_r, sel));
+    ENG_CHECK(launch1d("widen", widen_index_kernel, m_s, r.st, order + nc_ref, m_s, sel + m_r));
+    nodes = e->alloc<float>(3 * Mn);
+    ENG_ALLOC(nodes);
+    ENG_CHECK(rdm_gather_rows(shifted, Nc, 3, 3, sel, Mn, nodes, 3, r.st));
+    Mat sel_feats = e->mat(Mn, D);
+    ENG_ALLOC(sel_feats.p);
+    ENG_CHECK(rdm_gather_rows(vfeats.p, Nc, D, vfeats.ld, sel, Mn, sel_feats.p, sel_feats.ld, r.st));
+    float* packed = e->alloc<float>(2 * Nc);
+    float* sel_scores = e->alloc<float>(2 * Mn);
+    ENG_ALLOC(packed); ENG_ALLOC(sel_scores);
+    ENG_CHECK(launch1d("pack2", pack2_kernel, Nc, r.st, n2p, n2n, Nc, packed));
+    ENG_CHECK(rdm_gather_rows(packed, Nc, 2, 2, sel, Mn, sel_scores, 2, r.st));
+    tap(r, "nodes", nodes, Mn, 3, 3, 0);
+    tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
+
+    // ---------------------------------------------------------------- transformer #2, normalise
+    Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
+    ENG_ALLOC(nodes4.p);
+    ENG_CHECK(launch1d("pad_points", pad_points_kernel, Mn, r.st, nodes, Mn, nodes4.p));
+    buf2 = e->mat(Mn, D);
+    ENG_ALLOC(buf2.p);
+    ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2));
+    tap(r, "t2", buf2);
+  } else {
+    // infer.py:119-120 (Mulran) switches the vote layer off and model_infer.py:179-246 then leaves the
+    // superpoints undefined; defined as the un-shifted coarse points with the first transformer's features
+    int32_t host_flags[64];
+    ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
+    for (int i = 0; i < 2 * call; i += 2)
+      if (host_flags[i + 1] != 0) {
+        set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
+        return RDM_ERR_CAPACITY;
+      }
+    m_r = nc_ref; m_s = Nc - nc_ref; Mn = Nc;
+    RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: a cloud has no superpoints");
+    nodes = const_cast<float*>(lv[4].pts);
+    buf2 = x_c;
+    tap(r, "nodes", nodes, Mn, 3, 3, 0);
+  }
   Mat fn = e->mat(Mn, D);
   ENG_ALLOC(fn.p);
   ENG_CHECK(rdm_l2_normalize(buf2.p, buf2.ld, Mn, D, fn.p, fn.ld, r.st));

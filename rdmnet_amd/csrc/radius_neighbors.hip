@@ -388,6 +388,35 @@ extern "C" const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_by
   return reinterpret_cast<const float*>(g.sorted);
 }
 
+// Histogram of per-query neighbour counts (calibration of the neighbour limits): np.bincount(counts,
+// minlength = hist_n)[:hist_n] accumulated into hist.  Per-block LDS histogram, then one global atomic per
+// non-empty bin, so the many queries with similar counts do not serialise on HBM atomics.
+constexpr int kHistLds = 1024;
+__global__ __launch_bounds__(256) void rn_histogram_kernel(const int32_t* __restrict__ counts, int64_t n,
+                                                            int32_t* __restrict__ hist, int hist_n) {
+  __shared__ int32_t local[kHistLds];
+  for (int i = threadIdx.x; i < kHistLds; i += 256) local[i] = 0;
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t c = counts[i];
+    if (c >= 0 && c < hist_n) atomicAdd(&local[c], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < hist_n; i += 256)
+    if (local[i]) atomicAdd(hist + i, local[i]);
+}
+
+extern "C" int rdm_neighbor_histogram(const int32_t* counts, int64_t n, int32_t* hist, int hist_n, void* stream) {
+  RDM_REQUIRE(n >= 0 && hist_n > 0 && hist_n <= kHistLds, "rdm_neighbor_histogram: hist_n must be in 1..%d", kHistLds);
+  if (n == 0) return 0;
+  RDM_REQUIRE(counts && hist, "rdm_neighbor_histogram: null pointer");
+  const int64_t blocks = std::min<int64_t>(ceil_div<int64_t>(n, 256 * 8), 1024);
+  hipLaunchKernelGGL(rn_histogram_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), counts, n, hist, hist_n);
+  return launch_status("rn_histogram_kernel");
+}
+
 extern "C" size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch) {
   (void)batch;
   return rdm_radius_grid_workspace_bytes(n_s) + rdm::align_up(static_cast<size_t>(n_q > 0 ? n_q : 1));

@@ -16,6 +16,7 @@ class EngineConfig(ctypes.Structure):
                 ('num_correspondences', ctypes.c_int), ('dual_normalization', ctypes.c_int),
                 ('sinkhorn_iterations', ctypes.c_int), ('acceptance_radius', ctypes.c_float),
                 ('correspondence_threshold', ctypes.c_int), ('num_refinement_steps', ctypes.c_int),
+                ('use_vote', ctypes.c_int), ('attention_bf16', ctypes.c_int),
                 ('arena_bytes', ctypes.c_size_t)]
 
 
@@ -23,7 +24,7 @@ class EngineResult(ctypes.Structure):
     _fields_ = [('transform', ctypes.c_float * 16), ('n_correspondences', ctypes.c_int32),
                 ('n_hypotheses', ctypes.c_int32), ('best_hypothesis', ctypes.c_int32),
                 ('n_ref_nodes', ctypes.c_int64), ('n_src_nodes', ctypes.c_int64),
-                ('n_node_correspondences', ctypes.c_int64), ('level_sizes', ctypes.c_int64 * 5),
+                ('n_node_correspondences', ctypes.c_int64), ('level_sizes', ctypes.c_int64 * 5), ('level_ref_sizes', ctypes.c_int64 * 5),
                 ('ref_corr_points', ctypes.c_void_p), ('src_corr_points', ctypes.c_void_p),
                 ('corr_scores', ctypes.c_void_p), ('transform_dev', ctypes.c_void_p), ('arena_used', ctypes.c_size_t)]
 
@@ -57,6 +58,8 @@ def make_config(cfg, arena_bytes=0):
     c.sinkhorn_iterations = cfg.model.num_sinkhorn_iterations
     c.acceptance_radius, c.correspondence_threshold = fm.acceptance_radius, fm.correspondence_threshold
     c.num_refinement_steps = fm.num_refinement_steps
+    c.use_vote = int(bool(cfg.Vote.model_use_vote and cfg.Vote.inference_use_vote))
+    c.attention_bf16 = int(bool(getattr(cfg.thdroformer, 'attention_bf16', False)))
     c.arena_bytes = arena_bytes
     return c
 

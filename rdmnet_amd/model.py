@@ -32,6 +32,7 @@ class RDMNet:
         self._state = None   # name -> numpy float32
         self._w = None       # prepared device tensors
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
+        self.attention_bf16 = bool(getattr(cfg.thdroformer, 'attention_bf16', False))
         self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py)
 
     # ------------------------------------------------------------------ nn.Module-like surface
@@ -228,16 +229,16 @@ class RDMNet:
                 qkv = ops.gemm(f, W[p + '.qkv'][0], d, 3 * d, bias=W[p + '.qkv'][1])
                 q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
                 ops.rope(q, k, emb)
-                ops.attention(q[:n0], k[:n0], v[:n0], heads, out=hid[:n0])
-                ops.attention(q[n0:], k[n0:], v[n0:], heads, out=hid[n0:])
+                ops.attention(q[:n0], k[:n0], v[:n0], heads, out=hid[:n0], bf16=self.attention_bf16)
+                ops.attention(q[n0:], k[n0:], v[n0:], heads, out=hid[n0:], bf16=self.attention_bf16)
                 self._attention_tail(p, hid, f, fnew)
             else:
                 q = ops.gemm(f, W[p + '.q'][0], d, d, bias=W[p + '.q'][1])
                 kv1 = ops.gemm(f[n0:], W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
-                ops.attention(q[:n0], kv1[:, :d], kv1[:, d:], heads, out=hid[:n0])
+                ops.attention(q[:n0], kv1[:, :d], kv1[:, d:], heads, out=hid[:n0], bf16=self.attention_bf16)
                 self._attention_tail(p, hid[:n0], f[:n0], fnew[:n0])
                 kv0 = ops.gemm(fnew[:n0], W[p + '.kv'][0], d, 2 * d, bias=W[p + '.kv'][1])
-                ops.attention(q[n0:], kv0[:, :d], kv0[:, d:], heads, out=hid[n0:])
+                ops.attention(q[n0:], kv0[:, :d], kv0[:, d:], heads, out=hid[n0:], bf16=self.attention_bf16)
                 self._attention_tail(p, hid[n0:], f[n0:], fnew[n0:])
             f = fnew
         self._linear(name + '.out_proj', f, out=out)
@@ -254,9 +255,6 @@ class RDMNet:
     def forward(self, data_dict, taps=None):
         """experiments/model_infer.py:109-354 (inference).  `data_dict` as produced by the collate
         (rdmnet_amd.collate or the reference's), tensors on the GPU."""
-        if not self.use_vote:
-            raise NotImplementedError('inference without the vote layer is undefined in the reference '
-                                      '(model_infer.py:179-246 leaves ref_points_c unset)')
         W, cfg, dev = self._prepare(), self.cfg, self.device
         t = cfg.thdroformer
         taps = taps if taps is not None else {}
@@ -289,46 +287,54 @@ class RDMNet:
         p2p = ops.sigmoid_column(dec[:, cfg.backbone.output_dim:])
         out.update(ref_p2p_scores_c=p2p[:n_f], src_p2p_scores_c=p2p[n_f:])
 
-        # vote layer (rdmnet/vote/vote.py:83-117)
-        h = x_c
-        for i in range(len(cfg.Vote.MLPS)):
-            h = self._linear(f'vote.mlp_modules.{3 * i}', h)
-            h = ops.layer_norm(h, W[f'vote.mlp_modules.{3 * i + 1}.weight'], W[f'vote.mlp_modules.{3 * i + 1}.bias'],
-                               act=ACT_RELU)
-        off = self._linear('vote.ctr_reg', h)
-        shifted = ops.vote_shift(pts_c, off, cfg.Vote.MAX_TRANSLATE_RANGE)
-        vfeats = ops.layer_norm(x_c, W['vote.out_proj.0.weight'], W['vote.out_proj.0.bias'], residual=off[:, 3:])
-        taps['vote_xyz'], taps['vote_feats'] = shifted, vfeats
-        out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:])
-        n2n = ops.sigmoid_column(self._linear('proj_n2n_score', vfeats))
-
-        # NMS (vote.py:13-40): neighbours of the shifted nodes, greedy sweep, order-preserving compaction
         flags = torch.zeros(8, dtype=torch.int32, device=dev)  # [max_count, status, n_ref, n_src, p2n status...]
-        nms_idx = ops.radius_search_device(shifted, shifted, L[-1], L[-1], cfg.Vote.NMS_radius,
-                                           cfg.neighbor_limits[-1], flags)
-        keep = ops.nms(nms_idx, flags)
-        taps['nms_mask'], taps['nms_idx'] = keep, nms_idx
-        order = torch.empty((N_c,), dtype=torch.int32, device=dev)
-        ops.compact_indices(keep, 0, n_c, order, flags[2:])
-        ops.compact_indices(keep, n_c, N_c, order[n_c:], flags[3:])
-        fl = flags.cpu()  # sync: kept-node counts size everything downstream
-        if int(fl[1]) != 0:
-            raise RuntimeError('radius search capacity exceeded in NMS')
-        m_r, m_s = int(fl[2]), int(fl[3])
-        sel = torch.cat([order[:m_r], order[n_c:n_c + m_s]]).to(torch.int64)
-        nodes = ops.gather_rows(shifted, sel)
-        ref_c, src_c = nodes[:m_r], nodes[m_r:]
-        sel_feats = ops.gather_rows(vfeats, sel)
-        scores3 = ops.gather_rows(torch.stack([n2p, n2n], 1), sel)
-        out.update(ref_n2p_scores_c=scores3[:m_r, 0], src_n2p_scores_c=scores3[m_r:, 0],
-                   ref_n2n_scores_c=scores3[:m_r, 1], src_n2n_scores_c=scores3[m_r:, 1],
-                   ref_points_c=ref_c, src_points_c=src_c)
+        if self.use_vote:
+            # vote layer (rdmnet/vote/vote.py:83-117)
+            h = x_c
+            for i in range(len(cfg.Vote.MLPS)):
+                h = self._linear(f'vote.mlp_modules.{3 * i}', h)
+                h = ops.layer_norm(h, W[f'vote.mlp_modules.{3 * i + 1}.weight'], W[f'vote.mlp_modules.{3 * i + 1}.bias'],
+                                   act=ACT_RELU)
+            off = self._linear('vote.ctr_reg', h)
+            shifted = ops.vote_shift(pts_c, off, cfg.Vote.MAX_TRANSLATE_RANGE)
+            vfeats = ops.layer_norm(x_c, W['vote.out_proj.0.weight'], W['vote.out_proj.0.bias'], residual=off[:, 3:])
+            taps['vote_xyz'], taps['vote_feats'] = shifted, vfeats
+            out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:])
+            n2n = ops.sigmoid_column(self._linear('proj_n2n_score', vfeats))
 
-        # transformer #2 on the surviving nodes
-        buf2 = ops.feat_empty(m_r + m_s, t.output_dim, dev)
-        nodes4 = self._pts4(nodes)
-        self._thdroformer('transformer2', nodes4, sel_feats, m_r, t.num_layers2, buf2)
-        taps['t2_ref'], taps['t2_src'] = buf2[:m_r], buf2[m_r:]
+            # NMS (vote.py:13-40): neighbours of the shifted nodes, greedy sweep, order-preserving compaction
+            nms_idx = ops.radius_search_device(shifted, shifted, L[-1], L[-1], cfg.Vote.NMS_radius,
+                                               cfg.neighbor_limits[-1], flags)
+            keep = ops.nms(nms_idx, flags)
+            taps['nms_mask'], taps['nms_idx'] = keep, nms_idx
+            order = torch.empty((N_c,), dtype=torch.int32, device=dev)
+            ops.compact_indices(keep, 0, n_c, order, flags[2:])
+            ops.compact_indices(keep, n_c, N_c, order[n_c:], flags[3:])
+            fl = flags.cpu()  # sync: kept-node counts size everything downstream
+            if int(fl[1]) != 0:
+                raise RuntimeError('radius search capacity exceeded in NMS')
+            m_r, m_s = int(fl[2]), int(fl[3])
+            sel = torch.cat([order[:m_r], order[n_c:n_c + m_s]]).to(torch.int64)
+            nodes = ops.gather_rows(shifted, sel)
+            ref_c, src_c = nodes[:m_r], nodes[m_r:]
+            sel_feats = ops.gather_rows(vfeats, sel)
+            scores3 = ops.gather_rows(torch.stack([n2p, n2n], 1), sel)
+            out.update(ref_n2p_scores_c=scores3[:m_r, 0], src_n2p_scores_c=scores3[m_r:, 0],
+                       ref_n2n_scores_c=scores3[:m_r, 1], src_n2n_scores_c=scores3[m_r:, 1],
+                       ref_points_c=ref_c, src_points_c=src_c)
+
+            # transformer #2 on the surviving nodes
+            buf2 = ops.feat_empty(m_r + m_s, t.output_dim, dev)
+            nodes4 = self._pts4(nodes)
+            self._thdroformer('transformer2', nodes4, sel_feats, m_r, t.num_layers2, buf2)
+            taps['t2_ref'], taps['t2_src'] = buf2[:m_r], buf2[m_r:]
+        else:
+            # infer.py:119-120 (Mulran) disables the vote layer; model_infer.py:179-246 then leaves
+            # ref_points_c undefined.  Defined as: superpoints = un-shifted coarse points, features = first
+            # transformer's output (SURVEY.md §7 hard part 7; same definition in oracle/forward.py).
+            m_r, m_s = n_c, N_c - n_c
+            ref_c, src_c, buf2 = pts_c[:n_c], pts_c[n_c:], x_c
+            out.update(ref_n2p_scores_c=n2p[:n_c], src_n2p_scores_c=n2p[n_c:], ref_points_c=ref_c, src_points_c=src_c)
         fn = ops.l2_normalize(buf2)
         rfn, sfn = fn[:m_r], fn[m_r:]
         out.update(ref_feats_c=rfn, src_feats_c=sfn)

@@ -182,12 +182,13 @@ def rope(q, k, emb):
                           q.shape[0], q.shape[1], _lib.stream_ptr()), 'rdm_rope')
 
 
-def attention(q, k, v, heads, out=None):
+def attention(q, k, v, heads, out=None, bf16=False):
     L = _lib.lib()
     nq, d = q.shape
     if out is None:
         out = feat_empty(nq, d, q.device)
-    _lib.check(L.rdm_attention(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
+    fn = L.rdm_attention_bf16 if bf16 else L.rdm_attention
+    _lib.check(fn(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
                                nq, k.shape[0], heads, d // heads, _lib.stream_ptr()), 'rdm_attention')
     return out
 
