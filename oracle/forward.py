@@ -448,6 +448,23 @@ def forward(W, cfg, data, taps=None, impl=None):
     return out
 
 
+def procrustes_fp64(src, ref, w):
+    """weighted_procrustes (modules/registration/procrustes.py:6-73) in float64 numpy, returning also the
+    singular values of the covariance.  Test-side probe: when the inlier set is (nearly) collinear the
+    covariance is rank-deficient, the reference's fp32 torch.svd result is rounding noise, and a parity
+    bound against it is meaningless; the tests then bound the HIP pose against this fp64 solution."""
+    src, ref, w = (np.asarray(x, np.float64) for x in (src, ref, w))
+    w = w / (w.sum() + 1e-5)
+    cs, cr = (w[:, None] * src).sum(0), (w[:, None] * ref).sum(0)
+    H = ((src - cs) * w[:, None]).T @ (ref - cr)
+    U, S, Vt = np.linalg.svd(H)
+    V = Vt.T
+    R = V @ np.diag([1.0, 1.0, np.sign(np.linalg.det(V @ U.T))]) @ U.T
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, cr - R @ cs
+    return T, S
+
+
 def to_torch(state):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}
 

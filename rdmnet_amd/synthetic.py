@@ -107,3 +107,27 @@ def make_pair(pair_id, target_points=16000, tolerance=500):
     ref = ref[np.random.default_rng(1).permutation(ref.shape[0])]
     src = src[np.random.default_rng(2).permutation(src.shape[0])]
     return ref, src, T
+
+
+def make_low_overlap_pair(pair_id, target_points=16000, tolerance=500, fov_loss_deg=70.0):
+    """BASELINE.json configs[4] (Mulran-shaped): the second scan is taken >= 10 m away under an arbitrary
+    yaw and loses a `fov_loss_deg` azimuth sector of its own field of view (Mulran's Ouster is occluded
+    to the rear).  Irregular neighbourhoods at the sector's edges and far fewer valid patch pairs than the
+    KITTI-shaped `make_pair`.  Returns (ref, src, transform src -> ref)."""
+    rng = np.random.default_rng(7000 + int(pair_id))
+    boxes = _make_scene(rng)
+    fwd, lat = rng.uniform(10, 18), rng.uniform(-2.0, 2.0)
+    yaw = np.deg2rad(rng.uniform(-180, 180))
+    ref = _scan_to_target(boxes, (0.0, 0.0), 0.0, 15000 + pair_id, target_points, tolerance)
+    src = _scan_to_target(boxes, (fwd, lat), yaw, 19000 + pair_id, target_points, tolerance)
+    centre = rng.uniform(-np.pi, np.pi)
+    az = np.arctan2(src[:, 1], src[:, 0])
+    d = np.abs(np.angle(np.exp(1j * (az - centre))))
+    src = src[d > np.deg2rad(fov_loss_deg) / 2]
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    T = np.eye(4)
+    T[:3, :3] = [[c, -s_, 0], [s_, c, 0], [0, 0, 1]]
+    T[:3, 3] = [fwd, lat, 0.0]
+    ref = ref[np.random.default_rng(1).permutation(ref.shape[0])]
+    src = src[np.random.default_rng(2).permutation(src.shape[0])]
+    return ref, src, T

@@ -198,3 +198,59 @@ def test_bf16_attention_engine_equals_per_op_path_and_stays_close_to_fp32(golden
         outs[bf16] = taps['t1_ref'].cpu()
     diff = (outs[True] - outs[False]).abs().max() / outs[False].abs().max()
     assert 1e-6 < diff < 5e-2, float(diff)  # 8 bf16 attention layers vs fp32: percent-level, not bit-equal
+
+
+def test_low_overlap_pair_collate_is_bit_exact_and_pose_matches_oracle(oracle_native):
+    """configs[4]: Mulran-shaped pair (70 deg of the second scan's field of view missing, >= 10 m apart,
+    arbitrary yaw), vote layer off.  Index tensors bit-exact against the oracle's collate; pose and
+    correspondences against the oracle's forward."""
+    from oracle import forward as ofw
+    from rdmnet_amd import collate, config, engine, synthetic, weights
+    cfg = config.make_cfg()
+    cfg.Vote.inference_use_vote = False
+    ref, src, _ = synthetic.make_low_overlap_pair(1, target_points=5000, tolerance=400)
+    assert src.shape[0] < 0.9 * ref.shape[0]
+    odata = ofw.pyramid(np.concatenate([ref, src]), np.array([len(ref), len(src)], np.int64), cfg)
+    data = collate.collate_pair(ref, src, cfg, exact_shapes=True)
+    for key in ('points', 'neighbors', 'subsampling', 'upsampling'):
+        for a, b in zip(data[key], odata[key]):
+            assert torch.equal(a.cpu(), b), key
+    state = weights.synthetic_state_dict(cfg, seed=0)
+    eng = engine.Engine(cfg, state)
+    r1 = eng.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
+    T1, n1 = eng.transform(), r1.n_correspondences
+    r2 = eng.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
+    assert np.array_equal(T1, eng.transform()) and n1 == r2.n_correspondences  # deterministic
+    oout = ofw.forward(ofw.to_torch(state), cfg, odata)
+    # float stages against the oracle; the discrete decisions downstream (top-256 node pairs, per-patch
+    # hypotheses, argmax of inlier counts) amplify 1-ulp feature noise with random weights, so -- as in
+    # test_forward_gpu -- the pose bound is asserted teacher-forced on the oracle's Sinkhorn output.
+    from rdmnet_amd import model, ops
+    net = model.create_model(cfg).cuda()
+    net.load_state_dict(state)
+    out = net(collate.collate_pair(ref, src, cfg))
+    assert np.array_equal(out['estimated_transform'].cpu().numpy(), T1)  # engine == per-op path
+    for k in ('ref_feats_c', 'src_feats_c', 'ref_feats_f', 'src_feats_f'):
+        assert (out[k].cpu() - oout[k]).abs().max() <= 2e-4 * oout[k].abs().max(), k
+    fm = cfg.fine_matching
+    rc, sc, cs, T, counts = ops.lgr(oout['matching_scores'].cuda().contiguous(), oout['ref_node_corr_knn_points'].cuda().contiguous(),
+                                    oout['src_node_corr_knn_points'].cuda().contiguous(),
+                                    oout['ref_node_corr_knn_masks'].cuda().to(torch.uint8).contiguous(),
+                                    oout['src_node_corr_knn_masks'].cuda().to(torch.uint8).contiguous(), fm.acceptance_radius,
+                                    fm.correspondence_threshold, fm.num_refinement_steps)
+    C = int(counts[0])
+    assert C == oout['corr_scores'].shape[0] and torch.equal(rc[:C].cpu(), oout['ref_corr_points'])
+    # Low overlap + random weights leave a handful of inliers, here all but collinear: the covariance of the
+    # final Procrustes is rank-deficient (sigma2/sigma1 ~ 1e-6), so the reference's fp32 torch.svd pose is
+    # rounding noise (0.07 deg away from the float64 solution of the SAME inliers).  The bound that means
+    # something is against that float64 solution; against the oracle only when the problem is conditioned.
+    T_gpu = T.cpu().double().numpy()
+    rcp, scp, w = (oout[k].double().numpy() for k in ('ref_corr_points', 'src_corr_points', 'corr_scores'))
+    res = np.linalg.norm(rcp - (scp @ T_gpu[:3, :3].T + T_gpu[:3, 3]), axis=1)
+    assert np.abs(res - fm.acceptance_radius).min() > 1e-3  # no inlier decision on the edge
+    T64, S = ofw.procrustes_fp64(scp, rcp, w * (res < fm.acceptance_radius))
+    rre, rte = ofw.rre_rte(T_gpu, T64)
+    assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)  # degrees, metres (= 1e-3 cm)
+    if S[1] / S[0] > 1e-3:
+        rre, rte = ofw.rre_rte(T_gpu, oout['estimated_transform'].numpy())
+        assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)
