@@ -1,0 +1,12 @@
+"""python tools/gemm_one.py M K N [reps] -- repeated rdm_gemm launches of one shape (for rocprofv3 --pmc)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rdmnet_amd import ops
+m, k, n = (int(x) for x in sys.argv[1:4])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+a = torch.randn(m, k, device='cuda')
+b = torch.randn(k, (n + 3) // 4 * 4, device='cuda')
+for _ in range(reps):
+    ops.gemm(a, b, k, n)
+torch.cuda.synchronize()
