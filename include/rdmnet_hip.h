@@ -90,6 +90,33 @@ const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_
  * counts = out_counts of a width-0 (count-only) rdm_radius_neighbors call.  hist_n <= 1024. */
 int rdm_neighbor_histogram(const int32_t* counts, int64_t n, int32_t* hist, int hist_n, void* stream);
 
+/* ---- §8f rank 3: raw-scan preprocessing --------------------------------------------------------
+ * Centroid voxel down-sampling of one raw scan: points[n, ld] f32 with `channels` >= 3 leading columns
+ * (x, y, z, then e.g. intensity) -> out[m, ldo], m in *out_count (device int32).  Replaces
+ * preporcess/downsample_pcd_kitti.py:21-36 (Open3D 0.11.2 voxel_down_sample(0.3) on points + colors):
+ * index = floor((p - (min_bound - voxel/2)) / voxel) in float64, per-voxel means accumulated in float64.
+ * Open3D is not part of the reference tree -> parity unpinned; voxels are emitted in first-occurrence
+ * order (Open3D's hash-map order is unspecified).  status (device int32, caller zeroes): 1 = a point is
+ * non-finite or more than 2^21 voxels from the minimum (point skipped).  n < 2^26.                    */
+size_t rdm_voxel_downsample_workspace_bytes(int64_t n);
+int rdm_voxel_downsample(const float* points, int64_t n, int64_t ld, int channels, double voxel, float* out,
+                         int64_t ldo, int32_t* out_count, int32_t* status, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- §8f rank 4: RANSAC pose from correspondences ------------------------------------------------
+ * The reference's second evaluation mode (experiments/infer.py:75-82, eval.py:179-186 ->
+ * geotransformer/utils/open3d.py:173-203: Open3D registration_ransac_based_on_correspondence, point-to-point,
+ * ransac_n 4, 50 000 iterations, 0.3 m).  src_corr/ref_corr: device f32 [n_corr, 3].  Every iteration draws
+ * ransac_n correspondences with replacement (counter-based hash of (seed, iteration, draw)), fits a rigid
+ * transform (float64 Kabsch), scores it on all correspondences (float64); the winner is the iteration with
+ * most inliers, then lowest inlier RMSE, then lowest index; its transform is returned without refit.
+ * Outputs (device): transform f32[16] row-major 4x4 (identity if nothing fits), stats int32[2] =
+ * {winning iteration or -1, its inliers}, inlier_rmse f32[1], optional hyp_inliers int32[num_iterations].
+ * Open3D is not part of the reference tree -> parity unpinned (checked against oracle/preprocess.py).   */
+size_t rdm_ransac_workspace_bytes(int num_iterations);
+int rdm_ransac_correspondences(const float* src_corr, const float* ref_corr, int64_t n_corr, float distance_threshold,
+                               int ransac_n, int num_iterations, uint64_t seed, float* transform, int32_t* stats,
+                               float* inlier_rmse, int32_t* hyp_inliers, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- dense contraction ---------------------------------------------------------------------
  * C[b] = act((A[b] (m x k) * op(B[b])) / rowdiv[row] + bias[col]) in fp32 on the f32 MFMA.
  * trans_b = 0: B is [k, n] row-major (pre-transposed nn.Linear weights, KPConv weights viewed

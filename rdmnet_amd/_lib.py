@@ -34,6 +34,12 @@ SIGNATURES = {
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
     'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
+    'rdm_voxel_downsample_workspace_bytes': (c_size, [c_i64]),
+    'rdm_voxel_downsample': (c_int, [c_void, c_i64, c_i64, c_int, ctypes.c_double, c_void, c_i64, c_void, c_void, c_void,
+                                     c_size, c_void]),
+    'rdm_ransac_workspace_bytes': (c_size, [c_int]),
+    'rdm_ransac_correspondences': (c_int, [c_void, c_void, c_i64, c_f32, c_int, c_int, ctypes.c_uint64, c_void, c_void, c_void,
+                                           c_void, c_void, c_size, c_void]),
     'rdm_neighbor_histogram': (c_int, [c_void, c_i64, c_void, c_int, c_void]),
     'rdm_radius_grid_records': (c_void, [c_void, c_size, c_i64]),
     'rdm_row_positive': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void]),

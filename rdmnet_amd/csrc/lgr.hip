@@ -19,6 +19,7 @@
 // the identity for a zero covariance like torch.svd.  Sums are accumulated in fp64.
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "procrustes.h"
 
 namespace {
 
@@ -162,48 +163,6 @@ __device__ void block_sum_n(double (&v)[N], double* red) {
     for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
     v[k] = t;
   }
-}
-
-// Largest eigenvector of the symmetric 4x4 `a` (cyclic Jacobi, fp64).  q = (w, x, y, z).
-__device__ void horn_quaternion(double a[4][4], double q[4]) {
-  double vmat[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-  for (int sweep = 0; sweep < 24; ++sweep) {
-    double offd = 0.0, diag = 0.0;
-    for (int p = 0; p < 4; ++p) {
-      diag += a[p][p] * a[p][p];
-      for (int r = p + 1; r < 4; ++r) offd += a[p][r] * a[p][r];
-    }
-    if (offd <= 1e-34 * (diag + offd) || offd < 1e-300) break;  // converged to fp64 round-off
-    for (int p = 0; p < 3; ++p)
-      for (int r = p + 1; r < 4; ++r) {
-        if (fabs(a[p][r]) < 1e-300) continue;
-        const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; ++k) {
-          const double akp = a[k][p], akr = a[k][r];
-          a[k][p] = c * akp - s * akr;
-          a[k][r] = s * akp + c * akr;
-        }
-        for (int k = 0; k < 4; ++k) {
-          const double apk = a[p][k], ark = a[r][k];
-          a[p][k] = c * apk - s * ark;
-          a[r][k] = s * apk + c * ark;
-        }
-        for (int k = 0; k < 4; ++k) {
-          const double vkp = vmat[k][p], vkr = vmat[k][r];
-          vmat[k][p] = c * vkp - s * vkr;
-          vmat[k][r] = s * vkp + c * vkr;
-        }
-      }
-  }
-  int best = 0;
-  for (int i = 1; i < 4; ++i)
-    if (a[i][i] > a[best][best]) best = i;
-  double nrm = 0.0;
-  for (int k = 0; k < 4; ++k) nrm += vmat[k][best] * vmat[k][best];
-  nrm = sqrt(nrm);
-  for (int k = 0; k < 4; ++k) q[k] = vmat[k][best] / nrm;
 }
 
 // Weighted rigid fit src -> ref over entries [x0, x1) (procrustes.py:36-73).  Every thread of the

@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import config, dataset as ds_mod, evaluation, sharding, weights
+from . import config, dataset as ds_mod, evaluation, ops, sharding, weights
 from .engine import Engine
 
 
@@ -33,8 +33,8 @@ def load_state(path, cfg, seed=0):
 class Tester:
     """One engine on the current device; `run(stager)` processes this rank's pairs."""
 
-    def __init__(self, cfg, state, output_dir=None, save_npz=True):
-        self.cfg, self.output_dir, self.save_npz = cfg, output_dir, save_npz
+    def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True):
+        self.cfg, self.output_dir, self.save_npz, self.ransac = cfg, output_dir, save_npz, ransac
         self.engine = Engine(cfg, state)
         if save_npz and output_dir:
             self.engine.keep_taps(True)
@@ -70,7 +70,12 @@ class Tester:
         if self.output_dir:
             evaluation.append_pose(self.output_dir, item, T)
             if self.save_npz:
-                evaluation.save_pair_npz(self.output_dir, item, self.output_dict(item['ref_points'].shape[0]))
+                od = self.output_dict(item['ref_points'].shape[0])
+                T_ransac = None
+                if self.ransac:  # infer.py:75-82: distance 0.3, ransac_n 4, 50 000 iterations, on the GPU
+                    T_ransac = ops.ransac_correspondences(od['src_corr_points'].contiguous(), od['ref_corr_points'].contiguous(),
+                                                          0.3, 4, 50000)[0].cpu().numpy().astype(np.float64)
+                evaluation.save_pair_npz(self.output_dir, item, od, estimated_transform_ransac=T_ransac)
         if 'transform' in item:
             rc, sc, cs = self.engine.corr()
             rec.update(self.summary.update((item['seq_id'], item['src_frame'], item['ref_frame']),

@@ -314,3 +314,40 @@ def lgr(log_scores, ref_pts, src_pts, ref_mask, src_mask, radius, min_corr, step
                          cs.data_ptr(), T.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
                'rdm_lgr')
     return rc, sc, cs, T, counts
+
+
+def voxel_downsample(points, voxel):
+    """Raw-scan preprocessing (preporcess/downsample_pcd_kitti.py:21-36): points f32 [N, C>=3] on the GPU ->
+    per-voxel means [M, C] (all columns averaged, e.g. xyz + intensity), voxels in first-occurrence order."""
+    L = _lib.lib()
+    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.stride(1) == 1
+    n, c = points.shape
+    out = torch.empty((max(n, 1), c), dtype=torch.float32, device=points.device)
+    flags = torch.zeros((2,), dtype=torch.int32, device=points.device)  # [count, status]
+    ws = scratch(points.device, L.rdm_voxel_downsample_workspace_bytes(n))
+    _lib.check(L.rdm_voxel_downsample(points.data_ptr(), n, points.stride(0), c, float(voxel), out.data_ptr(), c,
+                                      flags.data_ptr(), flags[1:].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_voxel_downsample')
+    m, status = (int(x) for x in flags.cpu())  # the output size is data dependent: one read-back
+    if status != 0:
+        raise RuntimeError('rdm_voxel_downsample: non-finite point or extent beyond 2^21 voxels')
+    return out[:m]
+
+
+def ransac_correspondences(src_corr, ref_corr, distance_threshold=0.3, ransac_n=4, num_iterations=50000, seed=0,
+                           return_hypotheses=False):
+    """geotransformer/utils/open3d.py:173-203 on the GPU: -> (transform [4,4] f32 device, stats int32[2] device =
+    {winning iteration, inliers}, inlier rmse f32[1] device[, per-iteration inlier counts])."""
+    L = _lib.lib()
+    assert src_corr.is_cuda and src_corr.dtype == torch.float32 and src_corr.is_contiguous() and ref_corr.is_contiguous()
+    dev = src_corr.device
+    T = torch.empty((4, 4), dtype=torch.float32, device=dev)
+    stats = torch.empty((2,), dtype=torch.int32, device=dev)
+    rmse = torch.empty((1,), dtype=torch.float32, device=dev)
+    hyp = torch.empty((num_iterations,), dtype=torch.int32, device=dev) if return_hypotheses else None
+    ws = scratch(dev, L.rdm_ransac_workspace_bytes(num_iterations))
+    _lib.check(L.rdm_ransac_correspondences(src_corr.data_ptr(), ref_corr.data_ptr(), src_corr.shape[0], float(distance_threshold),
+                                            ransac_n, num_iterations, int(seed), T.data_ptr(), stats.data_ptr(), rmse.data_ptr(),
+                                            _lib.ptr(hyp), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_ransac_correspondences')
+    return (T, stats, rmse, hyp) if return_hypotheses else (T, stats, rmse)
