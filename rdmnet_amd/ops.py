@@ -320,12 +320,14 @@ def voxel_downsample(points, voxel):
     """Raw-scan preprocessing (preporcess/downsample_pcd_kitti.py:21-36): points f32 [N, C>=3] on the GPU ->
     per-voxel means [M, C] (all columns averaged, e.g. xyz + intensity), voxels in first-occurrence order."""
     L = _lib.lib()
-    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.stride(1) == 1
+    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2
     n, c = points.shape
+    assert n == 0 or points.stride(1) == 1
+    ld = points.stride(0) if n > 1 else c
     out = torch.empty((max(n, 1), c), dtype=torch.float32, device=points.device)
     flags = torch.zeros((2,), dtype=torch.int32, device=points.device)  # [count, status]
     ws = scratch(points.device, L.rdm_voxel_downsample_workspace_bytes(n))
-    _lib.check(L.rdm_voxel_downsample(points.data_ptr(), n, points.stride(0), c, float(voxel), out.data_ptr(), c,
+    _lib.check(L.rdm_voxel_downsample(points.data_ptr(), n, ld, c, float(voxel), out.data_ptr(), c,
                                       flags.data_ptr(), flags[1:].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
                'rdm_voxel_downsample')
     m, status = (int(x) for x in flags.cpu())  # the output size is data dependent: one read-back

@@ -46,9 +46,15 @@ def test_raw_scan_to_pose_pipeline_runs():
     from rdmnet_amd import config, engine, ops, weights
     cfg = config.make_cfg()
     eng = engine.Engine(cfg, weights.synthetic_state_dict(cfg, seed=0))
-    a = ops.voxel_downsample(torch.from_numpy(raw_scan(10, 120000)).cuda(), 0.3)[:, :3].contiguous()
-    b = ops.voxel_downsample(torch.from_numpy(raw_scan(11, 120000)).cuda(), 0.3)[:, :3].contiguous()
-    assert 10000 < a.shape[0] < 120000
+    def dense_scan(seed):  # ~6 returns per 0.3 m voxel, like a raw 64-beam sweep: 120 k points -> ~20 k voxels
+        base = raw_scan(seed, 20000)
+        rng = np.random.default_rng(seed + 100)
+        pts = np.repeat(base, 6, axis=0)
+        pts[:, :3] += rng.normal(0, 0.04, (pts.shape[0], 3)).astype(np.float32)
+        return pts[rng.permutation(pts.shape[0])]
+    a = ops.voxel_downsample(torch.from_numpy(dense_scan(10)).cuda(), 0.3)[:, :3].contiguous()
+    b = ops.voxel_downsample(torch.from_numpy(dense_scan(11)).cuda(), 0.3)[:, :3].contiguous()
+    assert 15000 < a.shape[0] < 60000
     res = eng.run(a, b)
     assert res.level_sizes[0] == a.shape[0] + b.shape[0] and np.isfinite(eng.transform()).all()
 
