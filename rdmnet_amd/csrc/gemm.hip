@@ -301,6 +301,48 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
   }
 }
 
+// Split-K reduce that also emits the GroupNorm column partials of its 64-row block (same layout, thread
+// mapping and summation order as gn_partial_kernel in norm.hip, whose separate pass it replaces):
+// grid = (row blocks of 64, column chunks of 256); cw = min(N, 256) columns x (256 / cw) row lanes.
+constexpr int kStatRows = 64;
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, double* stats) {
+  __shared__ double red[2][256];
+  const int r0 = blockIdx.x * kStatRows;
+  const int r1 = min(g.M, r0 + kStatRows);
+  const int cw = g.N < 256 ? g.N : 256;
+  const int lanes = 256 / cw;
+  const int col_in = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int col = blockIdx.y * 256 + col_in;
+  double s = 0.0, ss = 0.0;
+  if (rl < lanes && col < g.N) {
+    const float bv = g.bias ? g.bias[col] : 0.f;
+    const long long plane = static_cast<long long>(g.M) * g.N;
+    for (int r = r0 + rl; r < r1; r += lanes) {
+      const float* p = g.part + static_cast<long long>(r) * g.N + col;
+      float v = 0.f;
+      for (int k = 0; k < g.splits; ++k) v += p[k * plane];  // fixed order
+      if (g.rowdiv) v = v / g.rowdiv[r];
+      v = apply_act(v + bv, g.act);
+      g.C[static_cast<long long>(r) * g.ldc + col] = v;
+      const double d = v;
+      s += d;
+      ss += d * d;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < cw && col < g.N) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < lanes; ++k) {
+      a += red[0][k * cw + threadIdx.x];
+      b += red[1][k * cw + threadIdx.x];
+    }
+    stats[(static_cast<long long>(blockIdx.x) * 2 + 0) * g.N + col] = a;
+    stats[(static_cast<long long>(blockIdx.x) * 2 + 1) * g.N + col] = b;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
@@ -350,8 +392,14 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       g.part = static_cast<float*>(ws);
     }
   }
-  if (g.splits > 1) g.stats = nullptr;
-  if (stat_blocks) *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm)) : 0;
+  double* reduce_stats = nullptr;  // split-K: the statistics come from the reduce pass (64-row blocks)
+  if (g.splits > 1) {
+    if (batches == 1 && g.N % 4 == 0) reduce_stats = g.stats;
+    g.stats = nullptr;
+  }
+  if (stat_blocks)
+    *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm))
+                           : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, kStatRows)) : 0);
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   switch (tile) {
@@ -366,6 +414,11 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       break;
   }
   if (int e = launch_status("gemm_kernel")) return e;
+  if (g.splits > 1 && reduce_stats) {
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(ceil_div<long long>(m, kStatRows), ceil_div<long long>(n, 256)), dim3(256),
+                       0, st, g, reduce_stats);
+    return launch_status("splitk_reduce_stats_kernel");
+  }
   if (g.splits > 1) {
     const long long total = static_cast<long long>(batches) * m * n;
     const int blocks = static_cast<int>(std::min<long long>(ceil_div<long long>(total, 256), 2048));

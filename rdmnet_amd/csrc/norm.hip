@@ -122,6 +122,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, in
   }
 }
 
+// Same without the row flag, for wide matrices with few rows (coarse levels: 800 x 2048): one thread per
+// float4, grid over (rows, column quads) so that the launch has enough wavefronts to cover the latency.
+__global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int n, int c4, int ldx, const float* scale,
+                                                            const float* shift, const float* res, int ldr, int act,
+                                                            float* y, int ldy) {
+  const int64_t t = blockIdx.x * 256ll + threadIdx.x;
+  if (t >= static_cast<int64_t>(n) * c4) return;
+  const int row = static_cast<int>(t / c4), col = static_cast<int>(t % c4) * 4;
+  const float4 xv = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(row) * ldx + col);
+  const float4 sc = *reinterpret_cast<const float4*>(scale + col), sh = *reinterpret_cast<const float4*>(shift + col);
+  float v[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
+  if (res) {
+    const float4 rv = *reinterpret_cast<const float4*>(res + static_cast<int64_t>(row) * ldr + col);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (act == 2) v[k] = v[k] > 0.f ? v[k] : 0.1f * v[k];
+    else if (act == 1) v[k] = v[k] > 0.f ? v[k] : 0.f;
+  }
+  *reinterpret_cast<float4*>(y + static_cast<int64_t>(row) * ldy + col) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // y = act(LayerNorm(x (+ res)) * gamma + beta); one wavefront per row, c <= 2048
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, int c, int ldx,
                                                         const float* res, int ldr,
@@ -255,9 +278,17 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
                      static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
-                     static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
-                     static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
+  const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+  if (!positive && vec_ok && c >= 256)
+    hipLaunchKernelGGL(gn_apply_wide_kernel, dim3(ceil_div<int64_t>(n * (c / 4), 256)), dim3(256), 0, st, x, static_cast<int>(n),
+                       static_cast<int>(c / 4), static_cast<int>(ldx), ss, ss + c, residual, static_cast<int>(ldr), act, y,
+                       static_cast<int>(ldy));
+  else
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
+                       static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
+                       static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
   return launch_status("group_norm kernels");
 }
 
