@@ -301,26 +301,42 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
   }
 }
 
-// Split-K reduce that also emits the GroupNorm column partials of its 64-row block (same layout, thread
-// mapping and summation order as gn_partial_kernel in norm.hip, whose separate pass it replaces):
-// grid = (row blocks of 64, column chunks of 256); cw = min(N, 256) columns x (256 / cw) row lanes.
-constexpr int kStatRows = 64;
+// Split-K reduce that also emits the GroupNorm column partials of its row block (layout of gn_partial_kernel
+// in norm.hip, whose separate pass it replaces): grid = (row blocks, column chunks of 256); cw = min(N, 256)
+// columns x (256 / cw) row lanes, kStatRowsPerLane rows per lane -- few rows per thread, because every output
+// element costs `splits` dependent-latency loads and the matrices are small (M in the hundreds).
+constexpr int kStatRowsPerLane = 8;
+inline int stat_rows_per_block(long long n) { return kStatRowsPerLane * (256 / static_cast<int>(n < 256 ? n : 256)); }
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, double* stats) {
   __shared__ double red[2][256];
-  const int r0 = blockIdx.x * kStatRows;
-  const int r1 = min(g.M, r0 + kStatRows);
   const int cw = g.N < 256 ? g.N : 256;
   const int lanes = 256 / cw;
+  const int r0 = blockIdx.x * (kStatRowsPerLane * lanes);
+  const int r1 = min(g.M, r0 + kStatRowsPerLane * lanes);
   const int col_in = threadIdx.x % cw, rl = threadIdx.x / cw;
   const int col = blockIdx.y * 256 + col_in;
   double s = 0.0, ss = 0.0;
   if (rl < lanes && col < g.N) {
     const float bv = g.bias ? g.bias[col] : 0.f;
     const long long plane = static_cast<long long>(g.M) * g.N;
-    for (int r = r0 + rl; r < r1; r += lanes) {
-      const float* p = g.part + static_cast<long long>(r) * g.N + col;
-      float v = 0.f;
-      for (int k = 0; k < g.splits; ++k) v += p[k * plane];  // fixed order
+    // the kStatRowsPerLane rows of this thread are summed side by side: independent loads in flight per split
+    float acc[kStatRowsPerLane];
+    const float* p[kStatRowsPerLane];
+#pragma unroll
+    for (int u = 0; u < kStatRowsPerLane; ++u) {
+      const int r = min(r0 + rl + u * lanes, g.M - 1);
+      p[u] = g.part + static_cast<long long>(r) * g.N + col;
+      acc[u] = 0.f;
+    }
+    for (int k = 0; k < g.splits; ++k) {  // fixed order per element
+#pragma unroll
+      for (int u = 0; u < kStatRowsPerLane; ++u) acc[u] += p[u][k * plane];
+    }
+#pragma unroll
+    for (int u = 0; u < kStatRowsPerLane; ++u) {
+      const int r = r0 + rl + u * lanes;
+      if (r >= r1) break;
+      float v = acc[u];
       if (g.rowdiv) v = v / g.rowdiv[r];
       v = apply_act(v + bv, g.act);
       g.C[static_cast<long long>(r) * g.ldc + col] = v;
@@ -399,7 +415,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   }
   if (stat_blocks)
     *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm))
-                           : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, kStatRows)) : 0);
+                           : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, stat_rows_per_block(n))) : 0);
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   switch (tile) {
@@ -415,7 +431,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   }
   if (int e = launch_status("gemm_kernel")) return e;
   if (g.splits > 1 && reduce_stats) {
-    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(ceil_div<long long>(m, kStatRows), ceil_div<long long>(n, 256)), dim3(256),
+    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(ceil_div<long long>(m, stat_rows_per_block(n)), ceil_div<long long>(n, 256)), dim3(256),
                        0, st, g, reduce_stats);
     return launch_status("splitk_reduce_stats_kernel");
   }
