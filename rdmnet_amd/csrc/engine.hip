@@ -532,7 +532,7 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   const int64_t n0 = n_ref + n_src;
   // kernel scratch: the largest consumers are the grid-subsample tables and split-K partials
   r.ws_bytes = std::max<size_t>(rdm_grid_subsample_workspace_bytes(n0, 2),
-                                std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(64) << 20));
+                                std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(96) << 20));
   r.ws = e->alloc<char>(r.ws_bytes);
   ENG_ALLOC(r.ws);
   std::memset(res, 0, sizeof(*res));

@@ -14,6 +14,8 @@
 // fixed-order reduce, no atomics => deterministic) keeps the small-M / huge-K coarse levels busy.
 // Requirements: lda, ldb, K multiples of 4 and 16-byte aligned bases (callers pad with zeros).
 #include "../../include/rdmnet_hip.h"
+#include <cstdlib>
+
 #include "common.h"
 #include "internal.h"
 
@@ -374,7 +376,7 @@ extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
   // split-K is only chosen while fewer than 256 tiles exist and targets ~512 blocks, so the partials
   // never exceed (512 + 256) tiles of 128 x 128 floats; tiny problems need at most 16 copies.
   const size_t by_shape = static_cast<size_t>(m) * static_cast<size_t>(n) * 16;
-  const size_t by_tiles = static_cast<size_t>(768) * 128 * 128;
+  const size_t by_tiles = static_cast<size_t>(1024) * 128 * 128;
   return align_up(std::min(by_shape, by_tiles) * sizeof(float) * static_cast<size_t>(batches > 0 ? batches : 1));
 }
 
@@ -392,16 +394,33 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   if (n <= 32) tile = T128x32;
   // 128x128 tiles halve the L2->LDS traffic per flop; they pay off for large M, and for the coarse-level
   // KPConv contractions (M in the hundreds, K in the thousands) where split-K supplies the parallelism
-  else if (n >= 128 && (m >= 2048 || (m >= 256 && k >= 3072))) tile = T128;
+  else if (n >= 128 && m >= 2048) tile = T128;
   else tile = T64;
+  // developer knob for tuning runs (tools/gemm_sweep.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the heuristics
+  int force_splits = 0;
+  if (const char* tune = getenv("RDM_GEMM_TUNE")) {
+    int t = 0, sp = 0;
+    if (sscanf(tune, "%d,%d", &t, &sp) >= 1) {
+      if (t == 1) tile = T128;
+      else if (t == 2) tile = T64;
+      else if (t == 3) tile = T128x32;
+      force_splits = sp;
+    }
+  }
   const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   const long long tiles = ceil_div<long long>(m, bm) * ceil_div<long long>(n, bn) * batches;
   // deterministic split-K for the coarse levels (few tiles, K in the thousands): target ~512 blocks,
   // at least 128 of K per split
-  if (tiles < 256 && k >= 512) {
-    int s = static_cast<int>(ceil_div<long long>(512, tiles));
+  if ((tiles < 256 && k >= 512) || force_splits > 1) {
+    // tools/gemm_sweep.py: first put ~1.5 blocks on each of the 256 CUs (co-resident blocks hide each other's
+    // prologue/epilogue), then add splits only while each keeps >= 640 of K (beyond that, more splits only add
+    // partial traffic)
+    const int s_fill = static_cast<int>(ceil_div<long long>(384, tiles));
+    int s = static_cast<int>(std::min<long long>(k / 640, ceil_div<long long>(768, tiles)));
+    if (s < s_fill) s = s_fill;
     if (s > 16) s = 16;
     if (s > k / 128) s = static_cast<int>(k / 128);
+    if (force_splits > 0) s = force_splits;
     const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
     if (s > 1 && ws && ws_bytes >= need) {
       g.splits = s;
