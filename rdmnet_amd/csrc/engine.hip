@@ -54,6 +54,7 @@ struct rdm_engine {
   std::vector<void*> owned;   // device allocations of parameters
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
+  bool arena_exhausted = false, arena_fixed = false;  // fixed: the caller chose arena_bytes, never regrown
   void* pinned = nullptr;     // small host staging buffer for the size read-backs
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
@@ -90,6 +91,7 @@ namespace {
   do {                                                             \
     if ((ptr) == nullptr) {                                        \
       set_error("rdm_engine: activation arena exhausted (%zu B)", e->arena_cap); \
+      e->arena_exhausted = true;                                   \
       return RDM_ERR_WORKSPACE;                                    \
     }                                                              \
   } while (0)
@@ -360,6 +362,7 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
   rdm_engine* e = new rdm_engine();
   e->cfg = *cfg;
   e->arena_cap = cfg->arena_bytes ? cfg->arena_bytes : (size_t(3) << 30);
+  e->arena_fixed = cfg->arena_bytes != 0;
   hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
   if (err != hipSuccess) {
     set_error("rdm_engine_create: hipMalloc(%zu) failed: %s", e->arena_cap, hipGetErrorString(err));
@@ -517,11 +520,36 @@ extern "C" int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor
   return RDM_OK;
 }
 
+static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
+                           rdm_engine_result* res, void* stream);
+
+// The default 3 GiB arena covers pairs of ~2 x 25 k points; denser input (raw scans, KITTI-360-sized clouds)
+// grows it: on exhaustion the stream is drained, the arena doubled (288 GB of HBM leave room) and the pair
+// re-run.  An arena size chosen by the caller (rdm_engine_config.arena_bytes) is never changed.
 extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
                               int64_t n_src, rdm_engine_result* res, void* stream) {
   RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_run: null pointer");
   RDM_REQUIRE(e->finalized, "rdm_engine_run: call rdm_engine_finalize first");
   RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_run: empty cloud");
+  for (;;) {
+    e->arena_exhausted = false;
+    const int rc = engine_run_once(e, ref_points, n_ref, src_points, n_src, res, stream);
+    if (rc != RDM_ERR_WORKSPACE || !e->arena_exhausted || e->arena_fixed || e->arena_cap >= (size_t(96) << 30)) return rc;
+    RDM_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    RDM_HIP_CHECK(hipFree(e->arena));
+    e->arena = nullptr;
+    e->arena_cap *= 2;
+    const hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
+    if (err != hipSuccess) {
+      e->arena_cap = 0;
+      set_error("rdm_engine_run: growing the activation arena failed: %s", hipGetErrorString(err));
+      return RDM_ERR_HIP;
+    }
+  }
+}
+
+static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
+                           rdm_engine_result* res, void* stream) {
   const rdm_engine_config& c = e->cfg;
   e->arena_off = 0;
   e->taps.clear();
@@ -608,6 +636,19 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
     if (i < 4) {
       tap(r, ("subsampling" + std::to_string(i)).c_str(), sub[i].idx, sub[i].rows, sub[i].width, sub[i].width, 1);
       tap(r, ("upsampling" + std::to_string(i)).c_str(), up[i].idx, up[i].rows, up[i].width, up[i].width, 1);
+    }
+  }
+
+  // kernel scratch of the network part, sized from the actual pyramid: Linear+GroupNorm of level l is at most
+  // lv[l].n rows x (init_dim * 2^(l+1)) columns (backbone.py:27-70); the decoder and heads are narrower
+  {
+    size_t need = r.ws_bytes;
+    for (int l = 0; l < c.num_stages; ++l)
+      need = std::max(need, rdm_linear_group_norm_workspace_bytes(lv[l].n, int64_t(128) << l));
+    if (need > r.ws_bytes) {
+      r.ws_bytes = need;
+      r.ws = e->alloc<char>(r.ws_bytes);
+      ENG_ALLOC(r.ws);
     }
   }
 

@@ -102,3 +102,23 @@ def test_ransac_degenerate_inputs():
     empty = torch.zeros((0, 3), device='cuda')
     T, stats, rmse = ops.ransac_correspondences(empty, empty.clone(), 0.3, 4, 100)
     assert torch.equal(T.cpu(), torch.eye(4)) and stats.cpu().tolist() == [-1, 0]
+
+
+def test_engine_grows_its_arena_for_dense_input():
+    """2 x ~95 k points do not fit the default 3 GiB activation arena: the engine doubles it and re-runs; an arena
+    size fixed by the caller is an error instead."""
+    from rdmnet_amd import config, engine, ops, weights
+    cfg = config.make_cfg()
+    state = weights.synthetic_state_dict(cfg, seed=0)
+    a = ops.voxel_downsample(torch.from_numpy(raw_scan(20, 120000)).cuda(), 0.3)[:, :3].contiguous()
+    b = ops.voxel_downsample(torch.from_numpy(raw_scan(21, 120000)).cuda(), 0.3)[:, :3].contiguous()
+    assert a.shape[0] > 80000
+    eng = engine.Engine(cfg, state)
+    res = eng.run(a, b)
+    assert res.arena_used > (3 << 30) and np.isfinite(eng.transform()).all()
+    T1 = eng.transform()
+    eng.run(a, b)
+    assert np.array_equal(T1, eng.transform())
+    fixed = engine.Engine(cfg, state, arena_bytes=1 << 30)
+    with pytest.raises(RuntimeError, match='arena exhausted'):
+        fixed.run(a, b)
