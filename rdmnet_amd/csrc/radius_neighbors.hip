@@ -151,6 +151,13 @@ __global__ void rn_scatter_kernel(const float* s, int64_t ns, const int* pt_cell
   sorted[cell_start[c] + pt_slot[i]] = v;
 }
 
+// broadcast of lane `i` (wave-uniform) through scalar registers
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int i) {
+  const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), i);
+  const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), i);
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 // One wavefront per query.
 template <int CAP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
@@ -207,30 +214,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
-    for (int base = 0; base < total; base += 64) {
-      const int t = base + lane;
-      bool hit = false;
-      unsigned long long key = 0;
-      if (t < total) {
-        int seg = 0;
+    // two candidates per lane and step: both record loads are in flight before either is tested
+    for (int base = 0; base < total; base += 128) {
+      bool hit[2] = {false, false};
+      unsigned long long key[2] = {0, 0};
+      float4 p[2];
+      int tt[2];
 #pragma unroll
-        for (int step = 16; step > 0; step >>= 1)
-          if (seg + step < 27 && seg_pref[wave][seg + step] <= t) seg += step;
-        const float4 p = sorted[seg_start[wave][seg] + (t - seg_pref[wave][seg])];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        float d2 = dx * dx;
-        d2 = d2 + dy * dy;
-        d2 = d2 + dz * dz;
-        hit = d2 < r2;
-        key = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) |
-              static_cast<unsigned>(__float_as_int(p.w));
+      for (int u = 0; u < 2; ++u) {
+        tt[u] = base + 64 * u + lane;
+        if (tt[u] < total) {
+          int seg = 0;
+#pragma unroll
+          for (int step = 16; step > 0; step >>= 1)
+            if (seg + step < 27 && seg_pref[wave][seg + step] <= tt[u]) seg += step;
+          p[u] = sorted[seg_start[wave][seg] + (tt[u] - seg_pref[wave][seg])];
+        }
       }
-      const unsigned long long m = __ballot(hit);
-      if (hit) {
-        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < CAP) K[pos] = key;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (tt[u] < total) {
+          const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+          float d2 = dx * dx;
+          d2 = d2 + dy * dy;
+          d2 = d2 + dz * dz;
+          hit[u] = d2 < r2;
+          key[u] = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) |
+                   static_cast<unsigned>(__float_as_int(p[u].w));
+        }
+        const unsigned long long m = __ballot(hit[u]);
+        if (hit[u]) {
+          const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < CAP) K[pos] = key[u];
+        }
+        count += __popcll(m);
       }
-      count += __popcll(m);
     }
   }
   if (lane == 0) {
@@ -250,6 +268,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   if (width <= 0) return;
 
   const int n = count < CAP ? count : CAP;
+  if (n <= 128) {
+    // rank sort in registers (the common case: a neighbourhood holds 40-100 points): each lane keeps up to two
+    // keys and counts the keys smaller than its own while every key is broadcast once with v_readlane -- no LDS
+    // traffic, no barriers; keys are unique (the index is part of the key), so ranks are a permutation
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long k0 = lane < n ? K[lane] : ~0ull;
+    const unsigned long long k1 = 64 + lane < n ? K[64 + lane] : ~0ull;
+    int r0 = 0, r1 = 0;
+    if (n <= 64) {  // one key per lane: half the comparisons
+      for (int i = 0; i < n; ++i) r0 += readlane64(k0, i) < k0 ? 1 : 0;
+    } else {
+      for (int i = 0; i < 64; ++i) {
+        const unsigned long long ki = readlane64(k0, i);
+        r0 += ki < k0 ? 1 : 0;
+        r1 += ki < k1 ? 1 : 0;
+      }
+      for (int i = 64; i < n; ++i) {
+        const unsigned long long ki = readlane64(k1, i - 64);
+        r0 += ki < k0 ? 1 : 0;
+        r1 += ki < k1 ? 1 : 0;
+      }
+    }
+    // every lane knows the final column of its keys: write the row directly (pads behind the n-th column)
+    int64_t* row = out_idx + qi * static_cast<int64_t>(width);
+    if (lane < n && r0 < width) row[r0] = static_cast<int64_t>(k0 & 0xffffffffull);
+    if (64 + lane < n && r1 < width) row[r1] = static_cast<int64_t>(k1 & 0xffffffffull);
+    for (int c = n + lane; c < width; c += 64) row[c] = ns;
+    return;
+  } else {
   int p2 = 1;
   while (p2 < n) p2 <<= 1;
   for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
@@ -285,6 +333,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  }
   // offset of this cloud's supports is already folded in (indices are global rows)
   int64_t* row = out_idx + qi * static_cast<int64_t>(width);
   for (int c = lane; c < width; c += 64)

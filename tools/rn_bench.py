@@ -3,9 +3,10 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rdmnet_amd import _lib, ops
-z = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'synthetic_pairs.npz'))
-pts = torch.from_numpy(np.concatenate([z['ref0'], z['src0']])).cuda()
-lens = torch.tensor([len(z['ref0']), len(z['src0'])], dtype=torch.int64).cuda()
+from rdmnet_amd import synthetic
+ref, src, _ = synthetic.make_pair(0)  # the bench workload: 2 x ~16 k points
+pts = torch.from_numpy(np.concatenate([ref, src])).cuda()
+lens = torch.tensor([len(ref), len(src)], dtype=torch.int64).cuda()
 L = _lib.lib()
 n = pts.shape[0]
 ws = torch.empty(L.rdm_radius_neighbors_workspace_bytes(n, n, 2), dtype=torch.uint8, device='cuda')
