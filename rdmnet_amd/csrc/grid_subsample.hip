@@ -30,6 +30,11 @@ namespace {
 using namespace rdm;
 
 constexpr int kT = 1024;
+// LDS-resident replay of the growth stages (P7) for clouds of up to kLdsM voxels / kLdsB buckets: the order lists
+// and the per-bucket tables then live in 144 KB of the CU's 160 KB LDS instead of HBM (one workgroup per CU)
+constexpr int kLdsM = 10304, kLdsB = 10304;
+constexpr int kOwn = (kLdsM + kT - 1) / kT;  // stage elements owned by one thread
+constexpr size_t kLdsBytes = 3 * sizeof(unsigned short) * kLdsM + 2 * sizeof(unsigned) * kLdsB;
 constexpr int kMaxStages = 40;
 constexpr unsigned long long kEmpty = ~0ull;
 
@@ -118,6 +123,109 @@ __device__ int block_scan(int n, F get, int* out, int* lds, bool reverse) {
   }
   __syncthreads();
   return total;
+}
+
+// P7 with everything but the voxel keys in LDS.  Thread `tid` owns the stage elements t in [c0, c1) through all
+// phases of a stage, so bucket ids, firstness and run offsets stay in registers.  bf: first time of a bucket,
+// later its run offset; bcl: bucket count (low 16 bits) and fill cursor (high 16 bits).  Returns the final list.
+__device__ unsigned short* replay_lds(const GridArgs& a, const unsigned long long* __restrict__ ekey, int M,
+                                      unsigned short* cur, unsigned short* nxt, unsigned short* tmp, unsigned* bf,
+                                      unsigned* bcl, int* s_scan) {
+  const int tid = threadIdx.x;
+  for (int j = 0; j < a.sched.n; ++j) {
+    const int k0 = a.sched.at[j];
+    if (k0 >= M) break;
+    int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
+    if (k1 > M) k1 = M;
+    const unsigned B = static_cast<unsigned>(a.sched.buckets[j]);
+    const int n = k1;
+    for (unsigned x = tid; x < B; x += kT) {
+      bf[x] = 0xffffffffu;
+      bcl[x] = 0;
+    }
+    const int per = (n + kT - 1) / kT;
+    const int c0 = min(tid * per, n), c1 = min(c0 + per, n);
+    unsigned long long key[kOwn];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {  // all key loads of the thread in flight together
+      const int t = c0 + u;
+      key[u] = 0;
+      if (t < c1) key[u] = ekey[t < k0 ? cur[t] : t];
+    }
+    __syncthreads();
+    unsigned bk[kOwn];
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      const int t = c0 + u;
+      bk[u] = 0;
+      if (t < c1) {
+        bk[u] = static_cast<unsigned>(key[u] % static_cast<unsigned long long>(B));
+        atomicMin(&bf[bk[u]], static_cast<unsigned>(t));
+        atomicAdd(&bcl[bk[u]], 1u);
+      }
+    }
+    __syncthreads();
+    // run offsets: buckets in descending first time = exclusive suffix sums of (first ? count : 0)
+    int val[kOwn], local = 0;
+    unsigned first_mask = 0;
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      const int t = c0 + u;
+      val[u] = 0;
+      if (t < c1 && bf[bk[u]] == static_cast<unsigned>(t)) {
+        first_mask |= 1u << u;
+        val[u] = static_cast<int>(bcl[bk[u]] & 0xffffu);
+      }
+      local += val[u];
+    }
+    int total;
+    const int pre = block_prefix(local, s_scan, total);  // (barriers inside: every firstness test is done)
+    int running = total - pre - local;
+    int offv[kOwn];
+#pragma unroll
+    for (int u = kOwn - 1; u >= 0; --u) {
+      offv[u] = running;
+      running += val[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u)
+      if (first_mask & (1u << u)) bf[bk[u]] = static_cast<unsigned>(offv[u]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u) {
+      const int t = c0 + u;
+      if (t < c1) {
+        const unsigned slot = atomicAdd(&bcl[bk[u]], 0x10000u) >> 16;
+        tmp[bf[bk[u]] + slot] = static_cast<unsigned short>(t);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kOwn; ++u)
+      if (first_mask & (1u << u)) {
+        const int c = static_cast<int>(bcl[bk[u]] & 0xffffu);
+        unsigned short* L = tmp + offv[u];
+        for (int x = 1; x < c; ++x) {  // newest first inside a bucket
+          const unsigned short v = L[x];
+          int y = x - 1;
+          while (y >= 0 && L[y] < v) {
+            L[y + 1] = L[y];
+            --y;
+          }
+          L[y + 1] = v;
+        }
+      }
+    __syncthreads();
+    for (int pos = c0; pos < c1; ++pos) {
+      const int t = tmp[pos];
+      nxt[pos] = t < k0 ? cur[t] : static_cast<unsigned short>(t);
+    }
+    __syncthreads();
+    unsigned short* sw = cur;
+    cur = nxt;
+    nxt = sw;
+  }
+  return cur;
 }
 
 __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
@@ -282,71 +390,85 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __syncthreads();
 
   // ---- P7: replay the container's growth stages to obtain its iteration order
-  for (int j = 0; j < a.sched.n; ++j) {
-    const int k0 = a.sched.at[j];
-    if (k0 >= M) break;
-    int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
-    if (k1 > M) k1 = M;
-    const int B = a.sched.buckets[j];
-    const int n = k1;  // every element ranked < k0 is already in `cur`
-    for (int x = tid; x < B; x += kT) {
-      bf[x] = 0x7fffffff;
-      bc[x] = 0;
-      bl[x] = 0;
-    }
-    __syncthreads();
-    for (int t = tid; t < n; t += kT) {
-      const int e = t < k0 ? cur[t] : t;
-      const int bkt = static_cast<int>(ekey[e] % static_cast<unsigned long long>(B));
-      bt[t] = bkt;
-      atomicMin(&bf[bkt], t);
-      atomicAdd(&bc[bkt], 1);
-    }
-    __syncthreads();
-    block_scan(
-        n,
-        [&](int t) {
-          const int bkt = bt[t];
-          return ld_agent(&bf[bkt]) == t ? ld_agent(&bc[bkt]) : 0;
-        },
-        off, s_scan, true);
-    for (int t = tid; t < n; t += kT) {
-      const int bkt = bt[t];
-      const int base = off[ld_agent(&bf[bkt])];
-      const int slot = atomicAdd(&bl[bkt], 1);
-      tmp[base + slot] = t;
-    }
-    __syncthreads();
-    for (int t = tid; t < n; t += kT) {
-      const int bkt = bt[t];
-      if (ld_agent(&bf[bkt]) != t) continue;
-      const int c = ld_agent(&bc[bkt]);
-      int* L = tmp + off[t];
-      for (int x = 1; x < c; ++x) {  // newest first inside a bucket
-        const int val = L[x];
-        int y = x - 1;
-        while (y >= 0 && L[y] < val) {
-          L[y + 1] = L[y];
-          --y;
-        }
-        L[y + 1] = val;
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  int last_b = 0;
+  for (int j = 0; j < a.sched.n && a.sched.at[j] < M; ++j) last_b = a.sched.buckets[j];
+  const bool in_lds = M <= kLdsM && last_b <= kLdsB;  // uniform over the block
+  const unsigned short* lds_order = nullptr;
+  if (in_lds) {
+    unsigned short* l_cur = reinterpret_cast<unsigned short*>(s_dyn);
+    unsigned short* l_nxt = l_cur + kLdsM;
+    unsigned short* l_tmp = l_nxt + kLdsM;
+    unsigned* l_bf = reinterpret_cast<unsigned*>(l_tmp + kLdsM);
+    unsigned* l_bcl = l_bf + kLdsB;
+    lds_order = replay_lds(a, ekey, M, l_cur, l_nxt, l_tmp, l_bf, l_bcl, s_scan);
+  } else {
+    for (int j = 0; j < a.sched.n; ++j) {
+      const int k0 = a.sched.at[j];
+      if (k0 >= M) break;
+      int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
+      if (k1 > M) k1 = M;
+      const int B = a.sched.buckets[j];
+      const int n = k1;  // every element ranked < k0 is already in `cur`
+      for (int x = tid; x < B; x += kT) {
+        bf[x] = 0x7fffffff;
+        bc[x] = 0;
+        bl[x] = 0;
       }
+      __syncthreads();
+      for (int t = tid; t < n; t += kT) {
+        const int e = t < k0 ? cur[t] : t;
+        const int bkt = static_cast<int>(ekey[e] % static_cast<unsigned long long>(B));
+        bt[t] = bkt;
+        atomicMin(&bf[bkt], t);
+        atomicAdd(&bc[bkt], 1);
+      }
+      __syncthreads();
+      block_scan(
+          n,
+          [&](int t) {
+            const int bkt = bt[t];
+            return ld_agent(&bf[bkt]) == t ? ld_agent(&bc[bkt]) : 0;
+          },
+          off, s_scan, true);
+      for (int t = tid; t < n; t += kT) {
+        const int bkt = bt[t];
+        const int base = off[ld_agent(&bf[bkt])];
+        const int slot = atomicAdd(&bl[bkt], 1);
+        tmp[base + slot] = t;
+      }
+      __syncthreads();
+      for (int t = tid; t < n; t += kT) {
+        const int bkt = bt[t];
+        if (ld_agent(&bf[bkt]) != t) continue;
+        const int c = ld_agent(&bc[bkt]);
+        int* L = tmp + off[t];
+        for (int x = 1; x < c; ++x) {  // newest first inside a bucket
+          const int val = L[x];
+          int y = x - 1;
+          while (y >= 0 && L[y] < val) {
+            L[y + 1] = L[y];
+            --y;
+          }
+          L[y + 1] = val;
+        }
+      }
+      __syncthreads();
+      for (int pos = tid; pos < n; pos += kT) {
+        const int t = tmp[pos];
+        nxt[pos] = t < k0 ? cur[t] : t;
+      }
+      __syncthreads();
+      int* sw = cur;
+      cur = nxt;
+      nxt = sw;
     }
-    __syncthreads();
-    for (int pos = tid; pos < n; pos += kT) {
-      const int t = tmp[pos];
-      nxt[pos] = t < k0 ? cur[t] : t;
-    }
-    __syncthreads();
-    int* sw = cur;
-    cur = nxt;
-    nxt = sw;
   }
 
   // ---- P8: emit in list order (grid_subsampling_cpu.cpp:44-47)
   float* out = a.tmp_points + 3 * start;
   for (int pos = tid; pos < M; pos += kT) {
-    const int e = cur[pos];
+    const int e = in_lds ? static_cast<int>(lds_order[pos]) : cur[pos];
     out[3 * pos] = epts[3 * e];
     out[3 * pos + 1] = epts[3 * e + 1];
     out[3 * pos + 2] = epts[3 * e + 2];
@@ -478,7 +600,10 @@ extern "C" int rdm_grid_subsample(const float* points, int64_t n_points, const i
     return RDM_ERR_WORKSPACE;
   }
   fill_schedule(n_points + 1, &a.sched);
-  hipLaunchKernelGGL(grid_subsample_kernel, dim3(batch), dim3(kT), 0, st, a);
+  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grid_subsample_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes));
+  RDM_HIP_CHECK(lds_attr);
+  hipLaunchKernelGGL(grid_subsample_kernel, dim3(batch), dim3(kT), kLdsBytes, st, a);
   if (int e = launch_status("grid_subsample_kernel")) return e;
   const int blocks = static_cast<int>(ceil_div<int64_t>(3 * n_points, 256 * 4));
   hipLaunchKernelGGL(compact_clouds_kernel, dim3(blocks > 0 ? blocks : 1, batch), dim3(256), 0, st,

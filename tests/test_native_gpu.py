@@ -64,6 +64,20 @@ def test_random_and_edge_clouds_match_oracle(ext, oracle_native):
             assert np.array_equal(io, ig), (n0, n1, scale, voxel)
 
 
+@pytest.mark.parametrize('n0,n1,scale', [(40000, 9000, 40.0), (9000, 30000, 25.0), (10400, 10200, 300.0)])
+def test_large_clouds_cover_both_order_replay_paths(ext, oracle_native, n0, n1, scale):
+    """The hash-map order replay runs from LDS up to 10304 voxels per cloud and from HBM beyond; each case has one
+    cloud on either side (third case: every point its own voxel, right at the boundary)."""
+    o = oracle_native.restatement()
+    rng = np.random.default_rng(n0)
+    pts = (rng.uniform(-1, 1, (n0 + n1, 3)) * np.array([scale, scale, 2.0])).astype(np.float32)
+    lens = np.array([n0, n1], dtype=np.int64)
+    po, lo = o.grid_subsampling(pts, lens, np.float32(0.6))
+    pg, lg = gpu_grid(ext)(pts, lens, np.float32(0.6))
+    assert min(lo) <= 10304 < max(lo) or scale == 300.0, lo
+    assert np.array_equal(lo, lg) and np.array_equal(po, pg)
+
+
 def test_empty_cloud_in_batch(ext, oracle_native):
     o = oracle_native.restatement()
     pts = np.random.default_rng(2).standard_normal((50, 3)).astype(np.float32)
