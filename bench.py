@@ -129,6 +129,9 @@ def main():
                     help='engine: one native call per pair (rdm_engine_run); python: per-op mirror (rdmnet_amd.model)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) in production; gloo only to exercise the\n'
                     'multi-process logic on a single GPU (with RDM_BENCH_SHARE_DEVICE=1)')
+    ap.add_argument('--layer-events-every', type=int, default=8,
+                    help='record the per-KPConv-layer HIP events (roofline) on every N-th pair of a stream: 42 event\n'
+                         'records per pair cost ~13 %% of the throughput with 4 pairs in flight; 0 = never')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -191,10 +194,11 @@ def main():
     if args.path == 'engine':
         for _ in range(args.streams):
             eng = engine.Engine(cfg, state, device=dev)
-            eng.enable_profile(True)
+            eng.enable_profile(False)
             engines.append(eng)
 
-    def run_range(indices, stream, rec, lat_out, prof_out, eng):
+    def run_range(indices, stream, rec, lat_out, prof_out, eng, events_every=None):
+        events_every = args.layer_events_every if events_every is None else events_every
         ctx = torch.cuda.stream(stream) if stream is not None else None
         if ctx is not None:
             ctx.__enter__()
@@ -205,9 +209,11 @@ def main():
                 ts = time.perf_counter()
                 pid = (rank + i * world) % len(dev_pairs)
                 if eng is not None:
+                    sampled = prof_out is not None and events_every > 0 and (slot // max(len(streams), 1)) % events_every == 0
+                    eng.enable_profile(sampled)
                     res = eng.run(*dev_pairs[pid])  # returns after the pose has been read back
                     T, n_corr = eng.transform(), res.n_correspondences
-                    if prof_out is not None:
+                    if sampled:
                         prof_out.extend(eng.kpconv_profile())
                 else:
                     T, n_corr = step(i)
@@ -295,7 +301,7 @@ def main():
     isolated = None
     if len(streams) > 1 and engines:
         iso_prof = []
-        run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, [], iso_prof, engines[0])
+        run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, [], iso_prof, engines[0], 1)
         fence()
         if errors:
             raise errors[0]

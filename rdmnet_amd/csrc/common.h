@@ -100,6 +100,28 @@ __device__ __forceinline__ int wave_sum_i(int v) {
   return v;
 }
 
+// Small device-side fills and copies.  The runtime's hipMemsetAsync / hipMemcpyAsync go through blit kernels
+// with extra barrier packets and host-side bookkeeping; with several pairs in flight per GPU those cost
+// noticeably more than a plain kernel launch, so the hot path uses these instead.
+template <typename T>
+__global__ void fill_words_kernel(T* p, int64_t n, T v) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ inline void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+template <typename T>
+inline void fill_words(T* p, int64_t n, T v, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(fill_words_kernel<T>, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+}
+inline void copy_words(const void* src, void* dst, int n_words, hipStream_t st) {
+  if (n_words > 0)
+    hipLaunchKernelGGL(copy_words_kernel, dim3((n_words + 255) / 256), dim3(256), 0, st, static_cast<const uint32_t*>(src),
+                       static_cast<uint32_t*>(dst), n_words);
+}
+
 // Relaxed agent-scope load: bypasses this CU's L1, so it observes L2 atomics of other waves.
 template <typename T>
 __device__ __forceinline__ T ld_agent(const T* p) {

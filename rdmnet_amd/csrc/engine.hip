@@ -55,7 +55,8 @@ struct rdm_engine {
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
   bool arena_exhausted = false, arena_fixed = false;  // fixed: the caller chose arena_bytes, never regrown
-  void* pinned = nullptr;     // small host staging buffer for the size read-backs
+  void* pinned = nullptr;     // small host staging buffer for the size read-backs (mapped: kernels write it)
+  void* pinned_dev = nullptr; // its device address
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
   bool keep_taps = false;
@@ -348,7 +349,8 @@ int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
 }
 
 int d2h(Run& r, const void* dev, size_t bytes, void* host_dst) {
-  RDM_HIP_CHECK(hipMemcpyAsync(r.e->pinned, dev, bytes, hipMemcpyDeviceToHost, r.st));
+  // a kernel stores straight into the mapped pinned buffer (no runtime copy operation on the stream)
+  copy_words(dev, r.e->pinned_dev, static_cast<int>((bytes + 3) / 4), r.st);
   RDM_HIP_CHECK(hipStreamSynchronize(r.st));
   std::memcpy(host_dst, r.e->pinned, bytes);
   return RDM_OK;
@@ -369,7 +371,8 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
     delete e;
     return RDM_ERR_HIP;
   }
-  err = hipHostMalloc(&e->pinned, 4096, hipHostMallocDefault);
+  err = hipHostMalloc(&e->pinned, 4096, hipHostMallocMapped);
+  if (err == hipSuccess) err = hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0);
   if (err != hipSuccess) {
     set_error("rdm_engine_create: hipHostMalloc failed: %s", hipGetErrorString(err));
     hipFree(e->arena);
@@ -601,7 +604,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
 
   int32_t* flags = e->alloc<int32_t>(64);
   ENG_ALLOC(flags);
-  RDM_HIP_CHECK(hipMemsetAsync(flags, 0, 64 * sizeof(int32_t), r.st));
+  fill_words<int32_t>(flags, 64, 0, r.st);
   Table nb[5], sub[4], up[4];
   float radius = c.init_radius;
   int call = 0;
@@ -937,8 +940,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     float T[16];
     int32_t counts[4];
   } tailbuf;
-  RDM_HIP_CHECK(hipMemcpyAsync(r.e->pinned, T, 16 * sizeof(float), hipMemcpyDeviceToHost, r.st));
-  RDM_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(r.e->pinned) + 64, counts, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, r.st));
+  copy_words(T, r.e->pinned_dev, 16, r.st);
+  copy_words(counts, static_cast<char*>(r.e->pinned_dev) + 64, 3, r.st);
   RDM_HIP_CHECK(hipStreamSynchronize(r.st));
   std::memcpy(tailbuf.T, r.e->pinned, 64);
   std::memcpy(tailbuf.counts, static_cast<char*>(r.e->pinned) + 64, 12);

@@ -361,6 +361,6 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
   hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), 0, st, ref_corr, src_corr, corr_scores,
                      acceptance_radius, num_refinement_steps, w, gate, transform);
-  RDM_HIP_CHECK(hipMemcpyAsync(counts, w.meta, 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  copy_words(w.meta, counts, 3, st);
   return launch_status("lgr kernels");
 }

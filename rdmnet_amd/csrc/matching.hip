@@ -419,7 +419,7 @@ extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const fl
     return RDM_ERR_WORKSPACE;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  RDM_HIP_CHECK(hipMemsetAsync(node_count, 0, sizeof(int32_t) * n_nodes, st));
+  fill_words<int32_t>(node_count, n_nodes, 0, st);
   hipLaunchKernelGGL(p2n_assign_kernel, dim3(ceil_div<int64_t>(n_points, 256)), dim3(256),
                      static_cast<size_t>(n_nodes) * 16, st, points, static_cast<int>(n_points), nodes,
                      static_cast<int>(n_nodes), owner, d_own, node_count);

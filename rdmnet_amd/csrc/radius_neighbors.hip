@@ -385,7 +385,7 @@ extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const i
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(rn_bbox_kernel, dim3(1), dim3(1024), 0, st, s_points, n_s, radius, batch, g.meta);
-  RDM_HIP_CHECK(hipMemsetAsync(g.cell_count, 0, sizeof(int) * kMaxCells, st));
+  fill_words<int>(g.cell_count, kMaxCells, 0, st);
   if (n_s > 0) {
     const int blocks = static_cast<int>(ceil_div<int64_t>(n_s, 256));
     hipLaunchKernelGGL(rn_count_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, s_lengths, batch, g.meta,
