@@ -117,6 +117,24 @@ def pose_error(T_est, T_gt):
     return float(np.degrees(ang)), float(np.linalg.norm(T_gt[:3, 3] - T_est[:3, 3]))
 
 
+def cpu_budget():
+    """Host CPUs this process may use: affinity mask capped by the cgroup quota (cpu.max / cfs_quota_us)."""
+    n = float(len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, float(quota) / float(period))
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, q / per)
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -132,6 +150,9 @@ def main():
     ap.add_argument('--layer-events-every', type=int, default=8,
                     help='record the per-KPConv-layer HIP events (roofline) on every N-th pair of a stream: 42 event\n'
                          'records per pair cost ~13 %% of the throughput with 4 pairs in flight; 0 = never')
+    ap.add_argument('--wait-us', type=int, default=-1,
+                    help='how an engine waits at its size read-backs: 0 = hipStreamSynchronize (spins a core per pair in\n'
+                         'flight), N > 0 = poll and sleep N us; -1 = choose from the CPU budget of this rank')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -190,11 +211,16 @@ def main():
     import threading
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
 
+    # spinning waits need a core per pair in flight on every rank; poll + sleep when the budget is smaller
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    budget = cpu_budget() / max(local_world, 1)
+    wait_us = args.wait_us if args.wait_us >= 0 else (0 if budget >= 2 * args.streams else 50)
     engines = []
     if args.path == 'engine':
         for _ in range(args.streams):
             eng = engine.Engine(cfg, state, device=dev)
             eng.enable_profile(False)
+            eng.set_wait(wait_us)
             engines.append(eng)
 
     def run_range(indices, stream, rec, lat_out, prof_out, eng, events_every=None):
@@ -334,6 +360,7 @@ def main():
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'points_per_pair': n_points,
                        'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
+                       'host_cpus_per_rank': budget, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},

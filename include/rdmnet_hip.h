@@ -336,6 +336,10 @@ int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const 
                    rdm_engine_result* result_host, void* stream);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
+/* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,
+ * which spins a host core per in-flight pair; sleep_us > 0 polls hipStreamQuery and sleeps that long in between (for
+ * hosts whose CPU quota is smaller than ranks x pairs in flight). */
+int rdm_engine_set_wait(rdm_engine* e, int sleep_us);
 int rdm_engine_enable_profile(rdm_engine* e, int enable);
 int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);

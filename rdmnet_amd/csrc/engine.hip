@@ -17,6 +17,8 @@
 #include <vector>
 
 #include "../../include/rdmnet_hip.h"
+#include <ctime>
+
 #include "common.h"
 #include "internal.h"
 
@@ -57,6 +59,7 @@ struct rdm_engine {
   bool arena_exhausted = false, arena_fixed = false;  // fixed: the caller chose arena_bytes, never regrown
   void* pinned = nullptr;     // small host staging buffer for the size read-backs (mapped: kernels write it)
   void* pinned_dev = nullptr; // its device address
+  int wait_sleep_us = 0;      // 0: hipStreamSynchronize (spins a core); > 0: poll hipStreamQuery and sleep in between
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
   bool keep_taps = false;
@@ -348,10 +351,29 @@ int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
   return launch_status(what);
 }
 
+// Wait for the engine's stream at a size read-back.  The runtime's synchronize busy-waits: with several pairs in
+// flight per GPU and 8 ranks per node that is 32 spinning cores; hosts with a small CPU quota poll instead.
+int wait_stream(Run& r) {
+  if (r.e->wait_sleep_us <= 0) {
+    RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+    return RDM_OK;
+  }
+  for (;;) {
+    const hipError_t q = hipStreamQuery(r.st);
+    if (q == hipSuccess) return RDM_OK;
+    if (q != hipErrorNotReady) {
+      set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
+      return RDM_ERR_HIP;
+    }
+    timespec ts{0, static_cast<long>(r.e->wait_sleep_us) * 1000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
 int d2h(Run& r, const void* dev, size_t bytes, void* host_dst) {
   // a kernel stores straight into the mapped pinned buffer (no runtime copy operation on the stream)
   copy_words(dev, r.e->pinned_dev, static_cast<int>((bytes + 3) / 4), r.st);
-  RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+  ENG_CHECK(wait_stream(r));
   std::memcpy(host_dst, r.e->pinned, bytes);
   return RDM_OK;
 }
@@ -496,6 +518,12 @@ extern "C" int rdm_engine_enable_profile(rdm_engine* e, int enable) {
     e->events.resize(3 * 16);
     for (auto& ev : e->events) RDM_HIP_CHECK(hipEventCreate(&ev));
   }
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_set_wait(rdm_engine* e, int sleep_us) {
+  RDM_REQUIRE(e && sleep_us >= 0, "rdm_engine_set_wait: bad arguments");
+  e->wait_sleep_us = sleep_us;
   return RDM_OK;
 }
 
@@ -942,7 +970,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   } tailbuf;
   copy_words(T, r.e->pinned_dev, 16, r.st);
   copy_words(counts, static_cast<char*>(r.e->pinned_dev) + 64, 3, r.st);
-  RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+  ENG_CHECK(wait_stream(r));
   std::memcpy(tailbuf.T, r.e->pinned, 64);
   std::memcpy(tailbuf.counts, static_cast<char*>(r.e->pinned) + 64, 12);
   std::memcpy(res->transform, tailbuf.T, 64);

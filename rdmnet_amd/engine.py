@@ -94,6 +94,10 @@ class Engine:
             self.L.rdm_engine_destroy(self._h)
             self._h = ctypes.c_void_p()
 
+    def set_wait(self, sleep_us=0):
+        """0: spin in hipStreamSynchronize at the size read-backs; > 0: poll and sleep (frees the host core)."""
+        _lib.check(self.L.rdm_engine_set_wait(self._h, int(sleep_us)), 'rdm_engine_set_wait')
+
     def enable_profile(self, enable=True):
         _lib.check(self.L.rdm_engine_enable_profile(self._h, int(enable)), 'rdm_engine_enable_profile')
 
