@@ -208,8 +208,16 @@ __global__ void coarse_rowsum_kernel(const float* s, int m, int n, int ld, float
 __global__ void coarse_colsum_kernel(const float* s, int m, int n, int ld, float* csum) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  float acc = 0.f;
-  for (int i = 0; i < m; ++i) acc += s[static_cast<int64_t>(i) * ld + j];
+  float acc = 0.f;  // rows are added in ascending order (as the reference's sum over dim 0), 8 loads in flight
+  int i = 0;
+  for (; i + 8 <= m; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s[static_cast<int64_t>(i + u) * ld + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < m; ++i) acc += s[static_cast<int64_t>(i) * ld + j];
   csum[j] = acc;
 }
 __global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* rsum, const float* csum,
@@ -227,23 +235,47 @@ __global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* 
 
 // Global top-k (k <= 1024) of an m x n matrix, descending, ties by ascending flat index.
 // One workgroup: three radix-select passes on the float bit pattern, then a bitonic sort.
+// `gate` (optional, a TopkState): run only if its fallback flag is set, i.e. as the fallback of the multi-workgroup path below.
 __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n, int ld, int k,
                                                     int64_t* out_row, int64_t* out_col, float* out_val,
-                                                    int32_t* out_count) {
+                                                    int32_t* out_count, const unsigned* gate) {
+  if (gate && gate[5] == 0) return;  // TopkState::fallback
   __shared__ unsigned hist[4096];
   __shared__ unsigned long long cand[2048];
   __shared__ unsigned sh_prefix, sh_need, sh_ncand;
   __shared__ unsigned wcnt[17];
-  const int64_t total = static_cast<int64_t>(m) * n;
+  const int total = m * n;  // (host side guarantees m * n < 2^31)
+  const int sw_w = threadIdx.x >> 6, sw_lane = threadIdx.x & 63;
+// one sweep over the matrix without integer divisions: wavefront w takes rows w, w+16, ..., lanes stride the columns
+#define RDM_SWEEP(BODY)                                                           \
+  for (int row = sw_w; row < m; row += 16) {                                      \
+    const float* pr = s + static_cast<int64_t>(row) * ld;                         \
+    const int tb = row * n;                                                       \
+    for (int c0 = 0; c0 < n; c0 += 512) { /* 8 independent loads in flight */     \
+      float vv[8];                                                                \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                             \
+        const int col = c0 + 64 * q + sw_lane;                                    \
+        vv[q] = col < n ? pr[col] : -1.f;                                         \
+      }                                                                           \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                             \
+        const int col = c0 + 64 * q + sw_lane;                                    \
+        if (col < n) {                                                            \
+          const float v = vv[q];                                                  \
+          const int t = tb + col;                                                 \
+          (void)t;                                                                \
+          BODY                                                                    \
+        }                                                                         \
+      }                                                                           \
+    }                                                                             \
+  }
   // count eligible (>= 0) entries
   if (threadIdx.x == 0) sh_ncand = 0;
   __syncthreads();
   unsigned elig = 0;
-  for (int64_t t = threadIdx.x; t < total; t += blockDim.x)
-    elig += s[(t / n) * ld + (t % n)] >= 0.f ? 1 : 0;
+  RDM_SWEEP(elig += v >= 0.f ? 1 : 0;)
   atomicAdd(&sh_ncand, elig);
   __syncthreads();
-  const int kk = min<int64_t>(k, sh_ncand);
+  const int kk = min<int>(k, static_cast<int>(sh_ncand));
   __syncthreads();
   if (kk == 0) {
     if (threadIdx.x == 0) *out_count = 0;
@@ -258,12 +290,10 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n
     const int nb = 1 << bits[pass];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
-      const float v = s[(t / n) * ld + (t % n)];
-      if (v < 0.f) continue;
+    RDM_SWEEP(if (v >= 0.f) {
       const unsigned u = __float_as_uint(v);
       if ((u & mask_hi) == prefix) atomicAdd(&hist[(u >> shifts[pass]) & (nb - 1)], 1u);
-    }
+    })
     __syncthreads();
     // find the bin holding the need-th largest value: wavefront 0 scans from the top, 64 bins per lane
     if (threadIdx.x < 64) {
@@ -299,26 +329,46 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n
   if (threadIdx.x == 0) sh_ncand = 0;
   __syncthreads();
   // greater-than entries: any order (sorted below)
-  for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
-    const float v = s[(t / n) * ld + (t % n)];
-    if (v < 0.f) continue;
+  RDM_SWEEP(if (v >= 0.f) {
     const unsigned u = __float_as_uint(v);
     if (u > prefix) {
       const unsigned pos = atomicAdd(&sh_ncand, 1u);
       if (pos < 2048) cand[pos] = (static_cast<unsigned long long>(~u) << 32) | static_cast<unsigned>(t);
     }
-  }
+  })
   __syncthreads();
   const unsigned n_gt = sh_ncand;
   __syncthreads();
-  // equal entries in ascending flat index: chunked ordered scan
-  if (threadIdx.x == 0) sh_need = 0;  // reused: number of equal entries taken so far
+  // equal entries: the `need` lowest flat indices among them.  Usually the value is unique (need == 1, one
+  // entry): one more sweep lists the equal entries in `hist` (reused), a short selection keeps the lowest
+  // indices; only a value with more than 4096 duplicates falls back to the ordered chunk scan.
+  if (threadIdx.x == 0) sh_need = 0;  // reused: number of equal entries listed / taken so far
   __syncthreads();
-  for (int64_t t0 = 0; t0 < total && sh_need < need; t0 += blockDim.x) {
-    const int64_t t = t0 + threadIdx.x;
+  RDM_SWEEP(if (v >= 0.f && __float_as_uint(v) == prefix) {
+    const unsigned pos = atomicAdd(&sh_need, 1u);
+    if (pos < 4096) hist[pos] = static_cast<unsigned>(t);
+  })
+  __syncthreads();
+  const unsigned n_eq = sh_need;
+  __syncthreads();
+  if (n_eq <= 4096) {
+    // rank of every listed index among the list (indices are distinct); ranks < need are kept
+    for (unsigned i = threadIdx.x; i < n_eq; i += blockDim.x) {
+      const unsigned mine = hist[i];
+      unsigned r = 0;
+      for (unsigned j = 0; j < n_eq; ++j) r += hist[j] < mine ? 1u : 0u;
+      if (r < need) cand[n_gt + r] = (static_cast<unsigned long long>(~prefix) << 32) | mine;
+    }
+    __syncthreads();
+  } else {
+  if (threadIdx.x == 0) sh_need = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < total && sh_need < need; t0 += blockDim.x) {
+    const int t = t0 + threadIdx.x;
     bool eq = false;
     if (t < total) {
-      const float v = s[(t / n) * ld + (t % n)];
+      const unsigned ur = static_cast<unsigned>(t) / static_cast<unsigned>(n);
+      const float v = s[static_cast<int64_t>(ur) * ld + (static_cast<unsigned>(t) - ur * static_cast<unsigned>(n))];
       eq = v >= 0.f && __float_as_uint(v) == prefix;
     }
     // ordered rank inside the chunk
@@ -344,6 +394,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n
     if (threadIdx.x == 0) sh_need += wcnt[16];
     __syncthreads();
   }
+  }
+#undef RDM_SWEEP
   // sort kk candidates: key = (~value bits, flat index) ascending == value desc, index asc
   int p2 = 1;
   while (p2 < kk) p2 <<= 1;
@@ -429,10 +481,151 @@ extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const fl
   return launch_status("point_to_node kernels");
 }
 
+// ---- multi-workgroup top-k: the single-workgroup kernel above needs ~130 us on one CU for a 330 x 320 matrix
+// (five sweeps over 105 k scores); here the sweeps run on the whole GPU:
+//   1. histogram of the top 12 bits of every eligible score (LDS per block, flushed with integer atomics);
+//      one wavefront finds the bin that holds the k-th largest score
+//   2. the same for the next 12 bits of the scores inside that bin (real score matrices put thousands there)
+//   3. every score at or above that 24-bit prefix is appended to a candidate list (any order)
+//   4. one workgroup sorts the (at most kTopkCand) candidates by (score desc, flat index asc) and emits the first k
+// The result is the same function of the matrix as topk_kernel (ties by ascending flat index); more than
+// kTopkCand candidates (thousands of scores sharing their top 12 bits) fall back to topk_kernel.
+constexpr int kTopkBins = 4096, kTopkCand = 2048, kTopkRows = 8;
+struct TopkState {  // device scratch
+  unsigned eligible;   // scores >= 0
+  unsigned bin0;       // threshold bin of bits [31:20]
+  unsigned need1;      // how many of bin0's scores are still needed
+  unsigned bin1;       // threshold bin of bits [19:8] inside bin0
+  unsigned n_cand;     // candidates appended
+  unsigned fallback;   // 1: candidate list overflowed, topk_kernel must run
+  unsigned pad[2];
+};
+
+// LEVEL 0: histogram of bits [31:20] of all eligible scores; LEVEL 1: bits [19:8] of the scores inside bin0
+template <int LEVEL>
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ s, int m, int n, int ld,
+                                                         const TopkState* __restrict__ st, unsigned* __restrict__ ghist) {
+  __shared__ unsigned hist[kTopkBins];
+  for (int i = threadIdx.x; i < kTopkBins; i += 256) hist[i] = 0;
+  __syncthreads();
+  const unsigned bin0 = LEVEL == 1 ? st->bin0 : 0;
+  const int r0 = blockIdx.x * kTopkRows, r1 = min(m, r0 + kTopkRows);
+  for (int row = r0 + (threadIdx.x >> 6); row < r1; row += 4)
+    for (int col = threadIdx.x & 63; col < n; col += 64) {
+      const float v = s[static_cast<int64_t>(row) * ld + col];
+      if (v < 0.f) continue;
+      const unsigned u = __float_as_uint(v);
+      if (LEVEL == 0) atomicAdd(&hist[u >> 20], 1u);
+      else if ((u >> 20) == bin0) atomicAdd(&hist[(u >> 8) & 0xfffu], 1u);
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTopkBins; i += 256)
+    if (hist[i]) atomicAdd(&ghist[i], hist[i]);
+}
+
+// the bin that holds the need-th largest entry of the histogram, and how many entries of that bin are needed
+template <int LEVEL>
+__global__ __launch_bounds__(64) void topk_pick_kernel(const unsigned* __restrict__ ghist, int k, TopkState* st) {
+  const int lane = threadIdx.x, per = kTopkBins / 64;
+  const int hi = kTopkBins - 1 - lane * per;  // this lane owns bins hi, hi-1, ..., hi-per+1
+  unsigned mine = 0;
+  for (int q = 0; q < per; ++q) mine += ghist[hi - q];
+  unsigned incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const unsigned total = __shfl(incl, 63, 64);
+  const unsigned need = LEVEL == 0 ? min(static_cast<unsigned>(k), total) : st->need1;
+  if (LEVEL == 0 && lane == 0) {
+    st->eligible = total;
+    st->n_cand = 0;
+    st->fallback = 0;
+    if (need == 0) {  // nothing eligible: no bin qualifies
+      st->bin0 = kTopkBins;
+      st->need1 = 0;
+    }
+  }
+  if (LEVEL == 1 && lane == 0 && need == 0) st->bin1 = kTopkBins;
+  const unsigned before = incl - mine;
+  if (need > 0 && before < need && incl >= need) {  // exactly one lane
+    unsigned acc = before;
+    int b = hi;
+    for (; b > hi - per + 1; --b) {
+      if (acc + ghist[b] >= need) break;
+      acc += ghist[b];
+    }
+    if (LEVEL == 0) {
+      st->bin0 = static_cast<unsigned>(b);
+      st->need1 = need - acc;
+    } else {
+      st->bin1 = static_cast<unsigned>(b);
+    }
+  }
+}
+
+// every score above the 24-bit threshold prefix (bin0, bin1) or sharing it is a candidate
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int m, int n, int ld, TopkState* st,
+                                                            unsigned long long* __restrict__ cand) {
+  const unsigned thr = (st->bin0 << 12) | (st->bin1 & 0xfffu);
+  const bool none = st->bin0 >= kTopkBins;
+  const int r0 = blockIdx.x * kTopkRows, r1 = min(m, r0 + kTopkRows);
+  for (int row = r0 + (threadIdx.x >> 6); row < r1; row += 4)
+    for (int col = threadIdx.x & 63; col < n; col += 64) {
+      const float v = s[static_cast<int64_t>(row) * ld + col];
+      if (v < 0.f || none) continue;
+      const unsigned u = __float_as_uint(v);
+      if ((u >> 8) >= thr) {
+        const unsigned pos = atomicAdd(&st->n_cand, 1u);
+        if (pos < kTopkCand) cand[pos] = (static_cast<unsigned long long>(~u) << 32) | static_cast<unsigned>(row * n + col);
+      }
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ cand, TopkState* st, int n,
+                                                           int k, int64_t* out_row, int64_t* out_col, float* out_val,
+                                                           int32_t* out_count) {
+  __shared__ unsigned long long keys[kTopkCand];
+  const unsigned nc = st->n_cand;
+  if (nc > kTopkCand) {  // thousands of scores share their top 24 bits: the single-workgroup kernel runs instead
+    if (threadIdx.x == 0) st->fallback = 1;
+    return;
+  }
+  const int kk = static_cast<int>(min(static_cast<unsigned>(k), st->eligible));
+  int p2 = 1;
+  while (p2 < static_cast<int>(nc)) p2 <<= 1;
+  for (int i = threadIdx.x; i < p2; i += 1024) keys[i] = i < static_cast<int>(nc) ? cand[i] : ~0ull;
+  __syncthreads();
+  for (int a = 2; a <= p2; a <<= 1)
+    for (int j = a >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < p2; i += 1024) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          if ((x > y) == ((i & a) == 0)) {
+            keys[i] = y;
+            keys[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < kk; i += 1024) {
+    const unsigned long long c = keys[i];
+    const unsigned flat = static_cast<unsigned>(c & 0xffffffffull);
+    out_row[i] = flat / n;
+    out_col[i] = flat % n;
+    out_val[i] = __uint_as_float(~static_cast<unsigned>(c >> 32));
+  }
+  if (threadIdx.x == 0) *out_count = kk;
+}
+
 extern "C" size_t rdm_coarse_matching_workspace_bytes(int64_t m, int64_t n) {
   rdm::Arena a(nullptr, 0);
   a.take<float>(m > 0 ? m : 1);
   a.take<float>(n > 0 ? n : 1);
+  a.take<unsigned>(2 * kTopkBins + 8);
+  a.take<unsigned long long>(kTopkCand);
   return a.off;
 }
 
@@ -448,6 +641,8 @@ extern "C" int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t 
   Arena ar(ws, ws_bytes);
   float* rsum = ar.take<float>(m);
   float* csum = ar.take<float>(n);
+  unsigned* ghist = ar.take<unsigned>(2 * kTopkBins + 8);  // two histograms + TopkState behind them
+  unsigned long long* cand = ar.take<unsigned long long>(kTopkCand);
   if (!ar.ok) {
     set_error("rdm_coarse_matching: workspace too small");
     return RDM_ERR_WORKSPACE;
@@ -463,7 +658,16 @@ extern "C" int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t 
   hipLaunchKernelGGL(coarse_dual_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD,
                      dual_normalization ? rsum : static_cast<const float*>(nullptr),
                      dual_normalization ? csum : static_cast<const float*>(nullptr), ref_mask, src_mask);
+  TopkState* ts = reinterpret_cast<TopkState*>(ghist + 2 * kTopkBins);
+  const int tb = ceil_div(M, kTopkRows);
+  fill_words<unsigned>(ghist, 2 * kTopkBins + 8, 0u, st);
+  hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist);
+  hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(1), dim3(64), 0, st, ghist, k, ts);
+  hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist + kTopkBins);
+  hipLaunchKernelGGL(topk_pick_kernel<1>, dim3(1), dim3(64), 0, st, ghist + kTopkBins, k, ts);
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, cand);
+  hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), 0, st, cand, ts, N, k, ref_idx, src_idx, out_scores, out_count);
   hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
-                     out_count);
+                     out_count, reinterpret_cast<const unsigned*>(ts));  // only runs if the candidate list overflowed
   return launch_status("coarse matching kernels");
 }

@@ -138,3 +138,26 @@ def test_linear_group_norm_fused_matches_torch(ops, m, k, n):
     y = ops.linear_group_norm(padded(x), padded(w), k, n, bias.cuda(), gamma.cuda(), beta.cuda(), 32, rowdiv=rowdiv.cuda(),
                               act=ops.ACT_LEAKY, residual=padded(res))
     assert (y.cpu().double() - ref).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize('m,n,lo,k', [(332, 316, -1.0, 256), (70, 90, 0.999, 256), (5, 7, 0.0, 256), (40, 60, 0.9995, 64)])
+def test_coarse_matching_topk_paths(ops, m, n, lo, k):
+    """Global top-k of the matching scores: descending, ties by ascending flat index.  Case 2/4 put thousands of scores
+    into one histogram bin (more than the 2048-candidate list) -> the single-workgroup fallback; both must agree
+    with a lexicographic sort of the matrix the call leaves behind."""
+    rng = np.random.default_rng(m)
+    sim = rng.uniform(lo, 1.0, (m, n)).astype(np.float32)
+    sim[rng.integers(0, m, 50), rng.integers(0, n, 50)] = sim[0, 0]  # exact duplicates -> ties
+    rmask = (rng.uniform(size=m) > 0.1).astype(np.uint8)
+    cmask = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    s = padded(torch.from_numpy(sim))
+    ri, si, sc, cnt = ops.coarse_matching(s, torch.from_numpy(rmask).cuda(), torch.from_numpy(cmask).cuda(), k, dual=False)
+    v = s.cpu().numpy()
+    flat = v.reshape(-1)
+    elig = np.flatnonzero(flat >= 0)
+    order = elig[np.lexsort((elig, -flat[elig].astype(np.float64)))][:k]
+    c = int(cnt)
+    assert c == min(k, elig.size)
+    assert np.array_equal(ri.cpu().numpy()[:c], order // n) and np.array_equal(si.cpu().numpy()[:c], order % n)
+    assert np.array_equal(sc.cpu().numpy()[:c], flat[order])
+    assert (v[rmask == 0] == -1).all() and (v[:, cmask == 0] == -1).all()
