@@ -178,6 +178,13 @@ int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t l
 int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
                    int64_t ldr, const float* gamma, const float* beta, float eps, int act, float* y,
                    int64_t ldy, void* stream);
+/* rdm_linear_layer_norm: y = act(LayerNorm(x W + bias [+ residual])) in one launch for the transformer width
+ * (n = 128, k % 16 == 0, W [128, k] = the nn.Linear weight as stored, row stride ldw >= k): the Linear + residual
+ * LayerNorm pairs of the attention layers
+ * (rdmnet/thdroformer/thdroformer.py:159-173, modules/transformer/vanilla_transformer.py:87-103, output_layer.py:13-21). */
+int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int64_t m, int64_t n,
+                          int64_t k, const float* residual, int64_t ldr, const float* gamma, const float* beta, float eps,
+                          int act, float* y, int64_t ldy, void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
 /* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the

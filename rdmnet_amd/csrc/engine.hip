@@ -40,6 +40,7 @@ struct HostParam {
 
 struct Linear {  // B operand [K_pad, N_pad] + bias
   float* b = nullptr;
+  float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused Linear + LayerNorm, out == 128 only
   float* bias = nullptr;
   int64_t in = 0, out = 0, kpad = 0, ldb = 0;
 };
@@ -258,13 +259,33 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
 // Everything of an attention layer after softmax(QK^T)V: output projection, residual LayerNorm, FFN,
 // residual LayerNorm (thdroformer.py:142-173 / vanilla_transformer.py:69-103, output_layer.py:6-21).
 // `out` is a pre-allocated view (rows of the stacked [ref; src] state).
+// LayerNorm(Linear(x) + residual): one fused launch at the transformer width (rdm_linear_layer_norm), else two
+int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat& x, const Mat& res, Mat& y, bool alloc_out) {
+  rdm_engine* e = r.e;
+  auto it = e->lin.find(lin);
+  if (it == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s", lin.c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear& L = it->second;
+  if (L.wt) {
+    if (alloc_out) {
+      y = e->mat(x.rows, L.out);
+      ENG_ALLOC(y.p);
+    }
+    return rdm_linear_layer_norm(x.p, x.ld, L.wt, L.kpad, L.bias, x.rows, L.out, L.kpad, res.p, res.ld, vecp(r, norm + ".weight"),
+                                 vecp(r, norm + ".bias"), 1e-5f, 0, y.p, y.ld, r.st);
+  }
+  Mat h;
+  ENG_CHECK(linear(r, lin, x, h));
+  return layer_norm(r, norm, h, &res, 0, y, alloc_out);
+}
+
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
-  Mat h2, y, z1, z2;
-  ENG_CHECK(linear(r, p + ".attention.linear", hid, h2));
-  ENG_CHECK(layer_norm(r, p + ".attention.norm", h2, &x, 0, y));
+  Mat y, z1;
+  ENG_CHECK(linear_ln(r, p + ".attention.linear", p + ".attention.norm", hid, x, y, true));
   ENG_CHECK(linear(r, p + ".output.expand", y, z1, 1));
-  ENG_CHECK(linear(r, p + ".output.squeeze", z1, z2));
-  return layer_norm(r, p + ".output.norm", z2, &y, 0, out, false);
+  return linear_ln(r, p + ".output.squeeze", p + ".output.norm", z1, y, out, false);
 }
 
 // rdmnet/thdroformer/thdroformer.py:266-347 on the STACKED [ref; src] rows: every op whose weights
@@ -456,6 +477,12 @@ int make_linear(rdm_engine* e, const std::string& key, const std::vector<const H
   for (auto* bb : bs) bias.insert(bias.end(), bb->data.begin(), bb->data.end());
   ENG_CHECK(upload(e, b, &L.b));
   ENG_CHECK(upload(e, bias, &L.bias));
+  if (ws.size() == 1 && out == 128 && L.kpad % 16 == 0) {
+    std::vector<float> wt(static_cast<size_t>(out) * L.kpad, 0.f);
+    for (int64_t o = 0; o < out; ++o)
+      for (int64_t i = 0; i < in; ++i) wt[o * L.kpad + i] = ws[0]->data[o * in + i];
+    ENG_CHECK(upload(e, wt, &L.wt));
+  }
   e->lin[key] = L;
   return RDM_OK;
 }

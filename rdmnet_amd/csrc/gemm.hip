@@ -286,6 +286,95 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
   }
 }
 
+// y = act(LayerNorm(x W + bias + residual)) for the transformer width (N = 128) in ONE launch: a workgroup owns
+// 16 complete rows (wavefront w the columns 32w..32w+31 over the whole K on the 16x16x4 MFMA, operands straight from
+// global memory with a permuted contraction: lane group kb takes k = kb*K/4 + step; W in its checkpoint layout
+// [128, K]), so the row statistics are a
+// 16-lane shuffle + one LDS exchange away.  Replaces a gemm_small + layernorm launch pair (48 per scan pair).
+struct LinLnArgs {
+  const float *A, *B, *bias, *res, *gamma, *beta;
+  float* out;
+  int M, K, lda, ldb, ldr, ldo, act;
+  float eps;
+};
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
+  __shared__ float red[2][4][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kb = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int kq = a.K / 4;  // K is a multiple of 16
+  const float* arow = a.A + static_cast<long long>(min(m0 + i, a.M - 1)) * a.lda + kb * kq;
+  // W is the nn.Linear weight as stored, [128, K] with k contiguous: the B operand of lane (column, kb) is a
+  // float4 of 4 consecutive k, exactly like the A operand
+  const float* brow0 = a.B + static_cast<long long>(32 * w + i) * a.ldb + kb * kq;
+  const float* brow1 = brow0 + 16ll * a.ldb;
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < kq; s0 += 4) {
+    const float4 av = *reinterpret_cast<const float4*>(arow + s0);
+    const float4 bv0 = *reinterpret_cast<const float4*>(brow0 + s0);
+    const float4 bv1 = *reinterpret_cast<const float4*>(brow1 + s0);
+    const float b0[4] = {bv0.x, bv0.y, bv0.z, bv0.w}, b1[4] = {bv1.x, bv1.y, bv1.z, bv1.w};
+    const float at[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], b0[t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], b1[t], acc1, 0, 0, 0);
+    }
+  }
+  // lane (i, g = kb) holds rows 4g + r of columns 32w + i and 32w + 16 + i
+  const int g = kb, c0 = 32 * w + i, c1 = c0 + 16;
+  const float bias0 = a.bias ? a.bias[c0] : 0.f, bias1 = a.bias ? a.bias[c1] : 0.f;
+  float v0[4], v1[4], ps[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(m0 + 4 * g + r, a.M - 1);
+    v0[r] = acc0[r] + bias0;
+    v1[r] = acc1[r] + bias1;
+    if (a.res) {
+      v0[r] += a.res[static_cast<long long>(row) * a.ldr + c0];
+      v1[r] += a.res[static_cast<long long>(row) * a.ldr + c1];
+    }
+    ps[r] = v0[r] + v1[r];
+  }
+  auto rows_reduce = [&](float (&p)[4], int which) -> void {  // p[r] -> sum over the 128 columns of row 4g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) p[r] += __shfl_xor(p[r], o, 64);
+    if (i == 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[which][w][4 * g + r] = p[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      p[r] = ((red[which][0][4 * g + r] + red[which][1][4 * g + r]) + red[which][2][4 * g + r]) + red[which][3][4 * g + r];
+  };
+  rows_reduce(ps, 0);
+  float mean[4], sq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    mean[r] = ps[r] / 128.f;
+    const float d0 = v0[r] - mean[r], d1 = v1[r] - mean[r];
+    sq[r] = d0 * d0 + d1 * d1;
+  }
+  rows_reduce(sq, 1);
+  const float g0 = a.gamma[c0], g1 = a.gamma[c1], be0 = a.beta[c0], be1 = a.beta[c1];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 4 * g + r;
+    if (row >= a.M) continue;
+    const float rstd = 1.0f / __fsqrt_rn(sq[r] / 128.f + a.eps);
+    float o0 = (v0[r] - mean[r]) * rstd * g0 + be0, o1 = (v1[r] - mean[r]) * rstd * g1 + be1;
+    if (a.act == 1) {
+      o0 = o0 > 0.f ? o0 : 0.f;
+      o1 = o1 > 0.f ? o1 : 0.f;
+    }
+    a.out[static_cast<long long>(row) * a.ldo + c0] = o0;
+    a.out[static_cast<long long>(row) * a.ldo + c1] = o1;
+  }
+}
+
 __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
   const long long total = static_cast<long long>(batches) * g.M * g.N;
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
@@ -532,4 +621,26 @@ extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w
     return e;
   return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, residual, ldr, act, y, ldy,
                            positive, nws, gn_ws, stream);
+}
+
+// y = act(LayerNorm(x W^T + bias [+ residual]) * gamma + beta) with W [128, k] (nn.Linear weight as stored): the
+// Linear + residual LayerNorm pairs of the attention layers (thdroformer.py:159-173, vanilla_transformer.py:87-103,
+// output_layer.py:13-21) as one launch.  n must be 128 and k a multiple of 16; other widths use rdm_gemm + rdm_layer_norm.
+extern "C" int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int64_t m,
+                                     int64_t n, int64_t k, const float* residual, int64_t ldr, const float* gamma,
+                                     const float* beta, float eps, int act, float* y, int64_t ldy, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(x && w && gamma && beta && y, "rdm_linear_layer_norm: null pointer");
+  RDM_REQUIRE(n == 128 && k >= 16 && k % 16 == 0 && m >= 0 && ldx % 4 == 0 && ldw >= k && ldw % 4 == 0 && act >= 0 && act <= 1,
+              "rdm_linear_layer_norm: supports n = 128, k multiple of 16 (n=%lld k=%lld)", (long long)n, (long long)k);
+  RDM_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
+              "rdm_linear_layer_norm: x and w must be 16-byte aligned");
+  if (m == 0) return RDM_OK;
+  LinLnArgs a;
+  a.A = x; a.B = w; a.bias = bias; a.res = residual; a.gamma = gamma; a.beta = beta; a.out = y;
+  a.M = static_cast<int>(m); a.K = static_cast<int>(k); a.lda = static_cast<int>(ldx); a.ldb = static_cast<int>(ldw);
+  a.ldr = static_cast<int>(ldr); a.ldo = static_cast<int>(ldy); a.act = act; a.eps = eps;
+  hipLaunchKernelGGL(linear_ln128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return launch_status("linear_ln128_kernel");
 }

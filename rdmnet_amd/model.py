@@ -84,6 +84,11 @@ class RDMNet:
 
         def lin(name):
             W[name] = _dev_linear(S[name + '.weight'], S[name + '.bias'], dev)
+            w = S[name + '.weight']
+            if w.shape[0] == 128 and pad4(w.shape[1]) % 16 == 0:  # checkpoint layout for the fused Linear + LayerNorm
+                wt = torch.zeros((128, pad4(w.shape[1])), dtype=torch.float32)
+                wt[:, :w.shape[1]] = torch.from_numpy(np.ascontiguousarray(w))
+                W[name + '.wt'] = wt.to(dev)
 
         def vec(name):
             W[name] = torch.from_numpy(S[name]).to(dev)
@@ -206,11 +211,19 @@ class RDMNet:
         """Output projection, residual LayerNorm, FFN, residual LayerNorm (thdroformer.py:142-173,
         vanilla_transformer.py:69-103, output_layer.py:6-21); `out` = rows of the stacked state."""
         W = self._w
-        h2 = self._linear(p + '.attention.linear', hid)
-        y = ops.layer_norm(h2, W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], residual=x)
+        y = self._linear_ln(p + '.attention.linear', p + '.attention.norm', hid, x)
         z = self._linear(p + '.output.expand', y, act=ACT_RELU)
-        z = self._linear(p + '.output.squeeze', z)
-        return ops.layer_norm(z, W[p + '.output.norm.weight'], W[p + '.output.norm.bias'], residual=y, out=out)
+        return self._linear_ln(p + '.output.squeeze', p + '.output.norm', z, y, out=out)
+
+    def _linear_ln(self, lin, norm, x, residual, out=None):
+        """LayerNorm(Linear(x) + residual): one fused launch at the transformer width, two launches otherwise."""
+        W = self._w
+        b, bias, in_f, out_f = W[lin]
+        if lin + '.wt' in W:
+            return ops.linear_layer_norm(x, W[lin + '.wt'], pad4(in_f), out_f, bias, W[norm + '.weight'], W[norm + '.bias'],
+                                         residual=residual, out=out)
+        h = self._linear(lin, x)
+        return ops.layer_norm(h, W[norm + '.weight'], W[norm + '.bias'], residual=residual, out=out)
 
     def _thdroformer(self, name, pts4, x, n0, num_layers, out):
         """rdmnet/thdroformer/thdroformer.py:266-347 on the STACKED [ref; src] rows (same op sequence as

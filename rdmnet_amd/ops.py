@@ -141,6 +141,18 @@ def layer_norm(x, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=Non
     return y
 
 
+def linear_layer_norm(x, w, k, n, bias, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=None):
+    """act(LayerNorm(x[:, :k] @ w.T + bias [+ residual])) in one launch; w = nn.Linear weight [128, k] (n must be 128,
+    k a multiple of 16)."""
+    L = _lib.lib()
+    m = x.shape[0]
+    y = out if out is not None else feat_empty(m, n, x.device)
+    _lib.check(L.rdm_linear_layer_norm(x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(bias), m, n, k, _lib.ptr(residual),
+                                       _ld(residual) if residual is not None else 0, gamma.data_ptr(), beta.data_ptr(), eps,
+                                       act, y.data_ptr(), _ld(y), _lib.stream_ptr()), 'rdm_linear_layer_norm')
+    return y
+
+
 def gather_max(x, idx, width=None):
     L = _lib.lib()
     m, c = idx.shape[0], x.shape[1]

@@ -161,3 +161,26 @@ def test_coarse_matching_topk_paths(ops, m, n, lo, k):
     assert np.array_equal(ri.cpu().numpy()[:c], order // n) and np.array_equal(si.cpu().numpy()[:c], order % n)
     assert np.array_equal(sc.cpu().numpy()[:c], flat[order])
     assert (v[rmask == 0] == -1).all() and (v[:, cmask == 0] == -1).all()
+
+
+@pytest.mark.parametrize('m,k', [(1, 128), (431, 128), (563, 256), (77, 16), (1000, 2048)])
+def test_linear_layer_norm_fused_matches_torch(ops, m, k):
+    """LayerNorm(x W + b + residual) in one launch (transformer width 128) against torch fp64; tolerance 2e-5 of the
+    output range (fp32 accumulation over k, statistics over 128 columns)."""
+    rng = np.random.default_rng(m + k)
+    x = torch.from_numpy(rng.normal(size=(m, k)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(k, 128)) / np.sqrt(k)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=128).astype(np.float32))
+    res = torch.from_numpy(rng.normal(size=(m, 128)).astype(np.float32))
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, 128).astype(np.float32))
+    beta = torch.from_numpy(rng.normal(size=128).astype(np.float32))
+    for residual in (res, None):
+        h = x.double() @ w.double() + b.double() + (residual.double() if residual is not None else 0)
+        want = F.layer_norm(h, (128,), gamma.double(), beta.double(), 1e-5)
+        got = ops.linear_layer_norm(padded(x), w.t().contiguous().cuda(), k, 128, b.cuda(), gamma.cuda(), beta.cuda(),
+                                    residual=padded(residual) if residual is not None else None).cpu()
+        assert (got.double() - want).abs().max() <= 2e-5 * want.abs().max()
+    relu = ops.linear_layer_norm(padded(x), w.t().contiguous().cuda(), k, 128, b.cuda(), gamma.cuda(), beta.cuda(), act=1).cpu()
+    assert relu.min() >= 0
+    with pytest.raises(RuntimeError):
+        ops.linear_layer_norm(padded(x), w.t().contiguous().cuda(), k, 64, b.cuda(), gamma.cuda(), beta.cuda())
