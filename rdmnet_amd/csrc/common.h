@@ -108,7 +108,7 @@ __global__ void fill_words_kernel(T* p, int64_t n, T v) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n) p[i] = v;
 }
-__global__ inline void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+static __global__ void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }

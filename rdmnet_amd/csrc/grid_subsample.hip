@@ -255,7 +255,6 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   unsigned* ht_first = a.ht_first + ht_off;
   unsigned* ht_rank = a.ht_rank + ht_off;
   unsigned* pt_slot = a.pt_slot + start;
-  int* scan = a.scan + start;
   unsigned long long* ekey = a.ekey + start;
   int* ecnt = a.ecnt + start;
   int* ebase = a.ebase + start;
@@ -319,68 +318,182 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   const float ox = s_org[0], oy = s_org[1], oz = s_org[2];
   const unsigned long long nx = s_nxy[0], ny = s_nxy[1];
 
+  // The phases below run on ONE workgroup and are bound by the latency of dependent global accesses, so every
+  // loop handles a small group of points/voxels at a time with all of the group's loads (or returning atomics)
+  // issued before the first result is used.
+  constexpr int G = 4;
+
   // ---- P1: voxel key per point (grid_subsampling_cpu.cpp:28-35) + de-duplication
-  for (int i = tid; i < N; i += kT) {
-    const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
-    const unsigned long long ix =
-        static_cast<unsigned long long>(static_cast<long long>(floorf((px - ox) / v)));
-    const unsigned long long iy =
-        static_cast<unsigned long long>(static_cast<long long>(floorf((py - oy) / v)));
-    const unsigned long long iz =
-        static_cast<unsigned long long>(static_cast<long long>(floorf((pz - oz) / v)));
-    const unsigned long long key = ix + nx * iy + nx * ny * iz;
-    unsigned slot = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 40) & ht_mask;
-    while (true) {
-      const unsigned long long prev = atomicCAS(&ht_keys[slot], kEmpty, key);
-      if (prev == kEmpty || prev == key) break;
-      slot = (slot + 1) & ht_mask;
+  for (int i0 = tid; i0 < N; i0 += G * kT) {
+    unsigned long long key[G];
+    unsigned slot[G];
+    bool open[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int i = i0 + u * kT;
+      open[u] = i < N;
+      key[u] = 0;
+      slot[u] = 0;
+      if (open[u]) {
+        const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+        const unsigned long long ix = static_cast<unsigned long long>(static_cast<long long>(floorf((px - ox) / v)));
+        const unsigned long long iy = static_cast<unsigned long long>(static_cast<long long>(floorf((py - oy) / v)));
+        const unsigned long long iz = static_cast<unsigned long long>(static_cast<long long>(floorf((pz - oz) / v)));
+        key[u] = ix + nx * iy + nx * ny * iz;
+        slot[u] = static_cast<unsigned>((key[u] * 0x9E3779B97F4A7C15ull) >> 40) & ht_mask;
+      }
     }
-    atomicMin(&ht_first[slot], static_cast<unsigned>(i));
-    pt_slot[i] = slot;
+    bool any = true;
+    while (any) {  // linear probing, the group's CAS attempts in flight together
+      unsigned long long prev[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (open[u]) prev[u] = atomicCAS(&ht_keys[slot[u]], kEmpty, key[u]);
+      any = false;
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (open[u]) {
+          if (prev[u] == kEmpty || prev[u] == key[u]) {
+            open[u] = false;
+            const int i = i0 + u * kT;
+            atomicMin(&ht_first[slot[u]], static_cast<unsigned>(i));
+            pt_slot[i] = slot[u];
+          } else {
+            slot[u] = (slot[u] + 1) & ht_mask;
+            any = true;
+          }
+        }
+    }
   }
   __syncthreads();
 
-  // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map)
-  const int M = block_scan(
-      N, [&](int i) { return ld_agent(&ht_first[pt_slot[i]]) == static_cast<unsigned>(i) ? 1 : 0; },
-      scan, s_scan, false);
-  for (int i = tid; i < N; i += kT) {
-    const unsigned slot = pt_slot[i];
-    if (ld_agent(&ht_first[slot]) == static_cast<unsigned>(i)) {
-      ht_rank[slot] = static_cast<unsigned>(scan[i]);
-      ekey[scan[i]] = ld_agent(&ht_keys[slot]);
+  // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map).  Thread t owns
+  // the contiguous points [c0, c1); "first" flags are recomputed in the second sweep instead of stored.
+  int M;
+  {
+    const int per = (N + kT - 1) / kT;
+    const int c0 = min(tid * per, N), c1 = min(c0 + per, N);
+    auto first_flags = [&](int base, unsigned (&sl)[G], bool (&fl)[G]) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) sl[u] = base + u < c1 ? pt_slot[base + u] : 0u;
+      unsigned f[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) f[u] = base + u < c1 ? ld_agent(&ht_first[sl[u]]) : 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < G; ++u) fl[u] = base + u < c1 && f[u] == static_cast<unsigned>(base + u);
+    };
+    int local = 0;
+    for (int base = c0; base < c1; base += G) {
+      unsigned sl[G];
+      bool fl[G];
+      first_flags(base, sl, fl);
+#pragma unroll
+      for (int u = 0; u < G; ++u) local += fl[u] ? 1 : 0;
+    }
+    int total;
+    int rank = block_prefix(local, s_scan, total);
+    M = total;
+    for (int base = c0; base < c1; base += G) {
+      unsigned sl[G];
+      bool fl[G];
+      first_flags(base, sl, fl);
+      unsigned long long kk[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) kk[u] = fl[u] ? ld_agent(&ht_keys[sl[u]]) : 0ull;
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (fl[u]) {
+          ht_rank[sl[u]] = static_cast<unsigned>(rank);
+          ekey[rank] = kk[u];
+          ++rank;
+        }
     }
   }
   __syncthreads();
 
   // ---- P3..P6: per-voxel point lists in ascending point order, sequential fp32 sums
-  for (int i = tid; i < N; i += kT) atomicAdd(&ecnt[ht_rank[pt_slot[i]]], 1);
+  for (int i0 = tid; i0 < N; i0 += G * kT) {
+    unsigned sl[G], rk[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
+#pragma unroll
+    for (int u = 0; u < G; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (i0 + u * kT < N) atomicAdd(&ecnt[rk[u]], 1);
+  }
   __syncthreads();
   block_scan(M, [&](int e) { return ld_agent(&ecnt[e]); }, ebase, s_scan, false);
-  for (int i = tid; i < N; i += kT) {
-    const int e = static_cast<int>(ht_rank[pt_slot[i]]);
-    const int pos = atomicAdd(&efill[e], 1);
-    list[ebase[e] + pos] = i;
+  for (int i0 = tid; i0 < N; i0 += G * kT) {
+    unsigned sl[G], rk[G];
+    int pos[G], eb[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
+#pragma unroll
+    for (int u = 0; u < G; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      pos[u] = 0;
+      eb[u] = 0;
+      if (i0 + u * kT < N) {
+        pos[u] = atomicAdd(&efill[rk[u]], 1);
+        eb[u] = ebase[rk[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+      if (i0 + u * kT < N) list[eb[u] + pos[u]] = i0 + u * kT;
   }
   __syncthreads();
   for (int e = tid; e < M; e += kT) {
     const int c = ld_agent(&ecnt[e]);
     int* L = list + ebase[e];
-    for (int x = 1; x < c; ++x) {  // insertion sort: voxels hold a handful of points
-      const int val = L[x];
-      int y = x - 1;
-      while (y >= 0 && L[y] > val) {
-        L[y + 1] = L[y];
-        --y;
-      }
-      L[y + 1] = val;
-    }
     float sx = 0.f, sy = 0.f, sz = 0.f;  // SampledData::update, grid_subsampling_cpu.h:17-20
-    for (int x = 0; x < c; ++x) {
-      const int i = L[x];
-      sx += P[3 * i];
-      sy += P[3 * i + 1];
-      sz += P[3 * i + 2];
+    if (c <= 8) {
+      // the usual voxel holds a handful of points: sort the indices in registers (bubble network), fetch all the
+      // points, then add them in ascending point order
+      int id[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) id[x] = x < c ? L[x] : 0x7fffffff;
+#pragma unroll
+      for (int pass = 0; pass < 7; ++pass)
+#pragma unroll
+        for (int x = 0; x < 7 - pass; ++x) {
+          const int lo = min(id[x], id[x + 1]), hi = max(id[x], id[x + 1]);
+          id[x] = lo;
+          id[x + 1] = hi;
+        }
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const int i = x < c ? id[x] : 0;
+        px[x] = P[3 * i];
+        py[x] = P[3 * i + 1];
+        pz[x] = P[3 * i + 2];
+      }
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+        if (x < c) {
+          sx += px[x];
+          sy += py[x];
+          sz += pz[x];
+        }
+    } else {
+      for (int x = 1; x < c; ++x) {  // insertion sort
+        const int val = L[x];
+        int y = x - 1;
+        while (y >= 0 && L[y] > val) {
+          L[y + 1] = L[y];
+          --y;
+        }
+        L[y + 1] = val;
+      }
+      for (int x = 0; x < c; ++x) {
+        const int i = L[x];
+        sx += P[3 * i];
+        sy += P[3 * i + 1];
+        sz += P[3 * i + 2];
+      }
     }
     const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
     epts[3 * e] = sx * wgt;
