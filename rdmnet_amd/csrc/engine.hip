@@ -418,7 +418,7 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
   if (err == hipSuccess) err = hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0);
   if (err != hipSuccess) {
     set_error("rdm_engine_create: hipHostMalloc failed: %s", hipGetErrorString(err));
-    hipFree(e->arena);
+    (void)hipFree(e->arena);
     delete e;
     return RDM_ERR_HIP;
   }
@@ -428,10 +428,10 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
 
 extern "C" void rdm_engine_destroy(rdm_engine* e) {
   if (!e) return;
-  for (void* p : e->owned) hipFree(p);
-  for (auto& ev : e->events) hipEventDestroy(ev);
-  if (e->arena) hipFree(e->arena);
-  if (e->pinned) hipHostFree(e->pinned);
+  for (void* p : e->owned) (void)hipFree(p);
+  for (auto& ev : e->events) (void)hipEventDestroy(ev);
+  if (e->arena) (void)hipFree(e->arena);
+  if (e->pinned) (void)hipHostFree(e->pinned);
   delete e;
 }
 
@@ -494,7 +494,7 @@ bool ends_with(const std::string& s, const char* suf) {
 
 extern "C" int rdm_engine_finalize(rdm_engine* e) {
   RDM_REQUIRE(e, "rdm_engine_finalize: null engine");
-  for (void* p : e->owned) hipFree(p);
+  for (void* p : e->owned) (void)hipFree(p);
   e->owned.clear();
   e->lin.clear();
   e->vec.clear();
