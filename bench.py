@@ -138,8 +138,8 @@ def cpu_budget():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
-    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=120)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=4, help='pairs in flight per GPU (host threads, one HIP stream each)')
