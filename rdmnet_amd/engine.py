@@ -90,9 +90,13 @@ class Engine:
         self.result = EngineResult()
 
     def __del__(self):
-        if getattr(self, '_h', None) and self._h.value:
-            self.L.rdm_engine_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            try:
+                self.L.rdm_engine_destroy(h)
+            except Exception:  # interpreter shutdown: the library or ctypes may already be gone
+                pass
+            h.value = None
 
     def set_wait(self, sleep_us=0):
         """0: spin in hipStreamSynchronize at the size read-backs; > 0: poll and sleep (frees the host core)."""
