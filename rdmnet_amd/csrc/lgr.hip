@@ -277,13 +277,20 @@ __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, 
   const int C = w.meta[0], chunks = w.meta[1];
   double T[12];
   if (chunks > 0) {
-    if (threadIdx.x == 0) {
-      int best = 0;
-      for (int k = 1; k < chunks; ++k)
-        if (w.chunk_inliers[k] > w.chunk_inliers[best]) best = k;  // first maximum (torch.argmax)
-      w.meta[2] = best;
-      for (int k = 0; k < 12; ++k) Tf[k] = w.chunk_T[12 * best + k];
-    }
+    // first maximum of the inlier counts (torch.argmax): block-wide max of (count, -index) packed in 64 bits
+    __shared__ unsigned long long s_best[4];
+    unsigned long long mine = 0;
+    for (int k = threadIdx.x; k < chunks; k += blockDim.x)
+      mine = max(mine, (static_cast<unsigned long long>(static_cast<unsigned>(w.chunk_inliers[k])) << 32) |
+                           static_cast<unsigned>(0x7fffffff - k));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine = max(mine, static_cast<unsigned long long>(__shfl_xor(mine, o, 64)));
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    const unsigned long long all = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
+    const int best = 0x7fffffff - static_cast<int>(all & 0xffffffffull);
+    if (threadIdx.x == 0) w.meta[2] = best;
+    if (threadIdx.x < 12) Tf[threadIdx.x] = w.chunk_T[12 * best + threadIdx.x];
   } else {  // degenerate: no patch reaches the threshold -> start from all correspondences (:189-194)
     block_procrustes(src_corr, ref_corr, scores, nullptr, 0, C, red, T);
     if (threadIdx.x < 12) Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
