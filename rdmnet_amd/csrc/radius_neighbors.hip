@@ -170,180 +170,174 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   __shared__ int seg_pref[kWavesPerBlock][28];
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // the redo pass runs on a small grid and is a no-op unless some query of THIS call exceeded the small buffer
-  // (out_max is raised by the first pass); a full grid of wavefronts that exit at once costs ~10 us per call when
-  // several pairs share the GPU
-  if (only_redo && out_max && ld_agent(out_max) <= 256) return;
-  const int64_t q_stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  for (int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave; qi < nq; qi += q_stride) {
-    if (only_redo && !redo[qi]) continue;  // second pass: only the queries that overflowed the small buffer
-    const GridMeta g = *meta;
-    if (radius * g.inv_cell > 1.0f) {  // the grid was built for a smaller radius: 27 cells would miss neighbours
-      if (lane == 0) atomicExch(status, 2);
-      continue;
-    }
-    const float r2 = radius * radius;
-    const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
-    int64_t begin;
-    const int b = cloud_of(q_lengths, batch, qi, begin);
+  const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
+  if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  if (only_redo && !redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
+  const GridMeta g = *meta;
+  if (radius * g.inv_cell > 1.0f) {  // the grid was built for a smaller radius: 27 cells would miss neighbours
+    if (lane == 0) atomicExch(status, 2);
+    return;
+  }
+  const float r2 = radius * radius;
+  const float qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
+  int64_t begin;
+  const int b = cloud_of(q_lengths, batch, qi, begin);
 
-    unsigned long long* K = keys[wave];
-    int count = 0;
-    if (b < batch) {
-      int cx, cy, cz;
-      cell_of(g, qx, qy, qz, cx, cy, cz);
-      // lanes 0..26 own one neighbouring cell each
-      int my_n = 0, my_start = 0;
-      if (lane < 27) {
-        const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
-        const int x = cx + dx, y = cy + dy, z = cz + dz;
-        if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
-          const int c = b * g.cells_per_cloud + (z * g.dim[1] + y) * g.dim[0] + x;
-          my_n = cell_count[c];
-          my_start = cell_start[c];
-        }
-      }
-      int inc = my_n;
-  #pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        const int t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
-      }
-      if (lane < 27) {
-        seg_start[wave][lane] = my_start;
-        seg_pref[wave][lane] = inc - my_n;
-      }
-      const int total = __shfl(inc, 26, 64);
-      if (lane == 27) seg_pref[wave][27] = total;
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
-      // two candidates per lane and step: both record loads are in flight before either is tested
-      for (int base = 0; base < total; base += 128) {
-        bool hit[2] = {false, false};
-        unsigned long long key[2] = {0, 0};
-        float4 p[2];
-        int tt[2];
-  #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          tt[u] = base + 64 * u + lane;
-          if (tt[u] < total) {
-            int seg = 0;
-  #pragma unroll
-            for (int step = 16; step > 0; step >>= 1)
-              if (seg + step < 27 && seg_pref[wave][seg + step] <= tt[u]) seg += step;
-            p[u] = sorted[seg_start[wave][seg] + (tt[u] - seg_pref[wave][seg])];
-          }
-        }
-  #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (tt[u] < total) {
-            const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-            float d2 = dx * dx;
-            d2 = d2 + dy * dy;
-            d2 = d2 + dz * dz;
-            hit[u] = d2 < r2;
-            key[u] = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) |
-                     static_cast<unsigned>(__float_as_int(p[u].w));
-          }
-          const unsigned long long m = __ballot(hit[u]);
-          if (hit[u]) {
-            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < CAP) K[pos] = key[u];
-          }
-          count += __popcll(m);
-        }
+  unsigned long long* K = keys[wave];
+  int count = 0;
+  if (b < batch) {
+    int cx, cy, cz;
+    cell_of(g, qx, qy, qz, cx, cy, cz);
+    // lanes 0..26 own one neighbouring cell each
+    int my_n = 0, my_start = 0;
+    if (lane < 27) {
+      const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+      const int x = cx + dx, y = cy + dy, z = cz + dz;
+      if (x >= 0 && x < g.dim[0] && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) {
+        const int c = b * g.cells_per_cloud + (z * g.dim[1] + y) * g.dim[0] + x;
+        my_n = cell_count[c];
+        my_start = cell_start[c];
       }
     }
+    int inc = my_n;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane < 27) {
+      seg_start[wave][lane] = my_start;
+      seg_pref[wave][lane] = inc - my_n;
+    }
+    const int total = __shfl(inc, 26, 64);
+    if (lane == 27) seg_pref[wave][27] = total;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+    // two candidates per lane and step: both record loads are in flight before either is tested
+    for (int base = 0; base < total; base += 128) {
+      bool hit[2] = {false, false};
+      unsigned long long key[2] = {0, 0};
+      float4 p[2];
+      int tt[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        tt[u] = base + 64 * u + lane;
+        if (tt[u] < total) {
+          int seg = 0;
+#pragma unroll
+          for (int step = 16; step > 0; step >>= 1)
+            if (seg + step < 27 && seg_pref[wave][seg + step] <= tt[u]) seg += step;
+          p[u] = sorted[seg_start[wave][seg] + (tt[u] - seg_pref[wave][seg])];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (tt[u] < total) {
+          const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+          float d2 = dx * dx;
+          d2 = d2 + dy * dy;
+          d2 = d2 + dz * dz;
+          hit[u] = d2 < r2;
+          key[u] = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) |
+                   static_cast<unsigned>(__float_as_int(p[u].w));
+        }
+        const unsigned long long m = __ballot(hit[u]);
+        if (hit[u]) {
+          const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < CAP) K[pos] = key[u];
+        }
+        count += __popcll(m);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (out_counts) out_counts[qi] = count;
+    // one address for all queries: same-address atomics cost ~12 ns each, so only raise it when needed
+    if (out_max && count > ld_agent(out_max)) atomicMax(out_max, count);
+  }
+  if (count > CAP) {  // the sorted prefix cannot be produced from a truncated buffer
     if (lane == 0) {
-      if (out_counts) out_counts[qi] = count;
-      // one address for all queries: same-address atomics cost ~12 ns each, so only raise it when needed
-      if (out_max && count > ld_agent(out_max)) atomicMax(out_max, count);
+      if (only_redo || !redo) atomicExch(status, 1);
+      else redo[qi] = 1;
     }
-    if (count > CAP) {  // the sorted prefix cannot be produced from a truncated buffer
-      if (lane == 0) {
-        if (only_redo || !redo) atomicExch(status, 1);
-        else redo[qi] = 1;
-      }
-      if (width > 0 && !only_redo && redo) continue;  // the large-buffer pass writes this row
-    } else if (lane == 0 && redo && !only_redo) {
-      redo[qi] = 0;
-    }
-    if (width <= 0) continue;
+    if (width > 0 && !only_redo && redo) return;  // the large-buffer pass writes this row
+  } else if (lane == 0 && redo && !only_redo) {
+    redo[qi] = 0;
+  }
+  if (width <= 0) return;
 
-    const int n = count < CAP ? count : CAP;
-    if (n <= 128) {
-      // rank sort in registers (the common case: a neighbourhood holds 40-100 points): each lane keeps up to two
-      // keys and counts the keys smaller than its own while every key is broadcast once with v_readlane -- no LDS
-      // traffic, no barriers; keys are unique (the index is part of the key), so ranks are a permutation
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const unsigned long long k0 = lane < n ? K[lane] : ~0ull;
-      const unsigned long long k1 = 64 + lane < n ? K[64 + lane] : ~0ull;
-      int r0 = 0, r1 = 0;
-      if (n <= 64) {  // one key per lane: half the comparisons
-        for (int i = 0; i < n; ++i) r0 += readlane64(k0, i) < k0 ? 1 : 0;
-      } else {
-        for (int i = 0; i < 64; ++i) {
-          const unsigned long long ki = readlane64(k0, i);
-          r0 += ki < k0 ? 1 : 0;
-          r1 += ki < k1 ? 1 : 0;
-        }
-        for (int i = 64; i < n; ++i) {
-          const unsigned long long ki = readlane64(k1, i - 64);
-          r0 += ki < k0 ? 1 : 0;
-          r1 += ki < k1 ? 1 : 0;
-        }
-      }
-      // every lane knows the final column of its keys: write the row directly (pads behind the n-th column)
-      int64_t* row = out_idx + qi * static_cast<int64_t>(width);
-      if (lane < n && r0 < width) row[r0] = static_cast<int64_t>(k0 & 0xffffffffull);
-      if (64 + lane < n && r1 < width) row[r1] = static_cast<int64_t>(k1 & 0xffffffffull);
-      for (int c = n + lane; c < width; c += 64) row[c] = ns;
-      continue;
-    } else {
-    int p2 = 1;
-    while (p2 < n) p2 <<= 1;
-    for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
+  const int n = count < CAP ? count : CAP;
+  if (n <= 128) {
+    // rank sort in registers (the common case: a neighbourhood holds 40-100 points): each lane keeps up to two
+    // keys and counts the keys smaller than its own while every key is broadcast once with v_readlane -- no LDS
+    // traffic, no barriers; keys are unique (the index is part of the key), so ranks are a permutation
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // bitonic sort of p2 keys by one wavefront: every stage reads all of its pairs, then writes them
-    // (plain LDS accesses batched by the compiler; wavefront-scope fences order the stages)
-    for (int k = 2; k <= p2; k <<= 1)
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        unsigned long long lo[8], hi[8];
-        const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j (bit form below)
-  #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = lane + 64 * u;
-          if (t < pairs) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
-            lo[u] = K[i];
-            hi[u] = K[i + j];
-          }
-        }
-  #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = lane + 64 * u;
-          if (t < pairs) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-            const bool up = (i & k) == 0;
-            if ((lo[u] > hi[u]) == up) {
-              K[i] = hi[u];
-              K[i + j] = lo[u];
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    const unsigned long long k0 = lane < n ? K[lane] : ~0ull;
+    const unsigned long long k1 = 64 + lane < n ? K[64 + lane] : ~0ull;
+    int r0 = 0, r1 = 0;
+    if (n <= 64) {  // one key per lane: half the comparisons
+      for (int i = 0; i < n; ++i) r0 += readlane64(k0, i) < k0 ? 1 : 0;
+    } else {
+      for (int i = 0; i < 64; ++i) {
+        const unsigned long long ki = readlane64(k0, i);
+        r0 += ki < k0 ? 1 : 0;
+        r1 += ki < k1 ? 1 : 0;
+      }
+      for (int i = 64; i < n; ++i) {
+        const unsigned long long ki = readlane64(k1, i - 64);
+        r0 += ki < k0 ? 1 : 0;
+        r1 += ki < k1 ? 1 : 0;
       }
     }
-    // offset of this cloud's supports is already folded in (indices are global rows)
+    // every lane knows the final column of its keys: write the row directly (pads behind the n-th column)
     int64_t* row = out_idx + qi * static_cast<int64_t>(width);
-    for (int c = lane; c < width; c += 64)
-      row[c] = c < n ? static_cast<int64_t>(K[c] & 0xffffffffull) : ns;
-    __builtin_amdgcn_wave_barrier();
+    if (lane < n && r0 < width) row[r0] = static_cast<int64_t>(k0 & 0xffffffffull);
+    if (64 + lane < n && r1 < width) row[r1] = static_cast<int64_t>(k1 & 0xffffffffull);
+    for (int c = n + lane; c < width; c += 64) row[c] = ns;
+    return;
+  } else {
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // bitonic sort of p2 keys by one wavefront: every stage reads all of its pairs, then writes them
+  // (plain LDS accesses batched by the compiler; wavefront-scope fences order the stages)
+  for (int k = 2; k <= p2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long lo[8], hi[8];
+      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j (bit form below)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
+          lo[u] = K[i];
+          hi[u] = K[i + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const bool up = (i & k) == 0;
+          if ((lo[u] > hi[u]) == up) {
+            K[i] = hi[u];
+            K[i + j] = lo[u];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
+  // offset of this cloud's supports is already folded in (indices are global rows)
+  int64_t* row = out_idx + qi * static_cast<int64_t>(width);
+  for (int c = lane; c < width; c += 64)
+    row[c] = c < n ? static_cast<int64_t>(K[c] & 0xffffffffull) : ns;
 }
 
 }  // namespace
@@ -430,8 +424,7 @@ extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_
                      q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx, out_counts,
                      out_max, status, redo, 0);
   if (width > 0)
-    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(out_max ? std::min(qblocks, 64) : qblocks), dim3(64 * kWavesPerBlock), 0, st,
-                       q_points, n_q, n_s,
+    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, q_points, n_q, n_s,
                        q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx,
                        out_counts, out_max, status, redo, 1);
   return launch_status("rn_query_kernel");
