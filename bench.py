@@ -350,7 +350,8 @@ def main():
                 'bytes_per_launch': b_total / n_layers, 'us_per_launch': t_total / n_layers * 1e6,
                 'gather_only': {'kernel': 'kpconv_gather_kernel', 'achieved': b_gather / t_gather / 1e9 if t_gather > 0 else 0.0,
                                 'us_per_launch': t_gather / n_layers * 1e6},
-                'kpconv_ms_per_pair': t_total / args.steps * 1e3, 'one_pair_in_flight': isolated}
+                'kpconv_ms_per_pair': t_total / max(len(prof) / 14.0, 1.0) * 1e3,  # 14 KPConv layers per pair
+                'pairs_with_layer_events': len(prof) // 14, 'one_pair_in_flight': isolated}
 
     if rank == 0:
         result = {
