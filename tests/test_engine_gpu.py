@@ -98,3 +98,26 @@ def test_full_size_pair_properties(ctx, golden_dir):
     # run-to-run
     res2 = eng.run(rp, sp)
     assert np.array_equal(eng.transform(), T) and res2.n_correspondences == rc.shape[0]
+
+
+@pytest.mark.parametrize('n,scale', [(500, 20.0), (50, 5.0), (5, 1.0), (1, 1.0), (4000, 200.0)])
+def test_engine_handles_degenerate_clouds(ctx, n, scale):
+    """Tiny, single-point and extremely sparse clouds (every point its own voxel at all levels) run through the whole
+    path: no hang, no capacity error, a finite pose, sizes that shrink monotonically."""
+    rng = np.random.default_rng(n)
+    a = torch.from_numpy((rng.uniform(-1, 1, (n, 3)) * np.array([scale, scale, 2.0])).astype(np.float32)).cuda()
+    b = torch.from_numpy((rng.uniform(-1, 1, (max(n - 3, 1), 3)) * np.array([scale, scale, 2.0])).astype(np.float32)).cuda()
+    res = ctx['eng'].run(a, b)
+    assert np.isfinite(ctx['eng'].transform()).all()
+    assert res.level_sizes[0] == a.shape[0] + b.shape[0]
+    assert all(res.level_sizes[i] >= res.level_sizes[i + 1] >= 2 for i in range(4))
+    assert res.n_ref_nodes >= 1 and res.n_src_nodes >= 1 and res.n_correspondences >= 0
+
+
+def test_engine_reports_capacity_instead_of_truncating(ctx):
+    """20 000 points in a 4 m cube put > 1024 points into one search radius: the reference would return them all;
+    the kernels' per-query capacity is 1024, and exceeding it is an error, never a silent truncation."""
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.uniform(-2, 2, (20000, 3)).astype(np.float32)).cuda()
+    with pytest.raises(RuntimeError, match='capacity of 1024'):
+        ctx['eng'].run(a, a.clone())
