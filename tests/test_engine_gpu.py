@@ -121,3 +121,38 @@ def test_engine_reports_capacity_instead_of_truncating(ctx):
     a = torch.from_numpy(rng.uniform(-2, 2, (20000, 3)).astype(np.float32)).cuda()
     with pytest.raises(RuntimeError, match='capacity of 1024'):
         ctx['eng'].run(a, a.clone())
+
+
+def test_engines_are_reentrant_across_threads_and_streams(ctx):
+    """Four engines driven by four host threads on four streams (the bench's configuration) produce, for the same
+    pair, bit-identical poses and correspondence counts: the library keeps no global state."""
+    import threading
+    from rdmnet_amd import engine
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    ref_T, ref_n = None, None
+    ctx['eng'].run(rp, sp)
+    ref_T, ref_n = ctx['eng'].transform(), ctx['eng'].result.n_correspondences
+    engines = [engine.Engine(ctx['cfg'], ctx['state']) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    out, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                res = []
+                for _ in range(6):
+                    r = engines[k].run(rp, sp)
+                    res.append((engines[k].transform(), r.n_correspondences))
+                out[k] = res
+        except BaseException as e:
+            errs.append(e)
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for res in out:
+        for T, n in res:
+            assert n == ref_n and np.array_equal(T, ref_T)
