@@ -481,6 +481,8 @@ extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const fl
   return launch_status("point_to_node kernels");
 }
 
+namespace {
+
 // ---- multi-workgroup top-k: the single-workgroup kernel above needs ~130 us on one CU for a 330 x 320 matrix
 // (five sweeps over 105 k scores); here the sweeps run on the whole GPU:
 //   1. histogram of the top 12 bits of every eligible score (LDS per block, flushed with integer atomics);
@@ -619,6 +621,8 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long lo
   }
   if (threadIdx.x == 0) *out_count = kk;
 }
+
+}  // namespace
 
 extern "C" size_t rdm_coarse_matching_workspace_bytes(int64_t m, int64_t n) {
   rdm::Arena a(nullptr, 0);

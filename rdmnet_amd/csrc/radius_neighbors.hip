@@ -437,6 +437,7 @@ extern "C" const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_by
   return reinterpret_cast<const float*>(g.sorted);
 }
 
+namespace {
 // Histogram of per-query neighbour counts (calibration of the neighbour limits): np.bincount(counts,
 // minlength = hist_n)[:hist_n] accumulated into hist.  Per-block LDS histogram, then one global atomic per
 // non-empty bin, so the many queries with similar counts do not serialise on HBM atomics.
@@ -455,6 +456,8 @@ __global__ __launch_bounds__(256) void rn_histogram_kernel(const int32_t* __rest
   for (int i = threadIdx.x; i < hist_n; i += 256)
     if (local[i]) atomicAdd(hist + i, local[i]);
 }
+
+}  // namespace
 
 extern "C" int rdm_neighbor_histogram(const int32_t* counts, int64_t n, int32_t* hist, int hist_n, void* stream) {
   RDM_REQUIRE(n >= 0 && hist_n > 0 && hist_n <= kHistLds, "rdm_neighbor_histogram: hist_n must be in 1..%d", kHistLds);
