@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librdmnet_hip.so')
+LIB_PATH = os.environ.get('RDM_LIB_PATH') or os.path.join(_HERE, 'librdmnet_hip.so')  # override: A/B builds
 
 c_void = ctypes.c_void_p
 c_i64 = ctypes.c_int64
