@@ -142,15 +142,24 @@ __global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, co
   if (cnt > CAP && lane == 0) atomicExch(status, 1);
   volatile unsigned long long* K = keys;
   int filled = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const bool mine = i < n && owner[i] == node;
-    const unsigned long long mm = __ballot(mine);
-    if (mine) {
-      const int pos = filled + __popcll(mm & ((1ull << lane) - 1ull));
-      if (pos < CAP) K[pos] = (static_cast<unsigned long long>(__float_as_uint(d_own[i])) << 32) | static_cast<unsigned>(i);
+  for (int base = 0; base < n; base += 256) {  // four owner loads in flight per step (the scan is latency-bound)
+    int own[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      own[u] = i < n ? owner[i] : -1;
     }
-    filled += __popcll(mm);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + 64 * u + lane;
+      const bool mine = own[u] == node;
+      const unsigned long long mm = __ballot(mine);
+      if (mine) {
+        const int pos = filled + __popcll(mm & ((1ull << lane) - 1ull));
+        if (pos < CAP) K[pos] = (static_cast<unsigned long long>(__float_as_uint(d_own[i])) << 32) | static_cast<unsigned>(i);
+      }
+      filled += __popcll(mm);
+    }
   }
   const int cn = filled < CAP ? filled : CAP;
   int p2 = 1;
