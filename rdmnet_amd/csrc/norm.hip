@@ -199,14 +199,23 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns,
   int H = h;
   if (width) H = min(H, *width);
   float4 best = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-  for (int k = 0; k < H; ++k) {
-    const int64_t id = idx[static_cast<int64_t>(m) * ldi + k];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (id >= 0 && id < ns) v = *reinterpret_cast<const float4*>(x + id * ldx + c0);
-    best.x = fmaxf(best.x, v.x);
-    best.y = fmaxf(best.y, v.y);
-    best.z = fmaxf(best.z, v.z);
-    best.w = fmaxf(best.w, v.w);
+  const int64_t* row_idx = idx + static_cast<int64_t>(m) * ldi;
+  for (int k0 = 0; k0 < H; k0 += 8) {  // eight neighbour rows in flight (index -> row is a dependent load pair)
+    int64_t id[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) id[u] = k0 + u < H ? row_idx[k0 + u] : -1;
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = (id[u] >= 0 && id[u] < ns) ? *reinterpret_cast<const float4*>(x + id[u] * ldx + c0)
+                                        : (k0 + u < H ? make_float4(0.f, 0.f, 0.f, 0.f) : best);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      best.x = fmaxf(best.x, v[u].x);
+      best.y = fmaxf(best.y, v[u].y);
+      best.z = fmaxf(best.z, v[u].z);
+      best.w = fmaxf(best.w, v[u].w);
+    }
   }
   *reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy + c0) = best;
 }
