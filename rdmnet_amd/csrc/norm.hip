@@ -63,9 +63,19 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial
   const int col = blockIdx.x * 64 + ci;
   double s = 0.0, ss = 0.0;
   if (col < c)
-    for (int b = lane; b < nblk; b += 16) {
-      s += partial[(static_cast<int64_t>(b) * 2 + 0) * c + col];
-      ss += partial[(static_cast<int64_t>(b) * 2 + 1) * c + col];
+    for (int b0 = lane; b0 < nblk; b0 += 64) {  // four partial rows in flight, added in ascending order
+      double p0[4], p1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 16 * u;
+        p0[u] = b < nblk ? partial[(static_cast<int64_t>(b) * 2 + 0) * c + col] : 0.0;
+        p1[u] = b < nblk ? partial[(static_cast<int64_t>(b) * 2 + 1) * c + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += p0[u];
+        ss += p1[u];
+      }
     }
   sh[0][lane][ci] = s;
   sh[1][lane][ci] = ss;
