@@ -96,22 +96,31 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;   // per query x (replicated over g)
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // O[query 4g+r][d = 2x + t]
 
+  // K / V fragments of a key tile: the next tile's loads are issued before the current tile is multiplied
+  float kf_n[8];
+  float2 vv_n[4];
+  auto load_tile = [&](int k0) {
+    const int ki = min(k0 + x, a.nk - 1);
+    const float4* p = reinterpret_cast<const float4*>(a.k + static_cast<int64_t>(ki) * a.ldk + hoff + 8 * g);
+    const float4 u = p[0], w = p[1];
+    kf_n[0] = u.x; kf_n[1] = u.y; kf_n[2] = u.z; kf_n[3] = u.w;
+    kf_n[4] = w.x; kf_n[5] = w.y; kf_n[6] = w.z; kf_n[7] = w.w;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int kj = min(k0 + 4 * g + st, a.nk - 1);
+      vv_n[st] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(kj) * a.ldv + hoff + 2 * x);
+    }
+  };
+  if (wave * 16 < a.nk) load_tile(wave * 16);
   for (int k0 = wave * 16; k0 < a.nk; k0 += 64) {
     // ---- S^T[key 4g'+r][query x] over this key tile
     float kf[8];
-    {
-      const int ki = min(k0 + x, a.nk - 1);
-      const float4* p = reinterpret_cast<const float4*>(a.k + static_cast<int64_t>(ki) * a.ldk + hoff + 8 * g);
-      const float4 u = p[0], w = p[1];
-      kf[0] = u.x; kf[1] = u.y; kf[2] = u.z; kf[3] = u.w;
-      kf[4] = w.x; kf[5] = w.y; kf[6] = w.z; kf[7] = w.w;
-    }
     float2 vv[4];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int ki = min(k0 + 4 * g + st, a.nk - 1);
-      vv[st] = *reinterpret_cast<const float2*>(a.v + static_cast<int64_t>(ki) * a.ldv + hoff + 2 * x);
-    }
+    for (int t = 0; t < 8; ++t) kf[t] = kf_n[t];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) vv[st] = vv_n[st];
+    if (k0 + 64 < a.nk) load_tile(k0 + 64);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BF16) {
       // contraction index = 8*kappa + 4*step + i: lane group kappa holds features 8*kappa .. 8*kappa+7
