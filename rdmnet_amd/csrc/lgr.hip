@@ -115,18 +115,47 @@ __global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_score
 }
 
 // ------------------------------------------------------------------------------------------ layout
-__global__ __launch_bounds__(1024) void lgr_layout_kernel(int batch, int min_corr, LgrBuffers w) {
-  if (threadIdx.x != 0) return;  // batch <= a few hundred: a serial scan is a few microseconds
-  int acc = 0, chunks = 0;
-  for (int b = 0; b < batch; ++b) {
-    const int c = w.patch_count[b];
-    w.patch_offset[b] = acc;
-    acc += c;
-    if (c >= min_corr) w.chunk_patch[chunks++] = b;
+// One wavefront: exclusive prefix of the per-patch correspondence counts (= offsets in nonzero order) and the
+// ordered list of patches with >= min_corr correspondences.  Lane l owns patches 4l .. 4l+3 of each 256-patch chunk.
+__global__ __launch_bounds__(64) void lgr_layout_kernel(int batch, int min_corr, LgrBuffers w) {
+  const int lane = threadIdx.x;
+  int acc = 0, chunks = 0;  // running totals, identical in all lanes
+  for (int base = 0; base < batch; base += 256) {
+    int c[4], local = 0, nbig = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = base + 4 * lane + u;
+      c[u] = b < batch ? w.patch_count[b] : 0;
+      local += c[u];
+      nbig += (b < batch && c[u] >= min_corr) ? 1 : 0;
+    }
+    int inc = local, inb = nbig;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64), tb = __shfl_up(inb, o, 64);
+      if (lane >= o) {
+        inc += t;
+        inb += tb;
+      }
+    }
+    int off = acc + inc - local, slot = chunks + inb - nbig;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = base + 4 * lane + u;
+      if (b < batch) {
+        w.patch_offset[b] = off;
+        off += c[u];
+        if (c[u] >= min_corr) w.chunk_patch[slot++] = b;
+      }
+    }
+    acc += __shfl(inc, 63, 64);
+    chunks += __shfl(inb, 63, 64);
   }
-  w.meta[0] = acc;
-  w.meta[1] = chunks;
-  w.meta[2] = -1;
+  if (lane == 0) {
+    w.meta[0] = acc;
+    w.meta[1] = chunks;
+    w.meta[2] = -1;
+  }
 }
 
 __global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, int side, LgrBuffers w,
