@@ -81,14 +81,18 @@ __global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_score
     colok[j] = (arg < side && best > S[side * ld + j]) ? 1 : 0;
   }
   __syncthreads();
-  const unsigned char* rm = ref_mask + static_cast<int64_t>(b) * side;
-  const unsigned char* cm = src_mask + static_cast<int64_t>(b) * side;
+  // masks staged in LDS: the two loops below test side^2 (row, column) pairs per patch
+  __shared__ unsigned char rm[kSide], cm[kSide];
+  if (tid < side) rm[tid] = ref_mask[static_cast<int64_t>(b) * side + tid];
+  else if (tid >= 128 && tid < 128 + side) cm[tid - 128] = src_mask[static_cast<int64_t>(b) * side + tid - 128];
+  __syncthreads();
   auto is_corr = [&](int i, int j) {
     return rm[i] && cm[j] && ((rowok[i] && rowarg[i] == j) || (colok[j] && colarg[j] == i));
   };
   if (tid < side) {
     int c = 0;
-    for (int j = 0; j < side; ++j) c += is_corr(tid, j) ? 1 : 0;
+    if (rm[tid])
+      for (int j = 0; j < side; ++j) c += is_corr(tid, j) ? 1 : 0;
     rowcnt[tid] = c;
   }
   __syncthreads();
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_score
   __syncthreads();
   if (tid < side) {
     int pos = rowcnt[tid];
-    for (int j = 0; j < side; ++j)
+    for (int j = 0; rm[tid] && j < side; ++j)
       if (is_corr(tid, j)) {
         const int64_t o = static_cast<int64_t>(b) * kPerPatch + pos++;
         w.local_i[o] = tid;
