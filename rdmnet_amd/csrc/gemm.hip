@@ -483,7 +483,10 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   if (n <= 32) tile = T128x32;
   // 128x128 tiles halve the L2->LDS traffic per flop; they pay off for large M, and for the coarse-level
   // KPConv contractions (M in the hundreds, K in the thousands) where split-K supplies the parallelism
-  else if (n >= 128 && m >= 2048) tile = T128;
+  // ... but only for deep products: with K below ~512 a 128x128 block is mostly prologue and epilogue, and the four
+  // times more numerous 64x64 blocks overlap each other's latencies (tools/gemm_sweep_small.py: 41 -> <16 us at
+  // 3879 x 256 x 128)
+  else if (n >= 128 && m >= 2048 && k >= 512) tile = T128;
   else tile = T64;
   // developer knob for tuning runs (tools/gemm_sweep.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the heuristics
   int force_splits = 0;
