@@ -14,6 +14,7 @@
 // fixed-order reduce, no atomics => deterministic) keeps the small-M / huge-K coarse levels busy.
 // Requirements: lda, ldb, K multiples of 4 and 16-byte aligned bases (callers pad with zeros).
 #include "../../include/rdmnet_hip.h"
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -462,8 +463,8 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
-  // split-K is only chosen while fewer than 256 tiles exist and targets ~512 blocks, so the partials
-  // never exceed (512 + 256) tiles of 128 x 128 floats; tiny problems need at most 16 copies.
+  // split-K partials: at most 16 copies of the output, capped at 64 MB (the dispatch model never asks for more than
+  // the workspace it is given).
   const size_t by_shape = static_cast<size_t>(m) * static_cast<size_t>(n) * 16;
   const size_t by_tiles = static_cast<size_t>(1024) * 128 * 128;
   return align_up(std::min(by_shape, by_tiles) * sizeof(float) * static_cast<size_t>(batches > 0 ? batches : 1));
@@ -479,16 +480,42 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
-  enum { T128, T64, T128x32 } tile;
-  if (n <= 32) tile = T128x32;
-  // 128x128 tiles halve the L2->LDS traffic per flop; they pay off for large M, and for the coarse-level
-  // KPConv contractions (M in the hundreds, K in the thousands) where split-K supplies the parallelism
-  // ... but only for deep products: with K below ~512 a 128x128 block is mostly prologue and epilogue, and the four
-  // times more numerous 64x64 blocks overlap each other's latencies (tools/gemm_sweep_small.py: 41 -> <16 us at
-  // 3879 x 256 x 128)
-  else if (n >= 128 && m >= 2048 && k >= 512) tile = T128;
-  else tile = T64;
-  // developer knob for tuning runs (tools/gemm_sweep.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the heuristics
+  // Tile shape and split-K factor from a small cost model fitted to tools/gemm_sweep_graph.py (HIP-graph-replayed
+  // timings of every product shape of the path): a block costs a fixed prologue + epilogue plus a time per 64 of K;
+  // blocks run in rounds of (CUs x resident blocks); split-K adds the partial traffic and one more launch.
+  enum Tile { T128, T64, T128x32 };
+  // per 64 of K a block needs max(latency-bound time, MFMA time x blocks sharing the CU)
+  struct Cand { Tile tile; int bm, bn; double fixed_us, lat_k64_us, mfma_k64_us; int resident; };
+  static const Cand cands[3] = {{T128, 128, 128, 4.0, 2.6, 3.4, 3}, {T64, 64, 64, 3.0, 2.6, 0.86, 4}, {T128x32, 128, 32, 3.0, 1.9, 0.86, 3}};
+  Tile tile = T64;
+  int best_s = 1;
+  {
+    double best = 1e30;
+    const size_t ws_cap = ws ? ws_bytes : 0;
+    for (const Cand& c : cands) {
+      if (c.tile == T128x32 && n > 64) continue;
+      if (c.tile != T128x32 && n <= 32) continue;  // a 64-wide tile would be half empty
+      if (c.tile == T128 && n < 128) continue;
+      const long long tiles = ceil_div<long long>(m, c.bm) * ceil_div<long long>(n, c.bn) * batches;
+      const int max_s = k >= 256 ? static_cast<int>(std::min<long long>(16, k / 128)) : 1;
+      for (int sp = 1; sp <= max_s; ++sp) {
+        if (sp > 1 && static_cast<size_t>(m) * n * sp * batches * sizeof(float) > ws_cap) break;
+        const long long blocks = tiles * sp;
+        const double k_per = static_cast<double>(k) / sp / 64.0;
+        const long long per_round = 256ll * c.resident;
+        const long long full = blocks / per_round, rem = blocks % per_round;
+        double t = full * (c.fixed_us + k_per * std::max(c.lat_k64_us, c.mfma_k64_us * c.resident));
+        if (rem) t += c.fixed_us + k_per * std::max(c.lat_k64_us, c.mfma_k64_us * static_cast<double>(ceil_div<long long>(rem, 256)));
+        if (sp > 1) t += 5.0 + static_cast<double>(m) * n * sp * 8.0 / 2.5e6;  // reduce launch + partial write/read
+        if (t < best) {
+          best = t;
+          tile = c.tile;
+          best_s = sp;
+        }
+      }
+    }
+  }
+  // developer knob for tuning runs (tools/gemm_sweep*.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the model
   int force_splits = 0;
   if (const char* tune = getenv("RDM_GEMM_TUNE")) {
     int t = 0, sp = 0;
@@ -497,25 +524,15 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       else if (t == 2) tile = T64;
       else if (t == 3) tile = T128x32;
       force_splits = sp;
+      if (t >= 1 && t <= 3 && sp == 0) best_s = 1;
     }
   }
   const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
-  const long long tiles = ceil_div<long long>(m, bm) * ceil_div<long long>(n, bn) * batches;
-  // deterministic split-K for the coarse levels (few tiles, K in the thousands): target ~512 blocks,
-  // at least 128 of K per split
-  if ((tiles < 256 && k >= 512) || force_splits > 1) {
-    // tools/gemm_sweep.py: first put ~1.5 blocks on each of the 256 CUs (co-resident blocks hide each other's
-    // prologue/epilogue), then add splits only while each keeps >= 640 of K (beyond that, more splits only add
-    // partial traffic)
-    const int s_fill = static_cast<int>(ceil_div<long long>(384, tiles));
-    int s = static_cast<int>(std::min<long long>(k / 640, ceil_div<long long>(768, tiles)));
-    if (s < s_fill) s = s_fill;
-    if (s > 16) s = 16;
-    if (s > k / 128) s = static_cast<int>(k / 128);
-    if (force_splits > 0) s = force_splits;
-    const size_t need = static_cast<size_t>(m) * n * s * batches * sizeof(float);
-    if (s > 1 && ws && ws_bytes >= need) {
-      g.splits = s;
+  {
+    int sp = force_splits > 0 ? force_splits : best_s;
+    const size_t need = static_cast<size_t>(m) * n * sp * batches * sizeof(float);
+    if (sp > 1 && ws && ws_bytes >= need) {
+      g.splits = sp;
       g.part = static_cast<float*>(ws);
     }
   }

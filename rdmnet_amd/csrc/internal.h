@@ -14,8 +14,8 @@ int gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, fl
                     double* gn_partial, int* gn_blocks, void* stream);
 
 // Upper bound of block rows gemm_with_stats can produce for m rows.
-// (64-row tiles without split-K; the split-K reduce, taken only below 256 tiles = 16 k rows, uses as few as 8 rows)
-inline int64_t gemm_stats_max_blocks(int64_t m) { return m < 16384 ? (m + 7) / 8 + 1 : (m + 63) / 64 + 1; }
+// (64-row tiles without split-K; the split-K reduce uses as few as 8 rows per block)
+inline int64_t gemm_stats_max_blocks(int64_t m) { return (m + 7) / 8 + 1; }
 
 // GroupNorm given (optional) precomputed partials: nblk > 0 uses them, nblk == 0 computes them.
 int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
