@@ -474,8 +474,9 @@ namespace {
 
 int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
   const long long m = g.M, n = g.N, k = g.K;
-  if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && m <= 1536 && k % 16 == 0 && k >= 64 &&
-      m * n <= 1536 * 512) {
+  const char* tune_env = getenv("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
+  if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
+      m * n <= 1536 * 512 && !(tune_env && tune_env[0] != '0')) {
     if (stat_blocks) *stat_blocks = 0;
     hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");

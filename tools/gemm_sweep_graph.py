@@ -16,16 +16,16 @@ shapes = [('kp1_2', N[0], 480, 32), ('kp2_1', N[1], 480, 32), ('kp2_2', N[1], 96
           ('u4', N[4], 1024, 512), ('u4b', N[4], 512, 2048), ('u4c', N[4], 1024, 2048), ('u4d', N[4], 2048, 512),
           ('dec4', N[3], 1284, 1024), ('dec3', N[2], 1536, 512), ('dec2', N[1], 768, 257)]
 
-def timed(a, b, k, n, rd):
+def timed(a, b, k, n, rd, bias=None):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         for _ in range(3):
-            ops.gemm(a, b, k, n, rowdiv=rd)
+            ops.gemm(a, b, k, n, rowdiv=rd, bias=bias)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             for _ in range(20):
-                ops.gemm(a, b, k, n, rowdiv=rd)
+                ops.gemm(a, b, k, n, rowdiv=rd, bias=bias)
         g.replay(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
@@ -34,22 +34,23 @@ def timed(a, b, k, n, rd):
         e1.record(s); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 100 * 1e3
 
-tot_auto = tot_best = 0.0
-for name, m, k, n in shapes:
-    a = torch.randn(m, k, device='cuda'); b = torch.randn(k, (n + 3) // 4 * 4, device='cuda'); rd = torch.ones(m, device='cuda')
-    os.environ.pop('RDM_GEMM_TUNE', None)
-    auto = timed(a, b, k, n, rd)
-    res = []
-    for tile in (1, 2, 3):
-        for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
-            if sp > max(k // 64, 1) or (tile == 3 and n > 64):
-                continue
-            os.environ['RDM_GEMM_TUNE'] = f'{tile},{sp}'
-            try:
-                res.append((timed(a, b, k, n, rd), tile, sp))
-            except RuntimeError:
-                pass
-    res.sort()
-    tot_auto += auto; tot_best += res[0][0]
-    print(f'{name:6s} M={m:6d} K={k:5d} N={n:5d}: auto {auto:6.1f} us | ' + ', '.join(f'{us:.1f}(t{t},s{sp})' for us, t, sp in res[:4]), flush=True)
-print(f'sum auto {tot_auto:.0f} us, sum best {tot_best:.0f} us')
+if __name__ == '__main__':
+    tot_auto = tot_best = 0.0
+    for name, m, k, n in shapes:
+        a = torch.randn(m, k, device='cuda'); b = torch.randn(k, (n + 3) // 4 * 4, device='cuda'); rd = torch.ones(m, device='cuda')
+        os.environ.pop('RDM_GEMM_TUNE', None)
+        auto = timed(a, b, k, n, rd)
+        res = []
+        for tile in (1, 2, 3):
+            for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
+                if sp > max(k // 64, 1) or (tile == 3 and n > 64):
+                    continue
+                os.environ['RDM_GEMM_TUNE'] = f'{tile},{sp}'
+                try:
+                    res.append((timed(a, b, k, n, rd), tile, sp))
+                except RuntimeError:
+                    pass
+        res.sort()
+        tot_auto += auto; tot_best += res[0][0]
+        print(f'{name:6s} M={m:6d} K={k:5d} N={n:5d}: auto {auto:6.1f} us | ' + ', '.join(f'{us:.1f}(t{t},s{sp})' for us, t, sp in res[:4]), flush=True)
+    print(f'sum auto {tot_auto:.0f} us, sum best {tot_best:.0f} us')
