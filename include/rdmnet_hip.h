@@ -185,6 +185,16 @@ int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const floa
 int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int64_t m, int64_t n,
                           int64_t k, const float* residual, int64_t ldr, const float* gamma, const float* beta, float eps,
                           int act, float* y, int64_t ldy, void* stream);
+/* rdm_attention_tail: everything of an attention layer after softmax(QK^T)V in one launch:
+ *   y = LayerNorm(hidden Wo^T + bo + x); z = relu(y W1^T + b1); out = LayerNorm(z W2^T + b2 + y)
+ * (rdmnet/thdroformer/thdroformer.py:142-173 RPEAttentionLayer / :159-173, geotransformer/modules/transformer/
+ * vanilla_transformer.py:69-103, output_layer.py:6-21 AttentionOutput).  d = 128 with a 256-wide FFN; weights as
+ * nn.Linear stores them: wo [128,128], w1 [256,128], w2 [128,256], row strides ld_* (multiples of 4), 16-byte aligned.
+ * hidden, x, out: [m, 128] rows.  Other widths: rdm_linear_layer_norm / rdm_gemm + rdm_layer_norm.                  */
+int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                       const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
+                       const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
+                       const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out, void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
 /* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the

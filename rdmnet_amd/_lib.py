@@ -53,6 +53,8 @@ SIGNATURES = {
                                c_i64, c_void]),
     'rdm_linear_layer_norm': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void,
                                       c_f32, c_int, c_void, c_i64, c_void]),
+    'rdm_attention_tail': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void, c_i64,
+                                   c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void]),
     'rdm_gather_max': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_i64,
                                c_void]),
     'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,

@@ -84,6 +84,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane: four VALU adds with a DPP operand
+// (xor 1, xor 2 inside the quads, then the half-row and row mirrors) instead of four ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return v;
+}
+// Workgroup barrier that orders LDS traffic only: global loads issued earlier stay in flight across it
+// (__syncthreads() drains vmcnt as well).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

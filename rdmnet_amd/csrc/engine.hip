@@ -40,7 +40,7 @@ struct HostParam {
 
 struct Linear {  // B operand [K_pad, N_pad] + bias
   float* b = nullptr;
-  float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused Linear + LayerNorm, out == 128 only
+  float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused transformer kernels, out == 128 / 256 only
   float* bias = nullptr;
   int64_t in = 0, out = 0, kpad = 0, ldb = 0;
 };
@@ -268,7 +268,7 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
     return RDM_ERR_ARG;
   }
   const Linear& L = it->second;
-  if (L.wt) {
+  if (L.wt && L.out == 128) {
     if (alloc_out) {
       y = e->mat(x.rows, L.out);
       ENG_ALLOC(y.p);
@@ -282,6 +282,16 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
 }
 
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
+  rdm_engine* e = r.e;
+  auto lo = e->lin.find(p + ".attention.linear"), l1 = e->lin.find(p + ".output.expand"), l2 = e->lin.find(p + ".output.squeeze");
+  if (lo != e->lin.end() && l1 != e->lin.end() && l2 != e->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&
+      lo->second.out == 128 && lo->second.kpad == 128 && l1->second.out == 256 && l1->second.kpad == 128 &&
+      l2->second.out == 128 && l2->second.kpad == 256 && !getenv("RDM_NO_FUSED_TAIL")) {
+    const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
+    return rdm_attention_tail(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias, vecp(r, p + ".attention.norm.weight"),
+                              vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias, L2.wt, L2.kpad, L2.bias,
+                              vecp(r, p + ".output.norm.weight"), vecp(r, p + ".output.norm.bias"), 1e-5f, out.p, out.ld, r.st);
+  }
   Mat y, z1;
   ENG_CHECK(linear_ln(r, p + ".attention.linear", p + ".attention.norm", hid, x, y, true));
   ENG_CHECK(linear(r, p + ".output.expand", y, z1, 1));
@@ -477,7 +487,7 @@ int make_linear(rdm_engine* e, const std::string& key, const std::vector<const H
   for (auto* bb : bs) bias.insert(bias.end(), bb->data.begin(), bb->data.end());
   ENG_CHECK(upload(e, b, &L.b));
   ENG_CHECK(upload(e, bias, &L.bias));
-  if (ws.size() == 1 && out == 128 && L.kpad % 16 == 0) {
+  if (ws.size() == 1 && (out == 128 || out == 256) && L.kpad % 16 == 0) {
     std::vector<float> wt(static_cast<size_t>(out) * L.kpad, 0.f);
     for (int64_t o = 0; o < out; ++o)
       for (int64_t i = 0; i < in; ++i) wt[o * L.kpad + i] = ws[0]->data[o * in + i];

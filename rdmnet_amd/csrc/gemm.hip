@@ -47,7 +47,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B>
+// PF = global->register prefetch depth in K tiles (the loop barriers order LDS only, so the stages really stay in
+// flight): the skinny products of this path run a handful of blocks per CU and a block covers part of the load
+// latency itself.
+template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
@@ -75,9 +78,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int KC4 = BK / 4;                       // float4 per tile row
   constexpr int B_N4 = BK * BN / 4;                 // float4 in the B tile
   constexpr int B_V = (B_N4 + 255) / 256;           // float4 per thread for the B tile
-  float4 ra[A_V], rb[B_V];
+  float4 rga[PF][A_V], rgb[PF][B_V];
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](float4 (&ra)[A_V], float4 (&rb)[B_V], int kt) {
     const int k0 = kt * BK;
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const float4 (&ra)[A_V], const float4 (&rb)[B_V], int buf) {
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
       const int idx = tid + i * 256;
@@ -158,30 +161,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt0 < kt1) {
-    load_tiles(kt0);
-    store_tiles(0);
-  }
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (kt0 + s < kt1) load_tiles(rga[s], rgb[s], kt0 + s);
+  if (kt0 < kt1) store_tiles(rga[0], rgb[0], 0);
+  lds_barrier();
   const int lk = lane >> 5, li = lane & 31;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tiles(kt + 1);
+  for (int ktb = kt0; ktb < kt1; ktb += PF) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float af[FM], bf[FN];
+    for (int s = 0; s < PF; ++s) {
+      const int kt = ktb + s;
+      if (kt >= kt1) break;  // block-uniform
+      // LDS buffer of tile kt; PF is 1 or even, so the parity is static when PF > 1
+      const int buf = PF > 1 ? (s & 1) : ((kt - kt0) & 1);
+      // register stage s held tile kt, which is in LDS already: refill it with tile kt + PF
+      if (kt + PF < kt1) load_tiles(rga[s], rgb[s], kt + PF);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = As[buf][kk + lk][wm * TM + i * 32 + li];
+      for (int kk = 0; kk < BK; kk += 2) {
+        float af[FM], bf[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
+        for (int i = 0; i < FM; ++i) af[i] = As[buf][kk + lk][wm * TM + i * 32 + li];
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int j = 0; j < FN; ++j) bf[j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < kt1) store_tiles(rga[(s + 1) % PF], rgb[(s + 1) % PF], buf ^ 1);
+      lds_barrier();  // LDS only: the register prefetch stages stay in flight
     }
-    if (kt + 1 < kt1) store_tiles(buf ^ 1);
-    __syncthreads();
   }
 
   // epilogue
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
 
 // y = act(LayerNorm(x W + bias + residual)) for the transformer width (N = 128) in ONE launch: a workgroup owns
 // 16 complete rows (wavefront w the columns 32w..32w+31 over the whole K on the 16x16x4 MFMA, operands straight from
-// global memory with a permuted contraction: lane group kb takes k = kb*K/4 + step; W in its checkpoint layout
+// global memory with a permuted contraction: lane group kb takes k = 16*step + 4*kb + t; W in its checkpoint layout
 // [128, K]), so the row statistics are a
 // 16-lane shuffle + one LDS exchange away.  Replaces a gemm_small + layernorm launch pair (48 per scan pair).
 struct LinLnArgs {
@@ -304,14 +314,15 @@ __global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kb = lane >> 4;
   const int m0 = blockIdx.x * 16;
-  const int kq = a.K / 4;  // K is a multiple of 16
-  const float* arow = a.A + static_cast<long long>(min(m0 + i, a.M - 1)) * a.lda + kb * kq;
+  // contraction order: step s, lane group kb takes k = 16 s + 4 kb + t -- the four lane groups of a row read one
+  // contiguous 64-byte line per step (a lane-group-major split of K touches 64 different lines per load instead of 16)
+  const float* arow = a.A + static_cast<long long>(min(m0 + i, a.M - 1)) * a.lda + 4 * kb;
   // W is the nn.Linear weight as stored, [128, K] with k contiguous: the B operand of lane (column, kb) is a
   // float4 of 4 consecutive k, exactly like the A operand
-  const float* brow0 = a.B + static_cast<long long>(32 * w + i) * a.ldb + kb * kq;
+  const float* brow0 = a.B + static_cast<long long>(32 * w + i) * a.ldb + 4 * kb;
   const float* brow1 = brow0 + 16ll * a.ldb;
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < kq; s0 += 4) {
+  for (int s0 = 0; s0 < a.K; s0 += 16) {
     const float4 av = *reinterpret_cast<const float4*>(arow + s0);
     const float4 bv0 = *reinterpret_cast<const float4*>(brow0 + s0);
     const float4 bv1 = *reinterpret_cast<const float4*>(brow1 + s0);
@@ -373,6 +384,175 @@ __global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
     }
     a.out[static_cast<long long>(row) * a.ldo + c0] = o0;
     a.out[static_cast<long long>(row) * a.ldo + c1] = o1;
+  }
+}
+
+// Everything of an attention layer after softmax(QK^T)V in ONE launch (thdroformer.py:142-173,
+// vanilla_transformer.py:69-103, output_layer.py:6-21), at the transformer width 128 with a 256-wide FFN:
+//   y   = LayerNorm(hid Wo^T + bo + x)
+//   z   = relu(y W1^T + b1)
+//   out = LayerNorm(z W2^T + b2 + y)
+// All three products are row-local, so a workgroup owns 16 complete rows through the whole chain: 8 wavefronts, each a
+// 16-column slice of the 128-wide products (32 of the 256-wide one) on the 16x16x4 MFMA with the permuted contraction
+// of linear_ln128_kernel.  Every weight operand a lane needs (48 float4) is requested before the first MFMA -- one
+// L2 latency for the kernel instead of one per product; what bounds the kernel is the ~20 B/clk a CU gets from L2 for
+// its 320 KB of weights, so the barriers order LDS only (lds_barrier) and the later products' weights keep streaming
+// under the earlier products -- and y, z travel through LDS.  Replaces three launches.
+struct TailArgs {
+  const float *hid, *x, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
+  float* out;
+  int M, ldh, ldx, ldo, ldwo, ldw1, ldw2;
+  float eps;
+#ifdef RDM_TAIL_TIMING
+  unsigned long long* clk;  // tools/tail_lab.hip: shader-clock stamps of workgroup 0, wavefront 0
+#endif
+};
+#ifdef RDM_TAIL_TIMING
+#define TAIL_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.clk[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TAIL_STAMP(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
+  __shared__ __attribute__((aligned(16))) float ys[16][132];
+  __shared__ __attribute__((aligned(16))) float zs[16][260];
+  __shared__ float red[4][8][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kb = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int c = 16 * w + i;  // this lane's column of the 128-wide products
+  TAIL_STAMP(0);
+  // ---- all global operands up front -------------------------------------------------------------------------------
+  // (contraction order of every product: step s, lane group kb takes k = 16 s + 4 kb + t, so the four lane groups
+  // of a weight row read one contiguous 64-byte line per step)
+  // A CU draws ~20 B/clk from L2 whatever the pattern (tools/tail_lab.hip: 393 KB in 20 k clocks, one workgroup or 44),
+  // and a wavefront stalls at a load the texture path cannot accept yet: the weight loads are therefore ISSUED in
+  // slices between the MFMA steps of the previous product (sched_barrier keeps the compiler from regrouping them).
+  float4 bw0[8], bw1[2][8], bw2[16];
+  // small operands first: loads return in order, and the first LayerNorm needs these
+  float xres[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xres[r] = a.x[static_cast<long long>(min(m0 + 4 * kb + r, a.M - 1)) * a.ldx + c];
+  const float bo = a.bo ? a.bo[c] : 0.f, b2 = a.b2 ? a.b2[c] : 0.f;
+  const float b10 = a.b1 ? a.b1[32 * w + i] : 0.f, b11 = a.b1 ? a.b1[32 * w + 16 + i] : 0.f;
+  const float g1 = a.g1[c], be1 = a.be1[c], g2 = a.g2[c], be2 = a.be2[c];
+  const float* p1a = a.w1 + static_cast<long long>(32 * w + i) * a.ldw1 + 4 * kb;
+  const float* p1b = p1a + 16ll * a.ldw1;
+  const float* p2 = a.w2 + static_cast<long long>(c) * a.ldw2 + 4 * kb;
+  {
+    // the 16 x 128 attention rows, shared by all wavefronts: one coalesced float4 per thread into LDS (zs is free until
+    // the FFN product)
+    const int hr = tid >> 5, hc = (tid & 31) * 4;
+    const float4 hv = *reinterpret_cast<const float4*>(a.hid + static_cast<long long>(min(m0 + hr, a.M - 1)) * a.ldh + hc);
+    const float* p0 = a.wo + static_cast<long long>(c) * a.ldwo + 4 * kb;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bw0[s] = *reinterpret_cast<const float4*>(p0 + 16 * s);
+    *reinterpret_cast<float4*>(&zs[hr][hc]) = hv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  // rows 4kb + r of this lane's column: LayerNorm over the 128 columns (16 lanes x 8 wavefronts), two passes
+  auto layer_norm = [&](float (&v)[4], int slot, float gam, float bet) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = v[r];
+    float mean[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = row16_sum(p[r]);
+      if (i == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[slot + pass][w][4 * kb + r] = p[r];
+      lds_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) t += red[slot + pass][ww][4 * kb + r];  // fixed order
+        if (pass == 0) {
+          mean[r] = t / 128.f;
+          const float d = v[r] - mean[r];
+          p[r] = d * d;
+        } else {
+          const float rstd = 1.0f / __fsqrt_rn(t / 128.f + a.eps);
+          v[r] = (v[r] - mean[r]) * rstd * gam + bet;
+        }
+      }
+    }
+  };
+
+  // ---- y = LayerNorm(hid Wo^T + bo + x) ---------------------------------------------------------------------------
+  lds_barrier();
+  TAIL_STAMP(1);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bw1[0][s] = *reinterpret_cast<const float4*>(p1a + 16 * s);
+    bw1[1][s] = *reinterpret_cast<const float4*>(p1b + 16 * s);
+    const float4 ha = *reinterpret_cast<const float4*>(&zs[i][16 * s + 4 * kb]);
+    const float at[4] = {ha.x, ha.y, ha.z, ha.w}, bt[4] = {bw0[s].x, bw0[s].y, bw0[s].z, bw0[s].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], bt[t], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) bw2[s] = *reinterpret_cast<const float4*>(p2 + 16 * s);
+  __builtin_amdgcn_sched_barrier(0);
+  float y[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) y[r] = acc[r] + bo + xres[r];
+  TAIL_STAMP(2);
+  layer_norm(y, 0, g1, be1);
+  TAIL_STAMP(3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ys[4 * kb + r][c] = y[r];
+  lds_barrier();
+
+  // ---- z = relu(y W1^T + b1): columns 32w + 16t + i ---------------------------------------------------------------
+  TAIL_STAMP(4);
+  f32x4_t z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    bw2[8 + s] = *reinterpret_cast<const float4*>(p2 + 16 * (8 + s));
+    const float4 ya = *reinterpret_cast<const float4*>(&ys[i][16 * s + 4 * kb]);
+    const float at[4] = {ya.x, ya.y, ya.z, ya.w};
+    const float u0[4] = {bw1[0][s].x, bw1[0][s].y, bw1[0][s].z, bw1[0][s].w};
+    const float u1[4] = {bw1[1][s].x, bw1[1][s].y, bw1[1][s].z, bw1[1][s].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], u0[t], z0, 0, 0, 0);
+      z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], u1[t], z1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e0 = z0[r] + b10, e1 = z1[r] + b11;
+    zs[4 * kb + r][32 * w + i] = e0 > 0.f ? e0 : 0.f;
+    zs[4 * kb + r][32 * w + 16 + i] = e1 > 0.f ? e1 : 0.f;
+  }
+  lds_barrier();
+
+  // ---- out = LayerNorm(z W2^T + b2 + y) ---------------------------------------------------------------------------
+  TAIL_STAMP(5);
+  acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const float4 za = *reinterpret_cast<const float4*>(&zs[i][16 * s + 4 * kb]);
+    const float at[4] = {za.x, za.y, za.z, za.w}, bt[4] = {bw2[s].x, bw2[s].y, bw2[s].z, bw2[s].w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(at[t], bt[t], acc, 0, 0, 0);
+  }
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = acc[r] + b2 + y[r];
+  TAIL_STAMP(6);
+  layer_norm(o, 2, g2, be2);
+  TAIL_STAMP(7);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = m0 + 4 * kb + r;
+    if (row < a.M) a.out[static_cast<long long>(row) * a.ldo + c] = o[r];
   }
 }
 
@@ -451,13 +631,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, do
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK, int PF = 1>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
   if (trans_b)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF>), grid, dim3(256), 0, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF>), grid, dim3(256), 0, st, g);
 }
 
 }  // namespace
@@ -551,11 +731,13 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;  // 32-deep measured slower (LDS halves residency)
     case T64:
       // 32-deep k-tiles: 34 KB of LDS per block -> 4 blocks per CU (64-deep: 2); measured +2 % with 4 pairs in flight
-      if (k >= 48) launch<64, 64, 2, 2, 32>(g, batches, trans_b, st);
+      // (two k-tiles of register prefetch: -3 % over the path's shapes; four: no further gain -- what bounds these tiles
+      // is the ~20 B/clk a CU draws from L2, see tools/tail_lab.hip, not the latency of one load)
+      if (k >= 48) launch<64, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
       else launch<64, 64, 2, 2, 16>(g, batches, trans_b, st);
       break;
     case T128x32:
-      if (k >= 32) launch<128, 32, 4, 1, 32>(g, batches, trans_b, st);
+      if (k >= 32) launch<128, 32, 4, 1, 32, 2>(g, batches, trans_b, st);
       else launch<128, 32, 4, 1, 16>(g, batches, trans_b, st);
       break;
   }
@@ -665,4 +847,31 @@ extern "C" int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w
   hipLaunchKernelGGL(linear_ln128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status("linear_ln128_kernel");
+}
+
+// The tail of an attention layer (output projection + residual LayerNorm + FFN + residual LayerNorm) in one launch;
+// see attention_tail128_kernel.  Weights in checkpoint layout (k contiguous): wo [128,128], w1 [256,128], w2 [128,256].
+extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                                  const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
+                                  const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
+                                  const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
+                                  int64_t ld_out, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(hidden && x && wo && w1 && w2 && gamma1 && beta1 && gamma2 && beta2 && out, "rdm_attention_tail: null pointer");
+  RDM_REQUIRE(d == 128 && m >= 0, "rdm_attention_tail: supports d = 128 with a 256-wide FFN (d=%lld)", (long long)d);
+  RDM_REQUIRE(ld_hidden % 4 == 0 && ld_wo % 4 == 0 && ld_w1 % 4 == 0 && ld_w2 % 4 == 0 && ld_wo >= 128 && ld_w1 >= 128 &&
+                  ld_w2 >= 256 && ld_hidden >= 128 && ldx >= 128 && ld_out >= 128,
+              "rdm_attention_tail: bad leading dimensions");
+  RDM_REQUIRE(((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(wo) | reinterpret_cast<uintptr_t>(w1) |
+                reinterpret_cast<uintptr_t>(w2)) & 15) == 0,
+              "rdm_attention_tail: hidden and the weights must be 16-byte aligned");
+  if (m == 0) return RDM_OK;
+  TailArgs a;
+  a.hid = hidden; a.x = x; a.wo = wo; a.bo = bo; a.g1 = gamma1; a.be1 = beta1; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+  a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
+  a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
+  a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
+  hipLaunchKernelGGL(attention_tail128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return launch_status("attention_tail128_kernel");
 }

@@ -85,8 +85,8 @@ class RDMNet:
         def lin(name):
             W[name] = _dev_linear(S[name + '.weight'], S[name + '.bias'], dev)
             w = S[name + '.weight']
-            if w.shape[0] == 128 and pad4(w.shape[1]) % 16 == 0:  # checkpoint layout for the fused Linear + LayerNorm
-                wt = torch.zeros((128, pad4(w.shape[1])), dtype=torch.float32)
+            if w.shape[0] in (128, 256) and pad4(w.shape[1]) % 16 == 0:  # checkpoint layout for the fused transformer kernels
+                wt = torch.zeros((w.shape[0], pad4(w.shape[1])), dtype=torch.float32)
                 wt[:, :w.shape[1]] = torch.from_numpy(np.ascontiguousarray(w))
                 W[name + '.wt'] = wt.to(dev)
 
@@ -211,6 +211,12 @@ class RDMNet:
         """Output projection, residual LayerNorm, FFN, residual LayerNorm (thdroformer.py:142-173,
         vanilla_transformer.py:69-103, output_layer.py:6-21); `out` = rows of the stacked state."""
         W = self._w
+        lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
+        wts = [W.get(k + '.wt') for k in (lo, l1, l2)]
+        if all(w is not None for w in wts) and [tuple(w.shape) for w in wts] == [(128, 128), (256, 128), (128, 256)]:
+            return ops.attention_tail(hid, x, wts[0], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'],
+                                      wts[1], W[l1][1], wts[2], W[l2][1], W[p + '.output.norm.weight'],
+                                      W[p + '.output.norm.bias'], out=out)
         y = self._linear_ln(p + '.attention.linear', p + '.attention.norm', hid, x)
         z = self._linear(p + '.output.expand', y, act=ACT_RELU)
         return self._linear_ln(p + '.output.squeeze', p + '.output.norm', z, y, out=out)
@@ -219,7 +225,7 @@ class RDMNet:
         """LayerNorm(Linear(x) + residual): one fused launch at the transformer width, two launches otherwise."""
         W = self._w
         b, bias, in_f, out_f = W[lin]
-        if lin + '.wt' in W:
+        if lin + '.wt' in W and out_f == 128:
             return ops.linear_layer_norm(x, W[lin + '.wt'], pad4(in_f), out_f, bias, W[norm + '.weight'], W[norm + '.bias'],
                                          residual=residual, out=out)
         h = self._linear(lin, x)

@@ -184,3 +184,29 @@ def test_linear_layer_norm_fused_matches_torch(ops, m, k):
     assert relu.min() >= 0
     with pytest.raises(RuntimeError):
         ops.linear_layer_norm(padded(x), w.t().contiguous().cuda(), k, 64, b.cuda(), gamma.cuda(), beta.cuda())
+
+
+@pytest.mark.parametrize('m', [1, 16, 431, 700, 1001])
+def test_attention_tail_fused_matches_torch(ops, m):
+    """Output projection + residual LayerNorm + FFN + residual LayerNorm in one launch (thdroformer.py:142-173,
+    output_layer.py:6-21) against torch fp64; tolerance 3e-5 of the output range (three chained fp32 products and
+    two LayerNorms over 128 columns)."""
+    rng = np.random.default_rng(m)
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.normal(size=s) * scale).astype(np.float32))
+    hid, x = t(m, 128), t(m, 128)
+    wo, w1, w2 = t(128, 128, scale=128 ** -0.5), t(256, 128, scale=128 ** -0.5), t(128, 256, scale=256 ** -0.5)
+    bo, b1, b2 = t(128), t(256), t(128)
+    g1, g2 = (torch.from_numpy(rng.uniform(0.5, 1.5, 128).astype(np.float32)) for _ in range(2))
+    be1, be2 = t(128), t(128)
+    y = F.layer_norm(hid.double() @ wo.double().t() + bo.double() + x.double(), (128,), g1.double(), be1.double(), 1e-5)
+    z = torch.relu(y @ w1.double().t() + b1.double())
+    want = F.layer_norm(z @ w2.double().t() + b2.double() + y, (128,), g2.double(), be2.double(), 1e-5)
+    c = lambda v: v.cuda()
+    got = ops.attention_tail(padded(hid), padded(x), c(wo), c(bo), c(g1), c(be1), c(w1), c(b1), c(w2), c(b2), c(g2), c(be2)).cpu()
+    assert got.shape == (m, 128)
+    assert (got.double() - want).abs().max() <= 3e-5 * want.abs().max()
+    # the same through the three separate launches it replaces
+    y3 = ops.linear_layer_norm(padded(hid), c(wo), 128, 128, c(bo), c(g1), c(be1), residual=padded(x))
+    z3 = ops.gemm(y3, c(w1.t().contiguous()), 128, 256, bias=c(b1), act=1)
+    o3 = ops.linear_layer_norm(z3, c(w2), 256, 128, c(b2), c(g2), c(be2), residual=y3).cpu()
+    assert (got - o3).abs().max() <= 3e-5 * want.abs().max()
