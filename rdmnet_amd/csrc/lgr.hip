@@ -201,7 +201,7 @@ __device__ void block_sum_n(double (&v)[N], double* red) {
 // Weighted rigid fit src -> ref over entries [x0, x1) (procrustes.py:36-73).  Every thread of the
 // block must call it; T (3x4, row-major R|t) is valid in all threads on return.
 __device__ void block_procrustes(const float* src, const float* ref, const float* wts, const unsigned char* gate,
-                                 int x0, int x1, double* red, double T[12]) {
+                                 int x0, int x1, double* red, double T[12], double (*basis)[4] = nullptr) {
   double sw = 0.0;
   for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
     float w = wts[i];
@@ -214,11 +214,12 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
     block_sum_n<1>(t, red);
     sw = t[0] + 1e-5;
   }
+  const double inv_sw = 1.0 / sw;  // one fp64 division per fit instead of one per correspondence and pass
   double cs[3] = {0, 0, 0}, cr[3] = {0, 0, 0};
   for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
     float w = wts[i];
     if ((gate && !gate[i]) || w < 0.f) w = 0.f;
-    const double wn = w / sw;
+    const double wn = w * inv_sw;
     for (int d = 0; d < 3; ++d) {
       cs[d] += wn * src[3 * i + d];
       cr[d] += wn * ref[3 * i + d];
@@ -236,7 +237,7 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
   for (int i = x0 + threadIdx.x; i < x1; i += blockDim.x) {
     float w = wts[i];
     if ((gate && !gate[i]) || w < 0.f) w = 0.f;
-    const double wn = w / sw;
+    const double wn = w * inv_sw;
     double s[3], r[3];
     for (int d = 0; d < 3; ++d) {
       s[d] = src[3 * i + d] - cs[d];
@@ -253,7 +254,7 @@ __device__ void block_procrustes(const float* src, const float* ref, const float
                     {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                     {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
   double q[4];
-  horn_quaternion(N, q);
+  horn_quaternion(N, q, basis);
   const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
   double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw),     2 * (qx * qz + qy * qw),
                  2 * (qx * qy + qz * qw),     1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
@@ -302,12 +303,29 @@ __global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, c
 }
 
 // single block: pick the hypothesis, refine globally
+constexpr int kRefineStage = 4608;  // correspondences staged in LDS: 4608 * 29 B = 131 KB
 __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
                                                           const float* scores, float radius, int steps,
                                                           LgrBuffers w, unsigned char* gate, float* out_T) {
   __shared__ double red[9 * 16];
   __shared__ float Tf[12];
+  extern __shared__ float stage[];
   const int C = w.meta[0], chunks = w.meta[1];
+  // The refinement makes 4 passes over the correspondences per step; one workgroup, so every pass is a chain of
+  // dependent L2 round trips.  Up to kRefineStage correspondences are copied into LDS once (7 words each + the gate).
+  if (C <= kRefineStage) {
+    float* ls = stage;
+    float* lr = ls + 3 * C;
+    float* lw = lr + 3 * C;
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+      ls[i] = src_corr[i];
+      lr[i] = ref_corr[i];
+    }
+    for (int i = threadIdx.x; i < C; i += blockDim.x) lw[i] = scores[i];
+    src_corr = ls; ref_corr = lr; scores = lw;
+    gate = reinterpret_cast<unsigned char*>(lw + C);
+    __syncthreads();
+  }
   double T[12];
   if (chunks > 0) {
     // first maximum of the inlier counts (torch.argmax): block-wide max of (count, -index) packed in 64 bits
@@ -329,10 +347,11 @@ __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, 
     if (threadIdx.x < 12) Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
   }
   __syncthreads();
+  double basis[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};  // eigenvector frame carried from step to step
   for (int step = 0; step < steps; ++step) {
     for (int i = threadIdx.x; i < C; i += blockDim.x) gate[i] = is_inlier(Tf, src_corr, ref_corr, i, radius) ? 1 : 0;
     __syncthreads();
-    block_procrustes(src_corr, ref_corr, scores, gate, 0, C, red, T);
+    block_procrustes(src_corr, ref_corr, scores, gate, 0, C, red, T, basis);
     __syncthreads();
     if (threadIdx.x < 12) Tf[threadIdx.x] = static_cast<float>(T[threadIdx.x]);
     __syncthreads();
@@ -392,6 +411,8 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   if (!attr_set) {
     RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lgr_extract_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+    RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lgr_refine_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
     attr_set = true;
   }
   hipLaunchKernelGGL(lgr_extract_kernel, dim3(B), dim3(256), lds, st, log_scores, S, ref_knn_masks, src_knn_masks, w);
@@ -399,7 +420,7 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   hipLaunchKernelGGL(lgr_gather_kernel, dim3(B), dim3(64), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,
                      src_corr, corr_scores);
   hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
-  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), 0, st, ref_corr, src_corr, corr_scores,
+  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), kRefineStage * 29 + 64, st, ref_corr, src_corr, corr_scores,
                      acceptance_radius, num_refinement_steps, w, gate, transform);
   copy_words(w.meta, counts, 3, st);
   return launch_status("lgr kernels");

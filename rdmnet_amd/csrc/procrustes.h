@@ -5,16 +5,49 @@
 namespace rdm {
 
 // Largest eigenvector of the symmetric 4x4 `a` (cyclic Jacobi, fp64).  q = (w, x, y, z).
-__device__ inline void horn_quaternion(double a[4][4], double q[4]) {
+// `basis` (optional, orthonormal columns, updated in place) is the starting frame of the sweeps: the eigenvectors of a
+// nearby matrix -- the previous refinement step's -- leave V^T a V almost diagonal and the iteration converges in one or
+// two sweeps instead of six or seven; the stopping rule, and so the accuracy, is the same.
+__device__ inline void horn_quaternion(double a[4][4], double q[4], double (*basis)[4] = nullptr) {
   double vmat[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  if (basis) {
+    double av[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vmat[i][j] = basis[i][j];
+        av[i][j] = 0.0;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[i][j] += a[i][k] * vmat[k][j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = i; j < 4; ++j) {  // V^T (a V), symmetrised
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += vmat[k][i] * av[k][j];
+        a[i][j] = t;
+        a[j][i] = t;
+      }
+  }
   for (int sweep = 0; sweep < 24; ++sweep) {
     double offd = 0.0, diag = 0.0;
+#pragma unroll
     for (int p = 0; p < 4; ++p) {
       diag += a[p][p] * a[p][p];
+#pragma unroll
       for (int r = p + 1; r < 4; ++r) offd += a[p][r] * a[p][r];
     }
     if (offd <= 1e-34 * (diag + offd) || offd < 1e-300) break;  // converged to fp64 round-off
+#pragma unroll
     for (int p = 0; p < 3; ++p)
+#pragma unroll
       for (int r = p + 1; r < 4; ++r) {
         if (fabs(a[p][r]) < 1e-300) continue;
         const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
@@ -37,13 +70,27 @@ __device__ inline void horn_quaternion(double a[4][4], double q[4]) {
         }
       }
   }
-  int best = 0;
-  for (int i = 1; i < 4; ++i)
-    if (a[i][i] > a[best][best]) best = i;
+  // column of the largest eigenvalue (the first one among equals), picked with selects: a run-time column index
+  // would put vmat into scratch memory and every rotation above would pay a memory round trip
+  double best = a[0][0], v[4] = {vmat[0][0], vmat[1][0], vmat[2][0], vmat[3][0]};
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool take = a[i][i] > best;
+    best = take ? a[i][i] : best;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = take ? vmat[k][i] : v[k];
+  }
+  if (basis)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) basis[i][j] = vmat[i][j];
   double nrm = 0.0;
-  for (int k = 0; k < 4; ++k) nrm += vmat[k][best] * vmat[k][best];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nrm += v[k] * v[k];
   nrm = sqrt(nrm);
-  for (int k = 0; k < 4; ++k) q[k] = vmat[k][best] / nrm;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = v[k] / nrm;
 }
 
 

@@ -22,18 +22,23 @@ using namespace rdm;
 
 constexpr int kMaxSide = 128;
 
-constexpr int kHalf = (kMaxSide + 2) / 2;  // 65: each thread owns half a row and half a column
+constexpr int kHalf = 66;   // each thread owns half a row and half a column: 65 entries, padded to an even count
+constexpr int kPairs = kHalf / 2;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// 256 threads.  Thread t owns row (t>>1), columns [65*(t&1), 65*(t&1)+65) of the compacted score
+// 256 threads.  Thread t owns row (t>>1), columns [66*(t&1), 66*(t&1)+66) of the compacted score
 // block in REGISTERS, and likewise half of column (t>>1): the 100 iterations touch LDS only for the
-// broadcast potentials u, v.  A row's two halves are combined with one lane exchange.
+// broadcast potentials u, v.  A row's two halves are combined with one lane exchange.  The entries are held as
+// float2 pairs: the adds, the shift by the maximum and the scaling by log2(e) are packed-fp32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32, two entries per issue slot) -- the loop is VALU-issue bound (per entry: add, max,
+// subtract, multiply, v_exp_f32 at quarter rate, add), not LDS or latency bound.
 __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int m, int n,
                                                        const unsigned char* row_mask,
                                                        const unsigned char* col_mask, const float* alpha_p,
                                                        int iters, float* out) {
   extern __shared__ float lds[];
   __shared__ int rows[kMaxSide + 2], cols[kMaxSide + 2];
-  __shared__ float u[kMaxSide + 2], v[kMaxSide + 2];
+  __shared__ __attribute__((aligned(8))) float u[2 * kHalf], v[2 * kHalf];
   __shared__ int s_nr, s_nc;
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* S = scores + static_cast<int64_t>(b) * m * n;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
     Z[r * ldz + c] = (r < nr && c < nc) ? S[static_cast<int64_t>(rows[r]) * n + cols[c]] : alpha;
   }
   const float norm = -logf(static_cast<float>(nr) + static_cast<float>(nc));
-  for (int r = tid; r < kMaxSide + 2; r += 256) {
+  for (int r = tid; r < 2 * kHalf; r += 256) {
     u[r] = 0.f;
     v[r] = 0.f;
   }
@@ -73,38 +78,45 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   const int own = tid >> 1, half = tid & 1, base = half * kHalf;
   const float log_mu = own < nr ? norm : logf(static_cast<float>(nc)) + norm;
   const float log_nu = own < nc ? norm : logf(static_cast<float>(nr)) + norm;
-  float zr[kHalf], zc[kHalf];  // -inf marks "outside the block": contributes exp(-inf) = 0
+  f32x2 zr[kPairs], zc[kPairs];  // -inf marks "outside the block": contributes exp(-inf) = 0
 #pragma unroll
   for (int i = 0; i < kHalf; ++i) {
     const int c = base + i;
-    zr[i] = (own < R && c < C) ? Z[own * ldz + c] : -INFINITY;
-    zc[i] = (own < C && c < R) ? Z[c * ldz + own] : -INFINITY;
+    zr[i >> 1][i & 1] = (own < R && c < C) ? Z[own * ldz + c] : -INFINITY;
+    zc[i >> 1][i & 1] = (own < C && c < R) ? Z[c * ldz + own] : -INFINITY;
   }
+  // log_m - logsumexp over this thread's half (z + pot) combined with the neighbouring lane's half
+  auto update = [&](const f32x2 (&z)[kPairs], const float* pot, float log_m) -> float {
+    const f32x2* p2 = reinterpret_cast<const f32x2*>(pot + base);
+    f32x2 t[kPairs];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kPairs; ++i) {
+      t[i] = z[i] + p2[i];
+      mx = fmaxf(mx, fmaxf(t[i].x, t[i].y));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    const f32x2 mx2 = {mx, mx}, l2e = {1.4426950408889634f, 1.4426950408889634f};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kPairs; ++i) {
+      const f32x2 d = (t[i] - mx2) * l2e;   // exp(x) = exp2(x log2 e): the hardware exponential (v_exp_f32), as __expf
+      f32x2 e;
+      e.x = __builtin_amdgcn_exp2f(d.x);
+      e.y = __builtin_amdgcn_exp2f(d.y);
+      sum2 += e;
+    }
+    float sum = sum2.x + sum2.y;
+    sum += __shfl_xor(sum, 1, 64);
+    return log_m - (mx + logf(sum));
+  };
 
   for (int it = 0; it < iters; ++it) {
-    {  // u = log_mu - logsumexp_c(Z + v)
-      float mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < kHalf; ++i) mx = fmaxf(mx, zr[i] + v[base + i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < kHalf; ++i) sum += __expf(zr[i] + v[base + i] - mx);
-      sum += __shfl_xor(sum, 1, 64);
-      if (half == 0 && own < R) u[own] = log_mu - (mx + logf(sum));
-    }
+    const float un = update(zr, v, log_mu);  // u = log_mu - logsumexp_c(Z + v)
+    if (half == 0 && own < R) u[own] = un;
     __syncthreads();
-    {  // v = log_nu - logsumexp_r(Z + u)
-      float mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < kHalf; ++i) mx = fmaxf(mx, zc[i] + u[base + i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < kHalf; ++i) sum += __expf(zc[i] + u[base + i] - mx);
-      sum += __shfl_xor(sum, 1, 64);
-      if (half == 0 && own < C) v[own] = log_nu - (mx + logf(sum));
-    }
+    const float vn = update(zc, u, log_nu);  // v = log_nu - logsumexp_r(Z + u)
+    if (half == 0 && own < C) v[own] = vn;
     __syncthreads();
   }
 
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
 #pragma unroll
     for (int i = 0; i < kHalf; ++i) {
       const int c = base + i;
-      if (c < C) O[orow + cols[c]] = ((zr[i] + ur) + v[c]) - norm;
+      if (c < C) O[orow + cols[c]] = ((zr[i >> 1][i & 1] + ur) + v[c]) - norm;
     }
   }
 }
