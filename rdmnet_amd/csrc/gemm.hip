@@ -39,7 +39,15 @@ struct GemmArgs {
   int splits;            // split-K factor (partials go to `part`)
   float* part;           // [batch*splits, M, N] when splits > 1
   double* stats;         // optional GroupNorm partials [grid.y][2][N] (non split-K only)
+#ifdef RDM_GEMM_TIMING
+  unsigned long long* clk;  // tools/gemm_phase_lab.hip: shader-clock stamps of workgroup (0,0,0), thread 0
+#endif
 };
+#ifdef RDM_GEMM_TIMING
+#define GEMM_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g.clk[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.f ? v : 0.f;
@@ -57,13 +65,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // transposed-staged tiles use an odd row stride (scalar LDS writes of one k-column hit distinct
   // banks); the row-major B tile is written as float4 and keeps a 16-byte-aligned stride
   constexpr int LDA_S = BM + 1, LDB_S = TRANS_B ? BN + 1 : BN + 4;
-  __shared__ float As[2][BK][LDA_S];
-  __shared__ float Bs[2][BK][LDB_S];
-  __shared__ double stat_red[WM][BN][2];
+  // one LDS buffer: the A/B tiles during the K loop, then the row-major staging tile of the epilogue, then the
+  // exchange of the GroupNorm partial sums
+  constexpr int CR = BM < 64 ? BM : 64;   // output rows staged per epilogue pass
+  constexpr int LDC_S = BN + 4;
+  constexpr int TPR = BN / 4;             // threads per output row (one float4 each)
+  constexpr int RPI = 256 / TPR;          // rows per store iteration
+  constexpr int kBytesAB = (2 * BK * LDA_S + 2 * BK * LDB_S) * 4, kBytesC = CR * LDC_S * 4, kBytesStat = RPI * BN * 2 * 8;
+  constexpr int kBytes = kBytesAB > kBytesC ? (kBytesAB > kBytesStat ? kBytesAB : kBytesStat) : (kBytesC > kBytesStat ? kBytesC : kBytesStat);
+  static_assert((2 * BK * LDA_S * 4) % 16 == 0 && CR % RPI == 0, "tile layout");
+  __shared__ __attribute__((aligned(16))) char smem[kBytes];
+  float (*As)[BK][LDA_S] = reinterpret_cast<float (*)[BK][LDA_S]>(smem);
+  float (*Bs)[BK][LDB_S] = reinterpret_cast<float (*)[BK][LDB_S]>(smem + 2 * BK * LDA_S * 4);
+  float (*Cs)[LDC_S] = reinterpret_cast<float (*)[LDC_S]>(smem);
+  double (*stat_red)[1][2] = reinterpret_cast<double (*)[1][2]>(smem);    // [RPI * BN][1][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  GEMM_STAMP(0);
   const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
   const float* A = g.A + batch * g.sa;
   const float* B = g.B + batch * g.sb;
@@ -153,6 +173,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   };
 
+  // epilogue operands of this thread (bias of its 4 columns, divisor of its rows), requested before the K loop: at the
+  // end they would each cost a full memory round trip with nothing left to hide it
+  const bool partial = g.splits > 1;
+  const int c4 = (tid % TPR) * 4, rsub = tid / TPR;
+  const int gcol = n0 + c4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  float rdv[BM / RPI];
+  if (!partial && g.bias)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = gcol + e < g.N ? g.bias[gcol + e] : 0.f;
+#pragma unroll
+  for (int q = 0; q < BM / RPI; ++q) rdv[q] = (!partial && g.rowdiv) ? g.rowdiv[min(m0 + q * RPI + rsub, g.M - 1)] : 1.f;
+
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -166,6 +199,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (kt0 + s < kt1) load_tiles(rga[s], rgb[s], kt0 + s);
   if (kt0 < kt1) store_tiles(rga[0], rgb[0], 0);
   lds_barrier();
+  GEMM_STAMP(1);
   const int lk = lane >> 5, li = lane & 31;
   for (int ktb = kt0; ktb < kt1; ktb += PF) {
 #pragma unroll
@@ -194,56 +228,93 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
-  // epilogue
-  const bool partial = g.splits > 1;
+  // epilogue: the accumulators go through LDS into row-major order and leave as float4 rows -- 4 (at most 16)
+  // dwordx4 stores per thread instead of 16-64 dword stores; the store ISSUE rate, not bandwidth, is what the
+  // direct form was bound by (6-11 k clocks per workgroup, tools/gemm_phase_lab.hip)
+  GEMM_STAMP(2);
   const bool stats = g.stats != nullptr && !partial;
+  const bool has_rd = !partial && g.rowdiv != nullptr;
+  const int act = g.act;
   float* C = partial ? g.part + static_cast<long long>(blockIdx.z) * g.M * g.N : g.C + batch * g.sc;
   const int ldc = partial ? g.N : g.ldc;
+  const bool vec_ok = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  double cs[4] = {0.0, 0.0, 0.0, 0.0}, css[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int col = n0 + wn * TN + j * 32 + li;
-    const float bv = (!partial && g.bias && col < g.N) ? g.bias[col] : 0.f;
-    double cs = 0.0, css = 0.0;
+  for (int pass = 0; pass < BM / CR; ++pass) {
+    // (the K loop ended with a barrier: every wavefront is done with the A/B tiles)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+      const int rbase = wm * TM + i * 32 - pass * CR;  // this fragment's first row within the pass
+      if (rbase < 0 || rbase >= CR) continue;          // wavefront-uniform
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= g.M || col >= g.N) continue;
-        float v = acc[i][j][r];
-        if (!partial) {
-          if (g.rowdiv) v = v / g.rowdiv[row];
-          v = apply_act(v + bv, g.act);
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[rbase + (r & 3) + 8 * (r >> 2) + 4 * lk][wn * TN + j * 32 + li] = acc[i][j][r];
+    }
+    lds_barrier();
+    GEMM_STAMP(4);
+#pragma unroll
+    for (int it = 0; it < CR / RPI; ++it) {
+      const int lrow = it * RPI + rsub;
+      const int row = m0 + pass * CR + lrow;
+      if (row < g.M && gcol < g.N) {
+        const float4 t = *reinterpret_cast<const float4*>(&Cs[lrow][c4]);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        if (has_rd) {  // block-uniform
+          const float rd = rdv[pass * (CR / RPI) + it];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / rd;
         }
-        C[static_cast<long long>(row) * ldc + col] = v;
-        cs += v;
-        css += static_cast<double>(v) * v;
+        if (!partial) {
+          // bias + activation without branches: act 1 -> max(v, 0), act 2 -> v > 0 ? v : 0.1 v (apply_act's results)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = v[e] + bv[e];
+            const float neg = act == 2 ? 0.1f * u : 0.f;
+            v[e] = (act != 0 && !(u > 0.f)) ? neg : u;
+          }
+        }
+        float* dst = C + static_cast<long long>(row) * ldc + gcol;
+        if (vec_ok && gcol + 3 < g.N) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gcol + e < g.N) dst[e] = v[e];
+        }
+        if (stats) {  // block-uniform.  Columns past N hold act(0 + 0) = 0 (zero pad columns of B, no bias): no test needed
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cs[e] += v[e];
+            css[e] += static_cast<double>(v[e]) * v[e];
+          }
+        }
       }
     }
-    if (stats) {  // GroupNorm statistics of this block's rows, fixed combination order
-      cs += __shfl_xor(cs, 32, 64);
-      css += __shfl_xor(css, 32, 64);
-      if (lk == 0) {
-        stat_red[wm][wn * TN + j * 32 + li][0] = cs;
-        stat_red[wm][wn * TN + j * 32 + li][1] = css;
-      }
-    }
+    GEMM_STAMP(5);
+    lds_barrier();  // Cs is rewritten by the next pass / the statistics exchange (LDS only: the stores stay in flight)
   }
-  if (stats) {
-    __syncthreads();
+  if (stats) {  // GroupNorm statistics of this block's rows: RPI row groups per column, fixed combination order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      stat_red[rsub * BN + c4 + e][0][0] = cs[e];
+      stat_red[rsub * BN + c4 + e][0][1] = css[e];
+    }
+    lds_barrier();
     for (int cl = tid; cl < BN; cl += 256) {
       const int col = n0 + cl;
       if (col >= g.N) continue;
       double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        a += stat_red[w][cl][0];
-        b += stat_red[w][cl][1];
+      for (int w = 0; w < RPI; ++w) {
+        a += stat_red[w * BN + cl][0][0];
+        b += stat_red[w * BN + cl][0][1];
       }
       g.stats[(static_cast<long long>(blockIdx.y) * 2 + 0) * g.N + col] = a;
       g.stats[(static_cast<long long>(blockIdx.y) * 2 + 1) * g.N + col] = b;
     }
   }
+  GEMM_STAMP(3);
 }
 
 // Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
