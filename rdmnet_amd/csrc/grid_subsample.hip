@@ -228,8 +228,17 @@ __device__ unsigned short* replay_lds(const GridArgs& a, const unsigned long lon
   return cur;
 }
 
+constexpr int kBigCap = 2048;  // work list of crowded voxels; beyond it the owning thread sorts serially
+#ifdef RDM_GS_TIMING
+__device__ unsigned long long rdm_gs_clk[16];  // tools/gs_phase_lab.hip: shader-clock stamps of workgroup 0, thread 0
+#define GS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) rdm_gs_clk[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GS_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __shared__ int s_scan[kT / 64 + 2];
+  __shared__ int s_big[kBigCap], s_nbig;           // voxels with more than 8 points: done by whole wavefronts (P6)
+  __shared__ int s_sorted[kT / 64][64];
   __shared__ float s_red[2 * 3 * (kT / 64)];
   __shared__ float s_org[3];
   __shared__ unsigned long long s_nxy[2];
@@ -271,6 +280,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   int* bc = a.bc + b_off;
   int* bl = a.bl + b_off;
 
+  GS_STAMP(0);
   // ---- P0: bounding box (cloud.cpp:4-38), origin and nX, nY (grid_subsampling_cpu.cpp:9-20)
   {
     float lo[3] = {P[0], P[1], P[2]}, hi[3] = {P[0], P[1], P[2]};
@@ -323,6 +333,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   // issued before the first result is used.
   constexpr int G = 4;
 
+  GS_STAMP(1);
   // ---- P1: voxel key per point (grid_subsampling_cpu.cpp:28-35) + de-duplication
   for (int i0 = tid; i0 < N; i0 += G * kT) {
     unsigned long long key[G];
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   }
   __syncthreads();
 
+  GS_STAMP(2);
   // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map).  Thread t owns
   // the contiguous points [c0, c1); "first" flags are recomputed in the second sweep instead of stored.
   int M;
@@ -411,28 +423,34 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   }
   __syncthreads();
 
+  GS_STAMP(3);
   // ---- P3..P6: per-voxel point lists in ascending point order, sequential fp32 sums
-  for (int i0 = tid; i0 < N; i0 += G * kT) {
-    unsigned sl[G], rk[G];
+  // (16 points / ~10 voxels per thread at the first level: these loops take 8 points or 2 voxels per trip -- every
+  // trip is a chain of 3-4 dependent memory round trips of ~1 us with nothing else on the CU to hide them)
+  constexpr int G8 = 8;
+  for (int i0 = tid; i0 < N; i0 += G8 * kT) {
+    unsigned sl[G8], rk[G8];
 #pragma unroll
-    for (int u = 0; u < G; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
+    for (int u = 0; u < G8; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
 #pragma unroll
-    for (int u = 0; u < G; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
+    for (int u = 0; u < G8; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
 #pragma unroll
-    for (int u = 0; u < G; ++u)
+    for (int u = 0; u < G8; ++u)
       if (i0 + u * kT < N) atomicAdd(&ecnt[rk[u]], 1);
   }
   __syncthreads();
+  GS_STAMP(7);
   block_scan(M, [&](int e) { return ld_agent(&ecnt[e]); }, ebase, s_scan, false);
-  for (int i0 = tid; i0 < N; i0 += G * kT) {
-    unsigned sl[G], rk[G];
-    int pos[G], eb[G];
+  GS_STAMP(8);
+  for (int i0 = tid; i0 < N; i0 += G8 * kT) {
+    unsigned sl[G8], rk[G8];
+    int pos[G8], eb[G8];
 #pragma unroll
-    for (int u = 0; u < G; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
+    for (int u = 0; u < G8; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
 #pragma unroll
-    for (int u = 0; u < G; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
+    for (int u = 0; u < G8; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
 #pragma unroll
-    for (int u = 0; u < G; ++u) {
+    for (int u = 0; u < G8; ++u) {
       pos[u] = 0;
       eb[u] = 0;
       if (i0 + u * kT < N) {
@@ -441,67 +459,129 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < G; ++u)
+    for (int u = 0; u < G8; ++u)
       if (i0 + u * kT < N) list[eb[u] + pos[u]] = i0 + u * kT;
   }
   __syncthreads();
-  for (int e = tid; e < M; e += kT) {
-    const int c = ld_agent(&ecnt[e]);
-    int* L = list + ebase[e];
-    float sx = 0.f, sy = 0.f, sz = 0.f;  // SampledData::update, grid_subsampling_cpu.h:17-20
-    if (c <= 8) {
-      // the usual voxel holds a handful of points: sort the indices in registers (bubble network), fetch all the
-      // points, then add them in ascending point order
-      int id[8];
+  constexpr int V = 2;  // voxels per trip
+  if (tid == 0) s_nbig = 0;
+  __syncthreads();
+  GS_STAMP(9);
+  for (int e0 = tid; e0 < M; e0 += V * kT) {
+    int cnt[V], base[V];
 #pragma unroll
-      for (int x = 0; x < 8; ++x) id[x] = x < c ? L[x] : 0x7fffffff;
+    for (int q = 0; q < V; ++q) {
+      const int e = e0 + q * kT;
+      cnt[q] = e < M ? ld_agent(&ecnt[e]) : 0;
+      base[q] = e < M ? ebase[e] : 0;
+    }
+    // the usual voxel holds a handful of points: sort the indices in registers (bubble network), fetch all the
+    // points, then add them in ascending point order (SampledData::update, grid_subsampling_cpu.h:17-20)
+    int id[V][8];
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+#pragma unroll
+      for (int x = 0; x < 8; ++x) id[q][x] = (cnt[q] <= 8 && x < cnt[q]) ? list[base[q] + x] : 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < V; ++q)
 #pragma unroll
       for (int pass = 0; pass < 7; ++pass)
 #pragma unroll
         for (int x = 0; x < 7 - pass; ++x) {
-          const int lo = min(id[x], id[x + 1]), hi = max(id[x], id[x + 1]);
-          id[x] = lo;
-          id[x + 1] = hi;
+          const int lo = min(id[q][x], id[q][x + 1]), hi = max(id[q][x], id[q][x + 1]);
+          id[q][x] = lo;
+          id[q][x + 1] = hi;
         }
-      float px[8], py[8], pz[8];
+    float px[V][8], py[V][8], pz[V][8];
+#pragma unroll
+    for (int q = 0; q < V; ++q)
 #pragma unroll
       for (int x = 0; x < 8; ++x) {
-        const int i = x < c ? id[x] : 0;
-        px[x] = P[3 * i];
-        py[x] = P[3 * i + 1];
-        pz[x] = P[3 * i + 2];
+        const int i = (cnt[q] <= 8 && x < cnt[q]) ? id[q][x] : 0;
+        px[q][x] = P[3 * i];
+        py[q][x] = P[3 * i + 1];
+        pz[q][x] = P[3 * i + 2];
       }
 #pragma unroll
-      for (int x = 0; x < 8; ++x)
-        if (x < c) {
-          sx += px[x];
-          sy += py[x];
-          sz += pz[x];
+    for (int q = 0; q < V; ++q) {
+      const int e = e0 + q * kT, c = cnt[q];
+      if (e >= M) continue;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      if (c <= 8) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (x < c) {
+            sx += px[q][x];
+            sy += py[q][x];
+            sz += pz[q][x];
+          }
+      } else {
+        // a crowded voxel (near the sensor): a whole wavefront takes it below; the serial form -- one thread, an
+        // insertion sort with a memory round trip per step -- was most of this phase's time
+        const int slot = c <= 64 ? atomicAdd(&s_nbig, 1) : kBigCap;
+        if (slot < kBigCap) {
+          s_big[slot] = e;
+          continue;
         }
-    } else {
-      for (int x = 1; x < c; ++x) {  // insertion sort
-        const int val = L[x];
-        int y = x - 1;
-        while (y >= 0 && L[y] > val) {
-          L[y + 1] = L[y];
-          --y;
+        int* L = list + base[q];
+        for (int x = 1; x < c; ++x) {  // insertion sort
+          const int val = L[x];
+          int y = x - 1;
+          while (y >= 0 && L[y] > val) {
+            L[y + 1] = L[y];
+            --y;
+          }
+          L[y + 1] = val;
         }
-        L[y + 1] = val;
+        for (int x = 0; x < c; ++x) {
+          const int i = L[x];
+          sx += P[3 * i];
+          sy += P[3 * i + 1];
+          sz += P[3 * i + 2];
+        }
       }
-      for (int x = 0; x < c; ++x) {
-        const int i = L[x];
-        sx += P[3 * i];
-        sy += P[3 * i + 1];
-        sz += P[3 * i + 2];
-      }
+      const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
+      epts[3 * e] = sx * wgt;
+      epts[3 * e + 1] = sy * wgt;
+      epts[3 * e + 2] = sz * wgt;
     }
-    const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
-    epts[3 * e] = sx * wgt;
-    epts[3 * e + 1] = sy * wgt;
-    epts[3 * e + 2] = sz * wgt;
+  }
+  __syncthreads();
+  GS_STAMP(10);
+  {  // crowded voxels, one wavefront each: rank sort of the point indices (lane = list entry), then the sums in
+     // ascending point order from registers (the order fixes the fp32 result)
+    const int lane = tid & 63, w = tid >> 6;
+    const int nbig = min(s_nbig, kBigCap);
+    for (int k = w; k < nbig; k += kT / 64) {
+      const int e = s_big[k];
+      const int c = ld_agent(&ecnt[e]), base = ebase[e];
+      const int mine = lane < c ? list[base + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int j = 0; j < c; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
+      if (lane < c) s_sorted[w][rank] = mine;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int i = lane < c ? s_sorted[w][lane] : 0;
+      const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (int j = 0; j < c; ++j) {
+        sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
+        sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
+        sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+      }
+      if (lane == 0) {
+        const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
+        epts[3 * e] = sx * wgt;
+        epts[3 * e + 1] = sy * wgt;
+        epts[3 * e + 2] = sz * wgt;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   __syncthreads();
 
+  GS_STAMP(4);
   // ---- P7: replay the container's growth stages to obtain its iteration order
   extern __shared__ __align__(16) unsigned char s_dyn[];
   int last_b = 0;
@@ -578,6 +658,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
     }
   }
 
+  GS_STAMP(5);
   // ---- P8: emit in list order (grid_subsampling_cpu.cpp:44-47)
   float* out = a.tmp_points + 3 * start;
   for (int pos = tid; pos < M; pos += kT) {
@@ -587,6 +668,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
     out[3 * pos + 2] = epts[3 * e + 2];
   }
   if (tid == 0) a.out_lengths[b] = M;
+  GS_STAMP(6);
 }
 
 // Stack the per-cloud results contiguously (grid_subsampling_cpu.cpp:67-68).
