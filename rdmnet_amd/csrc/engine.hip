@@ -283,10 +283,11 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
 
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
   rdm_engine* e = r.e;
+  static const bool no_fused = getenv("RDM_NO_FUSED_TAIL") != nullptr;  // developer knob: the three separate launches
   auto lo = e->lin.find(p + ".attention.linear"), l1 = e->lin.find(p + ".output.expand"), l2 = e->lin.find(p + ".output.squeeze");
   if (lo != e->lin.end() && l1 != e->lin.end() && l2 != e->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&
       lo->second.out == 128 && lo->second.kpad == 128 && l1->second.out == 256 && l1->second.kpad == 128 &&
-      l2->second.out == 128 && l2->second.kpad == 256 && !getenv("RDM_NO_FUSED_TAIL")) {
+      l2->second.out == 128 && l2->second.kpad == 256 && !no_fused) {
     const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
     return rdm_attention_tail(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias, vecp(r, p + ".attention.norm.weight"),
                               vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias, L2.wt, L2.kpad, L2.bias,

@@ -98,77 +98,70 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int KC4 = BK / 4;                       // float4 per tile row
   constexpr int B_N4 = BK * BN / 4;                 // float4 in the B tile
   constexpr int B_V = (B_N4 + 255) / 256;           // float4 per thread for the B tile
-  float4 rga[PF][A_V], rgb[PF][B_V];
+  static_assert(PF == 1 || PF == 2, "one or two register stages");
+  // named stages (an array of stages indexed in a loop ended up in scratch memory)
+  float4 ra0[A_V], rb0[B_V], ra1[PF == 2 ? A_V : 1], rb1[PF == 2 ? B_V : 1];
 
+  // Loads are unconditional from clamped (always valid) addresses, the out-of-range parts are zeroed when the stage is
+  // written to LDS, and the K loop issues and stores a stage on every trip: no control flow in the loop body, so that
+  // (a) the compiler waits for the stage it needs (vmcnt(N)) and not for all outstanding loads, and (b) the whole
+  // trip is one scheduling region in which the address arithmetic, the loads and the LDS stores of the next tile can
+  // be placed BETWEEN the MFMAs of this one.  (K, lda, ldb are multiples of 4.)
   auto load_tiles = [&](float4 (&ra)[A_V], float4 (&rb)[B_V], int kt) {
-    const int k0 = kt * BK;
+    const int k0 = min(kt, kt1 - 1) * BK;  // past the end: the last tile again (stored to a buffer nobody reads)
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
-      const int gm = m0 + row, gk = k0 + kc;
-      ra[i] = (idx < A_N4 && gm < g.M && gk < g.K)
-                  ? *reinterpret_cast<const float4*>(A + static_cast<long long>(gm) * g.lda + gk)
-                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = *reinterpret_cast<const float4*>(A + static_cast<long long>(min(m0 + row, g.M - 1)) * g.lda + min(k0 + kc, g.K - 4));
     }
-    if (TRANS_B) {
 #pragma unroll
-      for (int i = 0; i < B_V; ++i) {
-        const int idx = tid + i * 256;
+    for (int i = 0; i < B_V; ++i) {
+      const int idx = tid + i * 256;
+      if (TRANS_B) {
         const int row = idx / KC4, kc = (idx % KC4) * 4;
-        const int gn = n0 + row, gk = k0 + kc;
-        rb[i] = (idx < B_N4 && gn < g.N && gk < g.K)
-                    ? *reinterpret_cast<const float4*>(B + static_cast<long long>(gn) * g.ldb + gk)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_V; ++i) {
-        const int idx = tid + i * 256;
+        rb[i] = *reinterpret_cast<const float4*>(B + static_cast<long long>(min(n0 + row, g.N - 1)) * g.ldb + min(k0 + kc, g.K - 4));
+      } else {
         const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-        const int gk = idx < B_N4 ? k0 + k : g.K, gn = n0 + n4;
-        const float* p = B + static_cast<long long>(gk) * g.ldb + gn;
-        if (gk < g.K && gn + 3 < g.ldb) {
-          rb[i] = *reinterpret_cast<const float4*>(p);
-        } else {
-          rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (gk < g.K) {
-            if (gn < g.ldb) rb[i].x = p[0];
-            if (gn + 1 < g.ldb) rb[i].y = p[1];
-            if (gn + 2 < g.ldb) rb[i].z = p[2];
-          }
-        }
+        rb[i] = *reinterpret_cast<const float4*>(B + static_cast<long long>(min(k0 + k, g.K - 1)) * g.ldb + min(n0 + n4, g.ldb - 4));
       }
     }
   };
-  auto store_tiles = [&](const float4 (&ra)[A_V], const float4 (&rb)[B_V], int buf) {
+  // (component-wise select: `ok ? v : zero4` on two float4 lvalues is lowered as a select of ADDRESSES through scratch)
+  auto masked = [](const float4& v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+  auto store_tiles = [&](const float4 (&ra)[A_V], const float4 (&rb)[B_V], int buf, int kt) {
+    const int k0 = min(kt, kt1 - 1) * BK;
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
-      if (idx >= A_N4) continue;
-      As[buf][kc + 0][row] = ra[i].x;
-      As[buf][kc + 1][row] = ra[i].y;
-      As[buf][kc + 2][row] = ra[i].z;
-      As[buf][kc + 3][row] = ra[i].w;
+      if (A_N4 % 256 != 0 && idx >= A_N4) continue;
+      const float4 v = masked(ra[i], m0 + row < g.M && k0 + kc < g.K);
+      As[buf][kc + 0][row] = v.x;
+      As[buf][kc + 1][row] = v.y;
+      As[buf][kc + 2][row] = v.z;
+      As[buf][kc + 3][row] = v.w;
     }
     if (TRANS_B) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + i * 256;
         const int row = idx / KC4, kc = (idx % KC4) * 4;
-        if (idx >= B_N4) continue;
-        Bs[buf][kc + 0][row] = rb[i].x;
-        Bs[buf][kc + 1][row] = rb[i].y;
-        Bs[buf][kc + 2][row] = rb[i].z;
-        Bs[buf][kc + 3][row] = rb[i].w;
+        if (B_N4 % 256 != 0 && idx >= B_N4) continue;
+        const float4 v = masked(rb[i], n0 + row < g.N && k0 + kc < g.K);
+        Bs[buf][kc + 0][row] = v.x;
+        Bs[buf][kc + 1][row] = v.y;
+        Bs[buf][kc + 2][row] = v.z;
+        Bs[buf][kc + 3][row] = v.w;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
         const int idx = tid + i * 256;
         const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-        if (idx < B_N4) *reinterpret_cast<float4*>(&Bs[buf][k][n4]) = rb[i];
+        if (B_N4 % 256 != 0 && idx >= B_N4) continue;
+        // ldb and the column are multiples of 4, so a quad is inside the row or outside it (pad columns of B hold zeros)
+        *reinterpret_cast<float4*>(&Bs[buf][k][n4]) = masked(rb[i], k0 + k < g.K && n0 + n4 < g.ldb);
       }
     }
   };
@@ -194,37 +187,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int lk = lane >> 5, li = lane & 31;
+  // one k-tile: read this tile's MFMA operands from LDS buffer `buf`, then -- interleaved by the scheduling groups
+  // below -- refill the free register stage with tile kt + PF, multiply, and put the next tile into the other buffer
+  auto step = [&](auto& fa, auto& fb, const auto& na, const auto& nb, int kt, int buf) {
+    float af[BK / 2][FM], bf[BK / 2][FN];
 #pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (kt0 + s < kt1) load_tiles(rga[s], rgb[s], kt0 + s);
-  if (kt0 < kt1) store_tiles(rga[0], rgb[0], 0);
+    for (int kk = 0; kk < BK; kk += 2) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[kk / 2][i] = As[buf][kk + lk][wm * TM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[kk / 2][j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the reads stay above (the scheduler would sink each next to its MFMA)
+    load_tiles(fa, fb, kt + PF);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk / 2][i], bf[kk / 2][j], acc[i][j], 0, 0, 0);
+    store_tiles(na, nb, buf ^ 1, kt + 1);  // on the last trip: a copy of the last tile, never read
+    // a wavefront issues in order, and a dependent MFMA holds the stream for 64 clocks: everything else of the trip
+    // goes into those shadows -- per MFMA a few VALU/SALU instructions, one global load, one LDS store
+#pragma unroll
+    for (int q = 0; q < (BK / 2) * FM * FN; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    lds_barrier();  // LDS only: the register prefetch stages stay in flight
+  };
+  if (kt0 < kt1) {  // (an empty K range -- more splits than k-tiles -- leaves the accumulators at zero)
+    load_tiles(ra0, rb0, kt0);
+    if constexpr (PF == 2) load_tiles(ra1, rb1, kt0 + 1);
+    store_tiles(ra0, rb0, 0, kt0);
+  }
   lds_barrier();
   GEMM_STAMP(1);
-  const int lk = lane >> 5, li = lane & 31;
-  for (int ktb = kt0; ktb < kt1; ktb += PF) {
-#pragma unroll
-    for (int s = 0; s < PF; ++s) {
-      const int kt = ktb + s;
-      if (kt >= kt1) break;  // block-uniform
-      // LDS buffer of tile kt; PF is 1 or even, so the parity is static when PF > 1
-      const int buf = PF > 1 ? (s & 1) : ((kt - kt0) & 1);
-      // register stage s held tile kt, which is in LDS already: refill it with tile kt + PF
-      if (kt + PF < kt1) load_tiles(rga[s], rgb[s], kt + PF);
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        float af[FM], bf[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = As[buf][kk + lk][wm * TM + i * 32 + li];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+  if (kt0 < kt1) {
+    if constexpr (PF == 1) {
+      for (int kt = kt0; kt < kt1; ++kt) step(ra0, rb0, ra0, rb0, kt, (kt - kt0) & 1);
+    } else {
+      for (int kt = kt0; kt < kt1; kt += 2) {
+        step(ra0, rb0, ra1, rb1, kt, 0);
+        if (kt + 1 < kt1) step(ra1, rb1, ra0, rb0, kt + 1, 1);
       }
-      if (kt + 1 < kt1) store_tiles(rga[(s + 1) % PF], rgb[(s + 1) % PF], buf ^ 1);
-      lds_barrier();  // LDS only: the register prefetch stages stay in flight
     }
   }
 
