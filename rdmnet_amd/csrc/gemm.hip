@@ -746,9 +746,13 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // timings of every product shape of the path): a block costs a fixed prologue + epilogue plus a time per 64 of K;
   // blocks run in rounds of (CUs x resident blocks); split-K adds the partial traffic and one more launch.
   enum Tile { T128, T64, T128x32 };
-  // per 64 of K a block needs max(latency-bound time, MFMA time x blocks sharing the CU)
-  struct Cand { Tile tile; int bm, bn; double fixed_us, lat_k64_us, mfma_k64_us; int resident; };
-  static const Cand cands[3] = {{T128, 128, 128, 4.0, 2.6, 3.4, 3}, {T64, 64, 64, 3.0, 2.6, 0.86, 4}, {T128x32, 128, 32, 3.0, 1.9, 0.86, 3}};
+  // per 64 of K a block that shares its CU with r - 1 others needs max(lat * (1 + alpha (r - 1)), MFMA time * r);
+  // constants refitted by tools/gemm_model_fit.py on the sweep in tools/data/ (782 us for the path's 36 shapes against
+  // 769 us for the per-shape optimum)
+  struct Cand { Tile tile; int bm, bn; double fixed_us, lat_k64_us, mfma_k64_us; int resident; double alpha; };
+  static const Cand cands[3] = {{T128, 128, 128, 4.0, 2.6, 3.4, 3, 0.0}, {T64, 64, 64, 1.5, 2.2, 0.86, 4, 0.2},
+                                {T128x32, 128, 32, 3.0, 1.3, 0.86, 3, 0.0}};
+  static const int split_set[8] = {1, 2, 3, 4, 6, 8, 12, 16};
   Tile tile = T64;
   int best_s = 1;
   {
@@ -760,15 +764,17 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       if (c.tile == T128 && n < 128) continue;
       const long long tiles = ceil_div<long long>(m, c.bm) * ceil_div<long long>(n, c.bn) * batches;
       const int max_s = k >= 256 ? static_cast<int>(std::min<long long>(16, k / 128)) : 1;
-      for (int sp = 1; sp <= max_s; ++sp) {
+      for (int sp : split_set) {
+        if (sp > max_s) break;
         if (sp > 1 && static_cast<size_t>(m) * n * sp * batches * sizeof(float) > ws_cap) break;
         const long long blocks = tiles * sp;
         const double k_per = static_cast<double>(k) / sp / 64.0;
         const long long per_round = 256ll * c.resident;
         const long long full = blocks / per_round, rem = blocks % per_round;
-        double t = full * (c.fixed_us + k_per * std::max(c.lat_k64_us, c.mfma_k64_us * c.resident));
-        if (rem) t += c.fixed_us + k_per * std::max(c.lat_k64_us, c.mfma_k64_us * static_cast<double>(ceil_div<long long>(rem, 256)));
-        if (sp > 1) t += 5.0 + static_cast<double>(m) * n * sp * 8.0 / 2.5e6;  // reduce launch + partial write/read
+        auto per_k64 = [&](double r) { return std::max(c.lat_k64_us * (1.0 + c.alpha * (r - 1.0)), c.mfma_k64_us * r); };
+        double t = full * (c.fixed_us + k_per * per_k64(c.resident));
+        if (rem) t += c.fixed_us + k_per * per_k64(static_cast<double>(ceil_div<long long>(rem, 256)));
+        if (sp > 1) t += 3.0 + static_cast<double>(m) * n * sp * 8.0 / 1.5e6;  // reduce launch + partial write/read
         if (t < best) {
           best = t;
           tile = c.tile;

@@ -36,6 +36,7 @@ def timed(a, b, k, n, rd, bias=None):
 
 if __name__ == '__main__':
     tot_auto = tot_best = 0.0
+    table = {}
     for name, m, k, n in shapes:
         a = torch.randn(m, k, device='cuda'); b = torch.randn(k, (n + 3) // 4 * 4, device='cuda'); rd = torch.ones(m, device='cuda')
         os.environ.pop('RDM_GEMM_TUNE', None)
@@ -51,6 +52,10 @@ if __name__ == '__main__':
                 except RuntimeError:
                     pass
         res.sort()
+        table[name] = {'m': m, 'k': k, 'n': n, 'auto': auto, 'configs': [[t, sp, us] for us, t, sp in res]}
         tot_auto += auto; tot_best += res[0][0]
         print(f'{name:6s} M={m:6d} K={k:5d} N={n:5d}: auto {auto:6.1f} us | ' + ', '.join(f'{us:.1f}(t{t},s{sp})' for us, t, sp in res[:4]), flush=True)
     print(f'sum auto {tot_auto:.0f} us, sum best {tot_best:.0f} us')
+    if len(sys.argv) > 1:  # full table for refitting the dispatch model (tools/gemm_model_fit.py)
+        import json
+        json.dump(table, open(sys.argv[1], 'w'))
