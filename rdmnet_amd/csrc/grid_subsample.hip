@@ -228,6 +228,7 @@ __device__ unsigned short* replay_lds(const GridArgs& a, const unsigned long lon
   return cur;
 }
 
+constexpr int kMaskChunks = 64;  // 64-point chunks per wavefront whose ballots P2 keeps in LDS
 constexpr int kBigCap = 2048;  // work list of crowded voxels; beyond it the owning thread sorts serially
 #ifdef RDM_GS_TIMING
 __device__ unsigned long long rdm_gs_clk[16];  // tools/gs_phase_lab.hip: shader-clock stamps of workgroup 0, thread 0
@@ -237,8 +238,13 @@ __device__ unsigned long long rdm_gs_clk[16];  // tools/gs_phase_lab.hip: shader
 #endif
 __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __shared__ int s_scan[kT / 64 + 2];
-  __shared__ int s_big[kBigCap], s_nbig;           // voxels with more than 8 points: done by whole wavefronts (P6)
-  __shared__ int s_sorted[kT / 64][64];
+  // scratch tables of P2 and P6 live in the dynamic LDS that P7's replay uses afterwards (144 KB, always allocated)
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  static_assert(kLdsBytes >= (kT / 64) * kMaskChunks * 8 + kBigCap * 4 + (kT / 64) * 64 * 4, "dynamic LDS too small");
+  unsigned long long (*s_mask)[kMaskChunks] = reinterpret_cast<unsigned long long (*)[kMaskChunks]>(s_dyn);  // P2 ballots
+  int* s_big = reinterpret_cast<int*>(s_dyn + (kT / 64) * kMaskChunks * 8);  // P6: voxels with more than 8 points
+  int (*s_sorted)[64] = reinterpret_cast<int (*)[64]>(s_dyn + (kT / 64) * kMaskChunks * 8 + kBigCap * 4);
+  __shared__ int s_nbig;
   __shared__ float s_red[2 * 3 * (kT / 64)];
   __shared__ float s_org[3];
   __shared__ unsigned long long s_nxy[2];
@@ -379,46 +385,68 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __syncthreads();
 
   GS_STAMP(2);
-  // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map).  Thread t owns
-  // the contiguous points [c0, c1); "first" flags are recomputed in the second sweep instead of stored.
+  // ---- P2: rank distinct keys by first occurrence (= insertion order into the reference's map).  Wavefront w owns
+  // the contiguous points [w0, w1) and walks them 64 at a time, lane = point: the slot reads are coalesced, the
+  // "first" flags of a chunk are a ballot (kept in LDS for the second sweep when the cloud has at most 64 k points,
+  // recomputed otherwise), ranks are a running count + the lane's population count, so the key list is written in order.
+  // (One CU resolves about one scattered address per clock -- tools/gs_phase_lab.hip -- and with a thread owning
+  // CONTIGUOUS points every one of these accesses was scattered.)
   int M;
   {
-    const int per = (N + kT - 1) / kT;
-    const int c0 = min(tid * per, N), c1 = min(c0 + per, N);
-    auto first_flags = [&](int base, unsigned (&sl)[G], bool (&fl)[G]) {
+    const int lane = tid & 63, w = tid >> 6;
+    constexpr int NW = kT / 64;
+    const int seg = ((N + NW * 64 - 1) / (NW * 64)) * 64;
+    const int w0 = min(w * seg, N), w1 = min(w0 + seg, N);
+    const bool keep = seg / 64 <= kMaskChunks;
+    auto first_masks = [&](int base, unsigned (&sl)[G], unsigned long long (&mk)[G]) {
 #pragma unroll
-      for (int u = 0; u < G; ++u) sl[u] = base + u < c1 ? pt_slot[base + u] : 0u;
+      for (int u = 0; u < G; ++u) sl[u] = base + 64 * u + lane < w1 ? pt_slot[base + 64 * u + lane] : 0u;
       unsigned f[G];
 #pragma unroll
-      for (int u = 0; u < G; ++u) f[u] = base + u < c1 ? ld_agent(&ht_first[sl[u]]) : 0xffffffffu;
+      for (int u = 0; u < G; ++u) f[u] = base + 64 * u + lane < w1 ? ld_agent(&ht_first[sl[u]]) : 0xffffffffu;
 #pragma unroll
-      for (int u = 0; u < G; ++u) fl[u] = base + u < c1 && f[u] == static_cast<unsigned>(base + u);
+      for (int u = 0; u < G; ++u) mk[u] = __ballot(f[u] == static_cast<unsigned>(base + 64 * u + lane));
     };
-    int local = 0;
-    for (int base = c0; base < c1; base += G) {
+    int local = 0;  // wavefront-uniform
+    for (int base = w0; base < w1; base += 64 * G) {
       unsigned sl[G];
-      bool fl[G];
-      first_flags(base, sl, fl);
+      unsigned long long mk[G];
+      first_masks(base, sl, mk);
 #pragma unroll
-      for (int u = 0; u < G; ++u) local += fl[u] ? 1 : 0;
+      for (int u = 0; u < G; ++u) {
+        local += __popcll(mk[u]);
+        if (keep && lane == 0 && base + 64 * u < w1) s_mask[w][(base - w0) / 64 + u] = mk[u];
+      }
     }
     int total;
-    int rank = block_prefix(local, s_scan, total);
+    int rank = block_prefix(lane == 63 ? local : 0, s_scan, total);  // lane 63: the count of all earlier wavefronts
+    rank = __shfl(rank, 63, 64);
     M = total;
-    for (int base = c0; base < c1; base += G) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = w0; base < w1; base += 64 * G) {
       unsigned sl[G];
-      bool fl[G];
-      first_flags(base, sl, fl);
+      unsigned long long mk[G];
+      if (keep) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          mk[u] = base + 64 * u < w1 ? s_mask[w][(base - w0) / 64 + u] : 0ull;
+          sl[u] = ((mk[u] >> lane) & 1ull) ? pt_slot[base + 64 * u + lane] : 0u;
+        }
+      } else {
+        first_masks(base, sl, mk);
+      }
       unsigned long long kk[G];
 #pragma unroll
-      for (int u = 0; u < G; ++u) kk[u] = fl[u] ? ld_agent(&ht_keys[sl[u]]) : 0ull;
+      for (int u = 0; u < G; ++u) kk[u] = ((mk[u] >> lane) & 1ull) ? ld_agent(&ht_keys[sl[u]]) : 0ull;
 #pragma unroll
-      for (int u = 0; u < G; ++u)
-        if (fl[u]) {
-          ht_rank[sl[u]] = static_cast<unsigned>(rank);
-          ekey[rank] = kk[u];
-          ++rank;
+      for (int u = 0; u < G; ++u) {
+        if ((mk[u] >> lane) & 1ull) {
+          const int r = rank + __popcll(mk[u] & below);
+          ht_rank[sl[u]] = static_cast<unsigned>(r);
+          ekey[r] = kk[u];
         }
+        rank += __popcll(mk[u]);
+      }
     }
   }
   __syncthreads();
@@ -428,6 +456,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   // (16 points / ~10 voxels per thread at the first level: these loops take 8 points or 2 voxels per trip -- every
   // trip is a chain of 3-4 dependent memory round trips of ~1 us with nothing else on the CU to hide them)
   constexpr int G8 = 8;
+  int* pt_rank = tmp;  // voxel rank of every point (tmp is a P7 array, free until then)
   for (int i0 = tid; i0 < N; i0 += G8 * kT) {
     unsigned sl[G8], rk[G8];
 #pragma unroll
@@ -436,31 +465,27 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
     for (int u = 0; u < G8; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
 #pragma unroll
     for (int u = 0; u < G8; ++u)
-      if (i0 + u * kT < N) atomicAdd(&ecnt[rk[u]], 1);
+      if (i0 + u * kT < N) {
+        atomicAdd(&ecnt[rk[u]], 1);
+        pt_rank[i0 + u * kT] = static_cast<int>(rk[u]);
+      }
   }
   __syncthreads();
   GS_STAMP(7);
   block_scan(M, [&](int e) { return ld_agent(&ecnt[e]); }, ebase, s_scan, false);
   GS_STAMP(8);
+  // the fill cursor of a voxel starts at its list base: one returning atomic per point gives the list position
+  for (int e = tid; e < M; e += kT) efill[e] = ebase[e];
+  __syncthreads();
   for (int i0 = tid; i0 < N; i0 += G8 * kT) {
-    unsigned sl[G8], rk[G8];
-    int pos[G8], eb[G8];
+    int rk[G8], pos[G8];
 #pragma unroll
-    for (int u = 0; u < G8; ++u) sl[u] = i0 + u * kT < N ? pt_slot[i0 + u * kT] : 0u;
+    for (int u = 0; u < G8; ++u) rk[u] = i0 + u * kT < N ? pt_rank[i0 + u * kT] : 0;
 #pragma unroll
-    for (int u = 0; u < G8; ++u) rk[u] = i0 + u * kT < N ? ht_rank[sl[u]] : 0u;
-#pragma unroll
-    for (int u = 0; u < G8; ++u) {
-      pos[u] = 0;
-      eb[u] = 0;
-      if (i0 + u * kT < N) {
-        pos[u] = atomicAdd(&efill[rk[u]], 1);
-        eb[u] = ebase[rk[u]];
-      }
-    }
+    for (int u = 0; u < G8; ++u) pos[u] = i0 + u * kT < N ? atomicAdd(&efill[rk[u]], 1) : 0;
 #pragma unroll
     for (int u = 0; u < G8; ++u)
-      if (i0 + u * kT < N) list[eb[u] + pos[u]] = i0 + u * kT;
+      if (i0 + u * kT < N) list[pos[u]] = i0 + u * kT;
   }
   __syncthreads();
   constexpr int V = 2;  // voxels per trip
@@ -583,7 +608,6 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
 
   GS_STAMP(4);
   // ---- P7: replay the container's growth stages to obtain its iteration order
-  extern __shared__ __align__(16) unsigned char s_dyn[];
   int last_b = 0;
   for (int j = 0; j < a.sched.n && a.sched.at[j] < M; ++j) last_b = a.sched.buckets[j];
   const bool in_lds = M <= kLdsM && last_b <= kLdsB;  // uniform over the block
