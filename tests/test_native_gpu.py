@@ -64,6 +64,21 @@ def test_random_and_edge_clouds_match_oracle(ext, oracle_native):
             assert np.array_equal(io, ig), (n0, n1, scale, voxel)
 
 
+@pytest.mark.parametrize('n0,n1,scale,voxel', [(65, 200, 0.02, 0.6), (3000, 9, 0.8, 0.6), (70000, 300, 30.0, 0.6),
+                                               (66000, 66000, 0.5, 2.4)])
+def test_crowded_voxels_and_long_clouds_match_oracle(ext, oracle_native, n0, n1, scale, voxel):
+    """Voxels with more than 8 points are summed by a whole wavefront (up to 64 points; 65 and 200 points in one voxel
+    take the serial path), and clouds of more than 65536 points recompute the first-occurrence ballots instead of
+    keeping them in LDS; the sums are sequential fp32 adds in point order, so everything is bit-exact."""
+    o = oracle_native.restatement()
+    rng = np.random.default_rng(n0 + n1)
+    pts = (rng.standard_normal((n0 + n1, 3)) * scale).astype(np.float32)
+    lens = np.array([n0, n1], dtype=np.int64)
+    po, lo = o.grid_subsampling(pts, lens, np.float32(voxel))
+    pg, lg = gpu_grid(ext)(pts, lens, np.float32(voxel))
+    assert np.array_equal(lo, lg) and np.array_equal(po, pg)
+
+
 @pytest.mark.parametrize('n0,n1,scale', [(40000, 9000, 40.0), (9000, 30000, 25.0), (10400, 10200, 300.0)])
 def test_large_clouds_cover_both_order_replay_paths(ext, oracle_native, n0, n1, scale):
     """The hash-map order replay runs from LDS up to 10304 voxels per cloud and from HBM beyond; each case has one
