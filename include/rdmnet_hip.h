@@ -221,6 +221,12 @@ int rdm_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, cons
  * stay fp32. */
 int rdm_attention_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                   float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads, int head_dim, void* stream);
+/* rdm_attention_self_pair: the self-attention of both stacked clouds in one launch -- rows [0, n0) attend to rows
+ * [0, n0), rows [n0, n0 + n1) to rows [n0, n0 + n1) (rdmnet/thdroformer/thdroformer.py:225-236 applies the self layer to
+ * ref and src separately); bf16 != 0 selects the bf16-operand variant.  Same results as two rdm_attention calls.   */
+int rdm_attention_self_pair(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                            float* out, int64_t ldo, int64_t n0, int64_t n1, int heads, int head_dim, int bf16,
+                            void* stream);
 
 /* ---- a8/a9 helpers ------------------------------------------------------------------------------
  * rdm_vote_shift: xyz + clamp(offset[:, :3], +-limit) (rdmnet/vote/vote.py:98-108).

@@ -65,6 +65,8 @@ SIGNATURES = {
                               c_void]),
     'rdm_attention_bf16': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
                               c_void]),
+    'rdm_attention_self_pair': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
+                                        c_int, c_void]),
     'rdm_vote_shift': (c_int, [c_void, c_void, c_i64, c_i64, c_f32, c_f32, c_f32, c_void, c_void]),
     'rdm_sigmoid_column': (c_int, [c_void, c_i64, c_i64, c_void, c_void]),
     'rdm_l2_normalize': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void]),

@@ -53,6 +53,9 @@ struct AttnArgs {
   int nq, nk, heads;
   int ldq, ldk, ldv, ldo;
   float inv_scale;  // sqrt(d)
+  // optional second, independent segment in the same launch (self-attention of the second cloud): workgroups
+  // blockIdx.x >= seg0_blocks take queries/keys starting at row `row1` with nq1 / nk1 rows; seg0_blocks = 0: none
+  int seg0_blocks, row1, nq1, nk1;
 };
 
 // One workgroup = 16 queries of one head; its 4 wavefronts split the key tiles (tile % 4 == wave)
@@ -75,11 +78,22 @@ __device__ __forceinline__ bf16x4_t pack_bf16(float a, float b, float c, float d
 // Q, K, V and the probabilities are rounded to bf16 in registers and contracted on the 16x16x16 bf16 MFMA;
 // logits, softmax statistics and both accumulators stay fp32.  HBM tensors are fp32 either way.
 template <bool BF16>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a_in) {
+  AttnArgs a = a_in;
+  int bx = blockIdx.x;
+  if (a.seg0_blocks > 0 && bx >= a.seg0_blocks) {  // block-uniform: the second cloud's rows
+    bx -= a.seg0_blocks;
+    a.q += static_cast<int64_t>(a.row1) * a.ldq;
+    a.k += static_cast<int64_t>(a.row1) * a.ldk;
+    a.v += static_cast<int64_t>(a.row1) * a.ldv;
+    a.out += static_cast<int64_t>(a.row1) * a.ldo;
+    a.nq = a.nq1;
+    a.nk = a.nk1;
+  }
   __shared__ float sm[4][16], sl[4][16];
   __shared__ float so[4][16][kHeadDim + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q0 = blockIdx.x * 16;
+  const int q0 = bx * 16;
   const int head = blockIdx.y;
   const int g = lane >> 4, x = lane & 15;
   const int hoff = head * kHeadDim;
@@ -269,6 +283,7 @@ static int attention_launch(const float* q, int64_t ldq, const float* k, int64_t
   a.ldq = static_cast<int>(ldq); a.ldk = static_cast<int>(ldk); a.ldv = static_cast<int>(ldv);
   a.ldo = static_cast<int>(ldo);
   a.inv_scale = sqrtf(static_cast<float>(head_dim));
+  a.seg0_blocks = 0; a.row1 = 0; a.nq1 = 0; a.nk1 = 0;
   const dim3 grid(ceil_div<int64_t>(n_q, 16), heads);
   if (bf16)
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
@@ -281,6 +296,38 @@ extern "C" int rdm_attention(const float* q, int64_t ldq, const float* k, int64_
                              int64_t ldv, float* out, int64_t ldo, int64_t n_q, int64_t n_k, int heads,
                              int head_dim, void* stream) {
   return attention_launch(q, ldq, k, ldk, v, ldv, out, ldo, n_q, n_k, heads, head_dim, false, stream);
+}
+
+// Self-attention of two stacked clouds in one launch: rows [0, n0) attend to rows [0, n0), rows [n0, n0 + n1) to rows
+// [n0, n0 + n1) (thdroformer.py:225-236 runs the self layer on ref and src separately; same results as two
+// rdm_attention calls).
+extern "C" int rdm_attention_self_pair(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                       float* out, int64_t ldo, int64_t n0, int64_t n1, int heads, int head_dim, int bf16,
+                                       void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q && k && v && out, "rdm_attention_self_pair: null pointer");
+  RDM_REQUIRE(head_dim == kHeadDim, "rdm_attention: head_dim must be %d", kHeadDim);
+  RDM_REQUIRE(n0 >= 0 && n1 >= 0 && heads > 0, "rdm_attention_self_pair: bad sizes");
+  RDM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 2 == 0 && ldo % 2 == 0, "rdm_attention: strides must be padded");
+  if (n0 == 0 || n1 == 0) {  // one cloud is empty: the plain launch on the other
+    if (n0 + n1 == 0) return RDM_OK;
+    const int64_t n = n0 + n1;  // (the non-empty cloud starts at row 0 either way)
+    return attention_launch(q, ldq, k, ldk, v, ldv, out, ldo, n, n, heads, head_dim, bf16 != 0, stream);
+  }
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.out = out;
+  a.nq = static_cast<int>(n0); a.nk = static_cast<int>(n0); a.heads = heads;
+  a.ldq = static_cast<int>(ldq); a.ldk = static_cast<int>(ldk); a.ldv = static_cast<int>(ldv);
+  a.ldo = static_cast<int>(ldo);
+  a.inv_scale = sqrtf(static_cast<float>(head_dim));
+  a.seg0_blocks = static_cast<int>(ceil_div<int64_t>(n0, 16));
+  a.row1 = static_cast<int>(n0); a.nq1 = static_cast<int>(n1); a.nk1 = static_cast<int>(n1);
+  const dim3 grid(a.seg0_blocks + ceil_div<int64_t>(n1, 16), heads);
+  if (bf16)
+    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return launch_status("attention_kernel");
 }
 
 extern "C" int rdm_attention_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,

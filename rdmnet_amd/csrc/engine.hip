@@ -322,9 +322,8 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
       ENG_CHECK(linear(r, p + ".qkv", f, qkv));
       Mat q = qkv.cols_from(0, d), k = qkv.cols_from(d, d), v = qkv.cols_from(2 * d, d);
       ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb.p, emb.ld, N, d, r.st));
-      ENG_CHECK(attend(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n0, heads, hd, r.st));
-      ENG_CHECK(attend(q.p + n0 * q.ld, q.ld, k.p + n0 * k.ld, k.ld, v.p + n0 * v.ld, v.ld, hid.p + n0 * hid.ld, hid.ld,
-                              n1, n1, heads, hd, r.st));
+      ENG_CHECK(rdm_attention_self_pair(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n1, heads, hd,
+                                        e->cfg.attention_bf16 ? 1 : 0, r.st));  // both clouds, one launch
       ENG_CHECK(attention_tail(r, p, hid, f, fnew));
     } else {
       Mat q, kv1, kv0;

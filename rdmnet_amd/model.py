@@ -248,8 +248,7 @@ class RDMNet:
                 qkv = ops.gemm(f, W[p + '.qkv'][0], d, 3 * d, bias=W[p + '.qkv'][1])
                 q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
                 ops.rope(q, k, emb)
-                ops.attention(q[:n0], k[:n0], v[:n0], heads, out=hid[:n0], bf16=self.attention_bf16)
-                ops.attention(q[n0:], k[n0:], v[n0:], heads, out=hid[n0:], bf16=self.attention_bf16)
+                ops.attention_self_pair(q, k, v, n0, heads, out=hid, bf16=self.attention_bf16)  # both clouds, one launch
                 self._attention_tail(p, hid, f, fnew)
             else:
                 q = ops.gemm(f, W[p + '.q'][0], d, d, bias=W[p + '.q'][1])

@@ -218,6 +218,17 @@ def attention(q, k, v, heads, out=None, bf16=False):
     return out
 
 
+def attention_self_pair(q, k, v, n0, heads, out=None, bf16=False):
+    """Self-attention of two stacked clouds (rows [0, n0) and [n0, n)) in one launch; same results as two attention calls."""
+    L = _lib.lib()
+    n, d = q.shape
+    if out is None:
+        out = feat_empty(n, d, q.device)
+    _lib.check(L.rdm_attention_self_pair(q.data_ptr(), _ld(q), k.data_ptr(), _ld(k), v.data_ptr(), _ld(v), out.data_ptr(), _ld(out),
+                                         n0, n - n0, heads, d // heads, int(bf16), _lib.stream_ptr()), 'rdm_attention_self_pair')
+    return out
+
+
 def vote_shift(xyz, offsets, limits):
     L = _lib.lib()
     out = torch.empty_like(xyz)

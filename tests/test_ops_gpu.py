@@ -210,3 +210,16 @@ def test_attention_tail_fused_matches_torch(ops, m):
     z3 = ops.gemm(y3, c(w1.t().contiguous()), 128, 256, bias=c(b1), act=1)
     o3 = ops.linear_layer_norm(z3, c(w2), 256, 128, c(b2), c(g2), c(be2), residual=y3).cpu()
     assert (got - o3).abs().max() <= 3e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize('n0,n1', [(350, 301), (16, 1), (0, 40), (33, 0)])
+def test_attention_self_pair_equals_two_launches(ops, n0, n1):
+    """Both clouds' self-attention in one launch (thdroformer.py:225-236) gives the bits of the two separate launches."""
+    g = torch.Generator().manual_seed(n0 + 7 * n1)
+    q, k, v = (torch.randn(n0 + n1, 128, generator=g).cuda() for _ in range(3))
+    for bf16 in (False, True):
+        both = ops.attention_self_pair(q, k, v, n0, 4, bf16=bf16)
+        if n0:
+            assert torch.equal(both[:n0], ops.attention(q[:n0], k[:n0], v[:n0], 4, bf16=bf16))
+        if n1:
+            assert torch.equal(both[n0:], ops.attention(q[n0:], k[n0:], v[n0:], 4, bf16=bf16))
