@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
       } else {
         // a crowded voxel (near the sensor): a whole wavefront takes it below; the serial form -- one thread, an
         // insertion sort with a memory round trip per step -- was most of this phase's time
-        const int slot = c <= 64 ? atomicAdd(&s_nbig, 1) : kBigCap;
+        const int slot = atomicAdd(&s_nbig, 1);  // (a full work list leaves the voxel to this thread, serially)
         if (slot < kBigCap) {
           s_big[slot] = e;
           continue;
@@ -580,19 +580,46 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
     for (int k = w; k < nbig; k += kT / 64) {
       const int e = s_big[k];
       const int c = ld_agent(&ecnt[e]), base = ebase[e];
-      const int mine = lane < c ? list[base + lane] : 0x7fffffff;
-      int rank = 0;
-      for (int j = 0; j < c; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
-      if (lane < c) s_sorted[w][rank] = mine;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int i = lane < c ? s_sorted[w][lane] : 0;
-      const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
       float sx = 0.f, sy = 0.f, sz = 0.f;
-      for (int j = 0; j < c; ++j) {
-        sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
-        sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
-        sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+      if (c <= 64) {
+        const int mine = lane < c ? list[base + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < c; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
+        if (lane < c) s_sorted[w][rank] = mine;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int i = lane < c ? s_sorted[w][lane] : 0;
+        const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+        for (int j = 0; j < c; ++j) {
+          sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
+          sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
+          sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+        }
+      } else {
+        // more than a wavefront of points in one voxel (a degenerate cloud can put ALL its points there): the same
+        // rank sort in chunks of 64 against chunks of 64 -- c^2/64 wavefront steps instead of one thread's c^2/4
+        // memory round trips -- with the sorted indices in `cur` (a P7 array, free until then)
+        for (int m0 = 0; m0 < c; m0 += 64) {
+          const int mine = m0 + lane < c ? list[base + m0 + lane] : 0x7fffffff;
+          int rank = 0;
+          for (int o0 = 0; o0 < c; o0 += 64) {
+            const int other = o0 + lane < c ? list[base + o0 + lane] : 0x7fffffff;
+            const int cnt = min(64, c - o0);
+            for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(other, j) < mine ? 1 : 0;
+          }
+          if (m0 + lane < c) cur[base + rank] = mine;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the sorted list was written by other lanes
+        for (int m0 = 0; m0 < c; m0 += 64) {
+          const int i = m0 + lane < c ? ld_agent(&cur[base + m0 + lane]) : 0;
+          const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+          const int cnt = min(64, c - m0);
+          for (int j = 0; j < cnt; ++j) {
+            sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
+            sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
+            sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+          }
+        }
       }
       if (lane == 0) {
         const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
