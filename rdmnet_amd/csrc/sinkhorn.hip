@@ -26,6 +26,76 @@ constexpr int kHalf = 66;   // each thread owns half a row and half a column: 65
 constexpr int kPairs = kHalf / 2;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The iterations for a block whose compacted side fits 4 * PAIRS entries: thread t owns row (t>>1), columns
+// [HALF*(t&1), HALF*(t&1) + HALF) with HALF = 2 * PAIRS, as float2 pairs in registers.  Three size classes (68, 100,
+// 132) are instantiated: a patch with 60 valid points per side does half the work of a full one, and most patches
+// are not full (the register arrays need static indexing, so the trip count cannot simply be a run-time bound).
+template <int PAIRS>
+__device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr, int nc, float norm, int iters, float* u, float* v,
+                                                 const int* rows, const int* cols, int m, int n, float* O) {
+  constexpr int HALF = 2 * PAIRS;
+  const int tid = threadIdx.x, R = nr + 1, C = nc + 1;
+  const int own = tid >> 1, half = tid & 1, base = half * HALF;
+  const float log_mu = own < nr ? norm : logf(static_cast<float>(nc)) + norm;
+  const float log_nu = own < nc ? norm : logf(static_cast<float>(nr)) + norm;
+  f32x2 zr[PAIRS], zc[PAIRS];  // -inf marks "outside the block": contributes exp(-inf) = 0
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const int c = base + i;
+    zr[i >> 1][i & 1] = (own < R && c < C) ? Z[own * ldz + c] : -INFINITY;
+    zc[i >> 1][i & 1] = (own < C && c < R) ? Z[c * ldz + own] : -INFINITY;
+  }
+  // log_m - logsumexp over this thread's half (z + pot) combined with the neighbouring lane's half
+  auto update = [&](const f32x2 (&z)[PAIRS], const float* pot, float log_m) -> float {
+    const f32x2* p2 = reinterpret_cast<const f32x2*>(pot + base);
+    f32x2 t[PAIRS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      t[i] = z[i] + p2[i];
+      mx = fmaxf(mx, fmaxf(t[i].x, t[i].y));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    const f32x2 mx2 = {mx, mx}, l2e = {1.4426950408889634f, 1.4426950408889634f};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+      const f32x2 d = (t[i] - mx2) * l2e;   // exp(x) = exp2(x log2 e): the hardware exponential (v_exp_f32), as __expf
+      f32x2 e;
+      e.x = __builtin_amdgcn_exp2f(d.x);
+      e.y = __builtin_amdgcn_exp2f(d.y);
+      sum2 += e;
+    }
+    float sum = sum2.x + sum2.y;
+    sum += __shfl_xor(sum, 1, 64);
+    return log_m - (mx + logf(sum));
+  };
+
+  for (int it = 0; it < iters; ++it) {
+    const float un = update(zr, v, log_mu);  // u = log_mu - logsumexp_c(Z + v)
+    if (half == 0 && own < R) u[own] = un;
+    __syncthreads();
+    const float vn = update(zc, u, log_nu);  // v = log_nu - logsumexp_r(Z + u)
+    if (half == 0 && own < C) v[own] = vn;
+    __syncthreads();
+  }
+
+  // dense output: fl(-1e12) everywhere, then the valid block
+  const float masked = -1.0e12f;
+  const int total = (m + 1) * (n + 1);
+  for (int t = tid; t < total; t += 256) O[t] = masked;
+  __syncthreads();
+  if (own < R) {
+    const float ur = u[own];
+    const int64_t orow = static_cast<int64_t>(rows[own]) * (n + 1);
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const int c = base + i;
+      if (c < C) O[orow + cols[c]] = ((zr[i >> 1][i & 1] + ur) + v[c]) - norm;
+    }
+  }
+}
+
 // 256 threads.  Thread t owns row (t>>1), columns [66*(t&1), 66*(t&1)+66) of the compacted score
 // block in REGISTERS, and likewise half of column (t>>1): the 100 iterations touch LDS only for the
 // broadcast potentials u, v.  A row's two halves are combined with one lane exchange.  The entries are held as
@@ -75,65 +145,10 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   }
   __syncthreads();
 
-  const int own = tid >> 1, half = tid & 1, base = half * kHalf;
-  const float log_mu = own < nr ? norm : logf(static_cast<float>(nc)) + norm;
-  const float log_nu = own < nc ? norm : logf(static_cast<float>(nr)) + norm;
-  f32x2 zr[kPairs], zc[kPairs];  // -inf marks "outside the block": contributes exp(-inf) = 0
-#pragma unroll
-  for (int i = 0; i < kHalf; ++i) {
-    const int c = base + i;
-    zr[i >> 1][i & 1] = (own < R && c < C) ? Z[own * ldz + c] : -INFINITY;
-    zc[i >> 1][i & 1] = (own < C && c < R) ? Z[c * ldz + own] : -INFINITY;
-  }
-  // log_m - logsumexp over this thread's half (z + pot) combined with the neighbouring lane's half
-  auto update = [&](const f32x2 (&z)[kPairs], const float* pot, float log_m) -> float {
-    const f32x2* p2 = reinterpret_cast<const f32x2*>(pot + base);
-    f32x2 t[kPairs];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < kPairs; ++i) {
-      t[i] = z[i] + p2[i];
-      mx = fmaxf(mx, fmaxf(t[i].x, t[i].y));
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    const f32x2 mx2 = {mx, mx}, l2e = {1.4426950408889634f, 1.4426950408889634f};
-    f32x2 sum2 = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < kPairs; ++i) {
-      const f32x2 d = (t[i] - mx2) * l2e;   // exp(x) = exp2(x log2 e): the hardware exponential (v_exp_f32), as __expf
-      f32x2 e;
-      e.x = __builtin_amdgcn_exp2f(d.x);
-      e.y = __builtin_amdgcn_exp2f(d.y);
-      sum2 += e;
-    }
-    float sum = sum2.x + sum2.y;
-    sum += __shfl_xor(sum, 1, 64);
-    return log_m - (mx + logf(sum));
-  };
-
-  for (int it = 0; it < iters; ++it) {
-    const float un = update(zr, v, log_mu);  // u = log_mu - logsumexp_c(Z + v)
-    if (half == 0 && own < R) u[own] = un;
-    __syncthreads();
-    const float vn = update(zc, u, log_nu);  // v = log_nu - logsumexp_r(Z + u)
-    if (half == 0 && own < C) v[own] = vn;
-    __syncthreads();
-  }
-
-  // dense output: fl(-1e12) everywhere, then the valid block
-  const float masked = -1.0e12f;
-  const int total = (m + 1) * (n + 1);
-  for (int t = tid; t < total; t += 256) O[t] = masked;
-  __syncthreads();
-  if (own < R) {
-    const float ur = u[own];
-    const int64_t orow = static_cast<int64_t>(rows[own]) * (n + 1);
-#pragma unroll
-    for (int i = 0; i < kHalf; ++i) {
-      const int c = base + i;
-      if (c < C) O[orow + cols[c]] = ((zr[i >> 1][i & 1] + ur) + v[c]) - norm;
-    }
-  }
+  const int side = R > C ? R : C;
+  if (side <= 68) sinkhorn_iterate<17>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
+  else if (side <= 100) sinkhorn_iterate<25>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
+  else sinkhorn_iterate<33>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
 }
 
 }  // namespace
