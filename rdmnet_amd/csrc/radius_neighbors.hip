@@ -158,6 +158,14 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
+#ifdef RDM_RN_TIMING
+__device__ unsigned* rdm_rn_clk;  // tools/rn_phase_lab.hip: [queries][8] shader clocks per phase
+#define RN_T0() unsigned long long rn_t = __builtin_amdgcn_s_memtime()
+#define RN_PHASE(k) do { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (lane == 0) rdm_rn_clk[qi * 8 + (k)] = static_cast<unsigned>(now - rn_t); rn_t = now; } while (0)
+#else
+#define RN_T0() do { } while (0)
+#define RN_PHASE(k) do { } while (0)
+#endif
 // One wavefront per query.
 template <int CAP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
   if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+  RN_T0();
   if (only_redo && !redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
   const GridMeta g = *meta;
   if (radius * g.inv_cell > 1.0f) {  // the grid was built for a smaller radius: 27 cells would miss neighbours
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   if (b < batch) {
     int cx, cy, cz;
     cell_of(g, qx, qy, qz, cx, cy, cz);
+    RN_PHASE(0);
     // lanes 0..26 own one neighbouring cell each
     int my_n = 0, my_start = 0;
     if (lane < 27) {
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
+    RN_PHASE(1);
     // two candidates per lane and step: both record loads are in flight before either is tested
     for (int base = 0; base < total; base += 128) {
       bool hit[2] = {false, false};
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
       }
     }
   }
+  RN_PHASE(2);
   if (lane == 0) {
     if (out_counts) out_counts[qi] = count;
     // one address for all queries: same-address atomics cost ~12 ns each, so only raise it when needed
@@ -291,11 +303,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
         r1 += ki < k1 ? 1 : 0;
       }
     }
+    RN_PHASE(3);
     // every lane knows the final column of its keys: write the row directly (pads behind the n-th column)
     int64_t* row = out_idx + qi * static_cast<int64_t>(width);
     if (lane < n && r0 < width) row[r0] = static_cast<int64_t>(k0 & 0xffffffffull);
     if (64 + lane < n && r1 < width) row[r1] = static_cast<int64_t>(k1 & 0xffffffffull);
     for (int c = n + lane; c < width; c += 64) row[c] = ns;
+    RN_PHASE(4);
     return;
   } else {
   int p2 = 1;
