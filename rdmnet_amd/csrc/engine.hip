@@ -683,12 +683,17 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(g.ws);
     return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
   };
+  std::vector<char> redo_queue(radius_redo_queue_bytes());
+  radius_redo_queue_reset(redo_queue.data());
   auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t) -> int {
     t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
     t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
     ENG_ALLOC(t.idx);
-    return rdm_radius_grid_query(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
-                                 t.flags + 1, r.ws, r.ws_bytes, r.st);
+    // the large-buffer second pass of all 14 searches is one launch after the loop (radius_redo_flush)
+    unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
+    ENG_ALLOC(redo_flags);
+    return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
+                                      t.flags + 1, redo_flags, redo_queue.data(), r.st);
   };
   Grid grids[5];
   for (int i = 0; i < 5; ++i) {
@@ -698,6 +703,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     if (i > 0) ENG_CHECK(search(lv[i - 1], grids[i], radius, c.neighbor_limits[i], up[i - 1]));
     radius *= 2.f;
   }
+  ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));
   for (int i = 0; i < 5; ++i) {
     tap(r, ("points" + std::to_string(i)).c_str(), lv[i].pts, lv[i].n, 3, 3, 0);
     tap(r, ("neighbors" + std::to_string(i)).c_str(), nb[i].idx, nb[i].rows, nb[i].width, nb[i].width, 1);

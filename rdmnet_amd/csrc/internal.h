@@ -22,4 +22,16 @@ int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n
                       const float* gamma, const float* beta, float eps, const float* residual, int64_t ldr, int act,
                       float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
 
+// Radius search with the second pass (queries with more than 256 neighbours, redone with the large buffer) deferred:
+// the first pass runs now and records the search in `queue` (radius_redo_queue_bytes() bytes of host memory, reset
+// once); radius_redo_flush launches ONE kernel for all recorded searches.  redo_flags: n_q bytes of device memory
+// that must stay valid until the flush (rdm_radius_grid_query keeps them in its scratch and runs both passes at once).
+size_t radius_redo_queue_bytes();
+void radius_redo_queue_reset(void* queue);
+int radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
+                               const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
+                               int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo_flags, void* queue,
+                               void* stream);
+int radius_redo_flush(void* queue, void* stream);
+
 }  // namespace rdm

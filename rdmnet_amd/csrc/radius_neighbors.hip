@@ -14,6 +14,7 @@
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -166,22 +167,44 @@ __device__ unsigned* rdm_rn_clk;  // tools/rn_phase_lab.hip: [queries][8] shader
 #define RN_T0() do { } while (0)
 #define RN_PHASE(k) do { } while (0)
 #endif
-// One wavefront per query.
+// One query by one wavefront (all 64 lanes call it; no block-level barrier inside).  K: CAP keys, seg_start_w /
+// seg_pref_w: 28 ints each, all private to the wavefront (LDS).
+struct RnQueryArgs {
+  const float* q;
+  int64_t nq, ns;
+  const int64_t* q_lengths;
+  int batch;
+  float radius;
+  const GridMeta* meta;
+  const int* cell_count;
+  const int* cell_start;
+  const float4* sorted;
+  int width;
+  int64_t* out_idx;
+  int32_t* out_counts;
+  int32_t* out_max;
+  int32_t* status;
+  unsigned char* redo;
+};
 template <int CAP>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
-    const float* q, int64_t nq, int64_t ns, const int64_t* q_lengths, int batch, float radius,
-    const GridMeta* meta, const int* cell_count, const int* cell_start, const float4* sorted,
-    int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo,
-    int only_redo) {
-  __shared__ unsigned long long keys[kWavesPerBlock][CAP];
-  __shared__ int seg_start[kWavesPerBlock][28];
-  __shared__ int seg_pref[kWavesPerBlock][28];
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
-  if (qi >= nq) return;  // whole wave exits together; no block-level barrier is used below
+__device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, int lane, unsigned long long* K, int* seg_start_w,
+                                             int* seg_pref_w, int only_redo) {
+  const float* q = a.q;
+  const int64_t ns = a.ns;
+  const int64_t* q_lengths = a.q_lengths;
+  const int batch = a.batch;
+  const float radius = a.radius;
+  const GridMeta* meta = a.meta;
+  const int* cell_count = a.cell_count;
+  const int* cell_start = a.cell_start;
+  const float4* sorted = a.sorted;
+  const int width = a.width;
+  int64_t* out_idx = a.out_idx;
+  int32_t* out_counts = a.out_counts;
+  int32_t* out_max = a.out_max;
+  int32_t* status = a.status;
+  unsigned char* redo = a.redo;
   RN_T0();
-  if (only_redo && !redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
   const GridMeta g = *meta;
   if (radius * g.inv_cell > 1.0f) {  // the grid was built for a smaller radius: 27 cells would miss neighbours
     if (lane == 0) atomicExch(status, 2);
@@ -192,7 +215,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
   int64_t begin;
   const int b = cloud_of(q_lengths, batch, qi, begin);
 
-  unsigned long long* K = keys[wave];
   int count = 0;
   if (b < batch) {
     int cx, cy, cz;
@@ -216,11 +238,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
       if (lane >= o) inc += t;
     }
     if (lane < 27) {
-      seg_start[wave][lane] = my_start;
-      seg_pref[wave][lane] = inc - my_n;
+      seg_start_w[lane] = my_start;
+      seg_pref_w[lane] = inc - my_n;
     }
     const int total = __shfl(inc, 26, 64);
-    if (lane == 27) seg_pref[wave][27] = total;
+    if (lane == 27) seg_pref_w[27] = total;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 
@@ -238,8 +260,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
           int seg = 0;
 #pragma unroll
           for (int step = 16; step > 0; step >>= 1)
-            if (seg + step < 27 && seg_pref[wave][seg + step] <= tt[u]) seg += step;
-          p[u] = sorted[seg_start[wave][seg] + (tt[u] - seg_pref[wave][seg])];
+            if (seg + step < 27 && seg_pref_w[seg + step] <= tt[u]) seg += step;
+          p[u] = sorted[seg_start_w[seg] + (tt[u] - seg_pref_w[seg])];
         }
       }
 #pragma unroll
@@ -354,6 +376,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(
     row[c] = c < n ? static_cast<int64_t>(K[c] & 0xffffffffull) : ns;
 }
 
+// First pass (CAP = 256, one wavefront per query, every query) and the stand-alone second pass (CAP = 1024, only the
+// queries whose `redo` flag the first pass set).
+template <int CAP>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(RnQueryArgs a, int only_redo) {
+  __shared__ unsigned long long keys[kWavesPerBlock][CAP];
+  __shared__ int seg_start[kWavesPerBlock][28];
+  __shared__ int seg_pref[kWavesPerBlock][28];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
+  if (qi >= a.nq) return;  // whole wave exits together
+  if (only_redo && !a.redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
+  rn_query_one<CAP>(a, qi, lane, keys[wave], seg_start[wave], seg_pref[wave], only_redo);
+}
+
+// The second pass of SEVERAL searches in one launch (the engine defers it: 14 searches per scan pair, and a launch
+// that finds nothing to do still costs its dispatch).  blockIdx.y = search; the wavefronts of a search walk its redo
+// flags 64 at a time and take the flagged queries one by one.
+constexpr int kRedoMax = 16;
+struct RnRedoBatch {
+  RnQueryArgs item[kRedoMax];
+  int n;
+};
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rn_redo_multi_kernel(RnRedoBatch b) {
+  __shared__ unsigned long long keys[kWavesPerBlock][1024];
+  __shared__ int seg_start[kWavesPerBlock][28];
+  __shared__ int seg_pref[kWavesPerBlock][28];
+  const RnQueryArgs& a = b.item[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t base = (blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave) * 64; base < a.nq; base += nwaves * 64) {
+    unsigned long long todo = __ballot(base + lane < a.nq && a.redo[base + lane] != 0);
+    while (todo) {
+      const int k = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      rn_query_one<1024>(a, base + k, lane, keys[wave], seg_start[wave], seg_pref[wave], 1);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the LDS buffers are reused by the next query
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -411,10 +474,12 @@ extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const i
   return launch_status("radius grid build");
 }
 
-extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points,
-                                     int64_t n_q, const int64_t* q_lengths, int batch, float radius, int width,
-                                     int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status,
-                                     void* ws, size_t ws_bytes, void* stream) {
+namespace {
+// shared by the C entry point and the engine's deferred form: first pass now; the second pass now (queue == null) or
+// appended to `queue` for rdm::radius_redo_flush
+int grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q, const int64_t* q_lengths,
+               int batch, float radius, int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status,
+               unsigned char* redo, RnRedoBatch* queue, hipStream_t st) {
   using namespace rdm;
   RDM_REQUIRE(grid_ws && q_lengths && status, "rdm_radius_grid_query: null pointer");
   RDM_REQUIRE(n_q >= 0 && batch > 0 && batch <= kMaxBatch && radius > 0.f, "rdm_radius_grid_query: bad arguments");
@@ -424,24 +489,57 @@ extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_
   Arena gar(grid_ws, grid_ws_bytes);
   GridViews g;
   RDM_REQUIRE(carve_grid(gar, n_s, &g), "rdm_radius_grid_query: grid workspace size does not match n_s");
+  RnQueryArgs a;
+  a.q = q_points; a.nq = n_q; a.ns = n_s; a.q_lengths = q_lengths; a.batch = batch; a.radius = radius; a.meta = g.meta;
+  a.cell_count = g.cell_count; a.cell_start = g.cell_start; a.sorted = g.sorted; a.width = width; a.out_idx = out_idx;
+  a.out_counts = out_counts; a.out_max = out_max; a.status = status; a.redo = redo;
+  const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
+  // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
+  // neighbours is redone by the large-buffer instance
+  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 0);
+  if (width > 0) {
+    if (queue && queue->n < kRedoMax) {
+      queue->item[queue->n++] = a;
+    } else {
+      hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 1);
+    }
+  }
+  return launch_status("rn_query_kernel");
+}
+}  // namespace
+
+size_t rdm::radius_redo_queue_bytes() { return sizeof(RnRedoBatch); }
+void rdm::radius_redo_queue_reset(void* queue) { static_cast<RnRedoBatch*>(queue)->n = 0; }
+int rdm::radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
+                                    const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
+                                    int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo_flags,
+                                    void* queue, void* stream) {
+  RDM_REQUIRE(redo_flags && queue, "radius_grid_query_deferred: null redo storage");
+  return grid_query(grid_ws, grid_ws_bytes, n_s, q_points, n_q, q_lengths, batch, radius, width, out_idx, out_counts, out_max,
+                    status, redo_flags, static_cast<RnRedoBatch*>(queue), static_cast<hipStream_t>(stream));
+}
+int rdm::radius_redo_flush(void* queue, void* stream) {
+  RnRedoBatch* b = static_cast<RnRedoBatch*>(queue);
+  if (b->n == 0) return RDM_OK;
+  // 64 workgroups (256 wavefronts) per search: two flag sweeps of 64 queries per wavefront cover a 32 k-point level
+  hipLaunchKernelGGL(rn_redo_multi_kernel, dim3(64, b->n), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
+  b->n = 0;
+  return launch_status("rn_redo_multi_kernel");
+}
+
+extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points,
+                                     int64_t n_q, const int64_t* q_lengths, int batch, float radius, int width,
+                                     int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  using namespace rdm;
   Arena ar(ws, ws_bytes);
-  unsigned char* redo = ar.take<unsigned char>(static_cast<size_t>(n_q));
+  unsigned char* redo = ar.take<unsigned char>(static_cast<size_t>(n_q > 0 ? n_q : 1));
   if (!ar.ok) {
     set_error("rdm_radius_grid_query: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
     return RDM_ERR_WORKSPACE;
   }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
-  // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
-  // neighbours is redone by the large-buffer instance (which exits at once for all other queries)
-  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, q_points, n_q, n_s,
-                     q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx, out_counts,
-                     out_max, status, redo, 0);
-  if (width > 0)
-    hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, q_points, n_q, n_s,
-                       q_lengths, batch, radius, g.meta, g.cell_count, g.cell_start, g.sorted, width, out_idx,
-                       out_counts, out_max, status, redo, 1);
-  return launch_status("rn_query_kernel");
+  return grid_query(grid_ws, grid_ws_bytes, n_s, q_points, n_q, q_lengths, batch, radius, width, out_idx, out_counts, out_max,
+                    status, redo, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_t n_s) {

@@ -114,6 +114,29 @@ def test_engine_handles_degenerate_clouds(ctx, n, scale):
     assert res.n_ref_nodes >= 1 and res.n_src_nodes >= 1 and res.n_correspondences >= 0
 
 
+def test_engine_deferred_large_buffer_pass_matches_per_op_searches(ctx):
+    """6 000 points in a 6 x 6 x 4 m box: 300-500 points inside a level-0 search radius, more than the first pass's
+    256-key buffer.  The engine defers the large-buffer pass of all 14 searches to one launch; the per-op path runs it
+    right after each search: same neighbour tables."""
+    rng = np.random.default_rng(5)
+    box = np.array([3.0, 3.0, 2.0])
+    a = (rng.uniform(-1, 1, (6000, 3)) * box).astype(np.float32)
+    b = (rng.uniform(-1, 1, (5500, 3)) * box).astype(np.float32)
+    data = ctx['collate'].collate_pair(a, b, ctx['cfg'])
+    ctx['eng'].run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    for i in range(5):
+        assert torch.equal(ctx['eng'].tensor(f'points{i}'), data['points'][i])
+        assert torch.equal(ctx['eng'].tensor(f'neighbors{i}'), data['neighbors'][i]), i
+        if i < 4:
+            assert torch.equal(ctx['eng'].tensor(f'subsampling{i}'), data['subsampling'][i]), i
+            assert torch.equal(ctx['eng'].tensor(f'upsampling{i}'), data['upsampling'][i]), i
+    # the case really overflows the small buffer
+    from rdmnet_amd import ext
+    p0, l0 = data['points'][0], data['lengths'][0]
+    full = ext.radius_neighbors(p0, p0, l0, l0, float(ctx['cfg'].backbone.init_radius))
+    assert int((full < p0.shape[0]).sum(1).max()) > 256
+
+
 def test_engine_reports_capacity_instead_of_truncating(ctx):
     """20 000 points in a 4 m cube put > 1024 points into one search radius: the reference would return them all;
     the kernels' per-query capacity is 1024, and exceeding it is an error, never a silent truncation."""
