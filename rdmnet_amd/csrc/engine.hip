@@ -860,6 +860,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     Grid nms_grid;
     ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
     ENG_CHECK(search(nodes_all, nms_grid, c.nms_radius, c.neighbor_limits[4], nms_t));
+    ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));  // (searches are recorded and run at the flush)
     uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);
     ENG_ALLOC(keep);
     ENG_CHECK(rdm_nms(nms_t.idx, Nc, nms_t.width, nms_t.width, nms_t.flags, keep, r.st));

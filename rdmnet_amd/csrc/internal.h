@@ -22,9 +22,10 @@ int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n
                       const float* gamma, const float* beta, float eps, const float* residual, int64_t ldr, int act,
                       float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
 
-// Radius search with the second pass (queries with more than 256 neighbours, redone with the large buffer) deferred:
-// the first pass runs now and records the search in `queue` (radius_redo_queue_bytes() bytes of host memory, reset
-// once); radius_redo_flush launches ONE kernel for all recorded searches.  redo_flags: n_q bytes of device memory
+// Radius searches batched: a call only records the search in `queue` (radius_redo_queue_bytes() bytes of host memory,
+// reset once; up to 16 searches -- further ones run at once); radius_redo_flush launches TWO kernels for all recorded
+// searches: the first pass, and the second pass (queries with more than 256 neighbours, redone with the large buffer).
+// The grids and all arguments must stay valid until the flush.  redo_flags: n_q bytes of device memory
 // that must stay valid until the flush (rdm_radius_grid_query keeps them in its scratch and runs both passes at once).
 size_t radius_redo_queue_bytes();
 void radius_redo_queue_reset(void* queue);

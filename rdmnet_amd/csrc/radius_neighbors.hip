@@ -396,8 +396,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(RnQueryAr
 constexpr int kRedoMax = 16;
 struct RnRedoBatch {
   RnQueryArgs item[kRedoMax];
+  int first_block[kRedoMax + 1];  // first pass in one launch: workgroup range of every search
   int n;
 };
+// First pass of SEVERAL searches in one launch: a 1-D grid, workgroup -> (search, query block) through first_block.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_multi_kernel(RnRedoBatch b) {
+  __shared__ unsigned long long keys[kWavesPerBlock][256];
+  __shared__ int seg_start[kWavesPerBlock][28];
+  __shared__ int seg_pref[kWavesPerBlock][28];
+  int it = 0;
+#pragma unroll
+  for (int k = 1; k < kRedoMax; ++k) it += (k < b.n && static_cast<int>(blockIdx.x) >= b.first_block[k]) ? 1 : 0;
+  const RnQueryArgs& a = b.item[it];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t qi = (blockIdx.x - b.first_block[it]) * static_cast<int64_t>(kWavesPerBlock) + wave;
+  if (qi >= a.nq) return;
+  rn_query_one<256>(a, qi, lane, keys[wave], seg_start[wave], seg_pref[wave], 0);
+}
 __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_redo_multi_kernel(RnRedoBatch b) {
   __shared__ unsigned long long keys[kWavesPerBlock][1024];
   __shared__ int seg_start[kWavesPerBlock][28];
@@ -496,20 +511,22 @@ int grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_
   const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
   // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
   // neighbours is redone by the large-buffer instance
-  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 0);
-  if (width > 0) {
-    if (queue && queue->n < kRedoMax) {
-      queue->item[queue->n++] = a;
-    } else {
-      hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 1);
-    }
+  if (queue && queue->n < kRedoMax && width > 0) {  // both passes run at the flush, together with the other searches
+    queue->first_block[queue->n + 1] = queue->first_block[queue->n] + qblocks;
+    queue->item[queue->n++] = a;
+    return RDM_OK;
   }
+  hipLaunchKernelGGL(rn_query_kernel<256>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 0);
+  if (width > 0) hipLaunchKernelGGL(rn_query_kernel<1024>, dim3(qblocks), dim3(64 * kWavesPerBlock), 0, st, a, 1);
   return launch_status("rn_query_kernel");
 }
 }  // namespace
 
 size_t rdm::radius_redo_queue_bytes() { return sizeof(RnRedoBatch); }
-void rdm::radius_redo_queue_reset(void* queue) { static_cast<RnRedoBatch*>(queue)->n = 0; }
+void rdm::radius_redo_queue_reset(void* queue) {
+  static_cast<RnRedoBatch*>(queue)->n = 0;
+  static_cast<RnRedoBatch*>(queue)->first_block[0] = 0;
+}
 int rdm::radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
                                     const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
                                     int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo_flags,
@@ -521,10 +538,12 @@ int rdm::radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t
 int rdm::radius_redo_flush(void* queue, void* stream) {
   RnRedoBatch* b = static_cast<RnRedoBatch*>(queue);
   if (b->n == 0) return RDM_OK;
+  hipLaunchKernelGGL(rn_query_multi_kernel, dim3(b->first_block[b->n]), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
   // 64 workgroups (256 wavefronts) per search: two flag sweeps of 64 queries per wavefront cover a 32 k-point level
   hipLaunchKernelGGL(rn_redo_multi_kernel, dim3(64, b->n), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
   b->n = 0;
-  return launch_status("rn_redo_multi_kernel");
+  b->first_block[0] = 0;
+  return launch_status("rn_query_multi_kernel");
 }
 
 extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points,
