@@ -696,8 +696,24 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
                                       t.flags + 1, redo_flags, redo_queue.data(), r.st);
   };
   Grid grids[5];
+  {  // the five level grids with one set of launches (radius r_i = 2^i r_0)
+    const float* gp[5];
+    int64_t gn[5];
+    const int64_t* gl[5];
+    float gr[5];
+    void* gw[5];
+    size_t gb[5];
+    float rad = radius;
+    for (int i = 0; i < 5; ++i, rad *= 2.f) {
+      grids[i].n_s = lv[i].n;
+      grids[i].bytes = rdm_radius_grid_workspace_bytes(lv[i].n);
+      grids[i].ws = e->alloc<char>(grids[i].bytes);
+      ENG_ALLOC(grids[i].ws);
+      gp[i] = lv[i].pts; gn[i] = lv[i].n; gl[i] = lv[i].lengths; gr[i] = rad; gw[i] = grids[i].ws; gb[i] = grids[i].bytes;
+    }
+    ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
+  }
   for (int i = 0; i < 5; ++i) {
-    ENG_CHECK(build_grid(lv[i], radius, grids[i]));
     ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i]));
     if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i]));
     if (i > 0) ENG_CHECK(search(lv[i - 1], grids[i], radius, c.neighbor_limits[i], up[i - 1]));

@@ -27,6 +27,10 @@ int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n
 // searches: the first pass, and the second pass (queries with more than 256 neighbours, redone with the large buffer).
 // The grids and all arguments must stay valid until the flush.  redo_flags: n_q bytes of device memory
 // that must stay valid until the flush (rdm_radius_grid_query keeps them in its scratch and runs both passes at once).
+// rdm_radius_grid_build for up to 8 support clouds (the levels of a pair) with one set of launches.
+int radius_grid_build_multi(int n, const float* const* s_points, const int64_t* n_s, const int64_t* const* s_lengths, int batch,
+                            const float* radius, void* const* grid_ws, const size_t* grid_ws_bytes, void* stream);
+
 size_t radius_redo_queue_bytes();
 void radius_redo_queue_reset(void* queue);
 int radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,

@@ -35,8 +35,31 @@ struct GridMeta {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // One block: bounding box of all support points, grid geometry.
-__global__ __launch_bounds__(1024) void rn_bbox_kernel(const float* s, int64_t ns, float radius,
-                                                       int batch, GridMeta* meta) {
+// Several grids (the five levels of a pair) are built by the same launches: blockIdx.y = grid.
+constexpr int kBuildMax = 8;
+struct RnBuildItem {
+  const float* s;
+  int64_t ns;
+  const int64_t* lengths;
+  float radius;
+  GridMeta* meta;
+  int* cell_count;
+  int* cell_start;
+  int* pt_cell;
+  int* pt_slot;
+  float4* sorted;
+};
+struct RnBuildBatch {
+  RnBuildItem item[kBuildMax];
+  int n, batch;
+};
+__global__ __launch_bounds__(1024) void rn_bbox_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.x];
+  const float* s = it.s;
+  const int64_t ns = it.ns;
+  const float radius = it.radius;
+  const int batch = bb.batch;
+  GridMeta* meta = it.meta;
   __shared__ float red[16 * 6];
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   for (int64_t i = threadIdx.x; i < ns; i += blockDim.x)
@@ -112,44 +135,54 @@ __device__ __forceinline__ int cloud_of(const int64_t* lengths, int batch, int64
   return batch;  // beyond the stacked rows
 }
 
-__global__ void rn_count_kernel(const float* s, int64_t ns, const int64_t* s_lengths, int batch,
-                                const GridMeta* meta, int* cell_count, int* pt_cell, int* pt_slot) {
+// cell_count of the cells the bounding box gave this grid (the arrays are sized for kMaxCells)
+__global__ void rn_zero_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
+  const int ncell = it.meta->cells_per_cloud * bb.batch;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) it.cell_count[c] = 0;
+}
+
+__global__ void rn_count_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= ns) return;
-  const GridMeta g = *meta;
+  if (i >= it.ns) return;
+  const float* s = it.s;
+  const GridMeta g = *it.meta;
   int64_t begin;
-  const int b = cloud_of(s_lengths, batch, i, begin);
-  if (b >= batch) {
-    pt_cell[i] = -1;
+  const int b = cloud_of(it.lengths, bb.batch, i, begin);
+  if (b >= bb.batch) {
+    it.pt_cell[i] = -1;
     return;
   }
   int cx, cy, cz;
   cell_of(g, s[3 * i], s[3 * i + 1], s[3 * i + 2], cx, cy, cz);
   const int c = b * g.cells_per_cloud + (cz * g.dim[1] + cy) * g.dim[0] + cx;
-  pt_cell[i] = c;
-  pt_slot[i] = atomicAdd(&cell_count[c], 1);
+  it.pt_cell[i] = c;
+  it.pt_slot[i] = atomicAdd(&it.cell_count[c], 1);
 }
 
-__global__ void rn_alloc_kernel(GridMeta* meta, int batch, const int* cell_count, int* cell_start) {
-  const int ncell = meta->cells_per_cloud * batch;
+__global__ void rn_alloc_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
+  const int ncell = it.meta->cells_per_cloud * bb.batch;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
-    const int n = cell_count[c];
-    cell_start[c] = n > 0 ? atomicAdd(&meta->total, n) : 0;
+    const int n = it.cell_count[c];
+    it.cell_start[c] = n > 0 ? atomicAdd(&it.meta->total, n) : 0;
   }
 }
 
-__global__ void rn_scatter_kernel(const float* s, int64_t ns, const int* pt_cell, const int* pt_slot,
-                                  const int* cell_start, float4* sorted) {
+__global__ void rn_scatter_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= ns) return;
-  const int c = pt_cell[i];
+  if (i >= it.ns) return;
+  const int c = it.pt_cell[i];
   if (c < 0) return;
+  const float* s = it.s;
   float4 v;
   v.x = s[3 * i];
   v.y = s[3 * i + 1];
   v.z = s[3 * i + 2];
   v.w = __int_as_float(static_cast<int>(i));
-  sorted[cell_start[c] + pt_slot[i]] = v;
+  it.sorted[it.cell_start[c] + it.pt_slot[i]] = v;
 }
 
 // broadcast of lane `i` (wave-uniform) through scalar registers
@@ -462,31 +495,41 @@ extern "C" size_t rdm_radius_grid_workspace_bytes(int64_t n_s) {
   return a.off;
 }
 
-extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch,
-                                     float radius, void* grid_ws, size_t grid_ws_bytes, void* stream) {
-  using namespace rdm;
-  RDM_REQUIRE(s_lengths && grid_ws, "rdm_radius_grid_build: null pointer");
-  RDM_REQUIRE(n_s >= 0 && n_s < (1ll << 31) && batch > 0 && batch <= kMaxBatch && radius > 0.f,
-              "rdm_radius_grid_build: bad arguments (n_s=%lld batch=%d)", (long long)n_s, batch);
-  RDM_REQUIRE(n_s == 0 || s_points, "rdm_radius_grid_build: null points");
-  Arena ar(grid_ws, grid_ws_bytes);
-  GridViews g;
-  if (!carve_grid(ar, n_s, &g)) {
-    set_error("rdm_radius_grid_build: workspace too small (%zu < %zu bytes)", grid_ws_bytes, ar.off);
-    return RDM_ERR_WORKSPACE;
+int rdm::radius_grid_build_multi(int n, const float* const* s_points, const int64_t* n_s, const int64_t* const* s_lengths,
+                                 int batch, const float* radius, void* const* grid_ws, const size_t* grid_ws_bytes, void* stream) {
+  RDM_REQUIRE(n >= 1 && n <= kBuildMax && batch > 0 && batch <= kMaxBatch, "rdm_radius_grid_build: bad arguments (n=%d batch=%d)", n, batch);
+  RnBuildBatch bb;
+  bb.n = n; bb.batch = batch;
+  int64_t max_ns = 0;
+  for (int k = 0; k < n; ++k) {
+    RDM_REQUIRE(s_lengths[k] && grid_ws[k], "rdm_radius_grid_build: null pointer");
+    RDM_REQUIRE(n_s[k] >= 0 && n_s[k] < (1ll << 31) && radius[k] > 0.f, "rdm_radius_grid_build: bad arguments (n_s=%lld)", (long long)n_s[k]);
+    RDM_REQUIRE(n_s[k] == 0 || s_points[k], "rdm_radius_grid_build: null points");
+    Arena ar(grid_ws[k], grid_ws_bytes[k]);
+    GridViews g;
+    if (!carve_grid(ar, n_s[k], &g)) {
+      set_error("rdm_radius_grid_build: workspace too small (%zu < %zu bytes)", grid_ws_bytes[k], ar.off);
+      return RDM_ERR_WORKSPACE;
+    }
+    bb.item[k] = RnBuildItem{s_points[k], n_s[k], s_lengths[k], radius[k], g.meta, g.cell_count, g.cell_start, g.pt_cell, g.pt_slot, g.sorted};
+    max_ns = std::max(max_ns, n_s[k]);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(rn_bbox_kernel, dim3(1), dim3(1024), 0, st, s_points, n_s, radius, batch, g.meta);
-  fill_words<int>(g.cell_count, kMaxCells, 0, st);
-  if (n_s > 0) {
-    const int blocks = static_cast<int>(ceil_div<int64_t>(n_s, 256));
-    hipLaunchKernelGGL(rn_count_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, s_lengths, batch, g.meta,
-                       g.cell_count, g.pt_cell, g.pt_slot);
-    hipLaunchKernelGGL(rn_alloc_kernel, dim3(1024), dim3(256), 0, st, g.meta, batch, g.cell_count, g.cell_start);
-    hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks), dim3(256), 0, st, s_points, n_s, g.pt_cell, g.pt_slot,
-                       g.cell_start, g.sorted);
+  hipLaunchKernelGGL(rn_bbox_kernel, dim3(n), dim3(1024), 0, st, bb);
+  hipLaunchKernelGGL(rn_zero_kernel, dim3(256, n), dim3(256), 0, st, bb);
+  if (max_ns > 0) {
+    const int blocks = static_cast<int>(ceil_div<int64_t>(max_ns, 256));
+    hipLaunchKernelGGL(rn_count_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(rn_alloc_kernel, dim3(256, n), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
   }
   return launch_status("radius grid build");
+}
+
+extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch,
+                                     float radius, void* grid_ws, size_t grid_ws_bytes, void* stream) {
+  RDM_REQUIRE(s_lengths && grid_ws, "rdm_radius_grid_build: null pointer");
+  return rdm::radius_grid_build_multi(1, &s_points, &n_s, &s_lengths, batch, &radius, &grid_ws, &grid_ws_bytes, stream);
 }
 
 namespace {
