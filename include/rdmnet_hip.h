@@ -256,6 +256,12 @@ size_t rdm_point_to_node_workspace_bytes(int64_t n_points, int64_t n_nodes);
 int rdm_point_to_node(const float* points, int64_t n_points, const float* nodes, int64_t n_nodes, int k,
                       int64_t* knn_idx, uint8_t* knn_mask, uint8_t* node_mask, int32_t* status, void* ws,
                       size_t ws_bytes, void* stream);
+/* rdm_point_to_node_pair: the same grouping for the two clouds of a pair (a: ref, b: src) with one set of launches;
+ * workspace: rdm_point_to_node_workspace_bytes(n_a, m_a) + rdm_point_to_node_workspace_bytes(n_b, m_b).         */
+int rdm_point_to_node_pair(const float* points_a, int64_t n_a, const float* nodes_a, int64_t m_a, const float* points_b,
+                           int64_t n_b, const float* nodes_b, int64_t m_b, int k, int64_t* knn_idx_a, uint8_t* knn_mask_a,
+                           uint8_t* node_mask_a, int64_t* knn_idx_b, uint8_t* knn_mask_b, uint8_t* node_mask_b,
+                           int32_t* status, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a12: coarse matching -------------------------------------------------------------------------
  * Replaces SuperPointMatching.forward (geotransformer/modules/geotransformer/superpoint_matching.py:

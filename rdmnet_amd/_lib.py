@@ -75,6 +75,8 @@ SIGNATURES = {
     'rdm_point_to_node_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_point_to_node': (c_int, [c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void, c_void, c_void,
                                   c_size, c_void]),
+    'rdm_point_to_node_pair': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_int, c_void, c_void, c_void,
+                                       c_void, c_void, c_void, c_void, c_void, c_size, c_void]),
     'rdm_coarse_matching_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_coarse_matching': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_void, c_void, c_void,
                                     c_void, c_void, c_size, c_void]),

@@ -955,8 +955,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   uint8_t* s_nm = e->alloc<uint8_t>(m_s);
   ENG_ALLOC(r_knn); ENG_ALLOC(s_knn); ENG_ALLOC(r_km); ENG_ALLOC(s_km); ENG_ALLOC(r_nm); ENG_ALLOC(s_nm);
   int32_t* p2n_status = flags + 62;
-  ENG_CHECK(rdm_point_to_node(pf_ref, nf_ref, nodes, m_r, K, r_knn, r_km, r_nm, p2n_status, r.ws, r.ws_bytes, r.st));
-  ENG_CHECK(rdm_point_to_node(pf_src, nf_src, nodes + 3 * m_r, m_s, K, s_knn, s_km, s_nm, p2n_status, r.ws, r.ws_bytes, r.st));
+  ENG_CHECK(rdm_point_to_node_pair(pf_ref, nf_ref, nodes, m_r, pf_src, nf_src, nodes + 3 * m_r, m_s, K, r_knn, r_km, r_nm, s_knn,
+                                   s_km, s_nm, p2n_status, r.ws, r.ws_bytes, r.st));  // both clouds, one set of launches
   Mat sim = e->mat(m_r, m_s);
   ENG_ALLOC(sim.p);
   ENG_CHECK(rdm_gemm(fn.p, fn.ld, 0, fn.p + m_r * fn.ld, fn.ld, 0, 1, sim.p, sim.ld, 0, m_r, m_s, D, 1, nullptr, nullptr, 0,
@@ -992,14 +992,19 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float* s_pf = e->alloc<float>(B * K * D);
   ENG_ALLOC(r_idx); ENG_ALLOC(s_idx); ENG_ALLOC(r_pm); ENG_ALLOC(s_pm); ENG_ALLOC(r_pts); ENG_ALLOC(s_pts);
   ENG_ALLOC(r_pf); ENG_ALLOC(s_pf);
-  ENG_CHECK(rdm_gather_rows(r_knn, m_r, 2 * K, 2 * K, r_sel, B, r_idx, 2 * K, r.st));
-  ENG_CHECK(rdm_gather_rows(s_knn, m_s, 2 * K, 2 * K, s_sel, B, s_idx, 2 * K, r.st));
-  ENG_CHECK(rdm_gather_rows(r_km, m_r, K / 4, K / 4, r_sel, B, r_pm, K / 4, r.st));
-  ENG_CHECK(rdm_gather_rows(s_km, m_s, K / 4, K / 4, s_sel, B, s_pm, K / 4, r.st));
-  ENG_CHECK(rdm_gather_rows(pf_ref, nf_ref, 3, 3, r_idx, B * K, r_pts, 3, r.st));
-  ENG_CHECK(rdm_gather_rows(pf_src, nf_src, 3, 3, s_idx, B * K, s_pts, 3, r.st));
-  ENG_CHECK(rdm_gather_rows(feats_f.p, nf_ref, D, feats_f.ld, r_idx, B * K, r_pf, D, r.st));
-  ENG_CHECK(rdm_gather_rows(feats_f.p + nf_ref * feats_f.ld, nf_src, D, feats_f.ld, s_idx, B * K, s_pf, D, r.st));
+  {  // the eight patch gathers as two launches: (knn indices, knn masks) x (ref, src), then (points, features) x (ref, src)
+    const void* x1[4] = {r_knn, s_knn, r_km, s_km};
+    const int64_t ns1[4] = {m_r, m_s, m_r, m_s}, w1[4] = {2 * K, 2 * K, K / 4, K / 4}, mm1[4] = {B, B, B, B};
+    const int64_t* i1[4] = {r_sel, s_sel, r_sel, s_sel};
+    void* y1[4] = {r_idx, s_idx, r_pm, s_pm};
+    ENG_CHECK(gather_rows_multi(4, x1, ns1, w1, w1, i1, mm1, y1, w1, r.st));
+    const void* x2[4] = {pf_ref, pf_src, feats_f.p, feats_f.p + nf_ref * feats_f.ld};
+    const int64_t ns2[4] = {nf_ref, nf_src, nf_ref, nf_src}, w2[4] = {3, 3, D, D}, lx2[4] = {3, 3, feats_f.ld, feats_f.ld};
+    const int64_t mm2[4] = {B * K, B * K, B * K, B * K};
+    const int64_t* i2[4] = {r_idx, s_idx, r_idx, s_idx};
+    void* y2[4] = {r_pts, s_pts, r_pf, s_pf};
+    ENG_CHECK(gather_rows_multi(4, x2, ns2, w2, lx2, i2, mm2, y2, w2, r.st));
+  }
   float* sqrt_c = e->alloc<float>(K);
   float* scores = e->alloc<float>(B * K * K);
   float* ms = e->alloc<float>(B * (K + 1) * (K + 1));

@@ -27,6 +27,10 @@ int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n
 // searches: the first pass, and the second pass (queries with more than 256 neighbours, redone with the large buffer).
 // The grids and all arguments must stay valid until the flush.  redo_flags: n_q bytes of device memory
 // that must stay valid until the flush (rdm_radius_grid_query keeps them in its scratch and runs both passes at once).
+// Up to four rdm_gather_rows in one launch (independent gathers: none may read another's output).
+int gather_rows_multi(int n, const void* const* x, const int64_t* n_src, const int64_t* words, const int64_t* ldx,
+                      const int64_t* const* idx, const int64_t* m, void* const* y, const int64_t* ldy, void* stream);
+
 // rdm_radius_grid_build for up to 8 support clouds (the levels of a pair) with one set of launches.
 int radius_grid_build_multi(int n, const float* const* s_points, const int64_t* n_s, const int64_t* const* s_lengths, int batch,
                             const float* radius, void* const* grid_ws, const size_t* grid_ws_bytes, void* stream);

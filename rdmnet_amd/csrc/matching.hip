@@ -100,8 +100,8 @@ __device__ __forceinline__ float ref_sq_dist(float x0, float x1, float x2, float
 }
 
 // one thread per point: owner = argmin over nodes (first minimum), d_own = that distance
-__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
-                                                         int32_t* owner, float* d_own, int32_t* node_count) {
+__device__ __forceinline__ void p2n_assign_body(const float* points, int n, const float* nodes, int m, int32_t* owner,
+                                                float* d_own, int32_t* node_count) {
   extern __shared__ float sn[];  // [m][4]: x, y, z, |node|^2
   for (int j = threadIdx.x; j < m; j += blockDim.x) {
     const float a = nodes[3 * j], b = nodes[3 * j + 1], c = nodes[3 * j + 2];
@@ -129,14 +129,41 @@ __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, in
   atomicAdd(&node_count[arg], 1);
 }
 
+__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
+                                                         int32_t* owner, float* d_own, int32_t* node_count) {
+  p2n_assign_body(points, n, nodes, m, owner, d_own, node_count);
+}
+
+// Both clouds of a pair in one launch (blockIdx.y = cloud): the two assignments are independent.
+struct P2nSeg {
+  const float* points;
+  int n;
+  const float* nodes;
+  int m;
+  int32_t* owner;
+  float* d_own;
+  int32_t* node_count;
+  int64_t* knn_idx;
+  unsigned char* knn_mask;
+  unsigned char* node_mask;
+};
+struct P2nPair {
+  P2nSeg seg[2];
+  int k;
+  int32_t* status;
+};
+__global__ __launch_bounds__(256) void p2n_assign_pair_kernel(P2nPair p) {
+  const P2nSeg& s = p.seg[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) * 256 >= s.n) return;  // whole workgroup
+  p2n_assign_body(s.points, s.n, s.nodes, s.m, s.owner, s.d_own, s.node_count);
+}
+
 // one wavefront per node: its points sorted by (d, index), first k kept (topk largest=False)
 template <int CAP>
-__global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, const float* d_own, int n, int m,
-                                                        int k, const int32_t* node_count, int64_t* knn_idx,
-                                                        unsigned char* knn_mask, unsigned char* node_mask,
-                                                        int32_t* status) {
-  __shared__ unsigned long long keys[CAP];
-  const int node = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void p2n_select_body(unsigned long long* keys, int node, const int32_t* owner, const float* d_own, int n,
+                                                int m, int k, const int32_t* node_count, int64_t* knn_idx,
+                                                unsigned char* knn_mask, unsigned char* node_mask, int32_t* status) {
+  const int lane = threadIdx.x;
   const int cnt = node_count[node];
   if (lane == 0) node_mask[node] = cnt > 0 ? 1 : 0;
   if (cnt > CAP && lane == 0) atomicExch(status, 1);
@@ -187,6 +214,22 @@ __global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, co
     knn_idx[static_cast<int64_t>(node) * k + c] = ok ? static_cast<int64_t>(K[c] & 0xffffffffull) : n;
     knn_mask[static_cast<int64_t>(node) * k + c] = ok ? 1 : 0;
   }
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, const float* d_own, int n, int m,
+                                                        int k, const int32_t* node_count, int64_t* knn_idx,
+                                                        unsigned char* knn_mask, unsigned char* node_mask,
+                                                        int32_t* status) {
+  __shared__ unsigned long long keys[CAP];
+  p2n_select_body<CAP>(keys, blockIdx.x, owner, d_own, n, m, k, node_count, knn_idx, knn_mask, node_mask, status);
+}
+template <int CAP>
+__global__ __launch_bounds__(64) void p2n_select_pair_kernel(P2nPair p) {
+  __shared__ unsigned long long keys[CAP];
+  const P2nSeg& s = p.seg[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= s.m) return;
+  p2n_select_body<CAP>(keys, blockIdx.x, s.owner, s.d_own, s.n, s.m, p.k, s.node_count, s.knn_idx, s.knn_mask, s.node_mask, p.status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -487,6 +530,38 @@ extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const fl
   hipLaunchKernelGGL(p2n_select_kernel<4096>, dim3(static_cast<unsigned>(n_nodes)), dim3(64), 0, st, owner, d_own,
                      static_cast<int>(n_points), static_cast<int>(n_nodes), k, node_count, knn_idx, knn_mask,
                      node_mask, status);
+  return launch_status("point_to_node kernels");
+}
+
+// rdm_point_to_node for the two clouds of a pair with one set of launches (same results as two calls).
+extern "C" int rdm_point_to_node_pair(const float* points_a, int64_t n_a, const float* nodes_a, int64_t m_a,
+                                      const float* points_b, int64_t n_b, const float* nodes_b, int64_t m_b, int k,
+                                      int64_t* knn_idx_a, uint8_t* knn_mask_a, uint8_t* node_mask_a, int64_t* knn_idx_b,
+                                      uint8_t* knn_mask_b, uint8_t* node_mask_b, int32_t* status, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(points_a && nodes_a && points_b && nodes_b && knn_idx_a && knn_mask_a && node_mask_a && knn_idx_b && knn_mask_b &&
+                  node_mask_b && status, "rdm_point_to_node_pair: null pointer");
+  RDM_REQUIRE(n_a > 0 && m_a > 0 && n_b > 0 && m_b > 0 && k > 0 && m_a <= 8192 && m_b <= 8192,
+              "rdm_point_to_node_pair: bad sizes (points=%lld/%lld nodes=%lld/%lld)", (long long)n_a, (long long)n_b,
+              (long long)m_a, (long long)m_b);
+  Arena ar(ws, ws_bytes);
+  P2nPair p;
+  p.k = k; p.status = status;
+  int32_t* counts = ar.take<int32_t>(m_a + m_b);  // contiguous: one fill
+  p.seg[0] = P2nSeg{points_a, static_cast<int>(n_a), nodes_a, static_cast<int>(m_a), ar.take<int32_t>(n_a), ar.take<float>(n_a), counts,
+                    knn_idx_a, knn_mask_a, node_mask_a};
+  p.seg[1] = P2nSeg{points_b, static_cast<int>(n_b), nodes_b, static_cast<int>(m_b), ar.take<int32_t>(n_b), ar.take<float>(n_b),
+                    counts ? counts + m_a : nullptr, knn_idx_b, knn_mask_b, node_mask_b};
+  if (!ar.ok) {
+    set_error("rdm_point_to_node_pair: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n_max = n_a > n_b ? n_a : n_b, m_max = m_a > m_b ? m_a : m_b;
+  fill_words<int32_t>(counts, m_a + m_b, 0, st);
+  hipLaunchKernelGGL(p2n_assign_pair_kernel, dim3(ceil_div<int64_t>(n_max, 256), 2), dim3(256), static_cast<size_t>(m_max) * 16, st, p);
+  hipLaunchKernelGGL(p2n_select_pair_kernel<4096>, dim3(static_cast<unsigned>(m_max), 2), dim3(64), 0, st, p);
   return launch_status("point_to_node kernels");
 }
 

@@ -255,7 +255,53 @@ __global__ void gather_rows_kernel(const uint32_t* x, int n_src, int c, int ldx,
     y[static_cast<int64_t>(row) * ldy + col] = ok ? x[id * ldx + col] : 0u;
 }
 
+// Up to four independent row gathers in one launch: a 1-D grid, workgroup -> (gather, row) through first_row.
+struct GatherItem {
+  const uint32_t* x;
+  int n_src, c, ldx;
+  const int64_t* idx;
+  uint32_t* y;
+  int ldy;
+};
+struct GatherBatch {
+  GatherItem item[4];
+  int first_row[5];
+  int n;
+};
+__global__ void gather_rows_multi_kernel(GatherBatch b) {
+  int it = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) it += (k < b.n && static_cast<int>(blockIdx.x) >= b.first_row[k]) ? 1 : 0;
+  const GatherItem& g = b.item[it];
+  const int row = blockIdx.x - b.first_row[it];
+  const int64_t id = g.idx[row];
+  const bool ok = id >= 0 && id < g.n_src;
+  for (int col = threadIdx.x; col < g.c; col += blockDim.x)
+    g.y[static_cast<int64_t>(row) * g.ldy + col] = ok ? g.x[id * g.ldx + col] : 0u;
+}
+
 }  // namespace
+
+int rdm::gather_rows_multi(int n, const void* const* x, const int64_t* n_src, const int64_t* words, const int64_t* ldx,
+                           const int64_t* const* idx, const int64_t* m, void* const* y, const int64_t* ldy, void* stream) {
+  RDM_REQUIRE(n >= 1 && n <= 4, "gather_rows_multi: 1..4 gathers");
+  GatherBatch b;
+  b.n = n;
+  b.first_row[0] = 0;
+  int64_t max_words = 0;
+  for (int k = 0; k < n; ++k) {
+    RDM_REQUIRE(x[k] && idx[k] && y[k] && words[k] > 0 && m[k] >= 0, "gather_rows_multi: bad arguments");
+    b.item[k] = GatherItem{static_cast<const uint32_t*>(x[k]), static_cast<int>(n_src[k]), static_cast<int>(words[k]),
+                           static_cast<int>(ldx[k]), idx[k], static_cast<uint32_t*>(y[k]), static_cast<int>(ldy[k])};
+    b.first_row[k + 1] = b.first_row[k] + static_cast<int>(m[k]);
+    max_words = std::max(max_words, words[k]);
+  }
+  if (b.first_row[n] == 0) return RDM_OK;
+  const int threads = max_words >= 256 ? 256 : (max_words >= 128 ? 128 : 64);
+  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(static_cast<unsigned>(b.first_row[n])), dim3(threads), 0,
+                     static_cast<hipStream_t>(stream), b);
+  return launch_status("gather_rows_multi_kernel");
+}
 
 extern "C" int rdm_gather_rows(const void* x, int64_t n_src, int64_t words, int64_t ldx, const int64_t* idx,
                                int64_t m, void* y, int64_t ldy, void* stream) {

@@ -308,6 +308,25 @@ def point_to_node(points, nodes, k, status):
     return nmask, knn, kmask
 
 
+def point_to_node_pair(points_a, nodes_a, points_b, nodes_b, k, status):
+    """point_to_node for the ref (a) and src (b) cloud with one set of launches -> ((nmask, knn, kmask) for a, for b)."""
+    L = _lib.lib()
+    dev = points_a.device
+    outs = []
+    for pts, nodes in ((points_a, nodes_a), (points_b, nodes_b)):
+        m = nodes.shape[0]
+        outs.append((torch.empty((m,), dtype=torch.uint8, device=dev), torch.empty((m, k), dtype=torch.int64, device=dev),
+                     torch.empty((m, k), dtype=torch.uint8, device=dev)))
+    na, ma, nb, mb = points_a.shape[0], nodes_a.shape[0], points_b.shape[0], nodes_b.shape[0]
+    ws = scratch(dev, L.rdm_point_to_node_workspace_bytes(na, ma) + L.rdm_point_to_node_workspace_bytes(nb, mb))
+    (nma, knna, kma), (nmb, knnb, kmb) = outs
+    _lib.check(L.rdm_point_to_node_pair(points_a.data_ptr(), na, nodes_a.data_ptr(), ma, points_b.data_ptr(), nb, nodes_b.data_ptr(),
+                                        mb, k, knna.data_ptr(), kma.data_ptr(), nma.data_ptr(), knnb.data_ptr(), kmb.data_ptr(),
+                                        nmb.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+               'rdm_point_to_node_pair')
+    return outs
+
+
 def coarse_matching(scores, ref_mask, src_mask, k, dual=True):
     """scores [m, n] view (overwritten) -> (ref_idx i64[k], src_idx i64[k], scores f32[k], count i32[1])."""
     L = _lib.lib()

@@ -223,3 +223,17 @@ def test_attention_self_pair_equals_two_launches(ops, n0, n1):
             assert torch.equal(both[:n0], ops.attention(q[:n0], k[:n0], v[:n0], 4, bf16=bf16))
         if n1:
             assert torch.equal(both[n0:], ops.attention(q[n0:], k[n0:], v[n0:], 4, bf16=bf16))
+
+
+def test_point_to_node_pair_equals_two_calls(ops):
+    """Both clouds' point-to-node grouping with one set of launches (point_to_node.py semantics) = two single calls."""
+    g = torch.Generator().manual_seed(11)
+    pa, pb = torch.randn(9000, 3, generator=g).cuda() * 20, torch.randn(7001, 3, generator=g).cuda() * 20
+    na, nb = pa[torch.randperm(9000, generator=g)[:330].cuda()].contiguous(), pb[torch.randperm(7001, generator=g)[:301].cuda()].contiguous()
+    st = torch.zeros(4, dtype=torch.int32, device='cuda')
+    both = ops.point_to_node_pair(pa, na, pb, nb, 128, st)
+    for got, (p, n) in zip(both, ((pa, na), (pb, nb))):
+        want = ops.point_to_node(p, n, 128, st)
+        for x, y in zip(got, want):
+            assert torch.equal(x, y)
+    assert int(st[0]) == 0
