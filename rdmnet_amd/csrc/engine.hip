@@ -133,6 +133,22 @@ int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, b
                   r.ws_bytes, r.st);
 }
 
+// two independent Linear layers as one launch when both are transformer-sized (gemm_pair)
+int linear_pair(Run& r, const std::string& name0, const Mat& x0, Mat& y0, const std::string& name1, const Mat& x1, Mat& y1) {
+  rdm_engine* e = r.e;
+  auto i0 = e->lin.find(name0), i1 = e->lin.find(name1);
+  if (i0 == e->lin.end() || i1 == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s", (i0 == e->lin.end() ? name0 : name1).c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear &L0 = i0->second, &L1 = i1->second;
+  y0 = e->mat(x0.rows, L0.out);
+  y1 = e->mat(x1.rows, L1.out);
+  ENG_ALLOC(y0.p); ENG_ALLOC(y1.p);
+  return gemm_pair(x0.p, x0.ld, L0.b, L0.ldb, y0.p, y0.ld, x0.rows, L0.out, L0.kpad, L0.bias, x1.p, x1.ld, L1.b, L1.ldb, y1.p,
+                   y1.ld, x1.rows, L1.out, L1.kpad, L1.bias, r.ws, r.ws_bytes, r.st);
+}
+
 float* vecp(Run& r, const std::string& name) {
   auto it = r.e->vec.find(name);
   return it == r.e->vec.end() ? nullptr : it->second;
@@ -327,8 +343,7 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
       ENG_CHECK(attention_tail(r, p, hid, f, fnew));
     } else {
       Mat q, kv1, kv0;
-      ENG_CHECK(linear(r, p + ".q", f, q));
-      ENG_CHECK(linear(r, p + ".kv", f.rows_from(n0, n1), kv1));
+      ENG_CHECK(linear_pair(r, p + ".q", f, q, p + ".kv", f.rows_from(n0, n1), kv1));  // independent: one launch
       ENG_CHECK(attend(q.p, q.ld, kv1.p, kv1.ld, kv1.p + d, kv1.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
       ENG_CHECK(attention_tail(r, p, hid.rows_from(0, n0), f.rows_from(0, n0), fnew.rows_from(0, n0)));
       ENG_CHECK(linear(r, p + ".kv", fnew.rows_from(0, n0), kv0));

@@ -333,8 +333,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // 128-B coalesced), and the four partial tiles are added through LDS in a fixed order.  The dependent
 // MFMA chain per wavefront is K/8 instructions instead of K/2, which is what bounds a 350 x 128 x 128
 // projection, not bandwidth.
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
-  __shared__ float red[4][32][33];
+__device__ __forceinline__ void gemm_small_body(const GemmArgs& g, float (*red)[32][33]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -376,6 +375,18 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
       g.C[static_cast<long long>(orow) * g.ldc + ocol] = apply_act(v, g.act);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+  __shared__ float red[4][32][33];
+  gemm_small_body(g, red);
+}
+// two independent products in one launch (blockIdx.z): the q and the k|v projection of a cross-attention layer
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs g0, GemmArgs g1) {
+  __shared__ float red[4][32][33];
+  const GemmArgs& g = blockIdx.z ? g1 : g0;
+  if (static_cast<int>(blockIdx.y) * 32 >= g.M || static_cast<int>(blockIdx.x) * 32 >= g.N) return;  // whole workgroup
+  gemm_small_body(g, red);
 }
 
 // y = act(LayerNorm(x W + bias + residual)) for the transformer width (N = 128) in ONE launch: a workgroup owns
@@ -855,6 +866,37 @@ int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ld
   g.sa = g.sb = g.sc = 0;
   g.act = 0; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
   return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+bool small_kernel_ok(long long m, long long n, long long k) {
+  return m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 && m * n <= 1536 * 512 && !getenv("RDM_GEMM_TUNE");
+}
+}  // namespace
+
+// Two bias-only products C_i = A_i B_i + bias_i in one launch when both fit the 32x32 K-split kernel (else two launches).
+int rdm::gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0, float* c0, int64_t ldc0, int64_t m0, int64_t n0,
+                   int64_t k0, const float* bias0, const float* a1, int64_t lda1, const float* b1, int64_t ldb1, float* c1,
+                   int64_t ldc1, int64_t m1, int64_t n1, int64_t k1, const float* bias1, void* ws, size_t ws_bytes, void* stream) {
+  if (m0 > 0 && m1 > 0 && small_kernel_ok(m0, n0, k0) && small_kernel_ok(m1, n1, k1) && lda0 % 4 == 0 && lda1 % 4 == 0 &&
+      ldb0 % 4 == 0 && ldb1 % 4 == 0 && ((reinterpret_cast<uintptr_t>(a0) | reinterpret_cast<uintptr_t>(a1)) & 15) == 0) {
+    GemmArgs g[2];
+    const float* A[2] = {a0, a1}; const float* B[2] = {b0, b1}; float* C[2] = {c0, c1}; const float* bias[2] = {bias0, bias1};
+    const int64_t M[2] = {m0, m1}, N[2] = {n0, n1}, K[2] = {k0, k1}, LA[2] = {lda0, lda1}, LB[2] = {ldb0, ldb1}, LC[2] = {ldc0, ldc1};
+    for (int i = 0; i < 2; ++i) {
+      g[i].A = A[i]; g[i].B = B[i]; g[i].C = C[i]; g[i].bias = bias[i]; g[i].rowdiv = nullptr;
+      g[i].M = static_cast<int>(M[i]); g[i].N = static_cast<int>(N[i]); g[i].K = static_cast<int>(K[i]);
+      g[i].lda = static_cast<int>(LA[i]); g[i].ldb = static_cast<int>(LB[i]); g[i].ldc = static_cast<int>(LC[i]);
+      g[i].sa = g[i].sb = g[i].sc = 0; g[i].act = 0; g[i].splits = 1; g[i].part = nullptr; g[i].stats = nullptr;
+    }
+    const long long gx = ceil_div<long long>(std::max(n0, n1), 32), gy = ceil_div<long long>(std::max(m0, m1), 32);
+    hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(gx, gy, 2), dim3(256), 0, static_cast<hipStream_t>(stream), g[0], g[1]);
+    return launch_status("gemm_small_pair_kernel");
+  }
+  if (m0 > 0)
+    if (int e = rdm_gemm(a0, lda0, 0, b0, ldb0, 0, 0, c0, ldc0, 0, m0, n0, k0, 1, bias0, nullptr, 0, ws, ws_bytes, stream)) return e;
+  if (m1 > 0) return rdm_gemm(a1, lda1, 0, b1, ldb1, 0, 0, c1, ldc1, 0, m1, n1, k1, 1, bias1, nullptr, 0, ws, ws_bytes, stream);
+  return RDM_OK;
 }
 
 extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,

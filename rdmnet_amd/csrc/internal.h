@@ -13,6 +13,12 @@ int gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, fl
                     int64_t n, int64_t k, const float* bias, const float* rowdiv, void* ws, size_t ws_bytes,
                     double* gn_partial, int* gn_blocks, void* stream);
 
+// Two independent products C_i = A_i B_i + bias_i (rdm_gemm semantics, no activation) in one launch when both are
+// transformer-sized; otherwise two rdm_gemm calls.
+int gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0, float* c0, int64_t ldc0, int64_t m0, int64_t n0,
+              int64_t k0, const float* bias0, const float* a1, int64_t lda1, const float* b1, int64_t ldb1, float* c1,
+              int64_t ldc1, int64_t m1, int64_t n1, int64_t k1, const float* bias1, void* ws, size_t ws_bytes, void* stream);
+
 // Upper bound of block rows gemm_with_stats can produce for m rows.
 // (64-row tiles without split-K; the split-K reduce uses as few as 8 rows per block)
 inline int64_t gemm_stats_max_blocks(int64_t m) { return (m + 7) / 8 + 1; }
