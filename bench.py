@@ -153,6 +153,9 @@ def main():
     ap.add_argument('--wait-us', type=int, default=-1,
                     help='how an engine waits at its size read-backs: 0 = hipStreamSynchronize (spins a core per pair in\n'
                          'flight), N > 0 = poll and sleep N us; -1 = choose from the CPU budget of this rank')
+    ap.add_argument('--ramp-seconds', type=float, default=5.0,
+                    help='untimed pairs run for this long before the warm-up steps so that host and GPU clocks are at their\n'
+                         'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -257,17 +260,17 @@ def main():
 
     errors = []
 
-    def run_all(first, count, rec, lat_out, prof_lists):
+    def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
         jobs = [[] for _ in streams]
         for slot in range(count):
             jobs[slot % len(streams)].append((slot, first + slot))
         if len(streams) == 1:
-            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0], engines[0] if engines else None)
+            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0], engines[0] if engines else None, events_every)
             if errors:
                 raise errors[0]
             return
         threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k],
-                                                            engines[k] if engines else None))
+                                                            engines[k] if engines else None, events_every))
                    for k in range(len(streams))]
         for t in threads:
             t.start()
@@ -276,6 +279,15 @@ def main():
         if errors:
             raise errors[0]
 
+    # Clock ramp (untimed, before the W warm-up steps): the first GPU process on a freshly started box runs 15-20 % slower
+    # for its first seconds -- idle host cores and GPU power states take that long to reach their steady clocks (measured:
+    # 400 vs 475 pairs/s for a first run, 475 for every later one; 4.5 s of untimed pairs closes the gap).
+    # The ramp also exercises the per-layer HIP events (every 2nd pair): in the first GPU process of a box the runtime's
+    # pool of timing signals grows once, after ~500 event records, with a ~45 ms stall of all streams -- which the
+    # default run would otherwise meet at its 97th-100th timed pair (-13 % on a 120-pair region).
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        run_all(0, 16 * len(streams), None, [], [[] for _ in streams], events_every=2 if args.layer_events_every > 0 else 0)
     run_all(0, args.warmup, None, [], [None] * len(streams))
     lat = []
     prof_lists = [[] for _ in streams]
@@ -288,6 +300,8 @@ def main():
     gathered = sharding.gather_records(records.to(comm_dev), world, dist)
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get('RDM_BENCH_DUMP_LAT'):  # developer: per-pair latencies in completion order
+        json.dump(lat, open(os.environ['RDM_BENCH_DUMP_LAT'], 'w'))
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -361,9 +375,10 @@ def main():
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'points_per_pair': n_points,
                        'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
-                       'host_cpus_per_rank': budget, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
+                       'host_cpus_per_rank': budget, 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
+            'mean_ms_per_pair_by_quarter': [float(np.mean(q)) for q in np.array_split(np.asarray(lat), 4)] if len(lat) >= 4 else None,
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},
             'roofline': roofline,
         }
