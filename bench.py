@@ -138,8 +138,8 @@ def cpu_budget():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=120)
-    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--steps', type=int, default=480)
+    ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=4, help='pairs in flight per GPU (host threads, one HIP stream each)')
@@ -284,7 +284,7 @@ def main():
     # 400 vs 475 pairs/s for a first run, 475 for every later one; 4.5 s of untimed pairs closes the gap).
     # The ramp also exercises the per-layer HIP events (every 2nd pair): in the first GPU process of a box the runtime's
     # pool of timing signals grows once, after ~500 event records, with a ~45 ms stall of all streams -- which the
-    # default run would otherwise meet at its 97th-100th timed pair (-13 % on a 120-pair region).
+    # default run would otherwise meet at its 97th-100th timed pair (-13 % on the 120-pair region that was the default then).
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < args.ramp_seconds:
         run_all(0, 16 * len(streams), None, [], [[] for _ in streams], events_every=2 if args.layer_events_every > 0 else 0)
