@@ -54,33 +54,47 @@ def make_pairs(n_pairs, cache_dir):
 
 
 def _cpu_baseline_worker(cache_dir, n_pairs, threads, budget_s):
-    """Runs in a child process (so a pathological host cannot stall the bench): the CPU port
-    (oracle restatement) of the same path, bounded sample."""
+    """Runs in a child process (so a pathological host cannot stall the bench): the CPU port (oracle restatement) of
+    the same path on a bounded sample of the bench's pairs -- SURVEY.md §8d / BASELINE.md §3: all host cores, median
+    of up to 5 pairs after one warm-up pair, collate and forward timed separately; then one pair on a single thread."""
     from oracle import forward as ofw
     from oracle import native
     from rdmnet_amd import config, weights
     cfg = config.make_cfg()
     W = ofw.to_torch(weights.synthetic_state_dict(cfg, seed=0))
     impl = native.reference() or native.restatement()
-    torch.set_num_threads(threads)
-    pairs = make_pairs(n_pairs, cache_dir)
-    t_all = t_pre = t_fwd = 0.0
-    n = 0
-    for ref, src, _ in pairs:
+    pairs = make_pairs(min(n_pairs, 6), cache_dir)
+
+    def one(ref, src):
         t0 = time.perf_counter()
         data = ofw.pyramid(np.concatenate([ref, src]), np.array([len(ref), len(src)], np.int64), cfg, impl=impl)
         t1 = time.perf_counter()
         ofw.forward(W, cfg, data, impl=impl)
-        t2 = time.perf_counter()
-        t_pre, t_fwd, t_all, n = t_pre + t1 - t0, t_fwd + t2 - t1, t_all + t2 - t0, n + 1
-        if t_all > budget_s:
+        return t1 - t0, time.perf_counter() - t1
+
+    torch.set_num_threads(threads)
+    t_start = time.perf_counter()
+    one(*pairs[0][:2])  # warm-up (thread pools, allocator)
+    pre, fwd = [], []
+    for k in range(5):
+        a, b = one(*pairs[(k + 1) % len(pairs)][:2])
+        pre.append(a)
+        fwd.append(b)
+        if time.perf_counter() - t_start > budget_s:
             break
+    med = float(np.median(np.asarray(pre) + np.asarray(fwd)))
+    single = None
+    if time.perf_counter() - t_start < 1.5 * budget_s:
+        torch.set_num_threads(1)
+        a, b = one(*pairs[1 % len(pairs)][:2])
+        single = {'value': 1.0 / (a + b), 'unit': 'pairs/s', 'cores': 1, 'collate_s': a, 'forward_s': b, 'sample': '1 pair, 1 run'}
     kind_native = 'reference C++ (oracle/_ref)' if native.reference() is not None else 'restatement C++'
     print('CPU_BASELINE ' + json.dumps({
-        'value': n / t_all, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-        'sample': f'{n} pair(s) of the bench workload; collate = {kind_native}, single-thread kd-tree/hash map '
-                  f'({t_pre / n:.2f} s/pair); forward = oracle/forward.py, torch fp32 on {threads} threads '
-                  f'({t_fwd / n:.2f} s/pair)'}))
+        'value': 1.0 / med, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+        'sample': f'median of {len(pre)} pair(s) of the bench workload after 1 warm-up pair; collate = {kind_native}, '
+                  f'single-thread kd-tree/hash map (median {float(np.median(pre)):.2f} s/pair); forward = oracle/forward.py, '
+                  f'torch fp32 on {threads} threads (median {float(np.median(fwd)):.2f} s/pair)',
+        'single_thread': single}))
 
 
 def cpu_baseline(cache_dir, n_pairs, timeout_s=150):
@@ -97,7 +111,7 @@ def cpu_baseline(cache_dir, n_pairs, timeout_s=150):
         return {'value': None, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'sample': 'failed: ' + p.stderr[-300:]}
     except subprocess.TimeoutExpired:
         return {'value': None, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-                'sample': f'did not finish one pair within {timeout_s} s'}
+                'sample': f'did not finish within {timeout_s} s'}
 
 
 def _no_nan(x):
@@ -135,12 +149,48 @@ def cpu_budget():
     return n
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: one child process per GPU (the reference's own multi-GPU entry
+    self-spawns too, experiments/test_batchoffline.py:255-264 with rank setup engine/base_tester.py:36-40,70-76).  Each
+    child is this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run would
+    set; rank 0's JSON line goes to the inherited stdout.  Returns the exit code (first failing rank's, else 0)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a dead rank would leave the others waiting at the next collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=480)
     ap.add_argument('--warmup', type=int, default=16)
-    ap.add_argument('--pairs', type=int, default=2, help='distinct synthetic pairs cycled through')
+    ap.add_argument('--pairs', type=int, default=8, help='distinct synthetic pairs cycled through')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=4, help='pairs in flight per GPU (host threads, one HIP stream each)')
     ap.add_argument('--path', choices=['engine', 'python'], default='engine',
@@ -156,13 +206,18 @@ def main():
     ap.add_argument('--ramp-seconds', type=float, default=5.0,
                     help='untimed pairs run for this long before the warm-up steps so that host and GPU clocks are at their\n'
                          'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
+    ap.add_argument('--host-steps', type=int, default=96,
+                    help='pairs of the host-to-host pass that follows the timed region (0 = skip)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
     if os.environ.get('RDM_BENCH_SHARE_DEVICE') == '1':
         local_rank = 0  # test hook: all ranks on one GPU
     torch.cuda.set_device(local_rank)
@@ -248,7 +303,7 @@ def main():
                     T, n_corr = step(i)
                 if rec is not None:
                     rre, rte = pose_error(T, pairs[pid][2])
-                    rec[slot] = torch.tensor([pid, rre, rte, n_corr])
+                    rec[slot] = torch.tensor([pid, rre, rte, n_corr, rank + i * world])
                     lat_out.append((time.perf_counter() - ts) * 1e3)
         except BaseException as exc:  # surfaced by run_all (a worker thread must not fail silently)
             errors.append(exc)
@@ -291,7 +346,7 @@ def main():
     run_all(0, args.warmup, None, [], [None] * len(streams))
     lat = []
     prof_lists = [[] for _ in streams]
-    records = torch.zeros((args.steps, 4), dtype=torch.float32)  # [pair_id, rre_deg, rte_m, n_corr]
+    records = torch.zeros((args.steps, 5), dtype=torch.float32)  # [pair_id, rre_deg, rte_m, n_corr, global step index]
     fence()
     t0 = time.perf_counter()
     run_all(args.warmup, args.steps, records, lat, prof_lists)
@@ -302,14 +357,51 @@ def main():
     elapsed = time.perf_counter() - t0
     if os.environ.get('RDM_BENCH_DUMP_LAT'):  # developer: per-pair latencies in completion order
         json.dump(lat, open(os.environ['RDM_BENCH_DUMP_LAT'], 'w'))
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        lat_t = torch.tensor(lat, dtype=torch.float32, device=comm_dev)
-        all_lat = [torch.empty_like(lat_t) for _ in range(world)]
-        dist.all_gather(all_lat, lat_t)
-        lat = torch.cat(all_lat).cpu().tolist()
+    elapsed, lat = sharding.reduce_timing(elapsed, lat, world, dist, comm_dev)  # max over ranks; all ranks' latencies
+
+    # ---- host-to-host rate (SURVEY §8d's definition of a pair: two clouds in HOST memory -> transform + correspondences
+    # in HOST memory).  Never `value`: a second, shorter region after the timed one.  Each in-flight pair copies its scans
+    # from pinned host memory on its own stream, runs the engine, and copies the correspondences back.
+    host_to_host = None
+    if engines and args.host_steps > 0:
+        pinned = [(torch.from_numpy(r).pin_memory(), torch.from_numpy(s_).pin_memory()) for r, s_, _ in pairs]
+
+        def h2h_range(indices, stream, eng):
+            ctx = torch.cuda.stream(stream) if stream is not None else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                eng.enable_profile(False)
+                for i in indices:
+                    pr, ps = pinned[(rank + i * world) % len(pinned)]
+                    res = eng.run(pr.to(dev, non_blocking=True), ps.to(dev, non_blocking=True))
+                    rc, sc, cs = eng.corr()
+                    host_out = torch.cat([rc, sc, cs[:, None]], 1).cpu()  # [n_corr, 7] on the host; the pose already is
+                    assert host_out.shape[0] == res.n_correspondences
+            except BaseException as exc:
+                errors.append(exc)
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+
+        jobs = [list(range(k, args.host_steps, len(streams))) for k in range(len(streams))]
+        fence()
+        th0 = time.perf_counter()
+        if len(streams) == 1:
+            h2h_range(jobs[0], streams[0], engines[0])
+        else:
+            threads = [threading.Thread(target=h2h_range, args=(jobs[k], streams[k], engines[k])) for k in range(len(streams))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        fence()
+        h_elapsed, _ = sharding.reduce_timing(time.perf_counter() - th0, [], world, dist, comm_dev)
+        if errors:
+            raise errors[0]
+        host_to_host = {'value': args.host_steps * world / h_elapsed, 'unit': 'pairs/s', 'steps': args.host_steps,
+                        'note': 'pinned host scans -> H2D -> engine -> D2H of correspondences (points + scores) and pose; '
+                                'measured after the timed region, same pairs in flight'}
 
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
     def kp_totals(prof):
@@ -380,6 +472,10 @@ def main():
             'p50_ms_per_pair': float(np.median(lat)),
             'mean_ms_per_pair_by_quarter': [float(np.mean(q)) for q in np.array_split(np.asarray(lat), 4)] if len(lat) >= 4 else None,
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},
+            'records': {'gathered': int(sum(g.shape[0] for g in gathered)),
+                        'distinct_steps': len({int(x) for g in gathered for x in g[:, 4].tolist()}),
+                        'distinct_pairs': len({int(x) for g in gathered for x in g[:, 0].tolist()})},
+            'host_to_host': host_to_host,
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:

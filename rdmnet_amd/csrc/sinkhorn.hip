@@ -13,6 +13,8 @@
 //   u = log_mu - logsumexp_j(Z + v)        logsumexp(x) = max + log(sum(exp(x - max)))
 //   v = log_nu - logsumexp_i(Z + u)
 //   out = ((Z + u) + v) - norm
+#include <atomic>
+
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 
@@ -71,12 +73,42 @@ __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr
     return log_m - (mx + logf(sum));
   };
 
+  // A side with all 128 points valid has 129 entries with the dustbin, one more than the 128 rows / columns the
+  // thread pairs own.  Row / column 128 is then the dustbin line; wavefront 0 (row) and wavefront 1 (column)
+  // evaluate it from LDS, three entries per lane, beside their own lines.
+  const int wave = tid >> 6, lane = tid & 63;
+  auto extra_line = [&](const float* zline, int zstride, const float* pot, int count, float log_m) -> float {
+    float t[3], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = lane + 64 * i;
+      t[i] = c < count ? zline[c * zstride] + pot[c] : -INFINITY;
+      mx = fmaxf(mx, t[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sum += __builtin_amdgcn_exp2f((t[i] - mx) * 1.4426950408889634f);
+    sum = wave_sum(sum);
+    return log_m - (mx + logf(sum));
+  };
+  const bool extra_row = R > 128, extra_col = C > 128;  // uniform over the workgroup
+  const float log_mu_bin = logf(static_cast<float>(nc)) + norm, log_nu_bin = logf(static_cast<float>(nr)) + norm;
+
   for (int it = 0; it < iters; ++it) {
     const float un = update(zr, v, log_mu);  // u = log_mu - logsumexp_c(Z + v)
     if (half == 0 && own < R) u[own] = un;
+    if (extra_row && wave == 0) {
+      const float ue = extra_line(Z + 128 * ldz, 1, v, C, log_mu_bin);
+      if (lane == 0) u[128] = ue;
+    }
     __syncthreads();
     const float vn = update(zc, u, log_nu);  // v = log_nu - logsumexp_r(Z + u)
     if (half == 0 && own < C) v[own] = vn;
+    if (extra_col && wave == 1) {
+      const float ve = extra_line(Z + 128, ldz, u, R, log_nu_bin);
+      if (lane == 0) v[128] = ve;
+    }
     __syncthreads();
   }
 
@@ -93,6 +125,11 @@ __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr
       const int c = base + i;
       if (c < C) O[orow + cols[c]] = ((zr[i >> 1][i & 1] + ur) + v[c]) - norm;
     }
+  }
+  if (extra_row) {  // the dustbin row of a full side (rows[128] = m)
+    const float ur = u[128];
+    const int64_t orow = static_cast<int64_t>(rows[128]) * (n + 1);
+    for (int c = tid; c < C; c += 256) O[orow + cols[c]] = ((Z[128 * ldz + c] + ur) + v[c]) - norm;
   }
 }
 
@@ -161,11 +198,16 @@ extern "C" int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64
               "rdm_sinkhorn: bad sizes (m=%lld n=%lld, max %d)", (long long)m, (long long)n, kMaxSide);
   if (batch == 0) return RDM_OK;
   const size_t lds = sizeof(float) * (static_cast<size_t>(m + 1) * ((n + 1) | 1) + 8);
-  static bool attr_set = false;
-  if (!attr_set) {  // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS
+  // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS; the attribute is a
+  // per-device setting, so it is remembered per device (a process may drive several GPUs)
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  RDM_HIP_CHECK(hipGetDevice(&dev));
+  const uint64_t bit = uint64_t(1) << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL(sinkhorn_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), lds,
                      static_cast<hipStream_t>(stream), scores, static_cast<int>(m), static_cast<int>(n), row_mask,

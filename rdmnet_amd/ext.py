@@ -37,10 +37,13 @@ _ws_cache = {}
 
 
 def _workspace(dev, nbytes):
-    buf = _ws_cache.get(dev)
+    # one workspace per (device, stream): concurrent callers on different streams must not share scratch, and a
+    # buffer is only ever replaced by work queued on its own stream (torch's allocator is stream-ordered)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _ws_cache[dev] = buf
+        _ws_cache[key] = buf
     return buf
 
 

@@ -33,8 +33,9 @@ def load_state(path, cfg, seed=0):
 class Tester:
     """One engine on the current device; `run(stager)` processes this rank's pairs."""
 
-    def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True):
+    def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True, write_poses=True):
         self.cfg, self.output_dir, self.save_npz, self.ransac = cfg, output_dir, save_npz, ransac
+        self.write_poses = write_poses  # False under several ranks: rank 0 writes all poses, in pair order, at the end
         self.engine = Engine(cfg, state)
         if save_npz and output_dir:
             self.engine.keep_taps(True)
@@ -68,7 +69,8 @@ class Tester:
         rec = {'seq_id': item['seq_id'], 'ref_frame': item['ref_frame'], 'src_frame': item['src_frame'],
                'n_corr': int(res.n_correspondences), 'ms': ms, 'transform': T}
         if self.output_dir:
-            evaluation.append_pose(self.output_dir, item, T)
+            if self.write_poses:
+                evaluation.append_pose(self.output_dir, item, T)
             if self.save_npz:
                 od = self.output_dict(item['ref_points'].shape[0])
                 T_ransac = None
@@ -134,21 +136,29 @@ def main(argv=None):
     if rank == 0:
         print(f'Data loader created: {time.time() - t0:.3f}s collapsed.')
         print(f'Calibrate neighbors: {cfg.neighbor_limits}.')
-    tester = Tester(cfg, load_state(args.weights, cfg), args.out, save_npz=not args.no_npz)
-    stager = ds_mod.PairStager(data, sharding.pairs_for_rank(len(data), rank, world))
+    tester = Tester(cfg, load_state(args.weights, cfg), args.out, save_npz=not args.no_npz, write_poses=world == 1)
+    mine = sharding.pairs_for_rank(len(data), rank, world)
+    stager = ds_mod.PairStager(data, mine)
     records = tester.run(stager, log=print if rank == 0 else None)
+    # one gather of fixed-size records: ids, counts, time, errors, the pose (12 floats) and the pair's dataset index
     rec = torch.tensor([[r['seq_id'], r['ref_frame'], r['src_frame'], r['n_corr'], r['ms'], r.get('r_RRE', float('nan')),
-                         r.get('r_RTE', float('nan'))] for r in records], dtype=torch.float32,
-                       device='cuda').reshape(-1, 7)
+                         r.get('r_RTE', float('nan')), *np.asarray(r['transform'], np.float64).reshape(-1)[:12], idx]
+                        for r, idx in zip(records, mine)], dtype=torch.float64, device='cuda').reshape(-1, 20)
     allrec = torch.cat(sharding.gather_records(rec, world, dist)).cpu().numpy()
     if rank == 0:
+        allrec = allrec[np.argsort(allrec[:, 19], kind='stable')]  # dataset order, whatever the rank count
+        if world > 1 and args.out:  # the single-rank file, not a rank-interleaved one (evaluation.pose_line format)
+            for row in allrec:
+                evaluation.append_pose(args.out, {'seq_id': int(row[0]), 'ref_frame': int(row[1]), 'src_frame': int(row[2])},
+                                       row[7:19].astype(np.float32))
         print(f'pairs: {allrec.shape[0]}, mean ms/pair: {allrec[:, 4].mean() if len(allrec) else 0:.2f}')
         if len(allrec) and np.isfinite(allrec[:, 5]).any():
             ok = (allrec[:, 5] < tester.summary.rre_threshold) & (allrec[:, 6] < tester.summary.rte_threshold)
             print('  Registration (all ranks), RR: {:.4f}, RRE: {:.3f}, RTE: {:.3f}'.format(
                 ok.mean(), allrec[ok, 5].mean() if ok.any() else 0.0, allrec[ok, 6].mean() if ok.any() else 0.0))
-            for line in tester.summary.lines()[1:]:
-                print(line + '  (rank 0 share)')
+            if world == 1:  # correspondence-level meters (PIR / IR / FMR) are accumulated per rank only
+                for line in tester.summary.lines()[1:]:
+                    print(line)
     if dist is not None:
         dist.destroy_process_group()
     return 0

@@ -390,9 +390,16 @@ class RDMNet:
         fm = cfg.fine_matching
         rc, sc, cs, T, counts = ops.lgr(ms, r_pts, s_pts, r_pm, s_pm, fm.acceptance_radius, fm.correspondence_threshold,
                                         fm.num_refinement_steps)
-        cn = torch.cat([counts, flags[4:5]]).cpu()  # sync: number of correspondences (+ capacity status)
+        # sync: number of correspondences + capacity status words (grouping; the collate's 13 radius searches, whose
+        # status nobody has read yet unless the collate ran with exact_shapes=True)
+        cflags = data_dict.get('_flags')
+        parts = [counts, flags[4:5]] + ([cflags[:, 1].to(torch.int32)] if cflags is not None else [])
+        cn = torch.cat(parts).cpu()
         if int(cn[3]) != 0:
             raise RuntimeError('point_to_node: a node owns more than 4096 points')
+        if cn.numel() > 4 and int(cn[4:].max()) != 0:
+            raise RuntimeError('radius search: a query of the collate exceeded the kernel capacity (neighbour tables are '
+                               'incomplete); the reference returns every neighbour')
         C = int(cn[0])
         taps['lgr'] = {'n_hypotheses': int(cn[1]), 'best': int(cn[2])}
         out.update(ref_corr_points=rc[:C], src_corr_points=sc[:C], corr_scores=cs[:C], estimated_transform=T)

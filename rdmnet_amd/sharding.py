@@ -26,6 +26,17 @@ def gather_records(records, world, dist=None):
     return [b[:int(c)] for b, c in zip(blocks, counts)]
 
 
+def reduce_timing(elapsed_s, latencies_ms, world, dist=None, device='cpu'):
+    """The timed region of a multi-rank run ends when the slowest rank ends: -> (max over ranks of elapsed_s, the
+    per-pair latencies of all ranks concatenated in rank order).  Ranks may hold different numbers of latencies."""
+    if world == 1 or dist is None:
+        return float(elapsed_s), list(latencies_ms)
+    tmax = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    lat = torch.tensor(list(latencies_ms), dtype=torch.float32, device=device).reshape(-1, 1)
+    return float(tmax.item()), torch.cat(gather_records(lat, world, dist)).reshape(-1).cpu().tolist()
+
+
 def summarize(all_records, rre_thresh=5.0, rte_thresh=2.0):
     """RR / mean RRE / mean RTE over successful pairs (experiments/eval.py:223-237 semantics).
     Record columns: [pair_id, rre_deg, rte_m, n_corr]."""

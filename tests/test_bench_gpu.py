@@ -1,0 +1,44 @@
+"""GPU: bench.py's multi-rank path on ONE device.  `python bench.py --gpus 2` with no launcher self-spawns two ranks
+(RDM_BENCH_SHARE_DEVICE=1 puts both on cuda:0, gloo carries the collectives); the JSON line must account for every
+step of both ranks exactly once."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_self_spawned_on_one_device():
+    r = run_bench('--gpus', '2', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--streams', '2', '--pairs', '4',
+                  '--host-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
+    assert r['n_gpus'] == 2 and r['steps'] == 8 and r['scaling'] == 'weak' and r['unit'] == 'pairs/s'
+    assert r['records'] == {'gathered': 16, 'distinct_steps': 16, 'distinct_pairs': 4}
+    assert r['registration']['pairs'] == 16
+    assert r['value'] > 0 and abs(r['value'] - 16 / (r['ms_per_step'] * 8 / 1e3)) < 1e-6 * r['value']
+    assert r['host_to_host']['value'] > 0 and r['cpu_baseline'] is None
+
+
+def test_single_rank_line_has_the_contract_fields():
+    r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--no-cpu-baseline')
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in r, key
+    assert r['n_gpus'] == 1 and r['vs_baseline'] is None and r['dtype'] == 'f32' and 'workload' in r['config']
+    rf = r['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9

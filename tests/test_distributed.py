@@ -15,8 +15,10 @@ def _worker(rank, world, port, n_pairs, out_q):
     mine = sharding.pairs_for_rank(n_pairs, rank, world)
     rec = torch.tensor([[p, 0.1 * p, 0.01 * p, 100 + p] for p in mine], dtype=torch.float32).reshape(-1, 4)
     allr = sharding.gather_records(rec, world, dist)
+    # the bench's timing reduction: max of the ranks' elapsed times, all latencies (ragged) in rank order
+    elapsed, lat = sharding.reduce_timing(1.0 + rank, [10.0 * rank + k for k in range(len(mine))], world, dist)
     if rank == 0:
-        out_q.put([r.tolist() for r in allr])
+        out_q.put(([r.tolist() for r in allr], elapsed, lat))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -28,7 +30,7 @@ def test_rank_strided_sharding_and_gather_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, 29617, n_pairs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, elapsed, lat = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -37,9 +39,42 @@ def test_rank_strided_sharding_and_gather_world2():
     assert ids == list(range(n_pairs))  # every pair exactly once
     summary = sharding.summarize([torch.tensor(g) for g in got])
     assert summary['pairs'] == n_pairs and summary['recall'] == 1.0
+    assert elapsed == 2.0 and lat == [0.0, 1.0, 2.0, 3.0, 10.0, 11.0, 12.0]
 
 
 def test_single_rank_is_identity():
     rec = torch.ones(3, 4)
     assert sharding.gather_records(rec, 1)[0] is rec
     assert sharding.pairs_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert sharding.reduce_timing(0.5, [1.0, 2.0], 1) == (0.5, [1.0, 2.0])
+
+
+def test_bench_self_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus N` without torch.distributed.run: the launcher half (bench.spawn_ranks) starts N copies
+    of the script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and propagates a failing rank's exit code.  The
+    children here are a stand-in script (no GPU in this test); the GPU test runs the real thing on one device."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench_src = open(os.path.join(root, 'bench.py')).read()
+    start = bench_src.index('def spawn_ranks(')
+    end = bench_src.index('\ndef main(')
+    script = tmp_path / 'fake_bench.py'
+    script.write_text('import os, sys, time\n' + bench_src[start:end] + textwrap.dedent('''
+        if __name__ == '__main__':
+            if 'WORLD_SIZE' not in os.environ:
+                sys.exit(spawn_ranks(int(sys.argv[1])))
+            r = os.environ['RANK']
+            open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rank' + r), 'w').write(' '.join(
+                os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))
+            if len(sys.argv) > 2 and sys.argv[2] == 'fail' and r == '1':
+                sys.exit(7)
+            if len(sys.argv) > 2 and sys.argv[2] == 'fail':
+                time.sleep(60)  # must be terminated by the launcher, not waited for
+    '''))
+    assert subprocess.run([sys.executable, str(script), '3'], timeout=60).returncode == 0
+    envs = [(tmp_path / f'rank{r}').read_text().split() for r in range(3)]
+    assert [e[0] for e in envs] == ['0', '1', '2'] and [e[1] for e in envs] == ['0', '1', '2']
+    assert all(e[2] == '3' and e[3] == '3' and e[4] == '127.0.0.1' for e in envs) and len({e[5] for e in envs}) == 1
+    assert subprocess.run([sys.executable, str(script), '2', 'fail'], timeout=30).returncode == 7

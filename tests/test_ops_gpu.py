@@ -237,3 +237,26 @@ def test_point_to_node_pair_equals_two_calls(ops):
         for x, y in zip(got, want):
             assert torch.equal(x, y)
     assert int(st[0]) == 0
+
+
+@pytest.mark.parametrize('nr,nc', [(128, 128), (128, 40), (17, 128), (127, 128), (128, 1), (101, 100), (69, 68)])
+def test_sinkhorn_full_and_partial_patches_match_oracle(ops, nr, nc):
+    """learnable_sinkhorn.py:13-66 on patches whose sides are FULL (128 valid points + dustbin = 129 lines, one more than the
+    128 lines the kernel's thread pairs own) and at the size-class boundaries; scattered masks.  Dustbin row and column
+    included: abs 2e-4 on log-scores of magnitude ~1e1-1e2, masked entries exactly fl(-1e12)."""
+    from oracle import forward as ofw
+    g = torch.Generator().manual_seed(1000 * nr + nc)
+    B = 3
+    scores = torch.randn(B, 128, 128, generator=g) * 4.0
+    rm, cm = torch.zeros(B, 128, dtype=torch.bool), torch.zeros(B, 128, dtype=torch.bool)
+    for b in range(B):
+        rm[b, torch.randperm(128, generator=g)[:nr]] = True
+        cm[b, torch.randperm(128, generator=g)[:nc]] = True
+    alpha = torch.tensor(1.0)
+    ref = ofw.sinkhorn(scores, rm, cm, alpha, 100)
+    out = ops.sinkhorn(scores.cuda(), rm.to(torch.uint8).cuda(), cm.to(torch.uint8).cuda(), alpha.reshape(1).cuda(), 100).cpu()
+    valid = ref > -1e11
+    assert torch.equal(out > -1e11, valid)
+    assert bool(valid[:, 128, :].any()) and bool(valid[:, :, 128].any())  # the dustbin lines are part of the check
+    assert (out[valid] - ref[valid]).abs().max().item() <= 2e-4
+    assert torch.equal(out[~valid], ref[~valid])
