@@ -274,6 +274,20 @@ int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t ld, const u
                         int64_t* src_idx, float* out_scores, int32_t* out_count, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* rdm_coarse_matching_features: the same stage from the L2-normalised superpoint features themselves
+ * (superpoint_matching.py:14-61 with pairwise_distance(normalized=True), ops/pairwise_distance.py:4-31): dot
+ * products, exp, row / column sums and the dual normalisation are evaluated in fp64 and rounded once to the
+ * fp32 score that is ranked.  The reference's top-k order hangs on relative score gaps down to 4e-7
+ * (tests/golden/coarse_order_analysis.json); this entry reproduces the reference's indices exactly when fed the
+ * reference's features, which the fp32 pipeline above (GEMM, then rdm_coarse_matching) cannot promise.
+ * ref_feats [m, d] (row stride ld_ref), src_feats [n, d]; d <= 448.                                         */
+size_t rdm_coarse_matching_features_workspace_bytes(int64_t m, int64_t n);
+int rdm_coarse_matching_features(const float* ref_feats, int64_t ld_ref, int64_t m, const float* src_feats,
+                                 int64_t ld_src, int64_t n, int64_t d, const uint8_t* ref_mask,
+                                 const uint8_t* src_mask, int dual_normalization, int k, int64_t* ref_idx,
+                                 int64_t* src_idx, float* out_scores, int32_t* out_count, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 /* ---- a14: Sinkhorn ---------------------------------------------------------------------------------
  * Replaces LearnableLogOptimalTransport.forward (geotransformer/modules/sinkhorn/
  * learnable_sinkhorn.py:13-66): scores [batch, m, n], masks [batch, m] / [batch, n] (1 = valid),

@@ -80,6 +80,9 @@ SIGNATURES = {
     'rdm_coarse_matching_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_coarse_matching': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int, c_void, c_void, c_void,
                                     c_void, c_void, c_size, c_void]),
+    'rdm_coarse_matching_features_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'rdm_coarse_matching_features': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_int, c_int,
+                                             c_void, c_void, c_void, c_void, c_void, c_size, c_void]),
     'rdm_sinkhorn': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_int, c_void, c_void]),
     'rdm_lgr_workspace_bytes': (c_size, [c_i64]),
     'rdm_lgr': (c_int, [c_void, c_void, c_void, c_void, c_void, c_i64, c_i64, c_f32, c_int, c_int, c_void, c_void,

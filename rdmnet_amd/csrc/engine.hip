@@ -972,18 +972,15 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   int32_t* p2n_status = flags + 62;
   ENG_CHECK(rdm_point_to_node_pair(pf_ref, nf_ref, nodes, m_r, pf_src, nf_src, nodes + 3 * m_r, m_s, K, r_knn, r_km, r_nm, s_knn,
                                    s_km, s_nm, p2n_status, r.ws, r.ws_bytes, r.st));  // both clouds, one set of launches
-  Mat sim = e->mat(m_r, m_s);
-  ENG_ALLOC(sim.p);
-  ENG_CHECK(rdm_gemm(fn.p, fn.ld, 0, fn.p + m_r * fn.ld, fn.ld, 0, 1, sim.p, sim.ld, 0, m_r, m_s, D, 1, nullptr, nullptr, 0,
-                     r.ws, r.ws_bytes, r.st));
   const int kc = c.num_correspondences;
   int64_t* r_sel = e->alloc<int64_t>(kc);
   int64_t* s_sel = e->alloc<int64_t>(kc);
   float* node_sc = e->alloc<float>(kc);
   int32_t* n_sel = flags + 63;
   ENG_ALLOC(r_sel); ENG_ALLOC(s_sel); ENG_ALLOC(node_sc);
-  ENG_CHECK(rdm_coarse_matching(sim.p, m_r, m_s, sim.ld, r_nm, s_nm, c.dual_normalization, kc, r_sel, s_sel, node_sc, n_sel,
-                                r.ws, r.ws_bytes, r.st));
+  RDM_REQUIRE(rdm_coarse_matching_features_workspace_bytes(m_r, m_s) <= r.ws_bytes, "rdm_engine: scratch too small");
+  ENG_CHECK(rdm_coarse_matching_features(fn.p, fn.ld, m_r, fn.p + m_r * fn.ld, fn.ld, m_s, D, r_nm, s_nm, c.dual_normalization,
+                                         kc, r_sel, s_sel, node_sc, n_sel, r.ws, r.ws_bytes, r.st));
   int32_t tail[2];
   ENG_CHECK(d2h(r, flags + 62, sizeof(tail), tail));
   if (tail[0] != 0) {

@@ -285,6 +285,77 @@ __global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* 
   s[static_cast<int64_t>(i) * ld + j] = v;
 }
 
+// ---- the same stage from the FEATURES, evaluated in fp64 (rdm_coarse_matching_features).
+// Why fp64: the reference's top-k order is decided by relative score gaps down to 4e-7 (tests/golden/
+// coarse_order_analysis.json); fp32 sums of ~300 terms in another order than the reference's BLAS / reduction move a
+// score by that much, the exact value does not (the reference's own fp32 evaluation agrees with fp64 at every position
+// on both golden cases).  The stage is tiny (m*n*d = 26 MFLOP), so exactness costs nothing measurable.
+// One workgroup per 16 x 16 tile of pairs; feature rows staged in LDS (row stride d+1: conflict-free column walks).
+__global__ __launch_bounds__(256) void coarse_scores64_kernel(const float* fr, int ldr, int m, const float* fs, int lds_, int n,
+                                                              int d, const unsigned char* rmask, const unsigned char* cmask,
+                                                              double* s, int ld) {
+  extern __shared__ float tile[];
+  float* a = tile;                    // [16][d+1]
+  float* b = tile + 16 * (d + 1);     // [16][d+1]
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  for (int t = threadIdx.x; t < 16 * d; t += 256) {
+    const int r = t / d, c = t % d;
+    a[r * (d + 1) + c] = i0 + r < m ? fr[static_cast<int64_t>(i0 + r) * ldr + c] : 0.f;
+    b[r * (d + 1) + c] = j0 + r < n ? fs[static_cast<int64_t>(j0 + r) * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15, i = i0 + ti, j = j0 + tj;
+  if (i >= m || j >= n) return;
+  double v = 0.0;
+  if (rmask[i] && cmask[j]) {
+    const float* pa = a + ti * (d + 1);
+    const float* pb = b + tj * (d + 1);
+    double acc0 = 0.0, acc1 = 0.0;
+    int c = 0;
+    for (; c + 2 <= d; c += 2) {
+      acc0 = fma(static_cast<double>(pa[c]), static_cast<double>(pb[c]), acc0);
+      acc1 = fma(static_cast<double>(pa[c + 1]), static_cast<double>(pb[c + 1]), acc1);
+    }
+    if (c < d) acc0 = fma(static_cast<double>(pa[c]), static_cast<double>(pb[c]), acc0);
+    double dist = 2.0 - 2.0 * (acc0 + acc1);  // pairwise_distance(normalized=True), clamp(min=1e-12)
+    dist = dist < 1e-12 ? 1e-12 : dist;
+    v = exp(-dist);
+  }
+  s[static_cast<int64_t>(i) * ld + j] = v;
+}
+__global__ void coarse_rowsum64_kernel(const double* s, int m, int n, int ld, double* rsum) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= m) return;
+  double acc = 0.0;
+  for (int j = threadIdx.x & 63; j < n; j += 64) acc += s[static_cast<int64_t>(i) * ld + j];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) rsum[i] = acc;
+}
+__global__ void coarse_colsum64_kernel(const double* s, int m, int n, int ld, double* csum) {
+  // one wavefront per 64 columns x a slice of rows would need a second pass; the matrix is small: 4 row slices per column
+  // block reduced through LDS in a fixed order
+  __shared__ double part[4][64];
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (j < n)
+    for (int i = slice; i < m; i += 4) acc += s[static_cast<int64_t>(i) * ld + j];
+  part[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && j < n) csum[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+__global__ void coarse_dual64_kernel(const double* s, int m, int n, int ld, const double* rsum, const double* csum,
+                                     const unsigned char* rmask, const unsigned char* cmask, float* out, int ldo) {
+  const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (t >= static_cast<int64_t>(m) * n) return;
+  const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
+  float v = -1.f;  // empty nodes never enter the ranking
+  if (rmask[i] && cmask[j]) {
+    const double x = s[static_cast<int64_t>(i) * ld + j];
+    v = static_cast<float>(rsum ? (x / rsum[i]) * (x / csum[j]) : x);
+  }
+  out[static_cast<int64_t>(i) * ldo + j] = v;
+}
+
 // Global top-k (k <= 1024) of an m x n matrix, descending, ties by ascending flat index.
 // One workgroup: three radix-select passes on the float bit pattern, then a bitonic sort.
 // `gate` (optional, a TopkState): run only if its fallback flag is set, i.e. as the fallback of the multi-workgroup path below.
@@ -708,6 +779,25 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long lo
 
 }  // namespace
 
+namespace {
+// global top-k of the [M, N] score matrix (the multi-workgroup path + its gated one-workgroup fallback)
+void launch_topk(const float* scores, int M, int N, int LD, int k, unsigned* ghist, unsigned long long* cand, int64_t* ref_idx,
+                 int64_t* src_idx, float* out_scores, int32_t* out_count, hipStream_t st) {
+  using namespace rdm;
+  TopkState* ts = reinterpret_cast<TopkState*>(ghist + 2 * kTopkBins);
+  const int tb = ceil_div(M, kTopkRows);
+  fill_words<unsigned>(ghist, 2 * kTopkBins + 8, 0u, st);
+  hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist);
+  hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(1), dim3(64), 0, st, ghist, k, ts);
+  hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist + kTopkBins);
+  hipLaunchKernelGGL(topk_pick_kernel<1>, dim3(1), dim3(64), 0, st, ghist + kTopkBins, k, ts);
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, cand);
+  hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), 0, st, cand, ts, N, k, ref_idx, src_idx, out_scores, out_count);
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
+                     out_count, reinterpret_cast<const unsigned*>(ts));  // only runs if the candidate list overflowed
+}
+}  // namespace
+
 extern "C" size_t rdm_coarse_matching_workspace_bytes(int64_t m, int64_t n) {
   rdm::Arena a(nullptr, 0);
   a.take<float>(m > 0 ? m : 1);
@@ -746,16 +836,56 @@ extern "C" int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t 
   hipLaunchKernelGGL(coarse_dual_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD,
                      dual_normalization ? rsum : static_cast<const float*>(nullptr),
                      dual_normalization ? csum : static_cast<const float*>(nullptr), ref_mask, src_mask);
-  TopkState* ts = reinterpret_cast<TopkState*>(ghist + 2 * kTopkBins);
-  const int tb = ceil_div(M, kTopkRows);
-  fill_words<unsigned>(ghist, 2 * kTopkBins + 8, 0u, st);
-  hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist);
-  hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(1), dim3(64), 0, st, ghist, k, ts);
-  hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist + kTopkBins);
-  hipLaunchKernelGGL(topk_pick_kernel<1>, dim3(1), dim3(64), 0, st, ghist + kTopkBins, k, ts);
-  hipLaunchKernelGGL(topk_collect_kernel, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, cand);
-  hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), 0, st, cand, ts, N, k, ref_idx, src_idx, out_scores, out_count);
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
-                     out_count, reinterpret_cast<const unsigned*>(ts));  // only runs if the candidate list overflowed
+  launch_topk(scores, M, N, LD, k, ghist, cand, ref_idx, src_idx, out_scores, out_count, st);
   return launch_status("coarse matching kernels");
+}
+
+extern "C" size_t rdm_coarse_matching_features_workspace_bytes(int64_t m, int64_t n) {
+  rdm::Arena a(nullptr, 0);
+  const int64_t ld = (n + 3) / 4 * 4;
+  a.take<double>(static_cast<size_t>(m > 0 ? m : 1) * ld);
+  a.take<float>(static_cast<size_t>(m > 0 ? m : 1) * ld);
+  a.take<double>(m > 0 ? m : 1);
+  a.take<double>(n > 0 ? n : 1);
+  a.take<unsigned>(2 * kTopkBins + 8);
+  a.take<unsigned long long>(kTopkCand);
+  return a.off;
+}
+
+extern "C" int rdm_coarse_matching_features(const float* ref_feats, int64_t ld_ref, int64_t m, const float* src_feats,
+                                            int64_t ld_src, int64_t n, int64_t d, const uint8_t* ref_mask,
+                                            const uint8_t* src_mask, int dual_normalization, int k, int64_t* ref_idx,
+                                            int64_t* src_idx, float* out_scores, int32_t* out_count, void* ws,
+                                            size_t ws_bytes, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(ref_feats && src_feats && ref_mask && src_mask && ref_idx && src_idx && out_scores && out_count,
+              "rdm_coarse_matching_features: null pointer");
+  RDM_REQUIRE(m > 0 && n > 0 && d > 0 && d <= 448 && k > 0 && k <= 1024 && m * n < (1ll << 31),
+              "rdm_coarse_matching_features: bad sizes (feature width <= 448: two 16-row tiles in 64 KB of LDS)");
+  Arena ar(ws, ws_bytes);
+  const int64_t ld = (n + 3) / 4 * 4;
+  double* s64 = ar.take<double>(static_cast<size_t>(m) * ld);
+  float* s32 = ar.take<float>(static_cast<size_t>(m) * ld);
+  double* rsum = ar.take<double>(m);
+  double* csum = ar.take<double>(n);
+  unsigned* ghist = ar.take<unsigned>(2 * kTopkBins + 8);
+  unsigned long long* cand = ar.take<unsigned long long>(kTopkCand);
+  if (!ar.ok) {
+    set_error("rdm_coarse_matching_features: workspace too small");
+    return RDM_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = static_cast<int>(m), N = static_cast<int>(n), LD = static_cast<int>(ld), D = static_cast<int>(d);
+  const size_t lds = sizeof(float) * 2 * 16 * (D + 1);
+  hipLaunchKernelGGL(coarse_scores64_kernel, dim3(ceil_div(N, 16), ceil_div(M, 16)), dim3(256), lds, st, ref_feats,
+                     static_cast<int>(ld_ref), M, src_feats, static_cast<int>(ld_src), N, D, ref_mask, src_mask, s64, LD);
+  if (dual_normalization) {
+    hipLaunchKernelGGL(coarse_rowsum64_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, s64, M, N, LD, rsum);
+    hipLaunchKernelGGL(coarse_colsum64_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, st, s64, M, N, LD, csum);
+  }
+  hipLaunchKernelGGL(coarse_dual64_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m * n, 256))), dim3(256), 0, st, s64, M, N, LD,
+                     dual_normalization ? rsum : static_cast<const double*>(nullptr),
+                     dual_normalization ? csum : static_cast<const double*>(nullptr), ref_mask, src_mask, s32, LD);
+  launch_topk(s32, M, N, LD, k, ghist, cand, ref_idx, src_idx, out_scores, out_count, st);
+  return launch_status("coarse matching (features) kernels");
 }

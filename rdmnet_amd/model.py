@@ -364,9 +364,9 @@ class RDMNet:
         taps.update(ref_node_masks=r_nmask, src_node_masks=s_nmask, ref_knn=r_knn, src_knn=s_knn,
                     ref_knn_masks=r_kmask, src_knn_masks=s_kmask)
         out.update(ref_feats_f=feats_f[:n_f], src_feats_f=feats_f[n_f:])
-        sim = ops.gemm(rfn, sfn, t.output_dim, m_s, trans_b=True)
-        r_sel, s_sel, node_scores, n_sel = ops.coarse_matching(sim, r_nmask, s_nmask, cfg.coarse_matching.num_correspondences,
-                                                               cfg.coarse_matching.dual_normalization)
+        r_sel, s_sel, node_scores, n_sel = ops.coarse_matching_features(rfn, sfn, r_nmask, s_nmask,
+                                                                        cfg.coarse_matching.num_correspondences,
+                                                                        cfg.coarse_matching.dual_normalization)
         B = int(n_sel.item())  # sync: number of patch correspondences (256 unless the clouds are tiny)
         r_sel, s_sel, node_scores = r_sel[:B], s_sel[:B], node_scores[:B]
         taps['node_corr_scores'] = node_scores

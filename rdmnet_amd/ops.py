@@ -343,6 +343,24 @@ def coarse_matching(scores, ref_mask, src_mask, k, dual=True):
     return ri, si, sc, cnt
 
 
+def coarse_matching_features(ref_feats, src_feats, ref_mask, src_mask, k, dual=True):
+    """L2-normalised superpoint features [m, d], [n, d] (views) -> (ref_idx i64[k], src_idx i64[k], scores f32[k],
+    count i32[1]); the stage is evaluated in fp64 (rdm_coarse_matching_features)."""
+    L = _lib.lib()
+    (m, d), n = ref_feats.shape, src_feats.shape[0]
+    dev = ref_feats.device
+    ri = torch.empty((k,), dtype=torch.int64, device=dev)
+    si = torch.empty((k,), dtype=torch.int64, device=dev)
+    sc = torch.empty((k,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = scratch(dev, L.rdm_coarse_matching_features_workspace_bytes(m, n))
+    _lib.check(L.rdm_coarse_matching_features(ref_feats.data_ptr(), _ld(ref_feats), m, src_feats.data_ptr(), _ld(src_feats), n, d,
+                                              ref_mask.data_ptr(), src_mask.data_ptr(), int(dual), k, ri.data_ptr(),
+                                              si.data_ptr(), sc.data_ptr(), cnt.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _lib.stream_ptr()), 'rdm_coarse_matching_features')
+    return ri, si, sc, cnt
+
+
 def sinkhorn(scores, row_mask, col_mask, alpha, iters):
     L = _lib.lib()
     b, m, n = scores.shape

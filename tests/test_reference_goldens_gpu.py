@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from sampling import compact_scores, sample
+from sampling import expand_scores, sample
 
 pytestmark = pytest.mark.gpu
 
@@ -92,29 +92,51 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     for k in ('ref_feats_f', 'src_feats_f', 'ref_p2p_scores_c', 'src_p2p_scores_c', 'ref_feats_c', 'src_feats_c'):
         rep['out/' + k] = rel(sample(npy(out[k])), g['out/' + k])
         assert rep['out/' + k] <= 2e-5, k
-    stable = bool(spread['corr_equal'])  # the reference reproduces its own discrete outputs across thread counts here
-    idx_equal = (np.array_equal(npy(out['ref_node_corr_indices']), g['out/ref_node_corr_indices'])
-                 and np.array_equal(npy(out['src_node_corr_indices']), g['out/src_node_corr_indices']))
-    rep['node_corr_indices_equal'] = idx_equal
-    rep['tap/node_corr_scores'] = rel(npy(taps['node_corr_scores']), g['tap/node_corr_scores']) if idx_equal else None
+    # ---- superpoint correspondences (superpoint_matching.py:14-83).  The reference's ORDER among its top-256 scores is
+    # decided by its own fp32 rounding: relative gaps between neighbouring scores go down to 3e-7, and the reference
+    # formula evaluated in fp64 on the reference's own features already disagrees with its fp32 order at 2-3 % of
+    # the positions (tests/golden/coarse_order_analysis.json).  So: the SET of pairs must be equal, and a pair may
+    # only sit at a position whose reference score equals its own reference score within 1e-5 (i.e. inside a near-tie
+    # group); everything per patch is then compared through that permutation, and correspondences as a set.
+    ref_pairs = list(zip(g['out/ref_node_corr_indices'].tolist(), g['out/src_node_corr_indices'].tolist()))
+    hip_pairs = list(zip(npy(out['ref_node_corr_indices']).tolist(), npy(out['src_node_corr_indices']).tolist()))
+    rep['node_corr_set_symmetric_difference'] = len(set(ref_pairs) ^ set(hip_pairs))
+    rep['node_corr_same_position_fraction'] = float(np.mean([a == b for a, b in zip(ref_pairs, hip_pairs)]))
+    sets_equal = rep['node_corr_set_symmetric_difference'] == 0 and len(hip_pairs) == len(ref_pairs)
     if tag == 'pair04':
-        assert stable and idx_equal
+        assert sets_equal, rep['node_corr_set_symmetric_difference']
+    if sets_equal:
+        pos = {p: i for i, p in enumerate(ref_pairs)}
+        perm = np.array([pos[p] for p in hip_pairs])  # HIP position -> reference position
+        rs = g['tap/node_corr_scores'].astype(np.float64)
+        rep['node_corr_max_tie_gap'] = float(np.abs(rs[perm] - rs).max() / rs.max())
+        assert rep['node_corr_max_tie_gap'] <= 1e-5                      # moved only inside near-tie groups
+        rep['tap/node_corr_scores'] = rel(npy(taps['node_corr_scores']), rs[perm])
         assert rep['tap/node_corr_scores'] <= 1e-5
-    if idx_equal:
-        for k in ('ref_node_corr_knn_masks', 'src_node_corr_knn_masks'):
-            assert np.array_equal(npy(out[k]).astype(bool), g['out/' + k]), k
-        for k in ('ref_node_corr_knn_points', 'src_node_corr_knn_points'):
-            assert np.array_equal(npy(out[k]), g['out/' + k]), k
-        ms = compact_scores(npy(out['matching_scores']), g['out/ref_node_corr_knn_masks'], g['out/src_node_corr_knn_masks'])
-        rep['out/matching_scores'] = rel(ms, g['out/matching_scores'])
+        rmask, smask = g['out/ref_node_corr_knn_masks'][perm], g['out/src_node_corr_knn_masks'][perm]
+        assert np.array_equal(npy(out['ref_node_corr_knn_masks']).astype(bool), rmask)
+        assert np.array_equal(npy(out['src_node_corr_knn_masks']).astype(bool), smask)
+        assert np.array_equal(npy(out['ref_node_corr_knn_points']), g['out/ref_node_corr_knn_points'][perm])
+        assert np.array_equal(npy(out['src_node_corr_knn_points']), g['out/src_node_corr_knn_points'][perm])
+        gold_ms = expand_scores(g['out/matching_scores'], g['out/ref_node_corr_knn_masks'], g['out/src_node_corr_knn_masks'])[perm]
+        hip_ms = npy(out['matching_scores'])
+        valid = gold_ms > -1e11
+        assert np.array_equal(hip_ms > -1e11, valid)
+        rep['out/matching_scores'] = rel(hip_ms[valid], gold_ms[valid])
         assert rep['out/matching_scores'] <= 1e-6
-        corr_equal = (np.array_equal(npy(out['ref_corr_points']), g['out/ref_corr_points'])
-                      and np.array_equal(npy(out['src_corr_points']), g['out/src_corr_points']))
-        rep['corr_points_equal'] = corr_equal
+        # point correspondences: the same set of (ref point, src point) rows, scores attached
+        def rows(rc, sc, cs):
+            a = np.concatenate([npy(rc), npy(sc), npy(cs)[:, None]], 1).astype(np.float64)
+            return a[np.lexsort(a[:, :6].T[::-1])]
+        hr = rows(out['ref_corr_points'], out['src_corr_points'], out['corr_scores'])
+        gr = rows(g['out/ref_corr_points'], g['out/src_corr_points'], g['out/corr_scores'])
+        corr_equal = hr.shape == gr.shape and np.array_equal(hr[:, :6], gr[:, :6])
+        rep['corr_points_equal_as_set'] = bool(corr_equal)
+        rep['n_corr'] = [int(hr.shape[0]), int(gr.shape[0])]
         if tag == 'pair04':
             assert corr_equal
         if corr_equal:
-            rep['out/corr_scores'] = rel(npy(out['corr_scores']), g['out/corr_scores'])
+            rep['out/corr_scores'] = rel(hr[:, 6], gr[:, 6])
             assert rep['out/corr_scores'] <= 2e-5
 
     # ---- pose
@@ -133,3 +155,25 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     assert torch.equal(rc, out['ref_corr_points']) and torch.equal(sc, out['src_corr_points']) and torch.equal(cs, out['corr_scores'])
     assert torch.equal(eng.tensor('nms_mask')[:, 0], taps['nms_mask'])
     assert torch.equal(eng.tensor('ref_node_corr_indices')[:, 0], out['ref_node_corr_indices'])
+
+
+def test_coarse_matching_reproduces_reference_indices_at_full_size(setup, golden_dir, oracle_native):
+    """Teacher-forced at full size: fed the oracle's superpoint features of the bundled pair (the oracle's own indices
+    equal the reference's, tests/test_oracle_forward.py), the HIP stage returns the REFERENCE's captured
+    ref/src_node_corr_indices -- same pairs, same order (superpoint_matching.py:14-83)."""
+    from oracle import forward as ofw
+    from rdmnet_amd import ops, weights
+    cfg = setup[0]
+    g = np.load(os.path.join(golden_dir, 'forward_pair04.npz'))
+    rp, sp = g['ref_points_in'], g['src_points_in']
+    odata = ofw.pyramid(np.concatenate([rp, sp]), np.array([len(rp), len(sp)], np.int64), cfg)
+    otaps = {}
+    oout = ofw.forward(ofw.to_torch(weights.synthetic_state_dict(cfg, seed=0)), cfg, odata, otaps)
+    ri, si, sc, cnt = ops.coarse_matching_features(oout['ref_feats_c'].cuda(), oout['src_feats_c'].cuda(),
+                                                   otaps['ref_node_masks'].cuda().to(torch.uint8),
+                                                   otaps['src_node_masks'].cuda().to(torch.uint8), 256)
+    k = int(cnt)
+    assert k == 256
+    assert np.array_equal(npy(ri), g['out/ref_node_corr_indices']) and np.array_equal(npy(si), g['out/src_node_corr_indices'])
+    _report.setdefault('pair04', {})['teacher_forced_coarse_scores'] = rel(npy(sc), g['tap/node_corr_scores'])
+    assert _report['pair04']['teacher_forced_coarse_scores'] <= 1e-6
