@@ -978,9 +978,18 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float* node_sc = e->alloc<float>(kc);
   int32_t* n_sel = flags + 63;
   ENG_ALLOC(r_sel); ENG_ALLOC(s_sel); ENG_ALLOC(node_sc);
-  RDM_REQUIRE(rdm_coarse_matching_features_workspace_bytes(m_r, m_s) <= r.ws_bytes, "rdm_engine: scratch too small");
-  ENG_CHECK(rdm_coarse_matching_features(fn.p, fn.ld, m_r, fn.p + m_r * fn.ld, fn.ld, m_s, D, r_nm, s_nm, c.dual_normalization,
-                                         kc, r_sel, s_sel, node_sc, n_sel, r.ws, r.ws_bytes, r.st));
+  {
+    void* cm_ws = r.ws;
+    size_t cm_bytes = rdm_coarse_matching_features_workspace_bytes(m_r, m_s);  // 12 B per superpoint pair
+    if (cm_bytes > r.ws_bytes) {  // thousands of superpoints per cloud (very sparse input)
+      cm_ws = e->alloc<char>(cm_bytes);
+      ENG_ALLOC(cm_ws);
+    } else {
+      cm_bytes = r.ws_bytes;
+    }
+    ENG_CHECK(rdm_coarse_matching_features(fn.p, fn.ld, m_r, fn.p + m_r * fn.ld, fn.ld, m_s, D, r_nm, s_nm,
+                                           c.dual_normalization, kc, r_sel, s_sel, node_sc, n_sel, cm_ws, cm_bytes, r.st));
+  }
   int32_t tail[2];
   ENG_CHECK(d2h(r, flags + 62, sizeof(tail), tail));
   if (tail[0] != 0) {

@@ -115,6 +115,15 @@ def main():
             if k == 'matching_scores':  # only the un-masked blocks carry information
                 a = compact_scores(a, np_(out['ref_node_corr_knn_masks']), np_(out['src_node_corr_knn_masks']))
             fx['out/' + k] = a
+        # un-sampled inputs of the coarse matching stage (superpoint_matching.py:14-83), for a teacher-forced check of the
+        # top-k ORDER: L2-normalised superpoint features and the non-empty-node masks of the reference's own grouping
+        from geotransformer.modules.ops import point_to_node_partition
+        n_f0 = int(data['lengths'][1][0])
+        fx['full/ref_feats_c'], fx['full/src_feats_c'] = np_(out['ref_feats_c']), np_(out['src_feats_c'])
+        fx['full/ref_node_masks'] = np_(point_to_node_partition(data['points'][1][:n_f0], out['ref_points_c'],
+                                                                my_cfg.model.num_points_in_patch)[1])
+        fx['full/src_node_masks'] = np_(point_to_node_partition(data['points'][1][n_f0:], out['src_points_c'],
+                                                                my_cfg.model.num_points_in_patch)[1])
         np.savez_compressed(os.path.join(HERE, f'forward_{tag}.npz'), **fx)
 
         # ---- pin the oracle: replay the restatement on the same inputs, record deviations

@@ -123,7 +123,9 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
         valid = gold_ms > -1e11
         assert np.array_equal(hip_ms > -1e11, valid)
         rep['out/matching_scores'] = rel(hip_ms[valid], gold_ms[valid])
-        assert rep['out/matching_scores'] <= 1e-6
+        # (the crop's patches are fuller and its log-scores 10x smaller: the reference against itself, 8 vs 1 thread,
+        # moves by 4e-7 of the maximum there)
+        assert rep['out/matching_scores'] <= (1e-6 if tag == 'pair04' else 3e-6)
         # point correspondences: the same set of (ref point, src point) rows, scores attached
         def rows(rc, sc, cs):
             a = np.concatenate([npy(rc), npy(sc), npy(cs)[:, None]], 1).astype(np.float64)
@@ -157,23 +159,21 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     assert torch.equal(eng.tensor('ref_node_corr_indices')[:, 0], out['ref_node_corr_indices'])
 
 
-def test_coarse_matching_reproduces_reference_indices_at_full_size(setup, golden_dir, oracle_native):
-    """Teacher-forced at full size: fed the oracle's superpoint features of the bundled pair (the oracle's own indices
-    equal the reference's, tests/test_oracle_forward.py), the HIP stage returns the REFERENCE's captured
-    ref/src_node_corr_indices -- same pairs, same order (superpoint_matching.py:14-83)."""
-    from oracle import forward as ofw
-    from rdmnet_amd import ops, weights
-    cfg = setup[0]
-    g = np.load(os.path.join(golden_dir, 'forward_pair04.npz'))
-    rp, sp = g['ref_points_in'], g['src_points_in']
-    odata = ofw.pyramid(np.concatenate([rp, sp]), np.array([len(rp), len(sp)], np.int64), cfg)
-    otaps = {}
-    oout = ofw.forward(ofw.to_torch(weights.synthetic_state_dict(cfg, seed=0)), cfg, odata, otaps)
-    ri, si, sc, cnt = ops.coarse_matching_features(oout['ref_feats_c'].cuda(), oout['src_feats_c'].cuda(),
-                                                   otaps['ref_node_masks'].cuda().to(torch.uint8),
-                                                   otaps['src_node_masks'].cuda().to(torch.uint8), 256)
+@pytest.mark.parametrize('tag', ['pair04', 'small'])
+def test_coarse_matching_reproduces_reference_indices_teacher_forced(golden_dir, tag):
+    """Fed the REFERENCE's own superpoint features and non-empty-node masks (the un-sampled `full/*` entries of the
+    golden file), the HIP stage returns the reference's captured ref/src_node_corr_indices -- the same pairs in the same
+    order -- and its scores (superpoint_matching.py:14-83).  329 x 313 candidates on the bundled pair, neighbouring
+    scores as close as 4e-7 relative (tests/golden/coarse_order_analysis.json)."""
+    from rdmnet_amd import ops
+    g = np.load(os.path.join(golden_dir, f'forward_{tag}.npz'))
+    ri, si, sc, cnt = ops.coarse_matching_features(torch.from_numpy(g['full/ref_feats_c']).cuda(),
+                                                   torch.from_numpy(g['full/src_feats_c']).cuda(),
+                                                   torch.from_numpy(g['full/ref_node_masks']).cuda().to(torch.uint8),
+                                                   torch.from_numpy(g['full/src_node_masks']).cuda().to(torch.uint8), 256)
     k = int(cnt)
-    assert k == 256
-    assert np.array_equal(npy(ri), g['out/ref_node_corr_indices']) and np.array_equal(npy(si), g['out/src_node_corr_indices'])
-    _report.setdefault('pair04', {})['teacher_forced_coarse_scores'] = rel(npy(sc), g['tap/node_corr_scores'])
-    assert _report['pair04']['teacher_forced_coarse_scores'] <= 1e-6
+    assert k == g['out/ref_node_corr_indices'].shape[0]
+    assert np.array_equal(npy(ri)[:k], g['out/ref_node_corr_indices']) and np.array_equal(npy(si)[:k], g['out/src_node_corr_indices'])
+    err = rel(npy(sc)[:k], g['tap/node_corr_scores'])
+    _report.setdefault(tag, {})['teacher_forced_coarse_scores'] = err
+    assert err <= 3e-6  # the reference's scores carry their own fp32 rounding
