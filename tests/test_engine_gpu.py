@@ -60,7 +60,9 @@ def test_engine_matches_oracle_and_is_deterministic(ctx):
     T1, n1 = eng.transform(), r1.n_correspondences
     assert torch.equal(eng.tensor('nms_mask')[:, 0].cpu().bool(), otaps['nms_mask'])
     rre, rte = ofw.rre_rte(T1, oout['estimated_transform'].numpy())
-    assert rre < 0.05 and rte < 5e-4, (rre, rte)
+    assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)  # the north star's bound, end to end
+    rc, sc, _ = eng.corr()
+    assert torch.equal(rc.cpu(), oout['ref_corr_points']) and torch.equal(sc.cpu(), oout['src_corr_points'])
     r2 = eng.run(torch.from_numpy(rp).cuda(), torch.from_numpy(sp).cuda())
     assert np.array_equal(eng.transform(), T1) and r2.n_correspondences == n1  # run-to-run bit-reproducible
 

@@ -151,6 +151,8 @@ def test_forward_end_to_end(ctx):
         assert rel_err(out[k], oo[k]) <= 2e-4, k
     assert set(out.keys()) == set(oo.keys())
     rre, rte = ofw.rre_rte(out['estimated_transform'].cpu().numpy(), oo['estimated_transform'].numpy())
-    # end-to-end the pose inherits the discrete-decision noise the reference shows against itself
-    # (tests/golden/oracle_vs_reference.json); the teacher-forced LGR test carries the 1e-3 bound.
-    assert rre < 0.05 and rte < 5e-4, (rre, rte)
+    # end to end: the discrete outputs equal the oracle's and the pose meets the north-star bound (1e-3 deg, 1e-3 cm)
+    assert torch.equal(out['ref_node_corr_indices'].cpu(), oo['ref_node_corr_indices'])
+    assert torch.equal(out['src_node_corr_indices'].cpu(), oo['src_node_corr_indices'])
+    assert torch.equal(out['ref_corr_points'].cpu(), oo['ref_corr_points']) and torch.equal(out['src_corr_points'].cpu(), oo['src_corr_points'])
+    assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)
