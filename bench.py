@@ -208,6 +208,8 @@ def main():
                          'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
     ap.add_argument('--host-steps', type=int, default=96,
                     help='pairs of the host-to-host pass that follows the timed region (0 = skip)')
+    ap.add_argument('--api-steps', type=int, default=96,
+                    help='pairs of the drop-in-API pass (Python collate + model(data_dict)) after the timed region (0 = skip)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -238,7 +240,6 @@ def main():
     if args.path == 'python':
         net = model.create_model(cfg).cuda(local_rank)
         net.load_state_dict(state)
-        net._prepare()
 
     if rank == 0:
         pairs = make_pairs(args.pairs, args.cache)
@@ -403,6 +404,72 @@ def main():
                         'note': 'pinned host scans -> H2D -> engine -> D2H of correspondences (points + scores) and pose; '
                                 'measured after the timed region, same pairs in flight'}
 
+    # ---- the drop-in operator API (north star: "keeps the existing model.forward operator API"): the same pairs through
+    # rdmnet_amd.collate (the reference's collate signature, 17 kernel launches issued from Python) + model(data_dict)
+    # (rdm_engine_forward: one native call) -> the reference's 31-key output_dict.  A second figure, never `value`.
+    api = None
+    if args.api_steps > 0:
+        if net is None:
+            net = model.create_model(cfg).cuda(local_rank)
+            net.load_state_dict(state)
+
+        def make_data(i):
+            r, s_ = dev_pairs[(rank + i * world) % len(dev_pairs)]
+            item = {'ref_points': r, 'src_points': s_, 'ref_feats': torch.ones((r.shape[0], 1), device=dev),
+                    'src_feats': torch.ones((s_.shape[0], 1), device=dev)}
+            data = collate.registration_collate_fn_stack_mode([item], cfg.backbone.num_stages, cfg.backbone.init_voxel_size,
+                                                              cfg.backbone.init_radius, cfg.neighbor_limits, device=dev)
+            data['testing'] = True
+            return data
+
+        def api_range(indices, stream):
+            ctx = torch.cuda.stream(stream) if stream is not None else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                for i in indices:
+                    out = net(make_data(i))
+                    out['estimated_transform'].cpu()
+            except BaseException as exc:
+                errors.append(exc)
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+
+        for warm in (True, False):
+            n_api = len(streams) * 2 if warm else args.api_steps
+            jobs = [list(range(k, n_api, len(streams))) for k in range(len(streams))]
+            fence()
+            ta0 = time.perf_counter()
+            threads = [threading.Thread(target=api_range, args=(jobs[k], streams[k])) for k in range(len(streams))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            fence()
+            a_elapsed, _ = sharding.reduce_timing(time.perf_counter() - ta0, [], world, dist, comm_dev)
+            if errors:
+                raise errors[0]
+        # forward only, one pair in flight: model(data_dict) (output_dict assembled) against the bare native call
+        fwd_model, fwd_native = [], []
+        eng_f = net._engine()
+        for i in range(8):
+            data = make_data(i)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            out = net(data)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            eng_f.forward(data)
+            torch.cuda.synchronize(dev)
+            t3 = time.perf_counter()
+            fwd_model.append((t2 - t1) * 1e3)
+            fwd_native.append((t3 - t2) * 1e3)
+        api = {'value': args.api_steps * world / a_elapsed, 'unit': 'pairs/s', 'steps': args.api_steps,
+               'forward_only_ms': {'model(data_dict)': float(np.median(fwd_model)), 'rdm_engine_forward': float(np.median(fwd_native))},
+               'note': 'rdmnet_amd.collate.registration_collate_fn_stack_mode + rdmnet_amd.model.RDMNet.__call__ (31-key '
+                       'output_dict), same pairs in flight; forward_only_ms: medians of 8 pairs, one in flight'}
+
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
     def kp_totals(prof):
         t_total = t_gather = b_total = b_gather = 0.0
@@ -476,6 +543,7 @@ def main():
                         'distinct_steps': len({int(x) for g in gathered for x in g[:, 4].tolist()}),
                         'distinct_pairs': len({int(x) for g in gathered for x in g[:, 0].tolist()})},
             'host_to_host': host_to_host,
+            'drop_in_api': api,
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:

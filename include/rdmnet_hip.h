@@ -377,6 +377,28 @@ int rdm_engine_finalize(rdm_engine* e);
 /* ref/src points: device f32 [n,3].  Synchronises `stream` (4 small read-backs of data-dependent sizes). */
 int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
                    rdm_engine_result* result_host, void* stream);
+
+/* The reference's `data_dict` (experiments/model_infer.py:113-124, produced by registration_collate_fn_stack_mode,
+ * geotransformer/utils/data.py:139-192) as device pointers: what RDMNet.forward(data_dict) reads.  Clouds are stacked
+ * [ref; src]; index tables are int64 row-major with the stated row stride (the reference hands over `[:, :limit]`
+ * views), pad index = number of support points.  `*_count` are optional device int32 scalars holding the effective
+ * table width min(limit, max_count) when a table was allocated wider than that (this library's own collate without
+ * the shape read-back); null = every column is valid, as in the reference's tensors.                              */
+typedef struct rdm_data_dict {
+  const float* features;  int64_t features_ld;       /* [n_points[0], 1] */
+  const float* points[5];                            /* [n_points[i], 3] contiguous */
+  const int64_t* lengths[5];                         /* device int64[2] per level */
+  int64_t n_points[5], n_ref[5];                     /* host copies: stacked rows per level, of which ref */
+  const int64_t* neighbors[5];   int64_t neighbors_width[5],   neighbors_ld[5];   const int32_t* neighbors_count[5];
+  const int64_t* subsampling[4]; int64_t subsampling_width[4], subsampling_ld[4]; const int32_t* subsampling_count[4];
+  const int64_t* upsampling[4];  int64_t upsampling_width[4],  upsampling_ld[4];  const int32_t* upsampling_count[4];
+} rdm_data_dict;
+
+/* rdm_engine_forward = RDMNet.forward(data_dict) alone (experiments/model_infer.py:109-354): the same native sequence
+ * as rdm_engine_run after its collate, on tables the caller built -- with this library's collate
+ * (rdmnet_amd.collate) or the reference's.  Same result structure, taps and waits as rdm_engine_run; bit-identical to
+ * it when fed the tables rdm_engine_run builds itself.                                                              */
+int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* data, rdm_engine_result* result_host, void* stream);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
 /* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,

@@ -210,7 +210,9 @@ struct Level {
 struct Table {
   int64_t* idx = nullptr;
   int64_t rows = 0, width = 0;
-  int32_t* flags = nullptr;  // device [2]: max_count, status
+  int64_t ld = 0;            // row stride; 0 = width (tables built by the engine's own collate)
+  int32_t* flags = nullptr;  // device [2]: max_count, status (optional: null = every column is valid)
+  int64_t stride() const { return ld ? ld : width; }
 };
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
@@ -231,7 +233,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   const int li = e->prof_layers;
   const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
-  ENG_CHECK(rdm_kpconv_gather_ordered(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.width, t.flags,
+  ENG_CHECK(rdm_kpconv_gather_ordered(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
                                       vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, order, r.st));
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
   Mat conv = e->mat(q.n, W.out);
@@ -247,7 +249,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   if (pool_src) {  // strided block: the shortcut max-pool over the same neighbour table (functional.py:54-67)
     *pool_out = e->mat(q.n, pool_src->cols);
     ENG_ALLOC(pool_out->p);
-    ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.width,
+    ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
                              t.flags, pool_out->p, pool_out->ld, r.st));
   }
   if (prof) {
@@ -604,19 +606,16 @@ extern "C" int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor
 }
 
 static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
-                           rdm_engine_result* res, void* stream);
+                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream);
 
 // The default 3 GiB arena covers pairs of ~2 x 25 k points; denser input (raw scans, KITTI-360-sized clouds)
 // grows it: on exhaustion the stream is drained, the arena doubled (288 GB of HBM leave room) and the pair
 // re-run.  An arena size chosen by the caller (rdm_engine_config.arena_bytes) is never changed.
-extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
-                              int64_t n_src, rdm_engine_result* res, void* stream) {
-  RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_run: null pointer");
-  RDM_REQUIRE(e->finalized, "rdm_engine_run: call rdm_engine_finalize first");
-  RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_run: empty cloud");
+static int engine_run_growing(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
+                              const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
   for (;;) {
     e->arena_exhausted = false;
-    const int rc = engine_run_once(e, ref_points, n_ref, src_points, n_src, res, stream);
+    const int rc = engine_run_once(e, ref_points, n_ref, src_points, n_src, dd, res, stream);
     if (rc != RDM_ERR_WORKSPACE || !e->arena_exhausted || e->arena_fixed || e->arena_cap >= (size_t(96) << 30)) return rc;
     RDM_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     RDM_HIP_CHECK(hipFree(e->arena));
@@ -631,8 +630,34 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   }
 }
 
+extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
+                              int64_t n_src, rdm_engine_result* res, void* stream) {
+  RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_run: null pointer");
+  RDM_REQUIRE(e->finalized, "rdm_engine_run: call rdm_engine_finalize first");
+  RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_run: empty cloud");
+  return engine_run_growing(e, ref_points, n_ref, src_points, n_src, nullptr, res, stream);
+}
+
+// RDMNet.forward alone (experiments/model_infer.py:109-354) on a data_dict the caller collated -- with this library's
+// collate or with the reference's (geotransformer/utils/data.py:139-192).
+extern "C" int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
+  RDM_REQUIRE(e && dd && res, "rdm_engine_forward: null pointer");
+  RDM_REQUIRE(e->finalized, "rdm_engine_forward: call rdm_engine_finalize first");
+  for (int i = 0; i < 5; ++i) {
+    RDM_REQUIRE(dd->points[i] && dd->lengths[i] && dd->neighbors[i] && dd->n_points[i] > 1 && dd->n_ref[i] > 0 &&
+                    dd->n_ref[i] < dd->n_points[i] && dd->neighbors_width[i] > 0 && dd->neighbors_ld[i] >= dd->neighbors_width[i],
+                "rdm_engine_forward: level %d of the data_dict is incomplete", i);
+    if (i < 4)
+      RDM_REQUIRE(dd->subsampling[i] && dd->upsampling[i] && dd->subsampling_width[i] > 0 && dd->upsampling_width[i] > 0 &&
+                      dd->subsampling_ld[i] >= dd->subsampling_width[i] && dd->upsampling_ld[i] >= dd->upsampling_width[i],
+                  "rdm_engine_forward: level %d of the data_dict is incomplete", i);
+  }
+  RDM_REQUIRE(dd->features && dd->features_ld >= 1, "rdm_engine_forward: features missing");
+  return engine_run_growing(e, nullptr, dd->n_ref[0], nullptr, dd->n_points[0] - dd->n_ref[0], dd, res, stream);
+}
+
 static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
-                           rdm_engine_result* res, void* stream) {
+                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
   const rdm_engine_config& c = e->cfg;
   e->arena_off = 0;
   e->taps.clear();
@@ -648,8 +673,56 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   ENG_ALLOC(r.ws);
   std::memset(res, 0, sizeof(*res));
 
-  // ---------------------------------------------------------------- collate (data.py:13-77)
   Level lv[5];
+  Table nb[5], sub[4], up[4];
+  int32_t* flags = e->alloc<int32_t>(64);
+  ENG_ALLOC(flags);
+  fill_words<int32_t>(flags, 64, 0, r.st);
+  int call = 0;
+  struct Grid { void* ws; size_t bytes; int64_t n_s; };
+  Grid grids[5] = {};
+  std::vector<char> redo_queue(radius_redo_queue_bytes());
+  radius_redo_queue_reset(redo_queue.data());
+  auto build_grid = [&](const Level& s, float rad, Grid& g) -> int {
+    g.n_s = s.n;
+    g.bytes = rdm_radius_grid_workspace_bytes(s.n);
+    g.ws = e->alloc<char>(g.bytes);
+    ENG_ALLOC(g.ws);
+    return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
+  };
+  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t) -> int {
+    t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
+    t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
+    ENG_ALLOC(t.idx);
+    // the large-buffer second pass of all 14 searches is one launch after the loop (radius_redo_flush)
+    unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
+    ENG_ALLOC(redo_flags);
+    return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
+                                      t.flags + 1, redo_flags, redo_queue.data(), r.st);
+  };
+  if (dd) {
+    // ------------------------------------------------------------ the caller's data_dict (model_infer.py:113-131)
+    for (int i = 0; i < 5; ++i) {
+      lv[i].pts = const_cast<float*>(dd->points[i]);
+      lv[i].n = dd->n_points[i];
+      lv[i].n_ref = dd->n_ref[i];
+      lv[i].lengths = const_cast<int64_t*>(dd->lengths[i]);
+      res->level_sizes[i] = lv[i].n;
+      res->level_ref_sizes[i] = lv[i].n_ref;
+      nb[i].idx = const_cast<int64_t*>(dd->neighbors[i]);
+      nb[i].rows = lv[i].n; nb[i].width = dd->neighbors_width[i]; nb[i].ld = dd->neighbors_ld[i];
+      nb[i].flags = const_cast<int32_t*>(dd->neighbors_count[i]);
+    }
+    for (int i = 0; i < 4; ++i) {
+      sub[i].idx = const_cast<int64_t*>(dd->subsampling[i]);
+      sub[i].rows = lv[i + 1].n; sub[i].width = dd->subsampling_width[i]; sub[i].ld = dd->subsampling_ld[i];
+      sub[i].flags = const_cast<int32_t*>(dd->subsampling_count[i]);
+      up[i].idx = const_cast<int64_t*>(dd->upsampling[i]);
+      up[i].rows = lv[i].n; up[i].width = dd->upsampling_width[i]; up[i].ld = dd->upsampling_ld[i];
+      up[i].flags = const_cast<int32_t*>(dd->upsampling_count[i]);
+    }
+  } else {
+  // ---------------------------------------------------------------- collate (data.py:13-77)
   lv[0].n = n0; lv[0].n_ref = n_ref;
   lv[0].pts = e->alloc<float>(3 * n0);
   lv[0].lengths = e->alloc<int64_t>(2);
@@ -682,35 +755,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   res->level_sizes[0] = n0;
   res->level_ref_sizes[0] = n_ref;
 
-  int32_t* flags = e->alloc<int32_t>(64);
-  ENG_ALLOC(flags);
-  fill_words<int32_t>(flags, 64, 0, r.st);
-  Table nb[5], sub[4], up[4];
   float radius = c.init_radius;
-  int call = 0;
-  // every level is searched three times with the same radius r_i (self, from level i+1, from level
-  // i-1 with 2*r_{i-1} = r_i): one grid per level serves all three (data.py:35-67)
-  struct Grid { void* ws; size_t bytes; int64_t n_s; };
-  auto build_grid = [&](const Level& s, float rad, Grid& g) -> int {
-    g.n_s = s.n;
-    g.bytes = rdm_radius_grid_workspace_bytes(s.n);
-    g.ws = e->alloc<char>(g.bytes);
-    ENG_ALLOC(g.ws);
-    return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
-  };
-  std::vector<char> redo_queue(radius_redo_queue_bytes());
-  radius_redo_queue_reset(redo_queue.data());
-  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t) -> int {
-    t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
-    t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
-    ENG_ALLOC(t.idx);
-    // the large-buffer second pass of all 14 searches is one launch after the loop (radius_redo_flush)
-    unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
-    ENG_ALLOC(redo_flags);
-    return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
-                                      t.flags + 1, redo_flags, redo_queue.data(), r.st);
-  };
-  Grid grids[5];
   {  // the five level grids with one set of launches (radius r_i = 2^i r_0)
     const float* gp[5];
     int64_t gn[5];
@@ -735,12 +780,13 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     radius *= 2.f;
   }
   ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));
+  }  // collate
   for (int i = 0; i < 5; ++i) {
     tap(r, ("points" + std::to_string(i)).c_str(), lv[i].pts, lv[i].n, 3, 3, 0);
-    tap(r, ("neighbors" + std::to_string(i)).c_str(), nb[i].idx, nb[i].rows, nb[i].width, nb[i].width, 1);
+    tap(r, ("neighbors" + std::to_string(i)).c_str(), nb[i].idx, nb[i].rows, nb[i].width, nb[i].stride(), 1);
     if (i < 4) {
-      tap(r, ("subsampling" + std::to_string(i)).c_str(), sub[i].idx, sub[i].rows, sub[i].width, sub[i].width, 1);
-      tap(r, ("upsampling" + std::to_string(i)).c_str(), up[i].idx, up[i].rows, up[i].width, up[i].width, 1);
+      tap(r, ("subsampling" + std::to_string(i)).c_str(), sub[i].idx, sub[i].rows, sub[i].width, sub[i].stride(), 1);
+      tap(r, ("upsampling" + std::to_string(i)).c_str(), up[i].idx, up[i].rows, up[i].width, up[i].stride(), 1);
     }
   }
 
@@ -758,9 +804,14 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   }
 
   // ---------------------------------------------------------------- encoder (backbone.py:72-107)
-  Mat x = e->mat(n0, 1);
-  ENG_ALLOC(x.p);
-  ENG_CHECK(launch1d("fill", fill_kernel, n0 * x.ld, r.st, x.p, n0 * x.ld, 1.0f));  // features = 1 (dataset.py:187-188)
+  Mat x;
+  if (dd) {  // data_dict['features'] (model_infer.py:113), [N0, 1]
+    x.p = const_cast<float*>(dd->features); x.rows = n0; x.cols = 1; x.ld = dd->features_ld;
+  } else {
+    x = e->mat(n0, 1);
+    ENG_ALLOC(x.p);
+    ENG_CHECK(launch1d("fill", fill_kernel, n0 * x.ld, r.st, x.p, n0 * x.ld, 1.0f));  // features = 1 (dataset.py:187-188)
+  }
   uint8_t* x_pos = e->alloc<uint8_t>(n0);
   ENG_ALLOC(x_pos);
   ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, r.st));
@@ -780,8 +831,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
       // visit the queries in the cell order of their level's search grid: neighbouring queries share most
       // neighbours, so gathered lines are re-used from L1 (results do not depend on the order)
-      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];
-      const float* order = rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s);
+      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];  // (no grids when the caller collated: row order then)
+      const float* order = qg.ws ? rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s) : nullptr;
       Mat y;
       if (b == 0) {
         ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y, order));
@@ -828,25 +879,26 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float* n2p = e->alloc<float>(Nc);
   ENG_ALLOC(n2p);
   ENG_CHECK(rdm_sigmoid_column(n2p_logit.p, n2p_logit.ld, Nc, n2p, r.st));
+  tap(r, "n2p_scores", n2p, Nc, 1, 1, 0);
 
   // ---------------------------------------------------------------- decoder (backbone.py:118-151)
   Mat dec;
   {
     Mat c4 = e->mat(lv[3].n, buf_c.cols + feats[3].cols);
     ENG_ALLOC(c4.p);
-    ENG_CHECK(rdm_upsample_concat(buf_c.p, Nc, buf_c.cols, buf_c.ld, up[3].idx, up[3].width, feats[3].p, feats[3].cols,
+    ENG_CHECK(rdm_upsample_concat(buf_c.p, Nc, buf_c.cols, buf_c.ld, up[3].idx, up[3].stride(), feats[3].p, feats[3].cols,
                                   feats[3].ld, lv[3].n, c4.p, c4.ld, r.st));
     Mat l4;
     ENG_CHECK(unary(r, "decoder.decoder4", c4, l4, 2, nullptr, nullptr));
     Mat c3 = e->mat(lv[2].n, l4.cols + feats[2].cols);
     ENG_ALLOC(c3.p);
-    ENG_CHECK(rdm_upsample_concat(l4.p, l4.rows, l4.cols, l4.ld, up[2].idx, up[2].width, feats[2].p, feats[2].cols,
+    ENG_CHECK(rdm_upsample_concat(l4.p, l4.rows, l4.cols, l4.ld, up[2].idx, up[2].stride(), feats[2].p, feats[2].cols,
                                   feats[2].ld, lv[2].n, c3.p, c3.ld, r.st));
     Mat l3;
     ENG_CHECK(unary(r, "decoder.decoder3", c3, l3, 2, nullptr, nullptr));
     Mat c2 = e->mat(lv[1].n, l3.cols + feats[1].cols);
     ENG_ALLOC(c2.p);
-    ENG_CHECK(rdm_upsample_concat(l3.p, l3.rows, l3.cols, l3.ld, up[1].idx, up[1].width, feats[1].p, feats[1].cols,
+    ENG_CHECK(rdm_upsample_concat(l3.p, l3.rows, l3.cols, l3.ld, up[1].idx, up[1].stride(), feats[1].p, feats[1].cols,
                                   feats[1].ld, lv[1].n, c2.p, c2.ld, r.st));
     ENG_CHECK(linear(r, "decoder.decoder2.mlp", c2, dec));
   }

@@ -34,6 +34,19 @@ class TensorView(ctypes.Structure):
                 ('dtype', ctypes.c_int)]
 
 
+class DataDict(ctypes.Structure):
+    """rdm_data_dict (include/rdmnet_hip.h): the reference's data_dict as device pointers."""
+    _fields_ = [('features', ctypes.c_void_p), ('features_ld', ctypes.c_int64),
+                ('points', ctypes.c_void_p * 5), ('lengths', ctypes.c_void_p * 5),
+                ('n_points', ctypes.c_int64 * 5), ('n_ref', ctypes.c_int64 * 5),
+                ('neighbors', ctypes.c_void_p * 5), ('neighbors_width', ctypes.c_int64 * 5),
+                ('neighbors_ld', ctypes.c_int64 * 5), ('neighbors_count', ctypes.c_void_p * 5),
+                ('subsampling', ctypes.c_void_p * 4), ('subsampling_width', ctypes.c_int64 * 4),
+                ('subsampling_ld', ctypes.c_int64 * 4), ('subsampling_count', ctypes.c_void_p * 4),
+                ('upsampling', ctypes.c_void_p * 4), ('upsampling_width', ctypes.c_int64 * 4),
+                ('upsampling_ld', ctypes.c_int64 * 4), ('upsampling_count', ctypes.c_void_p * 4)]
+
+
 class KpconvProfile(ctypes.Structure):
     _fields_ = [('m', ctypes.c_int64), ('h', ctypes.c_int64), ('c_in', ctypes.c_int64), ('c_out', ctypes.c_int64),
                 ('pooled_channels', ctypes.c_int64), ('gather_ms', ctypes.c_float), ('total_ms', ctypes.c_float)]
@@ -127,6 +140,64 @@ class Engine:
         _lib.check(self.L.rdm_engine_run(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
                                          src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()),
                    'rdm_engine_run')
+        return self.result
+
+    def forward(self, data_dict):
+        """RDMNet.forward(data_dict) as ONE native call (rdm_engine_forward).  data_dict: the collate's dictionary
+        (rdmnet_amd.collate or the reference's registration_collate_fn_stack_mode moved to this engine's device).
+        Returns the EngineResult; stage tensors through tensor() when keep_taps is on.  One host synchronisation
+        here (the ref/src split of the five levels) besides the engine's own."""
+        dev = self.device
+        keep = []  # tensors that must outlive the call
+
+        def dev_t(t, dtype):
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(t)
+            if t.device != dev or t.dtype != dtype:
+                t = t.to(device=dev, dtype=dtype)
+            keep.append(t)
+            return t
+
+        def table(t):
+            t = dev_t(t, torch.int64)
+            if t.dim() != 2 or t.stride(1) != 1 or t.shape[1] == 0:
+                t = t.contiguous()
+                keep.append(t)
+            return t
+
+        d = DataDict()
+        lengths = [dev_t(x, torch.int64).contiguous() for x in data_dict['lengths']]
+        keep.extend(lengths)
+        cflags = data_dict.get('_flags')  # status words of this library's collate (13 radius searches), if it built the dict
+        head = torch.stack([x[0] for x in lengths])
+        if cflags is not None:
+            head = torch.cat([head, cflags[:, 1].to(torch.int64)])
+        head = head.cpu().tolist()  # the one synchronisation of this wrapper
+        n_ref = head[:5]
+        if any(head[5:]):
+            raise RuntimeError('radius search: a query of the collate exceeded the kernel capacity (neighbour tables are '
+                               'incomplete); the reference returns every neighbour')
+        widths = data_dict.get('_widths', {})
+        feats = dev_t(data_dict['features'], torch.float32)
+        if feats.dim() != 2 or feats.stride(1) != 1:
+            feats = feats.reshape(feats.shape[0], -1).contiguous()
+            keep.append(feats)
+        d.features, d.features_ld = feats.data_ptr(), feats.stride(0) if feats.shape[0] > 1 else feats.shape[1]
+        for i in range(5):
+            p = dev_t(data_dict['points'][i], torch.float32).contiguous()
+            keep.append(p)
+            d.points[i], d.lengths[i], d.n_points[i], d.n_ref[i] = p.data_ptr(), lengths[i].data_ptr(), p.shape[0], int(n_ref[i])
+            for key, arr_i in (('neighbors', i), ('subsampling', i), ('upsampling', i)):
+                if key != 'neighbors' and i == 4:
+                    continue
+                t = table(data_dict[key][i])
+                getattr(d, key)[i] = t.data_ptr()
+                getattr(d, key + '_width')[i] = t.shape[1]
+                getattr(d, key + '_ld')[i] = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+                w = widths.get((key, i))
+                getattr(d, key + '_count')[i] = w.data_ptr() if w is not None else None
+        _lib.check(self.L.rdm_engine_forward(self._h, ctypes.byref(d), ctypes.byref(self.result), _lib.stream_ptr()),
+                   'rdm_engine_forward')
         return self.result
 
     def transform(self):

@@ -23,50 +23,67 @@ def _dev_linear(w, b, device):
     return bt.to(device), torch.from_numpy(np.ascontiguousarray(b)).to(device), in_f, out_f
 
 
-class RDMNet:
+class _Node(torch.nn.Module):
+    """A name in the reference's module tree: holds parameters / buffers and child nodes, nothing else."""
+
+
+class RDMNet(torch.nn.Module):
+    """A torch.nn.Module like the reference's (experiments/model_infer.py:26-107): `.cuda() / .to() / .eval()`,
+    `.parameters()`, `.state_dict()` with the reference's 497 keys in the reference's order, strict
+    `load_state_dict`, wrappable by DistributedDataParallel as geotransformer/engine/base_tester.py:113 does.  The
+    parameter tree is built from rdmnet_amd.weights.schema (generic container nodes: the arithmetic is not torch's);
+    `kernel_points` are buffers, as in modules/kpconv/kpconv.py:64-65."""
+
     def __init__(self, cfg, device=None):
+        super().__init__()
         self.cfg = cfg
-        self.device = torch.device(device) if device is not None else None
-        self.training = False
         self._schema = weights.schema(cfg)
-        self._state = None   # name -> numpy float32
-        self._w = None       # prepared device tensors
+        init = weights.synthetic_state_dict(cfg, seed=0)  # the reference initialises randomly too; a checkpoint follows
+        for key, shape in self._schema.items():
+            node, parts = self, key.split('.')
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            value = torch.from_numpy(np.ascontiguousarray(init[key], dtype=np.float32)).reshape(tuple(shape))
+            if parts[-1] == 'kernel_points':
+                node.register_buffer(parts[-1], value)
+            else:
+                node.register_parameter(parts[-1], torch.nn.Parameter(value, requires_grad=False))
+        self._w = None        # prepared device tensors of the per-op path
+        self._np_state = None  # name -> numpy float32 (what the kernels' weight preparation reads)
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
         self.attention_bf16 = bool(getattr(cfg.thdroformer, 'attention_bf16', False))
-        self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py)
+        self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py); .engine
+        self.fast_path = True          # forward(data_dict) as one native call; False = the per-op mirror
+        self.device = None
+        if device is not None:
+            self.to(device)
 
-    # ------------------------------------------------------------------ nn.Module-like surface
-    def cuda(self, device=None):
-        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
-        self._w = None
-        return self
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _apply(self, fn, *args, **kwargs):  # .cuda() / .to() / .float(): parameters moved -> prepared copies are stale
+        out = super()._apply(fn, *args, **kwargs)
+        self._w = self._np_state = None
+        p = next(self.parameters())
+        self.device = p.device if p.is_cuda else None
+        return out
 
-    def eval(self):
-        self.training = False
-        return self
+    def load_state_dict(self, state, strict=True, **kwargs):
+        """torch's loader (missing / unexpected keys and size mismatches raise RuntimeError when strict, like
+        base_tester.py:97-107 expects); numpy arrays are accepted as values."""
+        state = OrderedDict((k, torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v) for k, v in state.items())
+        out = super().load_state_dict(state, strict=strict, **kwargs)
+        self._w = self._np_state = None
+        return out
 
-    def state_dict(self):
-        if self._state is None:
-            self._state = weights.synthetic_state_dict(self.cfg, seed=0)
-        return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in self._state.items())
-
-    def load_state_dict(self, state, strict=True):
-        new = OrderedDict()
-        missing = [k for k in self._schema if k not in state]
-        unexpected = [k for k in state if k not in self._schema]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f'Error(s) in loading state_dict: missing {missing[:5]} unexpected {unexpected[:5]}')
-        for k, shape in self._schema.items():
-            if k not in state:
-                continue
-            v = state[k]
-            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-            if tuple(v.shape) != tuple(shape):
-                raise RuntimeError(f'size mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}')
-            new[k] = np.ascontiguousarray(v, dtype=np.float32)
-        self._state = new
-        self._w = None
-        return self
+    @property
+    def _state(self):
+        if self._np_state is None:
+            sd = self.state_dict()
+            # (np.array keeps 0-d entries 0-d -- optimal_transport.alpha -- which np.ascontiguousarray would not)
+            self._np_state = OrderedDict((k, np.array(sd[k].detach().cpu().numpy(), dtype=np.float32, order='C'))
+                                         for k in self._schema)
+        return self._np_state
 
     def set_thread_profile(self, records):
         """Per-thread list that receives one HIP-event record per KPConv layer (None disables)."""
@@ -78,8 +95,6 @@ class RDMNet:
             return self._w
         if self.device is None:
             self.cuda()
-        if self._state is None:
-            self.state_dict()
         S, dev, W = self._state, self.device, {}
 
         def lin(name):
@@ -176,7 +191,7 @@ class RDMNet:
         # leaky_relu(unary2(y) + shortcut): the add and the activation ride on unary2's GroupNorm apply
         return self._unary(name + '.unary2', y, act=ACT_LEAKY, residual=sc)
 
-    def encoder(self, data, taps=None):
+    def run_encoder(self, data, taps=None):
         """experiments/backbone.py:72-107."""
         cfg = self.cfg
         P, x = data['points'], data['features']
@@ -199,7 +214,7 @@ class RDMNet:
                 feats.append(x)
         return feats
 
-    def decoder(self, feats, data):
+    def run_decoder(self, feats, data):
         """experiments/backbone.py:118-151."""
         up = data['upsampling']
         l4 = self._unary('decoder.decoder4', ops.upsample_concat(feats[4], up[3], feats[3]))
@@ -269,10 +284,67 @@ class RDMNet:
         return out
 
     # ------------------------------------------------------------------ forward
+    def _engine(self):
+        """The native engine of the calling thread (an engine is not re-entrant; bench.py drives one forward per
+        host thread and stream), built from this module's state dict on first use."""
+        from . import engine as engine_mod
+        eng = getattr(self._tls, 'engine', None)
+        if eng is None or getattr(self._tls, 'engine_state', None) is not self._state:
+            if self.device is None:
+                self.cuda()
+            with torch.cuda.device(self.device):
+                eng = engine_mod.Engine(self.cfg, self._state, device=self.device)
+            eng.keep_taps(True)
+            self._tls.engine, self._tls.engine_state = eng, self._state
+        return eng
+
     @torch.no_grad()
     def forward(self, data_dict, taps=None):
         """experiments/model_infer.py:109-354 (inference).  `data_dict` as produced by the collate
-        (rdmnet_amd.collate or the reference's), tensors on the GPU."""
+        (rdmnet_amd.collate or the reference's), tensors on the GPU; returns the reference's 31-key output_dict.
+
+        Two host paths over the same kernels, bit-identical results (tests/test_engine_gpu.py): by default the whole
+        forward is ONE native call (rdm_engine_forward issues the ~550 launches from C++); with a `taps` dictionary
+        the per-op mirror below runs instead and records the stage tensors the parity tests compare."""
+        if taps is None and self.fast_path:
+            return self._forward_native(data_dict)
+        return self._forward_per_op(data_dict, taps)
+
+    def _forward_native(self, data_dict):
+        eng = self._engine()
+        res = eng.forward(data_dict)
+        cfg, k_pts = self.cfg, self.cfg.model.num_points_in_patch
+        n_c, n_f, n_0 = (int(res.level_ref_sizes[i]) for i in (4, 1, 0))
+        m_r, B = int(res.n_ref_nodes), int(res.n_node_correspondences)
+        pts_c, pts_f, pts = data_dict['points'][-1], data_dict['points'][1], data_dict['points'][0]
+        out = dict(ori_ref_points_c=pts_c[:n_c], ori_src_points_c=pts_c[n_c:], ref_points_f=pts_f[:n_f],
+                   src_points_f=pts_f[n_f:], ref_points=pts[:n_0], src_points=pts[n_0:])
+        p2p, dec = eng.tensor('p2p_scores')[:, 0], eng.tensor('decoder')
+        out.update(ref_p2p_scores_c=p2p[:n_f], src_p2p_scores_c=p2p[n_f:])
+        nodes, fn = eng.tensor('nodes'), eng.tensor('feats_c')
+        if self.use_vote:
+            shifted, sc = eng.tensor('vote_xyz'), eng.tensor('node_scores')
+            out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:],
+                       ref_n2p_scores_c=sc[:m_r, 0], src_n2p_scores_c=sc[m_r:, 0],
+                       ref_n2n_scores_c=sc[:m_r, 1], src_n2n_scores_c=sc[m_r:, 1])
+        else:
+            n2p = eng.tensor('n2p_scores')[:, 0]
+            out.update(ref_n2p_scores_c=n2p[:n_c], src_n2p_scores_c=n2p[n_c:])
+        out.update(ref_points_c=nodes[:m_r], src_points_c=nodes[m_r:], ref_feats_c=fn[:m_r], src_feats_c=fn[m_r:],
+                   ref_feats_f=dec[:n_f, :cfg.backbone.output_dim], src_feats_f=dec[n_f:, :cfg.backbone.output_dim],
+                   ref_node_corr_indices=eng.tensor('ref_node_corr_indices')[:, 0],
+                   src_node_corr_indices=eng.tensor('src_node_corr_indices')[:, 0],
+                   ref_node_corr_knn_points=eng.tensor('ref_node_corr_knn_points').reshape(B, k_pts, 3),
+                   src_node_corr_knn_points=eng.tensor('src_node_corr_knn_points').reshape(B, k_pts, 3),
+                   ref_node_corr_knn_masks=eng.tensor('ref_node_corr_knn_masks').bool(),
+                   src_node_corr_knn_masks=eng.tensor('src_node_corr_knn_masks').bool(),
+                   matching_scores=eng.tensor('matching_scores').reshape(B, k_pts + 1, k_pts + 1))
+        rc, sc_, cs = eng.corr()
+        out.update(ref_corr_points=rc, src_corr_points=sc_, corr_scores=cs, estimated_transform=eng.tensor('estimated_transform'))
+        return out
+
+    @torch.no_grad()
+    def _forward_per_op(self, data_dict, taps=None):
         W, cfg, dev = self._prepare(), self.cfg, self.device
         t = cfg.thdroformer
         taps = taps if taps is not None else {}
@@ -285,7 +357,7 @@ class RDMNet:
         out.update(ori_ref_points_c=pts_c[:n_c], ori_src_points_c=pts_c[n_c:], ref_points_f=pts_f[:n_f],
                    src_points_f=pts_f[n_f:], ref_points=pts[:n_0], src_points=pts[n_0:])
 
-        feats = self.encoder(data_dict, taps)
+        feats = self.run_encoder(data_dict, taps)
         f_c = feats[-1]
         taps['feats_c_enc'] = f_c
 
@@ -299,7 +371,7 @@ class RDMNet:
         n2p = ops.sigmoid_column(buf_c[:, t.output_dim:])
 
         feats[-1] = buf_c
-        dec = self.decoder(feats, data_dict)
+        dec = self.run_decoder(feats, data_dict)
         taps['decoder'] = dec
         feats_f = dec[:, :cfg.backbone.output_dim]
         p2p = ops.sigmoid_column(dec[:, cfg.backbone.output_dim:])
@@ -410,8 +482,6 @@ class RDMNet:
         if key not in self._w:
             self._w[key] = torch.full((rows,), float(c) ** 0.5, dtype=torch.float32, device=self.device)
         return self._w[key]
-
-    __call__ = forward
 
 
 def create_model(cfg):

@@ -26,16 +26,16 @@ def run_bench(*args, env_extra=None, timeout=900):
 
 def test_two_ranks_self_spawned_on_one_device():
     r = run_bench('--gpus', '2', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--streams', '2', '--pairs', '4',
-                  '--host-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
+                  '--host-steps', '4', '--api-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
     assert r['n_gpus'] == 2 and r['steps'] == 8 and r['scaling'] == 'weak' and r['unit'] == 'pairs/s'
     assert r['records'] == {'gathered': 16, 'distinct_steps': 16, 'distinct_pairs': 4}
     assert r['registration']['pairs'] == 16
     assert r['value'] > 0 and abs(r['value'] - 16 / (r['ms_per_step'] * 8 / 1e3)) < 1e-6 * r['value']
-    assert r['host_to_host']['value'] > 0 and r['cpu_baseline'] is None
+    assert r['host_to_host']['value'] > 0 and r['drop_in_api']['value'] > 0 and r['cpu_baseline'] is None
 
 
 def test_single_rank_line_has_the_contract_fields():
-    r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--no-cpu-baseline')
+    r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--api-steps', '8', '--no-cpu-baseline')
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in r, key

@@ -45,7 +45,7 @@ def test_encoder_blocks_match_oracle(setup):
     ofw, cfg, W, net, data = setup
     otaps, gtaps = {}, {}
     ofeats = ofw.encoder(W, cfg, data, otaps)
-    gfeats = net.encoder(to_cuda(data), gtaps)
+    gfeats = net.run_encoder(to_cuda(data), gtaps)
     for name in otaps:
         err = rel_err(gtaps[name].cpu(), otaps[name])
         assert err <= 5e-5, (name, err)  # fp32, different summation orders; grows slowly with depth
@@ -58,5 +58,5 @@ def test_encoder_blocks_match_oracle(setup):
     buf.copy_(torch.cat([gfeats[4][:, :256], torch.zeros(gfeats[4].shape[0], 1, device='cuda')], 1))
     gf[4] = buf
     dec_o = ofw.decoder(W, cfg, of, data)
-    dec_g = net.decoder(gf, to_cuda(data))
+    dec_g = net.run_decoder(gf, to_cuda(data))
     assert rel_err(dec_g.cpu(), dec_o) <= 5e-5

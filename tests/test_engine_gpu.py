@@ -93,8 +93,8 @@ def test_full_size_pair_properties(ctx, golden_dir):
     valid = nb < p0.shape[0]
     both = valid[:, 1:] & valid[:, :-1]
     assert bool((d[:, 1:][both] >= d[:, :-1][both]).all()) and bool((nb[:, 0] == torch.arange(p0.shape[0])).all())
-    # per-op mirror, same inputs
-    out = net(ctx['collate'].collate_pair(ref, src, cfg))
+    # per-op mirror, same inputs (a taps dictionary selects it; without one forward() is the native call)
+    out = net(ctx['collate'].collate_pair(ref, src, cfg), {})
     assert np.array_equal(T, out['estimated_transform'].cpu().numpy())
     assert torch.equal(rc, out['ref_corr_points']) and torch.equal(cs, out['corr_scores'])
     # run-to-run
@@ -181,3 +181,54 @@ def test_engines_are_reentrant_across_threads_and_streams(ctx):
     for res in out:
         for T, n in res:
             assert n == ref_n and np.array_equal(T, ref_T)
+
+
+@pytest.mark.parametrize('exact_shapes', [False, True])
+def test_model_forward_is_the_native_call_and_equals_engine_and_per_op_paths(ctx, golden_dir, exact_shapes):
+    """The drop-in operator: model(data_dict) (experiments/model_infer.py:109-354) runs rdm_engine_forward on the
+    collate's tables -- every one of the reference's 31 output keys equals the per-op mirror's bit for bit, and the pose /
+    correspondences equal rdm_engine_run's (which builds the same tables itself).  exact_shapes=True hands over index
+    tensors sliced to the reference's exact widths (non-contiguous views, as the reference's radius_search returns)."""
+    cfg, net, eng = ctx['cfg'], ctx['net'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    for ref, src in ((ctx['rp'], ctx['sp']), (z['ref1'], z['src1'])):
+        data = ctx['collate'].collate_pair(ref, src, cfg, exact_shapes=exact_shapes)
+        if exact_shapes:
+            assert not data['neighbors'][0].is_contiguous() or data['neighbors'][0].shape[1] == cfg.neighbor_limits[0]
+        out = net(data)
+        ref_out = net(data, {})
+        assert set(out.keys()) == set(ref_out.keys()) and len(out) == 31
+        for k in out:
+            assert out[k].dtype == ref_out[k].dtype and out[k].shape == ref_out[k].shape, k
+            assert torch.equal(out[k], ref_out[k]), k
+        eng.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
+        assert np.array_equal(eng.transform(), out['estimated_transform'].cpu().numpy())
+        rc, sc, cs = eng.corr()
+        assert torch.equal(rc, out['ref_corr_points']) and torch.equal(cs, out['corr_scores'])
+
+
+def test_model_is_a_torch_module_with_the_reference_checkpoint_layout(ctx):
+    """nn.Module surface the reference's harness uses (engine/base_tester.py:97-113): strict load_state_dict with the 497
+    checkpoint keys, .parameters(), .to(), .eval(); a wrong shape or a missing key raises RuntimeError."""
+    from rdmnet_amd import model, weights
+    cfg = ctx['cfg']
+    net = model.create_model(cfg)
+    assert isinstance(net, torch.nn.Module) and not net.training or net.eval() is net
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(weights.schema(cfg).keys()) and len(sd) == 497
+    n_par, n_buf = sum(p.numel() for p in net.parameters()), sum(b.numel() for b in net.buffers())
+    assert n_buf == 14 * 15 * 3 and n_par + n_buf == sum(int(np.prod(s)) for s in weights.schema(cfg).values())
+    assert not any(p.requires_grad for p in net.parameters())  # inference module
+    assert net.load_state_dict(ctx['state'], strict=True) is not None
+    bad = dict(ctx['state'])
+    bad.pop('optimal_transport.alpha')
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)
+    bad = dict(ctx['state'])
+    bad['proj_n2p_score.weight'] = np.zeros((2, 256), np.float32)
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(bad, strict=True)
+    net = net.to('cuda').eval()
+    assert next(net.parameters()).is_cuda and net.device.type == 'cuda'
+    out = net(ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], cfg))
+    assert out['estimated_transform'].shape == (4, 4)
