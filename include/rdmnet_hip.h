@@ -60,7 +60,9 @@ int rdm_grid_subsample(const float* points, int64_t n_points, const int64_t* len
  *   out_idx    [n_q, width] i64 (row stride = width); may be NULL when width == 0 (count-only pass)
  *   out_counts [n_q] i32 untruncated neighbour counts (may be NULL)
  *   out_max    [1] i32, atomically max-ed with the largest count (may be NULL; zero it first)
- *   status     [1] i32, set non-zero if a query had more neighbours than the kernel's capacity
+ *   status     [1] i32, non-zero on an internal error (2: the grid was built for a smaller radius).  There is no
+ *              neighbour-count limit: rows beyond the kernels' 1024-key buffer are produced in rounds of a radix
+ *              select over the (d2, index) keys, like the reference (radius_neighbors_cpu.cpp:36-64) returns them all
  * The reference's output width is max(count); call once with width = 0 to obtain it, or pass the
  * neighbour limit directly (the first min(limit, max) columns are identical).                  */
 size_t rdm_radius_neighbors_workspace_bytes(int64_t n_q, int64_t n_s, int batch);
@@ -409,6 +411,11 @@ int rdm_engine_enable_profile(rdm_engine* e, int enable);
 int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);
 int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor_view* out);
+/* Copies n stage tensors of the last run into caller buffers (dst[i]: rows * ld * element size bytes of names[i]) with
+ * one batched launch: how model(data_dict) fills the reference's output_dict (model_infer.py:133-334).           */
+int rdm_engine_export(rdm_engine* e, int n, const char* const* names, void* const* dst, void* stream);
+/* rdm_engine_get_tensor for n names at once (out[n]). */
+int rdm_engine_describe(rdm_engine* e, int n, const char* const* names, rdm_tensor_view* out);
 /* Plain device-to-device copy on `stream` (lets a host without a HIP binding read arena tensors). */
 int rdm_copy_device(void* dst, const void* src, size_t bytes, void* stream);
 

@@ -98,6 +98,8 @@ SIGNATURES = {
     'rdm_engine_get_profile': (c_int, [c_void, c_void, c_int]),
     'rdm_engine_keep_taps': (c_int, [c_void, c_int]),
     'rdm_engine_get_tensor': (c_int, [c_void, ctypes.c_char_p, c_void]),
+    'rdm_engine_describe': (c_int, [c_void, c_int, c_void, c_void]),
+    'rdm_engine_export': (c_int, [c_void, c_int, c_void, c_void, c_void]),
     'rdm_copy_device': (c_int, [c_void, c_void, c_size, c_void]),
 }
 

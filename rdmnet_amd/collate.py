@@ -55,7 +55,7 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
     if exact_shapes:
         fl = flags.cpu()
         if int(fl[:, 1].max()) != 0:
-            raise RuntimeError('radius search: a query exceeded the kernel capacity of 1024 neighbours')
+            raise RuntimeError('radius search: internal error (status word set)')
         call = 0
         for i in range(num_stages):
             neighbors[i] = neighbors[i][:, :min(neighbor_limits[i], int(fl[call, 0]))]

@@ -957,7 +957,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
     for (int i = 0; i < 2 * call; i += 2)
       if (host_flags[i + 1] != 0) {
-        set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
+        set_error("rdm_engine_run: a radius search failed (status %d: 2 = grid built for a smaller radius)", host_flags[i + 1]);
         return RDM_ERR_CAPACITY;
       }
     m_r = host_flags[60]; m_s = host_flags[61]; Mn = m_r + m_s;
@@ -995,7 +995,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
     for (int i = 0; i < 2 * call; i += 2)
       if (host_flags[i + 1] != 0) {
-        set_error("rdm_engine_run: a radius query exceeded the kernel capacity of 1024 neighbours (status %d)", host_flags[i + 1]);
+        set_error("rdm_engine_run: a radius search failed (status %d: 2 = grid built for a smaller radius)", host_flags[i + 1]);
         return RDM_ERR_CAPACITY;
       }
     m_r = nc_ref; m_s = Nc - nc_ref; Mn = Nc;
@@ -1132,6 +1132,84 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   tap(r, "corr_scores", cs, res->n_correspondences, 1, 1, 0);
   tap(r, "estimated_transform", T, 4, 4, 4, 0);
   return RDM_OK;
+}
+
+namespace {
+// up to 24 device-to-device copies in one launch (the output_dict of a forward): workgroup -> (item, 4 KB chunk)
+struct CopyBatch {
+  const uint32_t* src[24];
+  uint32_t* dst[24];
+  int first_block[25];  // prefix of 1024-word chunks
+  int words[24];
+  int n;
+};
+__global__ __launch_bounds__(256) void copy_multi_kernel(CopyBatch b) {
+  int it = 0;
+  for (int k = 1; k < b.n; ++k) it += static_cast<int>(blockIdx.x) >= b.first_block[k] ? 1 : 0;
+  const int base = (blockIdx.x - b.first_block[it]) * 1024;
+  const uint32_t* s = b.src[it];
+  uint32_t* d = b.dst[it];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = base + u * 256 + threadIdx.x;
+    if (i < b.words[it]) d[i] = s[i];
+  }
+}
+}  // namespace
+
+extern "C" int rdm_engine_describe(rdm_engine* e, int n, const char* const* names, rdm_tensor_view* out) {
+  RDM_REQUIRE(e && names && out && n >= 0, "rdm_engine_describe: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    auto it = e->taps.find(names[i]);
+    if (it == e->taps.end()) {
+      set_error("rdm_engine_describe: no tensor named %s (call rdm_engine_keep_taps first)", names[i]);
+      return RDM_ERR_ARG;
+    }
+    out[i] = it->second;
+  }
+  return RDM_OK;
+}
+
+// Copies `n` stage tensors of the last run (rdm_engine_keep_taps) into caller buffers with as few launches as possible.
+// dst[i] must hold rows * ld * element size bytes of tensor names[i] (as rdm_engine_get_tensor reports them).
+extern "C" int rdm_engine_export(rdm_engine* e, int n, const char* const* names, void* const* dst, void* stream) {
+  RDM_REQUIRE(e && names && dst && n >= 0, "rdm_engine_export: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CopyBatch b;
+  b.n = 0;
+  b.first_block[0] = 0;
+  auto flush = [&]() -> int {
+    if (b.n > 0 && b.first_block[b.n] > 0) {
+      hipLaunchKernelGGL(copy_multi_kernel, dim3(static_cast<unsigned>(b.first_block[b.n])), dim3(256), 0, st, b);
+      if (int rc = launch_status("copy_multi_kernel")) return rc;
+    }
+    b.n = 0;
+    b.first_block[0] = 0;
+    return RDM_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    auto it = e->taps.find(names[i]);
+    if (it == e->taps.end()) {
+      set_error("rdm_engine_export: no tensor named %s (call rdm_engine_keep_taps first)", names[i]);
+      return RDM_ERR_ARG;
+    }
+    const rdm_tensor_view& v = it->second;
+    const size_t esz = v.dtype == 1 ? 8 : (v.dtype == 2 ? 1 : 4);
+    const size_t bytes = static_cast<size_t>(v.rows) * v.ld * esz;
+    if (bytes == 0) continue;
+    RDM_REQUIRE(dst[i], "rdm_engine_export: null destination for %s", names[i]);
+    if (bytes % 4 != 0 || bytes / 4 > (size_t(1) << 30) || (reinterpret_cast<uintptr_t>(v.data) & 3) ||
+        (reinterpret_cast<uintptr_t>(dst[i]) & 3)) {  // odd byte counts (mask tensors): the runtime's copy
+      RDM_HIP_CHECK(hipMemcpyAsync(dst[i], v.data, bytes, hipMemcpyDeviceToDevice, st));
+      continue;
+    }
+    b.src[b.n] = static_cast<const uint32_t*>(v.data);
+    b.dst[b.n] = static_cast<uint32_t*>(dst[i]);
+    b.words[b.n] = static_cast<int>(bytes / 4);
+    b.first_block[b.n + 1] = b.first_block[b.n] + static_cast<int>((bytes / 4 + 1023) / 1024);
+    if (++b.n == 24) ENG_CHECK(flush());
+  }
+  return flush();
 }
 
 extern "C" int rdm_copy_device(void* dst, const void* src, size_t bytes, void* stream) {

@@ -219,9 +219,174 @@ struct RnQueryArgs {
   int32_t* status;
   unsigned char* redo;
 };
+// Bitonic sort of K[0, n) (n <= 1024, ascending) by one wavefront; K must hold the next power of two of n entries.
+__device__ __forceinline__ void rn_sort_keys(unsigned long long* K, int n, int lane) {
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // every stage reads all of its pairs, then writes them (plain LDS accesses batched by the compiler; wavefront-scope
+  // fences order the stages)
+  for (int k = 2; k <= p2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long lo[8], hi[8];
+      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j (bit form below)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
+          lo[u] = K[i];
+          hi[u] = K[i + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = lane + 64 * u;
+        if (t < pairs) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const bool up = (i & k) == 0;
+          if ((lo[u] > hi[u]) == up) {
+            K[i] = hi[u];
+            K[i + j] = lo[u];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Walks the candidates of a query (the points of its 27 cells, `total` of them) 128 per step and calls
+// f(hit, key) for both candidates of every lane -- uniformly, so that f may use wave ballots.
+template <typename F>
+__device__ __forceinline__ void rn_scan_candidates(const float4* sorted, const int* seg_start_w, const int* seg_pref_w, int total,
+                                                   float qx, float qy, float qz, float r2, int lane, F&& f) {
+  for (int base = 0; base < total; base += 128) {
+    float4 p[2];
+    int tt[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      tt[u] = base + 64 * u + lane;
+      if (tt[u] < total) {
+        int seg = 0;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+          if (seg + step < 27 && seg_pref_w[seg + step] <= tt[u]) seg += step;
+        p[u] = sorted[seg_start_w[seg] + (tt[u] - seg_pref_w[seg])];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bool hit = false;
+      unsigned long long key = 0;
+      if (tt[u] < total) {
+        const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+        float d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        hit = d2 < r2;
+        key = (static_cast<unsigned long long>(__float_as_uint(d2)) << 32) | static_cast<unsigned>(__float_as_int(p[u].w));
+      }
+      f(hit, key);
+    }
+  }
+}
+
+// A neighbourhood with more hits than the 1024-key buffer (the reference has no such limit:
+// radius_neighbors_cpu.cpp:36-64 returns every neighbour).  The row is produced in rounds of at most 1024 columns: a
+// radix select over the 64-bit (d2, index) keys -- 8-bit digits, one rescan of the candidates per digit, stopping as soon as
+// the keys up to the current prefix fit the buffer -- finds the next batch of smallest keys, which is collected, sorted
+// and written; the next round continues above the last key written.  Keys are unique (the index is part of the key).
+// K: 1024 keys, hist: 256 ints, both private to the wavefront.
+__device__ __forceinline__ void rn_dense_row(const RnQueryArgs& a, int64_t qi, int lane, unsigned long long* K, int* hist,
+                                             const int* seg_start_w, const int* seg_pref_w, int total, int count, float qx,
+                                             float qy, float qz, float r2) {
+  const int out_n = count < a.width ? count : a.width;
+  int64_t* row = a.out_idx + qi * static_cast<int64_t>(a.width);
+  unsigned long long lower = 0;  // keys <= lower are already written (valid once emitted > 0)
+  int emitted = 0;
+  while (emitted < out_n) {
+    const int want = out_n - emitted < 1024 ? out_n - emitted : 1024;
+    const bool have_lower = emitted > 0;
+    unsigned long long prefix = 0, upper = 0;
+    int below = 0, n = 0;
+    for (int shift = 56;; shift -= 8) {
+      for (int i = lane; i < 256; i += 64) hist[i] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      rn_scan_candidates(a.sorted, seg_start_w, seg_pref_w, total, qx, qy, qz, r2, lane, [&](bool hit, unsigned long long key) {
+        const bool in_prefix = shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+        if (hit && in_prefix && (!have_lower || key > lower)) atomicAdd(&hist[static_cast<int>(key >> shift) & 255], 1);
+      });
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // the digit whose bin holds the want-th remaining key: lane l owns bins 4l .. 4l+3
+      int h[4], sum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = hist[4 * lane + j];
+        sum += h[j];
+      }
+      int inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      const int target = want - below;  // >= 1, and the bins hold at least that many keys
+      const unsigned long long owner = __ballot(inc - sum < target && target <= inc);
+      const int src = __builtin_ctzll(owner);
+      int digit = 0, before = inc - sum, in_bin = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (in_bin == 0) {
+          if (before + h[j] >= target) {
+            digit = 4 * lane + j;
+            in_bin = h[j];
+          } else {
+            before += h[j];
+          }
+        }
+      }
+      digit = __shfl(digit, src, 64);
+      before = __shfl(before, src, 64);
+      in_bin = __shfl(in_bin, src, 64);
+      below += before;
+      prefix |= static_cast<unsigned long long>(digit) << shift;
+      if (below + in_bin <= 1024 || shift == 0) {
+        upper = shift == 0 ? prefix : (prefix | ((1ull << shift) - 1ull));
+        n = below + in_bin;
+        break;
+      }
+    }
+    // collect the keys in (lower, upper], sort, write
+    int cnt = 0;
+    rn_scan_candidates(a.sorted, seg_start_w, seg_pref_w, total, qx, qy, qz, r2, lane, [&](bool hit, unsigned long long key) {
+      const bool take = hit && key <= upper && (!have_lower || key > lower);
+      const unsigned long long m = __ballot(take);
+      if (take) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < 1024) K[pos] = key;
+      }
+      cnt += __popcll(m);
+    });
+    n = cnt < 1024 ? cnt : 1024;  // (= below + in_bin)
+    rn_sort_keys(K, n, lane);
+    const int m = n < out_n - emitted ? n : out_n - emitted;
+    for (int c = lane; c < m; c += 64) row[emitted + c] = static_cast<int64_t>(K[c] & 0xffffffffull);
+    lower = K[m - 1];
+    emitted += m;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // K is rewritten by the next round
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int c = out_n + lane; c < a.width; c += 64) row[c] = a.ns;
+}
+
 template <int CAP>
 __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, int lane, unsigned long long* K, int* seg_start_w,
-                                             int* seg_pref_w, int only_redo) {
+                                             int* seg_pref_w, int only_redo, int* hist = nullptr) {
   const float* q = a.q;
   const int64_t ns = a.ns;
   const int64_t* q_lengths = a.q_lengths;
@@ -248,7 +413,7 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
   int64_t begin;
   const int b = cloud_of(q_lengths, batch, qi, begin);
 
-  int count = 0;
+  int count = 0, total = 0;
   if (b < batch) {
     int cx, cy, cz;
     cell_of(g, qx, qy, qz, cx, cy, cz);
@@ -274,7 +439,7 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
       seg_start_w[lane] = my_start;
       seg_pref_w[lane] = inc - my_n;
     }
-    const int total = __shfl(inc, 26, 64);
+    total = __shfl(inc, 26, 64);
     if (lane == 27) seg_pref_w[27] = total;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -324,6 +489,10 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
     if (out_max && count > ld_agent(out_max)) atomicMax(out_max, count);
   }
   if (count > CAP) {  // the sorted prefix cannot be produced from a truncated buffer
+    if (CAP >= 1024 && hist != nullptr) {  // large-buffer pass: neighbourhoods beyond the buffer are produced in rounds
+      if (width > 0) rn_dense_row(a, qi, lane, K, hist, seg_start_w, seg_pref_w, total, count, qx, qy, qz, r2);
+      return;
+    }
     if (lane == 0) {
       if (only_redo || !redo) atomicExch(status, 1);
       else redo[qi] = 1;
@@ -366,43 +535,8 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
     for (int c = n + lane; c < width; c += 64) row[c] = ns;
     RN_PHASE(4);
     return;
-  } else {
-  int p2 = 1;
-  while (p2 < n) p2 <<= 1;
-  for (int i = n + lane; i < p2; i += 64) K[i] = ~0ull;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // bitonic sort of p2 keys by one wavefront: every stage reads all of its pairs, then writes them
-  // (plain LDS accesses batched by the compiler; wavefront-scope fences order the stages)
-  for (int k = 2; k <= p2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      unsigned long long lo[8], hi[8];
-      const int pairs = p2 >> 1;  // pair t -> i = 2*j*(t / j) + (t % j), partner i + j (bit form below)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = lane + 64 * u;
-        if (t < pairs) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // j is a power of two
-          lo[u] = K[i];
-          hi[u] = K[i + j];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = lane + 64 * u;
-        if (t < pairs) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const bool up = (i & k) == 0;
-          if ((lo[u] > hi[u]) == up) {
-            K[i] = hi[u];
-            K[i + j] = lo[u];
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
   }
+  rn_sort_keys(K, n, lane);
   // offset of this cloud's supports is already folded in (indices are global rows)
   int64_t* row = out_idx + qi * static_cast<int64_t>(width);
   for (int c = lane; c < width; c += 64)
@@ -416,11 +550,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_query_kernel(RnQueryAr
   __shared__ unsigned long long keys[kWavesPerBlock][CAP];
   __shared__ int seg_start[kWavesPerBlock][28];
   __shared__ int seg_pref[kWavesPerBlock][28];
+  __shared__ int hist[CAP >= 1024 ? kWavesPerBlock : 1][CAP >= 1024 ? 256 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t qi = blockIdx.x * static_cast<int64_t>(kWavesPerBlock) + wave;
   if (qi >= a.nq) return;  // whole wave exits together
   if (only_redo && !a.redo[qi]) return;  // second pass: only the queries that overflowed the small buffer
-  rn_query_one<CAP>(a, qi, lane, keys[wave], seg_start[wave], seg_pref[wave], only_redo);
+  rn_query_one<CAP>(a, qi, lane, keys[wave], seg_start[wave], seg_pref[wave], only_redo, CAP >= 1024 ? hist[wave] : nullptr);
 }
 
 // The second pass of SEVERAL searches in one launch (the engine defers it: 14 searches per scan pair, and a launch
@@ -450,6 +585,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_redo_multi_kernel(RnRe
   __shared__ unsigned long long keys[kWavesPerBlock][1024];
   __shared__ int seg_start[kWavesPerBlock][28];
   __shared__ int seg_pref[kWavesPerBlock][28];
+  __shared__ int hist[kWavesPerBlock][256];
   const RnQueryArgs& a = b.item[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
@@ -458,7 +594,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rn_redo_multi_kernel(RnRe
     while (todo) {
       const int k = __builtin_ctzll(todo);
       todo &= todo - 1;
-      rn_query_one<1024>(a, base + k, lane, keys[wave], seg_start[wave], seg_pref[wave], 1);
+      rn_query_one<1024>(a, base + k, lane, keys[wave], seg_start[wave], seg_pref[wave], 1, hist[wave]);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the LDS buffers are reused by the next query
       __builtin_amdgcn_wave_barrier();
     }

@@ -53,6 +53,7 @@ class KpconvProfile(ctypes.Structure):
 
 
 _DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
+_ESIZE = {0: 4, 1: 8, 2: 1}
 
 
 def make_config(cfg, arena_bytes=0):
@@ -101,6 +102,7 @@ class Engine:
                                                        len(shape)), 'rdm_engine_set_param')
             _lib.check(self.L.rdm_engine_finalize(self._h), 'rdm_engine_finalize')
         self.result = EngineResult()
+        self._export_cache = {}
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -175,8 +177,7 @@ class Engine:
         head = head.cpu().tolist()  # the one synchronisation of this wrapper
         n_ref = head[:5]
         if any(head[5:]):
-            raise RuntimeError('radius search: a query of the collate exceeded the kernel capacity (neighbour tables are '
-                               'incomplete); the reference returns every neighbour')
+            raise RuntimeError('radius search: a search of the collate reported an internal error (status word set)')
         widths = data_dict.get('_widths', {})
         feats = dev_t(data_dict['features'], torch.float32)
         if feats.dim() != 2 or feats.stride(1) != 1:
@@ -213,6 +214,30 @@ class Engine:
             _lib.check(self.L.rdm_copy_device(out.data_ptr(), v.data, out.numel() * out.element_size(), _lib.stream_ptr()),
                        'rdm_copy_device')
         return out[:, :v.cols]
+
+    def tensors(self, names):
+        """Copies of several stage tensors of the last run with one batched launch (rdm_engine_export): {name: tensor}.
+        All of them live in ONE allocation (strided views), so the call costs one torch.empty and one kernel."""
+        n = len(names)
+        key = tuple(names)
+        cached = self._export_cache.get(key)
+        if cached is None:
+            cached = self._export_cache[key] = ((ctypes.c_char_p * n)(*[x.encode() for x in names]), (TensorView * n)(),
+                                                (ctypes.c_void_p * n)())
+        arr_n, arr_v, arr_d = cached
+        _lib.check(self.L.rdm_engine_describe(self._h, n, arr_n, arr_v), 'rdm_engine_describe')
+        offs, total = [], 0
+        for v in arr_v:
+            offs.append(total)
+            total += (v.rows * v.ld * _ESIZE[v.dtype] + 15) // 16 * 16
+        buf = torch.empty((max(total, 16),), dtype=torch.uint8, device=self.device)
+        base = buf.data_ptr()
+        for i in range(n):
+            arr_d[i] = base + offs[i]
+        _lib.check(self.L.rdm_engine_export(self._h, n, arr_n, arr_d, _lib.stream_ptr()), 'rdm_engine_export')
+        typed = {0: buf.view(torch.float32), 1: buf.view(torch.int64), 2: buf}
+        return {names[i]: torch.as_strided(typed[v.dtype], (v.rows, v.cols), (v.ld, 1), offs[i] // _ESIZE[v.dtype])
+                for i, v in enumerate(arr_v)}
 
     def corr(self):
         """(ref_corr_points, src_corr_points, corr_scores) of the last run as fresh tensors."""

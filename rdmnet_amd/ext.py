@@ -105,6 +105,6 @@ def radius_neighbors(q_points, s_points, q_lengths, s_lengths, radius, *, width=
         out = torch.empty((nq, width), dtype=torch.int64, device=dev)
         if width > 0 and nq > 0:
             run(width, out)
-        if int(flags[1].item()) != 0:
-            raise RuntimeError('rdm_radius_neighbors: a query exceeded the kernel capacity of 1024 neighbours')
+        if int(flags[1].item()) != 0:  # (no neighbour-count limit: dense rows are produced in rounds; this is an internal error)
+            raise RuntimeError(f'rdm_radius_neighbors: status {int(flags[1].item())}')
     return out.cpu() if from_cpu else out

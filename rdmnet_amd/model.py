@@ -319,28 +319,31 @@ class RDMNet(torch.nn.Module):
         pts_c, pts_f, pts = data_dict['points'][-1], data_dict['points'][1], data_dict['points'][0]
         out = dict(ori_ref_points_c=pts_c[:n_c], ori_src_points_c=pts_c[n_c:], ref_points_f=pts_f[:n_f],
                    src_points_f=pts_f[n_f:], ref_points=pts[:n_0], src_points=pts[n_0:])
-        p2p, dec = eng.tensor('p2p_scores')[:, 0], eng.tensor('decoder')
+        names = ['p2p_scores', 'decoder', 'nodes', 'feats_c', 'ref_node_corr_indices', 'src_node_corr_indices',
+                 'ref_node_corr_knn_points', 'src_node_corr_knn_points', 'ref_node_corr_knn_masks',
+                 'src_node_corr_knn_masks', 'matching_scores', 'ref_corr_points', 'src_corr_points', 'corr_scores',
+                 'estimated_transform'] + (['vote_xyz', 'node_scores'] if self.use_vote else ['n2p_scores'])
+        t = eng.tensors(names)  # one allocation, one batched copy out of the engine's arena
+        p2p, dec, nodes, fn = t['p2p_scores'][:, 0], t['decoder'], t['nodes'], t['feats_c']
         out.update(ref_p2p_scores_c=p2p[:n_f], src_p2p_scores_c=p2p[n_f:])
-        nodes, fn = eng.tensor('nodes'), eng.tensor('feats_c')
         if self.use_vote:
-            shifted, sc = eng.tensor('vote_xyz'), eng.tensor('node_scores')
+            shifted, sc = t['vote_xyz'], t['node_scores']
             out.update(shifted_ref_points_c=shifted[:n_c], shifted_src_points_c=shifted[n_c:],
                        ref_n2p_scores_c=sc[:m_r, 0], src_n2p_scores_c=sc[m_r:, 0],
                        ref_n2n_scores_c=sc[:m_r, 1], src_n2n_scores_c=sc[m_r:, 1])
         else:
-            n2p = eng.tensor('n2p_scores')[:, 0]
+            n2p = t['n2p_scores'][:, 0]
             out.update(ref_n2p_scores_c=n2p[:n_c], src_n2p_scores_c=n2p[n_c:])
         out.update(ref_points_c=nodes[:m_r], src_points_c=nodes[m_r:], ref_feats_c=fn[:m_r], src_feats_c=fn[m_r:],
                    ref_feats_f=dec[:n_f, :cfg.backbone.output_dim], src_feats_f=dec[n_f:, :cfg.backbone.output_dim],
-                   ref_node_corr_indices=eng.tensor('ref_node_corr_indices')[:, 0],
-                   src_node_corr_indices=eng.tensor('src_node_corr_indices')[:, 0],
-                   ref_node_corr_knn_points=eng.tensor('ref_node_corr_knn_points').reshape(B, k_pts, 3),
-                   src_node_corr_knn_points=eng.tensor('src_node_corr_knn_points').reshape(B, k_pts, 3),
-                   ref_node_corr_knn_masks=eng.tensor('ref_node_corr_knn_masks').bool(),
-                   src_node_corr_knn_masks=eng.tensor('src_node_corr_knn_masks').bool(),
-                   matching_scores=eng.tensor('matching_scores').reshape(B, k_pts + 1, k_pts + 1))
-        rc, sc_, cs = eng.corr()
-        out.update(ref_corr_points=rc, src_corr_points=sc_, corr_scores=cs, estimated_transform=eng.tensor('estimated_transform'))
+                   ref_node_corr_indices=t['ref_node_corr_indices'][:, 0], src_node_corr_indices=t['src_node_corr_indices'][:, 0],
+                   ref_node_corr_knn_points=t['ref_node_corr_knn_points'].reshape(B, k_pts, 3),
+                   src_node_corr_knn_points=t['src_node_corr_knn_points'].reshape(B, k_pts, 3),
+                   ref_node_corr_knn_masks=t['ref_node_corr_knn_masks'].view(torch.bool),
+                   src_node_corr_knn_masks=t['src_node_corr_knn_masks'].view(torch.bool),
+                   matching_scores=t['matching_scores'].reshape(B, k_pts + 1, k_pts + 1),
+                   ref_corr_points=t['ref_corr_points'], src_corr_points=t['src_corr_points'],
+                   corr_scores=t['corr_scores'][:, 0], estimated_transform=t['estimated_transform'])
         return out
 
     @torch.no_grad()
@@ -402,7 +405,7 @@ class RDMNet(torch.nn.Module):
             ops.compact_indices(keep, n_c, N_c, order[n_c:], flags[3:])
             fl = flags.cpu()  # sync: kept-node counts size everything downstream
             if int(fl[1]) != 0:
-                raise RuntimeError('radius search capacity exceeded in NMS')
+                raise RuntimeError('radius search (NMS): internal error (status word set)')
             m_r, m_s = int(fl[2]), int(fl[3])
             sel = torch.cat([order[:m_r], order[n_c:n_c + m_s]]).to(torch.int64)
             nodes = ops.gather_rows(shifted, sel)
@@ -462,7 +465,7 @@ class RDMNet(torch.nn.Module):
         fm = cfg.fine_matching
         rc, sc, cs, T, counts = ops.lgr(ms, r_pts, s_pts, r_pm, s_pm, fm.acceptance_radius, fm.correspondence_threshold,
                                         fm.num_refinement_steps)
-        # sync: number of correspondences + capacity status words (grouping; the collate's 13 radius searches, whose
+        # sync: number of correspondences + status words (grouping capacity; the collate's 13 radius searches, whose
         # status nobody has read yet unless the collate ran with exact_shapes=True)
         cflags = data_dict.get('_flags')
         parts = [counts, flags[4:5]] + ([cflags[:, 1].to(torch.int32)] if cflags is not None else [])
@@ -470,8 +473,7 @@ class RDMNet(torch.nn.Module):
         if int(cn[3]) != 0:
             raise RuntimeError('point_to_node: a node owns more than 4096 points')
         if cn.numel() > 4 and int(cn[4:].max()) != 0:
-            raise RuntimeError('radius search: a query of the collate exceeded the kernel capacity (neighbour tables are '
-                               'incomplete); the reference returns every neighbour')
+            raise RuntimeError('radius search: a search of the collate reported an internal error (status word set)')
         C = int(cn[0])
         taps['lgr'] = {'n_hypotheses': int(cn[1]), 'best': int(cn[2])}
         out.update(ref_corr_points=rc[:C], src_corr_points=sc[:C], corr_scores=cs[:C], estimated_transform=T)

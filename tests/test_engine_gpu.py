@@ -139,13 +139,32 @@ def test_engine_deferred_large_buffer_pass_matches_per_op_searches(ctx):
     assert int((full < p0.shape[0]).sum(1).max()) > 256
 
 
-def test_engine_reports_capacity_instead_of_truncating(ctx):
-    """20 000 points in a 4 m cube put > 1024 points into one search radius: the reference would return them all;
-    the kernels' per-query capacity is 1024, and exceeding it is an error, never a silent truncation."""
+def test_engine_handles_neighbourhoods_beyond_every_buffer(ctx, oracle_native):
+    """6 000 points in a 2.4 m cube put ~3 000 points into a level-0 search radius -- more than the kernels' largest
+    (1024-key) buffer.  The reference returns every neighbour (radius_neighbors_cpu.cpp:36-64) and its callers keep the
+    `limit` nearest (radius_search.py:24-26); the engine does the same through the multi-round select: its tables equal
+    the per-op collate's and the oracle's (the reference's own C++ when oracle/_ref is present), and the pair runs
+    through to a finite pose."""
+    from oracle import forward as ofw
     rng = np.random.default_rng(0)
-    a = torch.from_numpy(rng.uniform(-2, 2, (20000, 3)).astype(np.float32)).cuda()
-    with pytest.raises(RuntimeError, match='capacity of 1024'):
-        ctx['eng'].run(a, a.clone())
+    a = rng.uniform(-1.2, 1.2, (6000, 3)).astype(np.float32)
+    b = rng.uniform(-1.2, 1.2, (5000, 3)).astype(np.float32)
+    res = ctx['eng'].run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert np.isfinite(ctx['eng'].transform()).all() and res.level_sizes[0] == 11000
+    data = ctx['collate'].collate_pair(a, b, ctx['cfg'])
+    odata = ofw.pyramid(np.concatenate([a, b]), np.array([len(a), len(b)], np.int64), ctx['cfg'])
+    for i in range(5):
+        assert torch.equal(ctx['eng'].tensor(f'points{i}').cpu(), odata['points'][i])
+        for key, tables in (('neighbors', data['neighbors']), ('subsampling', data['subsampling']), ('upsampling', data['upsampling'])):
+            if key != 'neighbors' and i == 4:
+                continue
+            w = odata[key][i].shape[1]
+            assert torch.equal(ctx['eng'].tensor(f'{key}{i}')[:, :w].cpu(), odata[key][i]), (key, i)
+            assert torch.equal(tables[i][:, :w].cpu(), odata[key][i]), (key, i)
+    from rdmnet_amd import ext
+    p0, l0 = data['points'][0], data['lengths'][0]
+    full = ext.radius_neighbors(p0, p0, l0, l0, float(ctx['cfg'].backbone.init_radius))
+    assert int((full < p0.shape[0]).sum(1).max()) > 1024  # the case really exceeds the largest buffer
 
 
 def test_engines_are_reentrant_across_threads_and_streams(ctx):

@@ -132,8 +132,9 @@ def test_synthetic_full_size_properties(ext):
 
 
 def test_dense_neighbourhoods_use_the_large_buffer_pass(ext, oracle_native):
-    """More than 256 neighbours per query: the second (1024-slot) pass must produce the same rows as the
-    oracle; more than 1024 must be reported, not silently truncated."""
+    """More than 256 neighbours per query: the second (1024-slot) pass must produce the same rows as the oracle;
+    beyond 1024 the row is produced in rounds (radix select over the (d2, index) keys) -- the reference has no limit
+    (radius_neighbors_cpu.cpp:36-64), neither has this: every neighbour, in order, full width and truncated."""
     o = oracle_native.restatement()
     rng = np.random.default_rng(7)
     pts = rng.uniform(-1.0, 1.0, size=(3000, 3)).astype(np.float32)
@@ -144,5 +145,16 @@ def test_dense_neighbourhoods_use_the_large_buffer_pass(ext, oracle_native):
         assert io.shape[1] > 256
         assert np.array_equal(io, ig), radius
         assert np.array_equal(gpu_radius(ext, pts, pts, lens, lens, radius, width=70), io[:, :70])
-    with pytest.raises(RuntimeError):
-        gpu_radius(ext, pts, pts, lens, lens, 3.0)  # every point of a cloud is a neighbour (> 1024)
+    for radius in (1.5, 3.0):  # 1.5: ~1000-1500 per query (rows on both sides of 1024); 3.0: every point of the cloud (1800 / 1200)
+        io = o.radius_neighbors(pts, pts, lens, lens, np.float32(radius))
+        ig = gpu_radius(ext, pts, pts, lens, lens, radius)
+        assert io.shape[1] > 1024
+        assert np.array_equal(io, ig), radius
+        assert np.array_equal(gpu_radius(ext, pts, pts, lens, lens, radius, width=81), io[:, :81])
+        assert np.array_equal(gpu_radius(ext, pts, pts, lens, lens, radius, width=1100), io[:, :1100])
+    # many points at the SAME distance (a regular lattice): ties are ordered by index through all radix digits
+    g = np.stack(np.meshgrid(*[np.arange(14, dtype=np.float32)] * 3, indexing='ij'), -1).reshape(-1, 3) * np.float32(0.25)
+    lens = np.array([len(g)], dtype=np.int64)
+    io = o.radius_neighbors(g, g, lens, lens, np.float32(2.0))
+    assert io.shape[1] > 1024
+    assert np.array_equal(io, gpu_radius(ext, g, g, lens, lens, 2.0))
