@@ -146,7 +146,30 @@ int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, i
                       const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
                       const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
                       void* stream);
-/* Same, visiting the queries in the order given by `order_records` (m x float4 whose 4th component
+/* rdm_kpconv_fused: the WHOLE KPConv.forward (kpconv.py:79-122) in one kernel for the fine levels -- c_in = 1 (c_out
+ * 64), 32 -> 32, 64 -> 64: out[m, c'] = (sum_k sum_c wf[m, k, c] W[k, c, c']) / nn[m] + bias[c'] with wf and nn as in
+ * rdm_kpconv_gather; the [m, 15*c] intermediate stays in LDS.  w_packed: W [15, c_in, c_out] reordered by
+ * rdm_kpconv_pack_weights (host arrays; rdm_kpconv_packed_floats floats).  gn_partial (optional): fp64 column sums /
+ * sums of squares of the output per block of rdm_kpconv_fused_rows_per_block(c_in) rows, [blocks][2][c_out] -- the
+ * input of the GroupNorm that follows every KPConv.  rdm_kpconv_fused_group_norm = that convolution +
+ * act(GroupNorm(.)) (modules.py:141-145, 205-207), workspace rdm_kpconv_fused_workspace_bytes.                    */
+int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out);
+int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in);
+size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out);
+int rdm_kpconv_pack_weights(const float* w_host, int64_t c_in, int64_t c_out, float* packed_host);
+int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,
+                     int64_t c, int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi,
+                     const int32_t* width, const float* kernel_points, float sigma, const float* w_packed,
+                     const float* bias, int64_t c_out, float* out, int64_t ldo, double* gn_partial, void* stream);
+size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out);
+int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                const float* kernel_points, float sigma, const float* w_packed, const float* bias,
+                                int64_t c_out, int groups, const float* gamma, const float* beta, float eps, int act,
+                                float* conv_out, int64_t ld_conv, float* y, int64_t ldy, void* ws, size_t ws_bytes,
+                                void* stream);
+/* Same as rdm_kpconv_gather, visiting the queries in the order given by `order_records` (m x float4 whose 4th component
  * holds the query row, e.g. rdm_radius_grid_records of the query level): neighbouring queries share
  * most of their neighbours, so the gathered lines are re-used from the CU's L1.  Results are identical. */
 int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_points, int64_t n_s,

@@ -42,6 +42,7 @@ struct Linear {  // B operand [K_pad, N_pad] + bias
   float* b = nullptr;
   float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused transformer kernels, out == 128 / 256 only
   float* bias = nullptr;
+  float* packed = nullptr;  // KPConv weights in the operand order of the fused kernel (c_in = 1, 32, 64), else null
   int64_t in = 0, out = 0, kpad = 0, ldb = 0;
 };
 
@@ -226,6 +227,43 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   }
   const Linear& W = it->second;
   const int64_t cin = x.cols, kdim = cin == 1 ? 16 : 15 * cin;
+  static const bool no_fused = getenv("RDM_NO_FUSED_KPCONV") != nullptr;  // developer knob: the gather + GEMM pair
+  if (W.packed && !no_fused) {
+    // fine levels (c_in = 1, 32, 64): the whole convolution is one kernel, the [M, 15 C] block never leaves the CU
+    float* gam = vecp(r, norm_name + ".norm.weight");
+    float* bet = vecp(r, norm_name + ".norm.bias");
+    if (!gam || !bet) {
+      set_error("rdm_engine: missing parameter %s.norm.*", norm_name.c_str());
+      return RDM_ERR_ARG;
+    }
+    Mat conv = e->mat(q.n, W.out);
+    y = e->mat(q.n, W.out);
+    ENG_ALLOC(conv.p); ENG_ALLOC(y.p);
+    RDM_REQUIRE(rdm_kpconv_fused_workspace_bytes(q.n, cin, W.out) <= r.ws_bytes, "rdm_engine: scratch too small");
+    const int li = e->prof_layers;
+    const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
+    if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
+    ENG_CHECK(rdm_kpconv_fused_group_norm(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
+                                          vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, r.groups, gam, bet,
+                                          1e-5f, 2, conv.p, conv.ld, y.p, y.ld, r.ws, r.ws_bytes, r.st));
+    if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
+    if (pool_src) {
+      *pool_out = e->mat(q.n, pool_src->cols);
+      ENG_ALLOC(pool_out->p);
+      ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
+                               t.flags, pool_out->p, pool_out->ld, r.st));
+    }
+    if (prof) {
+      RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
+      rdm_kpconv_profile p;
+      p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
+      p.gather_ms = p.total_ms = 0.f;
+      e->prof.push_back(p);
+      e->prof_layers++;
+    }
+    (void)order;
+    return RDM_OK;
+  }
   Mat wf = e->mat(q.n, kdim);
   ENG_ALLOC(wf.p);
   float* nn = e->alloc<float>(q.n > 0 ? q.n : 1);
@@ -539,6 +577,11 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
       auto bi = e->host.find(name.substr(0, name.size() - 8) + ".bias");
       RDM_REQUIRE(bi != e->host.end(), "rdm_engine_finalize: %s has no bias", name.c_str());
       ENG_CHECK(upload(e, bi->second.data, &L.bias));
+      if (rdm_kpconv_fused_supported(cin, cout)) {  // fine levels: gather + weight contraction in one kernel
+        std::vector<float> pk(rdm_kpconv_packed_floats(cin, cout));
+        ENG_CHECK(rdm_kpconv_pack_weights(p.data.data(), cin, cout, pk.data()));
+        ENG_CHECK(upload(e, pk, &L.packed));
+      }
       e->lin[name] = L;
     } else if (ends_with(name, ".weight") && p.shape.size() == 2) {
       const std::string base = name.substr(0, name.size() - 7);

@@ -1,0 +1,416 @@
+// a4 -- KPConv.forward as ONE kernel for the fine levels (C_in = 1, 32, 64): neighbourhood aggregation AND the
+// kernel-weight contraction, without the [M, 15*C] intermediate in HBM.
+//
+// Reference: geotransformer/modules/kpconv/kpconv.py:79-122.  For every query m:
+//   WF[m, k, c] = sum_h max(0, 1 - |s[idx[m,h]] - q[m] - kp[k]| / sigma) * feats[idx[m,h], c]      :91-105
+//   out[m, c']  = (sum_k sum_c WF[m, k, c] W[k, c, c']) / max(1, #{h : sum_c feats[idx[m,h], c] > 0}) + bias[c']   :107-121
+// The two-kernel form (kpconv.hip + gemm.hip) writes WF -- 15*C floats per query, 61 MB for the 32 k-point level at
+// C = 32 -- and reads it back; at C <= 64 that round trip costs as much as the gather itself.  Here a workgroup of
+// eight wavefronts aggregates QB queries (one wavefront per query at a time, the 16x16x4 MFMA formulation of
+// kpconv.hip), parks the QB x 15C block in LDS, and multiplies it by W on the same matrix cores: the A operand of
+// v_mfma_f32_16x16x4_f32 is a 16-B LDS read (16 queries x 4 consecutive k per instruction), the B operand one
+// coalesced 16-B global read per lane from a copy of W stored in operand order (rdm_kpconv_pack_weights).  The
+// epilogue divides by the neighbour count, adds the bias, writes the [M, C'] output and accumulates the fp64 column
+// sums GroupNorm needs (same partial layout as the GEMM epilogue, gemm.hip).
+//   C = 32: QB = 32 (2 row tiles x 2 column tiles x 2 K halves = 8 wavefronts), W = 61 KB read once per 32 queries
+//   C = 64: QB = 16 (1 row tile  x 4 column tiles x 2 K halves),                W = 245 KB read once per 16 queries
+//   LDS 78 KB per workgroup (62 KB block + per-wavefront neighbour staging): two workgroups per CU, so one gathers
+//   while the other multiplies.
+//   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
+//   channel.
+#include <atomic>
+
+#include "../../include/rdmnet_hip.h"
+#include "common.h"
+#include "internal.h"
+
+namespace {
+
+using namespace rdm;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKP = 15;
+constexpr int kMaxH = 128;
+
+struct FusedArgs {
+  const float* q_points;       // [M,3]
+  const float* s_points;       // [Ns,3]
+  const float* s_feats;        // [Ns, ldf]
+  const unsigned char* s_pos;  // [Ns]
+  const int64_t* idx;          // [M, ldi]
+  const float* kp;             // [15,3]
+  const int32_t* width;        // optional device int: effective row width
+  const float* w;              // packed weights (see rdm_kpconv_pack_weights)
+  const float* bias;           // [C']
+  float* out;                  // [M, ldo]
+  double* stats;               // [gridDim.x][2][C'] or null
+  int M, Ns, H;
+  int ldf, ldi, ldo;
+  float sigma;
+};
+
+// ---- C_in in {32, 64}
+template <int C, int QB, int ITERS>
+__global__ __launch_bounds__(512) void kpconv_fused_kernel(FusedArgs a) {
+  constexpr int VEC = C / 16;           // channels per lane and gather tile pass (channel = VEC*j + e)
+  constexpr int NT = C / 16;            // output column tiles (C' = C)
+  constexpr int RT = QB / 16;           // output row tiles
+  constexpr int TILES = NT * RT;        // 4
+  constexpr int KS = 8 / TILES;         // K split over wavefronts (2)
+  constexpr int K16 = kKP * C / 16;     // 16-deep contraction steps (30 / 60)
+  constexpr int LDW = kKP * C + 4;      // LDS row stride of the aggregated block (floats)
+  constexpr int QPW = QB / 8;           // queries per wavefront and iteration
+  constexpr int PF = 4;                 // neighbour groups fetched per trip
+  static_assert(TILES * KS == 8 && K16 % KS == 0, "wavefront roles");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* WF = smem;                                                        // [QB][LDW]
+  float4* nb_all = reinterpret_cast<float4*>(smem + QB * LDW);             // [8][kMaxH]: rel.xyz, w = support row
+  float* nn_s = smem + QB * LDW + 8 * kMaxH * 4;                           // [QB]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  float4* nb = nb_all + wave * kMaxH;
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  const float inv_sigma = 1.0f / a.sigma;  // (hardware sqrt + reciprocal multiply as in kpconv.hip)
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);
+  // roles of the contraction phase
+  const int tw = wave % TILES, kh = wave / TILES, rt = tw / NT, ct = tw % NT;
+  const float bias_v = a.bias[16 * ct + j];
+  double st_s = 0.0, st_ss = 0.0;  // GroupNorm column sums of this lane's column (rows 4g .. 4g+3 of every row tile it owns)
+
+  for (int it = 0; it < ITERS; ++it) {
+    const int q0 = (blockIdx.x * ITERS + it) * QB;
+    if (q0 >= a.M) break;  // (uniform over the workgroup)
+    // ------------------------------------------------------------ aggregation: QPW queries per wavefront
+    for (int qq = 0; qq < QPW; ++qq) {
+      const int ql = wave * QPW + qq, m = q0 + ql;
+      if (m >= a.M) break;
+      const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+      int positives = 0;
+      for (int h = lane; h < H; h += 64) {
+        const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+        float4 v;
+        if (id >= 0 && id < a.Ns) {
+          v.x = a.s_points[3 * id] - qx;
+          v.y = a.s_points[3 * id + 1] - qy;
+          v.z = a.s_points[3 * id + 2] - qz;
+          v.w = __int_as_float(static_cast<int>(id));
+          positives += a.s_pos[id];
+        } else {  // shadow neighbour: point at 1e6, zero features
+          v.x = 1.0e6f - qx;
+          v.y = 1.0e6f - qy;
+          v.z = 1.0e6f - qz;
+          v.w = __int_as_float(-1);
+        }
+        nb[h] = v;
+      }
+      positives = wave_sum_i(positives);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 acc[VEC];
+#pragma unroll
+      for (int t = 0; t < VEC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int h0 = 0; h0 < H; h0 += 4 * PF) {
+        float w[PF];
+        float f[PF][VEC];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          const int h = h0 + 4 * p + g;
+          int id = -1;
+          w[p] = 0.f;
+          if (h < H) {
+            const float4 v = nb[h];
+            id = __float_as_int(v.w);
+            const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            w[p] = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma);
+            if (j >= kKP || id < 0) w[p] = 0.f;
+          }
+          const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
+          if (id >= 0) {
+            if constexpr (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(row);
+              f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
+            } else {
+              const float2 t = *reinterpret_cast<const float2*>(row);
+              f[p][0] = t.x; f[p][1] = t.y;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) f[p][e] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][e], acc[e], 0, 0, 0);
+      }
+      // park WF[ql, k, c]: accumulator row 4g + r = kernel point, lane j holds channels VEC*j .. VEC*j + VEC-1
+      float* dst = WF + ql * LDW + VEC * j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * g + r;
+        if (k >= kKP) continue;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + k * C) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        else *reinterpret_cast<float2*>(dst + k * C) = make_float2(acc[0][r], acc[1][r]);
+      }
+      if (lane == 0) nn_s[ql] = static_cast<float>(positives > 1 ? positives : 1);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next query
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------ contraction: out[QB, C'] = WF[QB, 15C] W[15C, C']
+    // wavefront (rt, ct, kh): row tile rt, column tile ct, K steps [kh, kh+1) * K16 / KS.  Step s covers k = 16 s ..
+    // 16 s + 15 in the order lane group g -> k = 16 s + 4 g + e (e = the e-th of four MFMAs): A is one 16-B LDS read,
+    // B one 16-B global read of the packed weights.
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* arow = WF + (16 * rt + j) * LDW + 4 * g;
+      const float4* wp = reinterpret_cast<const float4*>(a.w) + static_cast<int64_t>(ct) * 64 + lane;
+      const int s_begin = kh * (K16 / KS), s_end = s_begin + K16 / KS;
+#pragma unroll 5
+      for (int s = s_begin; s < s_end; ++s) {
+        const float4 bv = wp[static_cast<int64_t>(s) * NT * 64];
+        const float4 av = *reinterpret_cast<const float4*>(arow + 16 * s);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, o1, 0, 0, 0);
+      }
+    }
+    f32x4 o = o0 + o1;
+    // K halves meet in the neighbour-staging area of the wavefront that owns the tile (idle since the barrier above)
+    f32x4* red = reinterpret_cast<f32x4*>(nb_all + tw * kMaxH);
+    if (kh == 1) red[lane] = o;
+    __syncthreads();
+    if (kh == 0) {
+      if (KS == 2) o = o + red[lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * rt + 4 * g + r, m = q0 + ql;
+        if (m < a.M) {
+          float v = o[r] / nn_s[ql];
+          v += bias_v;
+          a.out[static_cast<int64_t>(m) * a.ldo + 16 * ct + j] = v;
+          st_s += static_cast<double>(v);
+          st_ss += static_cast<double>(v) * static_cast<double>(v);
+        }
+      }
+    }
+    __syncthreads();  // WF and nn_s are rewritten by the next iteration
+  }
+  if (a.stats) {  // column sums of this workgroup's rows: lane groups g, then row tiles, in a fixed order
+    st_s = (st_s + __shfl_xor(st_s, 16, 64)) + (__shfl_xor(st_s, 32, 64) + __shfl_xor(st_s, 48, 64));
+    st_ss = (st_ss + __shfl_xor(st_ss, 16, 64)) + (__shfl_xor(st_ss, 32, 64) + __shfl_xor(st_ss, 48, 64));
+    double* ex = reinterpret_cast<double*>(smem);  // [TILES][16][2]
+    if (kh == 0 && g == 0) {
+      ex[(tw * 16 + j) * 2 + 0] = st_s;
+      ex[(tw * 16 + j) * 2 + 1] = st_ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+      const int c = threadIdx.x, cti = c / 16, cj = c % 16;
+      double s = 0.0, ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        s += ex[((r * NT + cti) * 16 + cj) * 2 + 0];
+        ss += ex[((r * NT + cti) * 16 + cj) * 2 + 1];
+      }
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + c] = s;
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = ss;
+    }
+  }
+}
+
+// ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
+constexpr int kC1Out = 64, kC1Qpw = 16;
+__global__ __launch_bounds__(256) void kpconv_fused_c1_kernel(FusedArgs a) {
+  __shared__ float4 nb_all[4][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
+  __shared__ double ex[4][kC1Out][2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, j = lane & 15;
+  float4* nb = nb_all[wave];
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  const float inv_sigma = 1.0f / a.sigma;
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);
+  float wcol[kKP];  // W[k][lane]
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) wcol[k] = a.w[k * kC1Out + lane];
+  const float bias_v = a.bias[lane];
+  double st_s = 0.0, st_ss = 0.0;
+  const int m0 = (blockIdx.x * 4 + wave) * kC1Qpw;
+  for (int qq = 0; qq < kC1Qpw; ++qq) {
+    const int m = m0 + qq;
+    if (m >= a.M) break;
+    const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+    int positives = 0;
+    for (int h = lane; h < H; h += 64) {
+      const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id >= 0 && id < a.Ns) {
+        v.x = a.s_points[3 * id] - qx;
+        v.y = a.s_points[3 * id + 1] - qy;
+        v.z = a.s_points[3 * id + 2] - qz;
+        v.w = a.s_feats[id * a.ldf];
+        positives += a.s_pos[id];
+      }
+      nb[h] = v;
+    }
+    positives = wave_sum_i(positives);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
+    for (int h = g; h < H; h += 4) {
+      const float4 v = nb[h];
+      const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);  // every lane (., j) now holds WF[k = j]
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < kKP; ++k)
+      o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k)), wcol[k], o);
+    float v = o / static_cast<float>(positives > 1 ? positives : 1);
+    v += bias_v;
+    a.out[static_cast<int64_t>(m) * a.ldo + lane] = v;
+    st_s += static_cast<double>(v);
+    st_ss += static_cast<double>(v) * static_cast<double>(v);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next query
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (a.stats) {
+    ex[wave][lane][0] = st_s;
+    ex[wave][lane][1] = st_ss;
+    __syncthreads();
+    if (wave == 0) {
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * kC1Out + lane] = (ex[0][lane][0] + ex[1][lane][0]) + (ex[2][lane][0] + ex[3][lane][0]);
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * kC1Out + lane] = (ex[0][lane][1] + ex[1][lane][1]) + (ex[2][lane][1] + ex[3][lane][1]);
+    }
+  }
+}
+
+template <int C, int QB>
+constexpr size_t fused_lds_bytes() { return sizeof(float) * (static_cast<size_t>(QB) * (kKP * C + 4) + 8 * kMaxH * 4 + QB); }
+
+constexpr int kItersC32 = 2, kItersC64 = 2;
+
+}  // namespace
+
+extern "C" int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out) {
+  return (c_in == 1 && c_out == kC1Out) || (c_in == 32 && c_out == 32) || (c_in == 64 && c_out == 64);
+}
+
+extern "C" int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in) {
+  return c_in == 1 ? 4 * kC1Qpw : (c_in == 32 ? 32 * kItersC32 : 16 * kItersC64);
+}
+
+extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
+  return c_in == 1 ? static_cast<size_t>(16) * c_out : static_cast<size_t>(kKP) * c_in * c_out;
+}
+
+// w [15, c_in, c_out] (the checkpoint layout, host) -> the B-operand order of the fused kernel (host):
+//   c_in = 1: [16, c_out] (row 15 zero);  otherwise float4 records [s][column tile][lane = 16 g + j] holding
+//   W[16 s + 4 g + e][16 tile + j], e = 0..3 (the row index of W is k * c_in + c).
+extern "C" int rdm_kpconv_pack_weights(const float* w, int64_t c_in, int64_t c_out, float* packed) {
+  using namespace rdm;
+  RDM_REQUIRE(w && packed && rdm_kpconv_fused_supported(c_in, c_out), "rdm_kpconv_pack_weights: unsupported (%lld -> %lld)",
+              (long long)c_in, (long long)c_out);
+  if (c_in == 1) {
+    for (int64_t k = 0; k < 16; ++k)
+      for (int64_t c = 0; c < c_out; ++c) packed[k * c_out + c] = k < kKP ? w[k * c_out + c] : 0.f;
+    return RDM_OK;
+  }
+  const int64_t nt = c_out / 16, k16 = kKP * c_in / 16;
+  for (int64_t s = 0; s < k16; ++s)
+    for (int64_t t = 0; t < nt; ++t)
+      for (int64_t lane = 0; lane < 64; ++lane)
+        for (int64_t e = 0; e < 4; ++e)
+          packed[((s * nt + t) * 64 + lane) * 4 + e] = w[(16 * s + 4 * (lane >> 4) + e) * c_out + 16 * t + (lane & 15)];
+  return RDM_OK;
+}
+
+extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,
+                                int64_t c, int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h,
+                                int64_t ldi, const int32_t* width, const float* kernel_points, float sigma,
+                                const float* w_packed, const float* bias, int64_t c_out, float* out, int64_t ldo,
+                                double* gn_partial, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && w_packed && bias && out,
+              "rdm_kpconv_fused: null pointer");
+  RDM_REQUIRE(rdm_kpconv_fused_supported(c, c_out), "rdm_kpconv_fused: unsupported channel counts %lld -> %lld", (long long)c,
+              (long long)c_out);
+  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0 && h <= kMaxH && ldo >= c_out, "rdm_kpconv_fused: bad sizes (h=%lld, max %d)",
+              (long long)h, kMaxH);
+  RDM_REQUIRE(c == 1 || (ldf % 4 == 0 && (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(w_packed) & 15) == 0),
+              "rdm_kpconv_fused: features / packed weights must be 16-byte aligned with a row stride that is a multiple of 4");
+  if (m == 0) return RDM_OK;
+  FusedArgs a;
+  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.kp = kernel_points;
+  a.width = width; a.w = w_packed; a.bias = bias; a.out = out; a.stats = gn_partial;
+  a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
+  a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned blocks = static_cast<unsigned>(ceil_div<int64_t>(m, rdm_kpconv_fused_rows_per_block(c)));
+  if (c == 1) {
+    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return launch_status("kpconv_fused_c1_kernel");
+  }
+  // > 64 KB of dynamic LDS needs the attribute once per device
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  RDM_HIP_CHECK(hipGetDevice(&dev));
+  const uint64_t bit = uint64_t(1) << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    const int l32 = static_cast<int>(fused_lds_bytes<32, 32>()), l64 = static_cast<int>(fused_lds_bytes<64, 16>());
+    const void* k32 = reinterpret_cast<const void*>(kpconv_fused_kernel<32, 32, kItersC32>);
+    const void* k64 = reinterpret_cast<const void*>(kpconv_fused_kernel<64, 16, kItersC64>);
+    RDM_HIP_CHECK(hipFuncSetAttribute(k32, hipFuncAttributeMaxDynamicSharedMemorySize, l32));
+    RDM_HIP_CHECK(hipFuncSetAttribute(k64, hipFuncAttributeMaxDynamicSharedMemorySize, l64));
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  const size_t lds32 = fused_lds_bytes<32, 32>(), lds64 = fused_lds_bytes<64, 16>();
+  if (c == 32)
+    hipLaunchKernelGGL((kpconv_fused_kernel<32, 32, kItersC32>), dim3(blocks), dim3(512), lds32, st, a);
+  else
+    hipLaunchKernelGGL((kpconv_fused_kernel<64, 16, kItersC64>), dim3(blocks), dim3(512), lds64, st, a);
+  return launch_status("kpconv_fused_kernel");
+}
+
+extern "C" size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out) {
+  const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(m > 0 ? m : 1, rdm_kpconv_fused_rows_per_block(c_in)));
+  return rdm::align_up(nblk * 2 * c_out * sizeof(double)) + rdm_group_norm_workspace_bytes(m, c_out) + 256;
+}
+
+// KPConv + the GroupNorm (+ activation) that follows it in every block of the backbone (modules.py:141-145, 205-207):
+// conv_out receives the convolution, y = act(GroupNorm(conv_out)).  The statistics come from the fused kernel's epilogue.
+extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                           const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                           const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                           const float* kernel_points, float sigma, const float* w_packed, const float* bias,
+                                           int64_t c_out, int groups, const float* gamma, const float* beta, float eps, int act,
+                                           float* conv_out, int64_t ld_conv, float* y, int64_t ldy, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(gamma && beta && conv_out && y, "rdm_kpconv_fused_group_norm: null pointer");
+  if (m == 0) return RDM_OK;
+  Arena ar(ws, ws_bytes);
+  const int nblk = static_cast<int>(ceil_div<int64_t>(m, rdm_kpconv_fused_rows_per_block(c)));
+  double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c_out);
+  const size_t gn_ws = rdm_group_norm_workspace_bytes(m, c_out);
+  char* nws = ar.take<char>(gn_ws);
+  if (!ar.ok) {
+    set_error("rdm_kpconv_fused_group_norm: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  if (int e = rdm_kpconv_fused(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
+                               w_packed, bias, c_out, conv_out, ld_conv, partial, stream))
+    return e;
+  return group_norm_finish(partial, nblk, conv_out, m, c_out, ld_conv, groups, gamma, beta, eps, nullptr, 0, act, y, ldy, nullptr,
+                           nws, gn_ws, stream);
+}

@@ -115,6 +115,8 @@ class RDMNet(torch.nn.Module):
                 b = torch.zeros((pad4(kdim), pad4(cout)), dtype=torch.float32)
                 b[:k * cin, :cout] = torch.from_numpy(S[name]).reshape(k * cin, cout)
                 W[name] = (b.to(dev), cin, cout)
+                if ops.kpconv_fused_supported(cin, cout):  # fine levels: gather + weight contraction in one kernel
+                    W[name + '.packed'] = torch.from_numpy(ops.kpconv_pack_weights(S[name])).to(dev)
             elif name.endswith('.weight') and S[name].ndim == 2:
                 lin(name[:-7])
             elif name.endswith('.bias') and (name[:-5] + '.weight') in S and S[name[:-5] + '.weight'].ndim == 2:
@@ -150,11 +152,19 @@ class RDMNet(torch.nn.Module):
         if prof is not None:
             e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             e0.record()
-        wf, nn = ops.kpconv_gather(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, width)
-        if prof is not None:
-            e1.record()
-        y = ops.linear_group_norm(wf, b, b.shape[0], cout, self._w[name + '.bias'], self._w[norm + '.norm.weight'],
-                                  self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, rowdiv=nn, act=ACT_LEAKY)
+        packed = self._w.get(name + '.weights.packed')
+        if packed is not None:
+            y = ops.kpconv_fused_group_norm(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, packed,
+                                            self._w[name + '.bias'], cout, self._w[norm + '.norm.weight'],
+                                            self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, width=width, act=ACT_LEAKY)
+            if prof is not None:
+                e1.record()
+        else:
+            wf, nn = ops.kpconv_gather(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, width)
+            if prof is not None:
+                e1.record()
+            y = ops.linear_group_norm(wf, b, b.shape[0], cout, self._w[name + '.bias'], self._w[norm + '.norm.weight'],
+                                      self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, rowdiv=nn, act=ACT_LEAKY)
         pooled = ops.gather_max(pool_src, idx, width) if pool_src is not None else None
         if prof is not None:
             e2.record()

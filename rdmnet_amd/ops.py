@@ -101,6 +101,55 @@ def kpconv_gather(q_points, s_points, s_feats, s_positive, idx, kernel_points, s
     return wf, nn
 
 
+def kpconv_fused_supported(c_in, c_out):
+    return bool(_lib.lib().rdm_kpconv_fused_supported(int(c_in), int(c_out)))
+
+
+def kpconv_pack_weights(w):
+    """KPConv weights [15, c_in, c_out] (numpy, checkpoint layout) -> float32 numpy array in the fused kernel's operand order."""
+    import numpy as np
+    L = _lib.lib()
+    _, c_in, c_out = w.shape
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty((L.rdm_kpconv_packed_floats(c_in, c_out),), dtype=np.float32)
+    _lib.check(L.rdm_kpconv_pack_weights(w.ctypes.data, c_in, c_out, out.ctypes.data), 'rdm_kpconv_pack_weights')
+    return out
+
+
+def kpconv_fused(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, w_packed, bias, c_out, width=None,
+                 want_partials=False):
+    """The whole KPConv.forward (kpconv.py:79-122) in one kernel (c_in = 1, 32, 64) -> out [m, c_out]
+    (, fp64 GroupNorm partials [blocks, 2, c_out])."""
+    L = _lib.lib()
+    m, c = q_points.shape[0], s_feats.shape[1]
+    out = feat_empty(m, c_out, q_points.device)
+    part = None
+    if want_partials:
+        nblk = -(-max(m, 1) // L.rdm_kpconv_fused_rows_per_block(c))
+        part = torch.empty((nblk, 2, c_out), dtype=torch.float64, device=q_points.device)
+    _lib.check(L.rdm_kpconv_fused(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(), c,
+                                  _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0), _lib.ptr(width),
+                                  kernel_points.data_ptr(), float(sigma), w_packed.data_ptr(), bias.data_ptr(), c_out,
+                                  out.data_ptr(), _ld(out), _lib.ptr(part), _lib.stream_ptr()), 'rdm_kpconv_fused')
+    return (out, part) if want_partials else out
+
+
+def kpconv_fused_group_norm(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, w_packed, bias, c_out, gamma,
+                            beta, groups, *, width=None, act=ACT_LEAKY, eps=1e-5):
+    """act(GroupNorm(KPConv(...))) -- the fused convolution followed by the normalisation every backbone block applies."""
+    L = _lib.lib()
+    m, c = q_points.shape[0], s_feats.shape[1]
+    conv, y = feat_empty(m, c_out, q_points.device), feat_empty(m, c_out, q_points.device)
+    ws = scratch(q_points.device, L.rdm_kpconv_fused_workspace_bytes(m, c, c_out))
+    _lib.check(L.rdm_kpconv_fused_group_norm(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(), c,
+                                             _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0),
+                                             _lib.ptr(width), kernel_points.data_ptr(), float(sigma), w_packed.data_ptr(),
+                                             bias.data_ptr(), c_out, groups, gamma.data_ptr(), beta.data_ptr(), eps, act,
+                                             conv.data_ptr(), _ld(conv), y.data_ptr(), _ld(y), ws.data_ptr(), ws.numel(),
+                                             _lib.stream_ptr()), 'rdm_kpconv_fused_group_norm')
+    return y
+
+
 def group_norm(x, gamma, beta, groups, *, act=ACT_NONE, residual=None, want_positive=False, eps=1e-5):
     L = _lib.lib()
     n, c = x.shape

@@ -260,3 +260,52 @@ def test_sinkhorn_full_and_partial_patches_match_oracle(ops, nr, nc):
     assert bool(valid[:, 128, :].any()) and bool(valid[:, :, 128].any())  # the dustbin lines are part of the check
     assert (out[valid] - ref[valid]).abs().max().item() <= 2e-4
     assert torch.equal(out[~valid], ref[~valid])
+
+
+@pytest.mark.parametrize('c,cout,h,m,ns', [(1, 64, 65, 1000, 1500), (32, 32, 65, 1000, 2000), (64, 64, 63, 700, 900), (32, 32, 3, 50, 60),
+                                           (64, 64, 70, 16, 40), (1, 64, 9, 1, 5), (32, 32, 65, 65, 300)])
+def test_kpconv_fused_matches_reference_formula(ops, c, cout, h, m, ns):
+    """The one-kernel KPConv (rdm_kpconv_fused: aggregation + kernel-weight contraction + count normalisation + bias,
+    kpconv.py:79-122) against the fp64 formula, on random clouds with pad slots, row counts that do not fill the last
+    workgroup, and a width cap; its GroupNorm partials against the column sums of its own output."""
+    g = torch.Generator().manual_seed(100 * c + h + m)
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_pts = s_pts[torch.randint(0, ns, (m,), generator=g)] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g) if c > 1 else torch.ones(ns, 1)
+    idx = torch.randint(0, ns, (m, h), generator=g)
+    n_valid = torch.randint(0, h + 1, (m,), generator=g)
+    idx = torch.where(torch.arange(h)[None] < n_valid[:, None], idx, torch.full_like(idx, ns))
+    kp = torch.randn(15, 3, generator=g)
+    W = torch.randn(15, c, cout, generator=g) / np.sqrt(15 * c)
+    bias = torch.randn(cout, generator=g)
+    sigma = 1.7
+    sp = torch.cat([s_pts, torch.full((1, 3), 1e6)]).double()
+    sf = torch.cat([feats, torch.zeros(1, c)]).double()
+    rel = sp[idx] - q_pts.double()[:, None]
+    infl = torch.clamp(1 - ((rel[:, :, None] - kp.double()) ** 2).sum(-1).sqrt() / sigma, min=0)
+    wf = torch.einsum('mhk,mhc->mkc', infl, sf[idx]).reshape(m, 15 * c)
+    pos = (feats.sum(1) > 0)
+    nn_ref = torch.cat([pos, torch.zeros(1, dtype=torch.bool)])[idx].sum(1).clamp(min=1).double()
+    ref = wf @ W.double().reshape(15 * c, cout) / nn_ref[:, None] + bias.double()
+    packed = torch.from_numpy(ops.kpconv_pack_weights(W.numpy())).cuda()
+    fd = padded(feats)
+    args = (q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), sigma, packed, bias.cuda(), cout)
+    out, part = ops.kpconv_fused(*args, want_partials=True)
+    got = out.cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # partials: [blocks, 2, cout] fp64 sums / sums of squares of the rows of each block
+    assert (part[:, 0].sum(0).cpu() - got.sum(0)).abs().max().item() <= 1e-9 * max(1.0, got.abs().sum(0).max().item())
+    assert (part[:, 1].sum(0).cpu() - (got * got).sum(0)).abs().max().item() <= 1e-9 * max(1.0, (got * got).sum(0).max().item())
+    # the same rows through the two-kernel form (gather + GEMM): same numbers up to the summation order
+    wf2, nn2 = ops.kpconv_gather(*args[:6], sigma)
+    kdim = 16 if c == 1 else 15 * c
+    b = torch.zeros((ops.pad4(kdim), ops.pad4(cout)))
+    b[:15 * c, :cout] = W.reshape(15 * c, cout)
+    two = ops.gemm(wf2, b.cuda(), ops.pad4(kdim), cout, bias=bias.cuda(), rowdiv=nn2)
+    assert (two.cpu().double() - got).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    # width cap = the reference's [:, :min(limit, max_count)]
+    if h > 4:
+        cap = torch.tensor([h - 3], dtype=torch.int32).cuda()
+        a = ops.kpconv_fused(*args, width=cap)
+        b2 = ops.kpconv_fused(*args[:4], idx[:, :h - 3].contiguous().cuda(), *args[5:])
+        assert torch.equal(a, b2)
