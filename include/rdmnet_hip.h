@@ -153,6 +153,7 @@ int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, i
  * sums of squares of the output per block of rdm_kpconv_fused_rows_per_block(c_in) rows, [blocks][2][c_out] -- the
  * input of the GroupNorm that follows every KPConv.  rdm_kpconv_fused_group_norm = that convolution +
  * act(GroupNorm(.)) (modules.py:141-145, 205-207), workspace rdm_kpconv_fused_workspace_bytes.                    */
+int rdm_kpconv_fused_enabled(void);   /* 1 iff RDM_FUSED_KPCONV is set: engine and per-op path then use the fused kernel */
 int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out);
 int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in);
 size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out);

@@ -34,6 +34,7 @@ SIGNATURES = {
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
     'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
+    'rdm_kpconv_fused_enabled': (c_int, []),
     'rdm_kpconv_fused_supported': (c_int, [c_i64, c_i64]),
     'rdm_kpconv_fused_rows_per_block': (c_i64, [c_i64]),
     'rdm_kpconv_packed_floats': (c_size, [c_i64, c_i64]),

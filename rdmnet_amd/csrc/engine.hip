@@ -227,8 +227,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   }
   const Linear& W = it->second;
   const int64_t cin = x.cols, kdim = cin == 1 ? 16 : 15 * cin;
-  static const bool no_fused = getenv("RDM_NO_FUSED_KPCONV") != nullptr;  // developer knob: the gather + GEMM pair
-  if (W.packed && !no_fused) {
+  if (W.packed && rdm_kpconv_fused_enabled()) {
     // fine levels (c_in = 1, 32, 64): the whole convolution is one kernel, the [M, 15 C] block never leaves the CU
     float* gam = vecp(r, norm_name + ".norm.weight");
     float* bet = vecp(r, norm_name + ".norm.bias");

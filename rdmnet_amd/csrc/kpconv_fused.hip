@@ -19,6 +19,7 @@
 //   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
 //   channel.
 #include <atomic>
+#include <cstdlib>
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
@@ -51,22 +52,22 @@ struct FusedArgs {
 };
 
 // ---- C_in in {32, 64}
-template <int C, int QB, int ITERS>
-__global__ __launch_bounds__(512) void kpconv_fused_kernel(FusedArgs a) {
+template <int C, int QB, int NW, int ITERS>
+__global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
   constexpr int VEC = C / 16;           // channels per lane and gather tile pass (channel = VEC*j + e)
   constexpr int NT = C / 16;            // output column tiles (C' = C)
   constexpr int RT = QB / 16;           // output row tiles
-  constexpr int TILES = NT * RT;        // 4
-  constexpr int KS = 8 / TILES;         // K split over wavefronts (2)
+  constexpr int TILES = NT * RT;        // output tiles of 16 x 16
+  constexpr int KS = NW / TILES;        // K split over wavefronts
   constexpr int K16 = kKP * C / 16;     // 16-deep contraction steps (30 / 60)
   constexpr int LDW = kKP * C + 4;      // LDS row stride of the aggregated block (floats)
-  constexpr int QPW = QB / 8;           // queries per wavefront and iteration
+  constexpr int QPW = QB / NW;          // queries per wavefront and iteration
   constexpr int PF = 4;                 // neighbour groups fetched per trip
-  static_assert(TILES * KS == 8 && K16 % KS == 0, "wavefront roles");
+  static_assert(TILES * KS == NW && QPW * NW == QB && (KS - 1) * TILES * 1024 <= NW * kMaxH * 16, "wavefront roles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* WF = smem;                                                        // [QB][LDW]
-  float4* nb_all = reinterpret_cast<float4*>(smem + QB * LDW);             // [8][kMaxH]: rel.xyz, w = support row
-  float* nn_s = smem + QB * LDW + 8 * kMaxH * 4;                           // [QB]
+  float4* nb_all = reinterpret_cast<float4*>(smem + QB * LDW);             // [NW][kMaxH]: rel.xyz, w = support row
+  float* nn_s = smem + QB * LDW + NW * kMaxH * 4;                          // [QB]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   float4* nb = nb_all + wave * kMaxH;
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(512) void kpconv_fused_kernel(FusedArgs a) {
     {
       const float* arow = WF + (16 * rt + j) * LDW + 4 * g;
       const float4* wp = reinterpret_cast<const float4*>(a.w) + static_cast<int64_t>(ct) * 64 + lane;
-      const int s_begin = kh * (K16 / KS), s_end = s_begin + K16 / KS;
-#pragma unroll 5
+      const int s_begin = kh * K16 / KS, s_end = (kh + 1) * K16 / KS;
+#pragma unroll 4
       for (int s = s_begin; s < s_end; ++s) {
         const float4 bv = wp[static_cast<int64_t>(s) * NT * 64];
         const float4 av = *reinterpret_cast<const float4*>(arow + 16 * s);
@@ -181,12 +182,14 @@ __global__ __launch_bounds__(512) void kpconv_fused_kernel(FusedArgs a) {
       }
     }
     f32x4 o = o0 + o1;
-    // K halves meet in the neighbour-staging area of the wavefront that owns the tile (idle since the barrier above)
-    f32x4* red = reinterpret_cast<f32x4*>(nb_all + tw * kMaxH);
-    if (kh == 1) red[lane] = o;
+    // the K slices of a tile meet in the neighbour-staging area (idle since the barrier above; the barrier that ends the
+    // iteration keeps the next aggregation from overwriting it early) and are added in slice order
+    f32x4* red = reinterpret_cast<f32x4*>(nb_all);  // [(KS - 1) * TILES][64]
+    if (kh > 0) red[((kh - 1) * TILES + tw) * 64 + lane] = o;
     __syncthreads();
     if (kh == 0) {
-      if (KS == 2) o = o + red[lane];
+#pragma unroll
+      for (int k = 1; k < KS; ++k) o = o + red[((k - 1) * TILES + tw) * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * rt + 4 * g + r, m = q0 + ql;
@@ -225,10 +228,10 @@ __global__ __launch_bounds__(512) void kpconv_fused_kernel(FusedArgs a) {
 }
 
 // ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
-constexpr int kC1Out = 64, kC1Qpw = 16;
-__global__ __launch_bounds__(256) void kpconv_fused_c1_kernel(FusedArgs a) {
-  __shared__ float4 nb_all[4][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
-  __shared__ double ex[4][kC1Out][2];
+constexpr int kC1Out = 64, kC1Waves = 16, kC1Qpw = 4;  // 64 queries per workgroup, four per wavefront
+__global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArgs a) {
+  __shared__ float4 nb_all[kC1Waves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
+  __shared__ double ex[kC1Waves][kC1Out][2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
   float4* nb = nb_all[wave];
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void kpconv_fused_c1_kernel(FusedArgs a) {
   for (int k = 0; k < kKP; ++k) wcol[k] = a.w[k * kC1Out + lane];
   const float bias_v = a.bias[lane];
   double st_s = 0.0, st_ss = 0.0;
-  const int m0 = (blockIdx.x * 4 + wave) * kC1Qpw;
+  const int m0 = (blockIdx.x * kC1Waves + wave) * kC1Qpw;
   for (int qq = 0; qq < kC1Qpw; ++qq) {
     const int m = m0 + qq;
     if (m >= a.M) break;
@@ -288,25 +291,45 @@ __global__ __launch_bounds__(256) void kpconv_fused_c1_kernel(FusedArgs a) {
     ex[wave][lane][1] = st_ss;
     __syncthreads();
     if (wave == 0) {
-      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * kC1Out + lane] = (ex[0][lane][0] + ex[1][lane][0]) + (ex[2][lane][0] + ex[3][lane][0]);
-      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * kC1Out + lane] = (ex[0][lane][1] + ex[1][lane][1]) + (ex[2][lane][1] + ex[3][lane][1]);
+      double s = 0.0, ss = 0.0;
+#pragma unroll
+      for (int w = 0; w < kC1Waves; ++w) {  // fixed order
+        s += ex[w][lane][0];
+        ss += ex[w][lane][1];
+      }
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * kC1Out + lane] = s;
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * kC1Out + lane] = ss;
     }
   }
 }
 
-template <int C, int QB>
-constexpr size_t fused_lds_bytes() { return sizeof(float) * (static_cast<size_t>(QB) * (kKP * C + 4) + 8 * kMaxH * 4 + QB); }
+template <int C, int QB, int NW>
+constexpr size_t fused_lds_bytes() { return sizeof(float) * (static_cast<size_t>(QB) * (kKP * C + 4) + NW * kMaxH * 4 + QB); }
 
-constexpr int kItersC32 = 2, kItersC64 = 2;
+// C = 32: 16 wavefronts x 1 query, 31 KB block + 32 KB staging = 63 KB -> two workgroups (32 wavefronts) per CU, the
+// occupancy of the stand-alone gather; C = 64: the 62 KB block leaves room for 8 wavefronts x 2 queries (78 KB, two per CU)
+constexpr int kQb32 = 16, kNw32 = 16, kIters32 = 2, kQb64 = 16, kNw64 = 8, kIters64 = 1;
 
 }  // namespace
+
+// Whether the engine and the per-op path route the fine levels through the fused kernel.  OFF by default: measured on
+// MI355X the fused form is throughput-neutral and 15-25 % slower per layer with one pair in
+// flight -- the 15*C floats per query it parks in LDS cap a CU at 16-32 queries in flight in lock-step phases, where the
+// stand-alone gather keeps 32 independent wavefronts busy.  RDM_FUSED_KPCONV=1 switches it on (both paths read this).
+extern "C" int rdm_kpconv_fused_enabled(void) {
+  static const bool on = [] {
+    const char* v = getenv("RDM_FUSED_KPCONV");
+    return v != nullptr && v[0] != '\0' && v[0] != '0';
+  }();
+  return on ? 1 : 0;
+}
 
 extern "C" int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out) {
   return (c_in == 1 && c_out == kC1Out) || (c_in == 32 && c_out == 32) || (c_in == 64 && c_out == 64);
 }
 
 extern "C" int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in) {
-  return c_in == 1 ? 4 * kC1Qpw : (c_in == 32 ? 32 * kItersC32 : 16 * kItersC64);
+  return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64);
 }
 
 extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
@@ -358,7 +381,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned blocks = static_cast<unsigned>(ceil_div<int64_t>(m, rdm_kpconv_fused_rows_per_block(c)));
   if (c == 1) {
-    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     return launch_status("kpconv_fused_c1_kernel");
   }
   // > 64 KB of dynamic LDS needs the attribute once per device
@@ -367,18 +390,18 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
   RDM_HIP_CHECK(hipGetDevice(&dev));
   const uint64_t bit = uint64_t(1) << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    const int l32 = static_cast<int>(fused_lds_bytes<32, 32>()), l64 = static_cast<int>(fused_lds_bytes<64, 16>());
-    const void* k32 = reinterpret_cast<const void*>(kpconv_fused_kernel<32, 32, kItersC32>);
-    const void* k64 = reinterpret_cast<const void*>(kpconv_fused_kernel<64, 16, kItersC64>);
+    const int l32 = static_cast<int>(fused_lds_bytes<32, kQb32, kNw32>()), l64 = static_cast<int>(fused_lds_bytes<64, kQb64, kNw64>());
+    const void* k32 = reinterpret_cast<const void*>(kpconv_fused_kernel<32, kQb32, kNw32, kIters32>);
+    const void* k64 = reinterpret_cast<const void*>(kpconv_fused_kernel<64, kQb64, kNw64, kIters64>);
     RDM_HIP_CHECK(hipFuncSetAttribute(k32, hipFuncAttributeMaxDynamicSharedMemorySize, l32));
     RDM_HIP_CHECK(hipFuncSetAttribute(k64, hipFuncAttributeMaxDynamicSharedMemorySize, l64));
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  const size_t lds32 = fused_lds_bytes<32, 32>(), lds64 = fused_lds_bytes<64, 16>();
+  const size_t lds32 = fused_lds_bytes<32, kQb32, kNw32>(), lds64 = fused_lds_bytes<64, kQb64, kNw64>();
   if (c == 32)
-    hipLaunchKernelGGL((kpconv_fused_kernel<32, 32, kItersC32>), dim3(blocks), dim3(512), lds32, st, a);
+    hipLaunchKernelGGL((kpconv_fused_kernel<32, kQb32, kNw32, kIters32>), dim3(blocks), dim3(64 * kNw32), lds32, st, a);
   else
-    hipLaunchKernelGGL((kpconv_fused_kernel<64, 16, kItersC64>), dim3(blocks), dim3(512), lds64, st, a);
+    hipLaunchKernelGGL((kpconv_fused_kernel<64, kQb64, kNw64, kIters64>), dim3(blocks), dim3(64 * kNw64), lds64, st, a);
   return launch_status("kpconv_fused_kernel");
 }
 

@@ -115,7 +115,7 @@ class RDMNet(torch.nn.Module):
                 b = torch.zeros((pad4(kdim), pad4(cout)), dtype=torch.float32)
                 b[:k * cin, :cout] = torch.from_numpy(S[name]).reshape(k * cin, cout)
                 W[name] = (b.to(dev), cin, cout)
-                if ops.kpconv_fused_supported(cin, cout):  # fine levels: gather + weight contraction in one kernel
+                if ops.kpconv_fused_enabled() and ops.kpconv_fused_supported(cin, cout):  # opt-in (RDM_FUSED_KPCONV=1)
                     W[name + '.packed'] = torch.from_numpy(ops.kpconv_pack_weights(S[name])).to(dev)
             elif name.endswith('.weight') and S[name].ndim == 2:
                 lin(name[:-7])

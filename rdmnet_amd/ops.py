@@ -101,6 +101,10 @@ def kpconv_gather(q_points, s_points, s_feats, s_positive, idx, kernel_points, s
     return wf, nn
 
 
+def kpconv_fused_enabled():
+    return bool(_lib.lib().rdm_kpconv_fused_enabled())
+
+
 def kpconv_fused_supported(c_in, c_out):
     return bool(_lib.lib().rdm_kpconv_fused_supported(int(c_in), int(c_out)))
 
