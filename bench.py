@@ -478,6 +478,7 @@ def main():
             if 'events' in rec:
                 e0, e1, e2 = rec['events']
                 tg, tt = e0.elapsed_time(e1) * 1e-3, e0.elapsed_time(e2) * 1e-3
+                rec['gather_ms'], rec['total_ms'] = tg * 1e3, tt * 1e3
             else:
                 tg, tt = rec['gather_ms'] * 1e-3, rec['total_ms'] * 1e-3
             t_total += tt
@@ -497,34 +498,66 @@ def main():
     # With several pairs in flight the event-bracketed durations above include the time a KPConv kernel
     # shares the CUs with other pairs' kernels.  A short single-stream pass after the timed region gives the
     # same kernels' durations when they own the GPU (reported beside, never instead of, the timed-region figure).
-    isolated = None
-    if len(streams) > 1 and engines:
-        iso_prof = []
+    iso_prof = []
+    if engines:
         run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, [], iso_prof, engines[0], 1)
         fence()
         if errors:
             raise errors[0]
-        it, ig, ib, ibg, per_layer = kp_totals(iso_prof)
-        if it > 0:
-            isolated = {'achieved': ib / it / 1e9, 'frac': ib / it / 1e9 / HBM_PEAK_GBS,
-                        'us_per_launch': it / max(len(iso_prof), 1) * 1e6,
-                        'gather_only_achieved': ibg / ig / 1e9 if ig > 0 else 0.0,
-                        'note': 'same kernels, one pair in flight (8 pairs after the timed region)'}
+    it, ig, ib, ibg, per_layer_iso = kp_totals(iso_prof)
+    if iso_prof:
+        per_layer = per_layer_iso
+
+    def mfma_totals(records):
+        """fp32 FLOPs and seconds of the KPConv weight contractions [M, 15 C] x [15 C, C'] of the non-strided layers
+        (the strided layers' second event interval also holds the shortcut max-pool)."""
+        fl = tt = 0.0
+        for rec in records:
+            if rec.get('pooled'):
+                continue
+            fl += 2.0 * rec['m'] * 15 * rec['cin'] * rec['cout']
+            tt += (rec['total_ms'] - rec['gather_ms']) * 1e-3
+        return fl, tt
+
     n_layers = max(len(prof), 1)
     traffic, traffic_note = None, None
-    pmc_file = os.path.join(ROOT, 'profiles', 'r01_pmc_kpconv_gather.json')
-    if os.path.exists(pmc_file):  # HBM bytes per gather dispatch from the committed rocprofv3 --pmc passes
-        pmc = json.load(open(pmc_file))
-        traffic, traffic_note = pmc['traffic_bytes_per_dispatch'], pmc['kernel'] + '; ' + pmc['source']
-    achieved = b_total / t_total / 1e9 if t_total > 0 else 0.0
+    for tag in ('r02', 'r01'):  # HBM bytes per gather dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
+        pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_kpconv_gather.json')
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            traffic, traffic_note = pmc['traffic_bytes_per_dispatch'], pmc['kernel'] + '; ' + pmc['source']
+            break
+    achieved = b_gather / t_gather / 1e9 if t_gather > 0 else 0.0
+    # `roofline`: the kernel the north star names -- the KPConv neighbourhood gather (kpconv_gather_kernel<*> +
+    # kpconv_gather_c1_kernel, 14 launches per pair).  achieved = SURVEY §8d gather bytes M*H*(8 + 12 + 4*C_in) per launch /
+    # the launch's duration (HIP events on its stream); `achieved`/`frac` are the TIMED REGION's (several pairs share the
+    # GPU), `one_pair_in_flight` the same kernels with the GPU to themselves; `traffic` (PMC) covers the same kernels.
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': traffic, 'traffic_scope': traffic_note,
-                'kernel': 'KPConv layer = kpconv_gather_kernel + its gemm_kernel (14 layers/pair)',
-                'bytes_per_launch': b_total / n_layers, 'us_per_launch': t_total / n_layers * 1e6,
-                'gather_only': {'kernel': 'kpconv_gather_kernel', 'achieved': b_gather / t_gather / 1e9 if t_gather > 0 else 0.0,
-                                'us_per_launch': t_gather / n_layers * 1e6},
-                'kpconv_ms_per_pair': t_total / max(len(prof) / 14.0, 1.0) * 1e3,  # 14 KPConv layers per pair
-                'pairs_with_layer_events': len(prof) // 14, 'one_pair_in_flight': isolated}
+                'kernel': 'kpconv_gather_kernel<*> + kpconv_gather_c1_kernel (KPConv neighbourhood gather, 14 launches/pair)',
+                'region': f'timed region, {len(streams)} pair(s) in flight',
+                'bytes_per_launch': b_gather / n_layers, 'us_per_launch': t_gather / n_layers * 1e6,
+                'pairs_with_layer_events': len(prof) // 14,
+                'one_pair_in_flight': ({'achieved': ibg / ig / 1e9, 'frac': ibg / ig / 1e9 / HBM_PEAK_GBS,
+                                        'us_per_launch': ig / max(len(iso_prof), 1) * 1e6,
+                                        'note': 'same kernels, 8 pairs on one stream after the timed region'} if ig > 0 else None),
+                # the whole KPConv layer (gather + weight GEMM + shortcut pool) against the same HBM peak, as round 1 reported it
+                'kpconv_layer': {'kernels': 'gather + gemm_kernel (weights) + gather_max (strided layers)',
+                                 'bytes_per_launch': b_total / n_layers,
+                                 'timed_region': {'achieved': b_total / t_total / 1e9 if t_total > 0 else 0.0,
+                                                  'frac': b_total / t_total / 1e9 / HBM_PEAK_GBS if t_total > 0 else 0.0,
+                                                  'us_per_launch': t_total / n_layers * 1e6},
+                                 'one_pair_in_flight': ({'achieved': ib / it / 1e9, 'frac': ib / it / 1e9 / HBM_PEAK_GBS,
+                                                         'us_per_launch': it / max(len(iso_prof), 1) * 1e6} if it > 0 else None),
+                                 'ms_per_pair_timed_region': t_total / max(len(prof) / 14.0, 1.0) * 1e3}}
+    # `roofline_mfma`: the kernel family that dominates the kernel time (gemm_kernel, fp32 MFMA): the KPConv weight
+    # contractions, from the same per-layer events; peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
+    mf, mt = mfma_totals(prof)
+    imf, imt = mfma_totals(iso_prof)
+    roofline_mfma = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> on the KPConv weight contractions [M,15C]x[15C,C\'] (9 non-strided layers/pair)',
+                     'achieved': mf / mt / 1e12 if mt > 0 else 0.0, 'peak': 157.3, 'unit': 'TFLOP/s',
+                     'frac': mf / mt / 1e12 / 157.3 if mt > 0 else 0.0, 'region': f'timed region, {len(streams)} pair(s) in flight',
+                     'one_pair_in_flight': ({'achieved': imf / imt / 1e12, 'frac': imf / imt / 1e12 / 157.3} if imt > 0 else None)}
 
     if rank == 0:
         result = {
@@ -545,6 +578,7 @@ def main():
             'host_to_host': host_to_host,
             'drop_in_api': api,
             'roofline': roofline,
+            'roofline_mfma': roofline_mfma,
         }
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(args.cache, args.pairs)

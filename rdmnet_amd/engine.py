@@ -129,7 +129,7 @@ class Engine:
             gather = p.m * p.h * (8 + 12 + 4 * p.c_in)
             total = gather + 4 * p.m * p.c_out + (p.m * p.h * (8 + 4 * p.pooled_channels) if p.pooled_channels else 0)
             out.append({'m': p.m, 'h': p.h, 'cin': p.c_in, 'cout': p.c_out, 'bytes': total, 'gather_bytes': gather,
-                        'gather_ms': p.gather_ms, 'total_ms': p.total_ms})
+                        'gather_ms': p.gather_ms, 'total_ms': p.total_ms, 'pooled': int(p.pooled_channels)})
         return out
 
     def keep_taps(self, enable=True):

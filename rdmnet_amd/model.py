@@ -174,7 +174,7 @@ class RDMNet(torch.nn.Module):
             pooled_channels = pool_src.shape[1] if pool_src is not None else 0
             nbytes = m * h * (8 + 12 + 4 * cin) + 4 * m * cout + (m * h * (8 + 4 * pooled_channels) if pooled_channels else 0)
             prof.append({'name': name, 'm': m, 'h': h, 'cin': cin, 'cout': cout, 'bytes': nbytes,
-                         'gather_bytes': m * h * (8 + 12 + 4 * cin), 'events': (e0, e1, e2)})
+                         'gather_bytes': m * h * (8 + 12 + 4 * cin), 'events': (e0, e1, e2), 'pooled': pooled_channels})
         return (y, pooled) if pool_src is not None else y
 
     def _unary(self, name, x, act=ACT_LEAKY, residual=None, want_positive=False):
