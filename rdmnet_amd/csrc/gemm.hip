@@ -795,18 +795,23 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     }
   }
   // developer knob for tuning runs (tools/gemm_sweep*.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the model
-  int force_splits = 0;
+  int force_splits = 0, exp_tile = 0;
   if (const char* tune = getenv("RDM_GEMM_TUNE")) {
     int t = 0, sp = 0;
     if (sscanf(tune, "%d,%d", &t, &sp) >= 1) {
       if (t == 1) tile = T128;
       else if (t == 2) tile = T64;
       else if (t == 3) tile = T128x32;
+      else if (t >= 4 && t <= 7) exp_tile = t;  // experimental tiles, tuning runs only (see the launch below)
       force_splits = sp;
-      if (t >= 1 && t <= 3 && sp == 0) best_s = 1;
+      if (t >= 1 && t <= 7 && sp == 0) best_s = 1;
     }
   }
-  const int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
+  int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
+  if (exp_tile == 4) { bm = 128; bn = 64; }
+  if (exp_tile == 5) { bm = 64; bn = 128; }
+  if (exp_tile == 6) { bm = 128; bn = 128; }
+  if (exp_tile == 7) { bm = 256; bn = 64; }
   {
     int sp = force_splits > 0 ? force_splits : best_s;
     const size_t need = static_cast<size_t>(m) * n * sp * batches * sizeof(float);
@@ -825,7 +830,11 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
                            : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, stat_rows_per_block(n))) : 0);
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
-  switch (tile) {
+  if (exp_tile == 4) launch<128, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
+  else if (exp_tile == 5) launch<64, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
+  else if (exp_tile == 6) launch<128, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
+  else if (exp_tile == 7) launch<256, 64, 4, 1, 32, 2>(g, batches, trans_b, st);
+  else switch (tile) {
     case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;  // 32-deep measured slower (LDS halves residency)
     case T64:
       // 32-deep k-tiles: 34 KB of LDS per block -> 4 blocks per CU (64-deep: 2); measured +2 % with 4 pairs in flight
