@@ -1,5 +1,6 @@
 // Shared host/device helpers for librdmnet_hip.so (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -75,6 +76,21 @@ struct Arena {
 };
 
 #ifdef __HIPCC__
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a PER-DEVICE property of a
+// kernel: `done` is a per-call-site bit mask indexed by the current device, so that a process driving several GPUs sets
+// it on each of them (a single `static bool` would leave the second GPU's launch failing).  Racing first calls only
+// repeat the same idempotent setting.
+inline hipError_t set_max_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return err;
+  const uint64_t bit = uint64_t(1) << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (err == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+  return err;
+}
+
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

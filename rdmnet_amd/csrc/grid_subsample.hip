@@ -846,9 +846,8 @@ extern "C" int rdm_grid_subsample(const float* points, int64_t n_points, const i
     return RDM_ERR_WORKSPACE;
   }
   fill_schedule(n_points + 1, &a.sched);
-  static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grid_subsample_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsBytes));
-  RDM_HIP_CHECK(lds_attr);
+  static std::atomic<uint64_t> lds_attr{0};
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(grid_subsample_kernel), static_cast<int>(kLdsBytes), lds_attr));
   hipLaunchKernelGGL(grid_subsample_kernel, dim3(batch), dim3(kT), kLdsBytes, st, a);
   if (int e = launch_status("grid_subsample_kernel")) return e;
   const int blocks = static_cast<int>(ceil_div<int64_t>(3 * n_points, 256 * 4));

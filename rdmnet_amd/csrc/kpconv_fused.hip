@@ -384,19 +384,12 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     return launch_status("kpconv_fused_c1_kernel");
   }
-  // > 64 KB of dynamic LDS needs the attribute once per device
-  static std::atomic<uint64_t> attr_set{0};
-  int dev = 0;
-  RDM_HIP_CHECK(hipGetDevice(&dev));
-  const uint64_t bit = uint64_t(1) << (dev & 63);
-  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    const int l32 = static_cast<int>(fused_lds_bytes<32, kQb32, kNw32>()), l64 = static_cast<int>(fused_lds_bytes<64, kQb64, kNw64>());
-    const void* k32 = reinterpret_cast<const void*>(kpconv_fused_kernel<32, kQb32, kNw32, kIters32>);
-    const void* k64 = reinterpret_cast<const void*>(kpconv_fused_kernel<64, kQb64, kNw64, kIters64>);
-    RDM_HIP_CHECK(hipFuncSetAttribute(k32, hipFuncAttributeMaxDynamicSharedMemorySize, l32));
-    RDM_HIP_CHECK(hipFuncSetAttribute(k64, hipFuncAttributeMaxDynamicSharedMemorySize, l64));
-    attr_set.fetch_or(bit, std::memory_order_release);
-  }
+  // (the C = 64 instance needs > 64 KB of dynamic LDS: the attribute is set once per device)
+  static std::atomic<uint64_t> attr32{0}, attr64{0};
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_fused_kernel<32, kQb32, kNw32, kIters32>),
+                                    static_cast<int>(fused_lds_bytes<32, kQb32, kNw32>()), attr32));
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_fused_kernel<64, kQb64, kNw64, kIters64>),
+                                    static_cast<int>(fused_lds_bytes<64, kQb64, kNw64>()), attr64));
   const size_t lds32 = fused_lds_bytes<32, kQb32, kNw32>(), lds64 = fused_lds_bytes<64, kQb64, kNw64>();
   if (c == 32)
     hipLaunchKernelGGL((kpconv_fused_kernel<32, kQb32, kNw32, kIters32>), dim3(blocks), dim3(64 * kNw32), lds32, st, a);

@@ -407,14 +407,9 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int S = static_cast<int>(side), B = static_cast<int>(batch);
   const size_t lds = sizeof(float) * (S + 1) * ((S + 1) | 1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lgr_extract_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lgr_refine_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_extract{0}, attr_refine{0};  // per device (rdm::set_max_dynamic_lds)
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(lgr_extract_kernel), 160 * 1024 - 4096, attr_extract));
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(lgr_refine_kernel), 160 * 1024 - 4096, attr_refine));
   hipLaunchKernelGGL(lgr_extract_kernel, dim3(B), dim3(256), lds, st, log_scores, S, ref_knn_masks, src_knn_masks, w);
   hipLaunchKernelGGL(lgr_layout_kernel, dim3(1), dim3(64), 0, st, B, correspondence_threshold, w);
   hipLaunchKernelGGL(lgr_gather_kernel, dim3(B), dim3(64), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,

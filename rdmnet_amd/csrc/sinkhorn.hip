@@ -198,17 +198,9 @@ extern "C" int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64
               "rdm_sinkhorn: bad sizes (m=%lld n=%lld, max %d)", (long long)m, (long long)n, kMaxSide);
   if (batch == 0) return RDM_OK;
   const size_t lds = sizeof(float) * (static_cast<size_t>(m + 1) * ((n + 1) | 1) + 8);
-  // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS; the attribute is a
-  // per-device setting, so it is remembered per device (a process may drive several GPUs)
+  // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS (set once per device)
   static std::atomic<uint64_t> attr_set{0};
-  int dev = 0;
-  RDM_HIP_CHECK(hipGetDevice(&dev));
-  const uint64_t bit = uint64_t(1) << (dev & 63);
-  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    RDM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-    attr_set.fetch_or(bit, std::memory_order_release);
-  }
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_kernel), 160 * 1024 - 4096, attr_set));
   hipLaunchKernelGGL(sinkhorn_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), lds,
                      static_cast<hipStream_t>(stream), scores, static_cast<int>(m), static_cast<int>(n), row_mask,
                      col_mask, alpha, iters, out);
