@@ -208,6 +208,8 @@ def main():
                          'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
     ap.add_argument('--host-steps', type=int, default=96,
                     help='pairs of the host-to-host pass that follows the timed region (0 = skip)')
+    ap.add_argument('--api-collate', choices=['native', 'python'], default='native',
+                    help='collate of the drop-in-API pass: native = rdm_engine_collate (one call), python = 17 launches from Python')
     ap.add_argument('--api-steps', type=int, default=96,
                     help='pairs of the drop-in-API pass (Python collate + model(data_dict)) after the timed region (0 = skip)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
@@ -268,7 +270,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     import threading
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
+    # (RDM_BENCH_HIGH_PRIORITY_STREAMS=k, developer experiment: the first k streams are created with high priority)
+    n_high = int(os.environ.get('RDM_BENCH_HIGH_PRIORITY_STREAMS', '0'))
+    streams = ([torch.cuda.Stream(device=dev, priority=-1 if k < n_high else 0) for k in range(args.streams)]
+               if args.streams > 1 else [None])
 
     # spinning waits need a core per pair in flight on every rank; poll + sleep when the budget is smaller
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
@@ -418,7 +423,8 @@ def main():
             item = {'ref_points': r, 'src_points': s_, 'ref_feats': torch.ones((r.shape[0], 1), device=dev),
                     'src_feats': torch.ones((s_.shape[0], 1), device=dev)}
             data = collate.registration_collate_fn_stack_mode([item], cfg.backbone.num_stages, cfg.backbone.init_voxel_size,
-                                                              cfg.backbone.init_radius, cfg.neighbor_limits, device=dev)
+                                                              cfg.backbone.init_radius, cfg.neighbor_limits, device=dev,
+                                                              engine=net.engine() if args.api_collate == 'native' else None)
             data['testing'] = True
             return data
 
@@ -467,8 +473,10 @@ def main():
             fwd_native.append((t3 - t2) * 1e3)
         api = {'value': args.api_steps * world / a_elapsed, 'unit': 'pairs/s', 'steps': args.api_steps,
                'forward_only_ms': {'model(data_dict)': float(np.median(fwd_model)), 'rdm_engine_forward': float(np.median(fwd_native))},
-               'note': 'rdmnet_amd.collate.registration_collate_fn_stack_mode + rdmnet_amd.model.RDMNet.__call__ (31-key '
-                       'output_dict), same pairs in flight; forward_only_ms: medians of 8 pairs, one in flight'}
+               'collate': args.api_collate,
+               'note': 'rdmnet_amd.collate.registration_collate_fn_stack_mode (engine=model.engine(): one native call) + '
+                       'rdmnet_amd.model.RDMNet.__call__ (31-key output_dict), same pairs in flight; forward_only_ms: medians of '
+                       '8 pairs, one in flight'}
 
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
     def kp_totals(prof):

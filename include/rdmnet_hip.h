@@ -387,7 +387,7 @@ typedef struct rdm_engine_result {
 typedef struct rdm_tensor_view {
   void* data;                 /* device pointer into the engine arena (valid until the next run) */
   int64_t rows, cols, ld;     /* ld in elements */
-  int dtype;                  /* 0 = f32, 1 = i64, 2 = u8 */
+  int dtype;                  /* 0 = f32, 1 = i64, 2 = u8, 3 = i32 */
 } rdm_tensor_view;
 
 typedef struct rdm_kpconv_profile {   /* one KPConv layer of the last run (HIP events on the run's stream) */
@@ -419,6 +419,14 @@ typedef struct rdm_data_dict {
   const int64_t* subsampling[4]; int64_t subsampling_width[4], subsampling_ld[4]; const int32_t* subsampling_count[4];
   const int64_t* upsampling[4];  int64_t upsampling_width[4],  upsampling_ld[4];  const int32_t* upsampling_count[4];
 } rdm_data_dict;
+
+/* rdm_engine_collate = the collate alone (registration_collate_fn_stack_mode / precompute_data_stack_mode,
+ * geotransformer/utils/data.py:13-77,139-192) as ONE native call: four subsamplings + 13 searches; the tables stay in the
+ * engine's arena as stage tensors "points0..4", "lengths0..4" (i64 [1,2]), "neighbors0..4", "subsampling0..3",
+ * "upsampling0..3" (i64 [n, limit]; effective widths in "search_flags", i32 [32,2] = {max count, status} per search in the
+ * order self / sub / up per level) -- fetch them with rdm_engine_export.  result_host receives the level sizes.      */
+int rdm_engine_collate(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
+                       rdm_engine_result* result_host, void* stream);
 
 /* rdm_engine_forward = RDMNet.forward(data_dict) alone (experiments/model_infer.py:109-354): the same native sequence
  * as rdm_engine_run after its collate, on tables the caller built -- with this library's collate

@@ -68,11 +68,35 @@ def precompute_data_stack_mode(points, lengths, num_stages, voxel_size, radius, 
 
 
 def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, search_radius, neighbor_limits,
-                                       precompute_data=True, device=None, exact_shapes=False):
+                                       precompute_data=True, device=None, exact_shapes=False, engine=None):
     """geotransformer/utils/data.py:139-192.  data_dicts: list (batch size 1 for this model) of dicts with
-    'ref_points', 'src_points', 'ref_feats', 'src_feats' (numpy or tensors) + passthrough keys."""
+    'ref_points', 'src_points', 'ref_feats', 'src_feats' (numpy or tensors) + passthrough keys.
+
+    engine (keyword only in spirit, not in the reference): an rdmnet_amd.engine.Engine built for the same configuration
+    (e.g. `model.engine()`).  The pyramid and its searches then run as ONE native call (rdm_engine_collate) instead of 17
+    launches issued from Python, with bit-identical tables; voxel size, radius and limits are the engine's (they must equal
+    the arguments)."""
     device = device or torch.device('cuda', torch.cuda.current_device())
     batch_size = len(data_dicts)
+    if engine is not None and precompute_data and batch_size == 1:
+        c = engine.cfg
+        if (num_stages != c.backbone.num_stages or abs(voxel_size - c.backbone.init_voxel_size) > 1e-9 or
+                abs(search_radius - c.backbone.init_radius) > 1e-9 or list(neighbor_limits) != list(c.neighbor_limits)):
+            raise ValueError('the engine was built for another pyramid configuration')
+        d = data_dicts[0]
+        ref = torch.as_tensor(d['ref_points']).to(device=device, dtype=torch.float32).contiguous()
+        src = torch.as_tensor(d['src_points']).to(device=device, dtype=torch.float32).contiguous()
+        collated = {k: v for k, v in d.items() if k not in ('ref_points', 'src_points', 'ref_feats', 'src_feats')}
+        collated.update(engine.collate(ref, src))
+        collated['features'] = torch.cat([torch.as_tensor(d['ref_feats']), torch.as_tensor(d['src_feats'])], 0).to(
+            device=device, dtype=torch.float32)
+        if exact_shapes:
+            fl = collated['_flags'].cpu()
+            if int(fl[:, 1].max()) != 0:
+                raise RuntimeError('radius search: internal error (status word set)')
+            for key in ('neighbors', 'subsampling', 'upsampling'):
+                collated[key] = [t[:, :min(t.shape[1], int(collated['_widths'][(key, i)][0]))] for i, t in enumerate(collated[key])]
+        return collated
     collated = {}
     for d in data_dicts:
         for k, v in d.items():

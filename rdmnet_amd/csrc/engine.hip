@@ -65,6 +65,7 @@ struct rdm_engine {
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
   bool keep_taps = false;
+  bool collate_only = false;  // rdm_engine_collate: stop after the pyramid and its searches
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -680,6 +681,20 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   return engine_run_growing(e, ref_points, n_ref, src_points, n_src, nullptr, res, stream);
 }
 
+// The collate alone (geotransformer/utils/data.py:13-77 on two clouds): the pyramid and its 13 searches stay in the engine's
+// arena as stage tensors ("points0".."points4", "lengths0".., "neighbors0".., "subsampling0".."subsampling3",
+// "upsampling0".., "search_flags") for rdm_engine_export; level sizes in result_host.  Taps are switched on by the call.
+extern "C" int rdm_engine_collate(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
+                                  int64_t n_src, rdm_engine_result* res, void* stream) {
+  RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_collate: null pointer");
+  RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_collate: empty cloud");
+  e->keep_taps = true;
+  e->collate_only = true;
+  const int rc = engine_run_growing(e, ref_points, n_ref, src_points, n_src, nullptr, res, stream);
+  e->collate_only = false;
+  return rc;
+}
+
 // RDMNet.forward alone (experiments/model_infer.py:109-354) on a data_dict the caller collated -- with this library's
 // collate or with the reference's (geotransformer/utils/data.py:139-192).
 extern "C" int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
@@ -824,12 +839,19 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));
   }  // collate
   for (int i = 0; i < 5; ++i) {
+    tap(r, ("lengths" + std::to_string(i)).c_str(), lv[i].lengths, 1, 2, 2, 1);
     tap(r, ("points" + std::to_string(i)).c_str(), lv[i].pts, lv[i].n, 3, 3, 0);
     tap(r, ("neighbors" + std::to_string(i)).c_str(), nb[i].idx, nb[i].rows, nb[i].width, nb[i].stride(), 1);
     if (i < 4) {
       tap(r, ("subsampling" + std::to_string(i)).c_str(), sub[i].idx, sub[i].rows, sub[i].width, sub[i].stride(), 1);
       tap(r, ("upsampling" + std::to_string(i)).c_str(), up[i].idx, up[i].rows, up[i].width, up[i].stride(), 1);
     }
+  }
+
+  tap(r, "search_flags", flags, 32, 2, 2, 3);  // per search: [max neighbour count, status] (int32)
+  if (e->collate_only) {
+    res->arena_used = e->arena_off;
+    return RDM_OK;
   }
 
   // kernel scratch of the network part, sized from the actual pyramid: Linear+GroupNorm of level l is at most
@@ -1236,7 +1258,7 @@ extern "C" int rdm_engine_export(rdm_engine* e, int n, const char* const* names,
       return RDM_ERR_ARG;
     }
     const rdm_tensor_view& v = it->second;
-    const size_t esz = v.dtype == 1 ? 8 : (v.dtype == 2 ? 1 : 4);
+    const size_t esz = v.dtype == 1 ? 8 : (v.dtype == 2 ? 1 : 4);  // 0 f32, 1 i64, 2 u8, 3 i32
     const size_t bytes = static_cast<size_t>(v.rows) * v.ld * esz;
     if (bytes == 0) continue;
     RDM_REQUIRE(dst[i], "rdm_engine_export: null destination for %s", names[i]);

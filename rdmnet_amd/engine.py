@@ -52,8 +52,8 @@ class KpconvProfile(ctypes.Structure):
                 ('pooled_channels', ctypes.c_int64), ('gather_ms', ctypes.c_float), ('total_ms', ctypes.c_float)]
 
 
-_DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
-_ESIZE = {0: 4, 1: 8, 2: 1}
+_DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8, 3: torch.int32}
+_ESIZE = {0: 4, 1: 8, 2: 1, 3: 4}
 
 
 def make_config(cfg, arena_bytes=0):
@@ -143,6 +143,35 @@ class Engine:
                                          src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()),
                    'rdm_engine_run')
         return self.result
+
+    _COLLATE_NAMES = ([f'points{i}' for i in range(5)] + [f'lengths{i}' for i in range(5)] + [f'neighbors{i}' for i in range(5)] +
+                      [f'subsampling{i}' for i in range(4)] + [f'upsampling{i}' for i in range(4)] + ['search_flags'])
+
+    def collate(self, ref_points, src_points):
+        """The reference's collate (registration_collate_fn_stack_mode, geotransformer/utils/data.py:139-192) for one pair as
+        ONE native call + one batched copy: float32 CUDA clouds [n,3] -> the data_dict (fresh tensors, independent of the
+        engine's arena) with 'points', 'lengths', 'neighbors', 'subsampling', 'upsampling', 'features', 'batch_size', plus
+        `_widths` / `_flags` (device-resident effective table widths, as rdmnet_amd.collate returns them)."""
+        assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
+        assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
+        _lib.check(self.L.rdm_engine_collate(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
+                                             src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()), 'rdm_engine_collate')
+        t = self.tensors(self._COLLATE_NAMES)
+        flags = t['search_flags'][:13]
+        d = {'points': [t[f'points{i}'] for i in range(5)], 'lengths': [t[f'lengths{i}'][0] for i in range(5)],
+             'neighbors': [t[f'neighbors{i}'] for i in range(5)], 'subsampling': [t[f'subsampling{i}'] for i in range(4)],
+             'upsampling': [t[f'upsampling{i}'] for i in range(4)], '_flags': flags, '_widths': {},
+             'features': torch.ones((ref_points.shape[0] + src_points.shape[0], 1), dtype=torch.float32, device=self.device),
+             'batch_size': 1}
+        # the engine searches every level's grid three times in a row -- self(i), sub(i), up(i-1) -- so that one grid serves
+        # them: flag rows 0 self0, 1 sub0, 2 self1, 3 sub1, 4 up0, 5 self2, 6 sub2, 7 up1, 8 self3, 9 sub3, 10 up2, 11 self4, 12 up3
+        for i in range(5):
+            row = 0 if i == 0 else 3 * i - 1
+            d['_widths'][('neighbors', i)] = flags[row]
+            if i < 4:
+                d['_widths'][('subsampling', i)] = flags[row + 1]
+                d['_widths'][('upsampling', i)] = flags[(4, 7, 10, 12)[i]]
+        return d
 
     def forward(self, data_dict):
         """RDMNet.forward(data_dict) as ONE native call (rdm_engine_forward).  data_dict: the collate's dictionary
@@ -235,7 +264,7 @@ class Engine:
         for i in range(n):
             arr_d[i] = base + offs[i]
         _lib.check(self.L.rdm_engine_export(self._h, n, arr_n, arr_d, _lib.stream_ptr()), 'rdm_engine_export')
-        typed = {0: buf.view(torch.float32), 1: buf.view(torch.int64), 2: buf}
+        typed = {0: buf.view(torch.float32), 1: buf.view(torch.int64), 2: buf, 3: buf.view(torch.int32)}
         return {names[i]: torch.as_strided(typed[v.dtype], (v.rows, v.cols), (v.ld, 1), offs[i] // _ESIZE[v.dtype])
                 for i, v in enumerate(arr_v)}
 

@@ -308,6 +308,10 @@ class RDMNet(torch.nn.Module):
             self._tls.engine, self._tls.engine_state = eng, self._state
         return eng
 
+    def engine(self):
+        """The calling thread's native engine (for rdmnet_amd.collate.registration_collate_fn_stack_mode(..., engine=...))."""
+        return self._engine()
+
     @torch.no_grad()
     def forward(self, data_dict, taps=None):
         """experiments/model_infer.py:109-354 (inference).  `data_dict` as produced by the collate

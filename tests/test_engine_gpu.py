@@ -251,3 +251,28 @@ def test_model_is_a_torch_module_with_the_reference_checkpoint_layout(ctx):
     assert next(net.parameters()).is_cuda and net.device.type == 'cuda'
     out = net(ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], cfg))
     assert out['estimated_transform'].shape == (4, 4)
+
+
+def test_native_collate_equals_per_op_collate_and_feeds_the_model(ctx, golden_dir):
+    """registration_collate_fn_stack_mode(..., engine=model.engine()) -- the reference's collate as ONE native call
+    (rdm_engine_collate) -- returns the same data_dict as the 17-launch Python collate, tensor for tensor (points, lengths,
+    the 13 index tables up to their effective widths, features), in fresh tensors that survive further engine runs; the model
+    on it equals rdm_engine_run."""
+    cfg, net, eng, collate = ctx['cfg'], ctx['net'], ctx['eng'], ctx['collate']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    b = cfg.backbone
+    for ref, src in ((ctx['rp'], ctx['sp']), (z['ref2'], z['src2'])):
+        item = {'seq_id': 3, 'ref_frame': 10, 'src_frame': 11, 'ref_points': ref, 'src_points': src,
+                'ref_feats': np.ones((len(ref), 1), np.float32), 'src_feats': np.ones((len(src), 1), np.float32)}
+        args = ([item], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits)
+        nat = collate.registration_collate_fn_stack_mode(*args, engine=net.engine(), exact_shapes=True)
+        ref_d = collate.registration_collate_fn_stack_mode(*args, exact_shapes=True)
+        assert nat['seq_id'] == 3 and nat['batch_size'] == 1 and torch.equal(nat['features'], ref_d['features'])
+        for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+            assert len(nat[key]) == len(ref_d[key])
+            for a, c in zip(nat[key], ref_d[key]):
+                assert a.dtype == c.dtype and torch.equal(a, c), key
+        net.engine().run(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda())  # overwrite the arena: the dict must not care
+        out = net(nat)
+        eng.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
+        assert np.array_equal(eng.transform(), out['estimated_transform'].cpu().numpy())
