@@ -210,7 +210,7 @@ def main():
                     help='pairs of the host-to-host pass that follows the timed region (0 = skip)')
     ap.add_argument('--api-collate', choices=['native', 'python'], default='native',
                     help='collate of the drop-in-API pass: native = rdm_engine_collate (one call), python = 17 launches from Python')
-    ap.add_argument('--api-steps', type=int, default=96,
+    ap.add_argument('--api-steps', type=int, default=192,
                     help='pairs of the drop-in-API pass (Python collate + model(data_dict)) after the timed region (0 = skip)')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
@@ -443,7 +443,7 @@ def main():
                     ctx.__exit__(None, None, None)
 
         for warm in (True, False):
-            n_api = len(streams) * 2 if warm else args.api_steps
+            n_api = len(streams) * 6 if warm else args.api_steps
             jobs = [list(range(k, n_api, len(streams))) for k in range(len(streams))]
             fence()
             ta0 = time.perf_counter()

@@ -162,7 +162,10 @@ class Engine:
              'neighbors': [t[f'neighbors{i}'] for i in range(5)], 'subsampling': [t[f'subsampling{i}'] for i in range(4)],
              'upsampling': [t[f'upsampling{i}'] for i in range(4)], '_flags': flags, '_widths': {},
              'features': torch.ones((ref_points.shape[0] + src_points.shape[0], 1), dtype=torch.float32, device=self.device),
-             'batch_size': 1}
+             'batch_size': 1,
+             # host copies of the ref/src split of every level (the collate already read them back): forward() then
+             # needs no synchronisation of its own before the native call
+             '_level_ref_sizes': [int(self.result.level_ref_sizes[i]) for i in range(5)]}
         # the engine searches every level's grid three times in a row -- self(i), sub(i), up(i-1) -- so that one grid serves
         # them: flag rows 0 self0, 1 sub0, 2 self1, 3 sub1, 4 up0, 5 self2, 6 sub2, 7 up1, 8 self3, 9 sub3, 10 up2, 11 self4, 12 up3
         for i in range(5):
@@ -199,14 +202,16 @@ class Engine:
         d = DataDict()
         lengths = [dev_t(x, torch.int64).contiguous() for x in data_dict['lengths']]
         keep.extend(lengths)
-        cflags = data_dict.get('_flags')  # status words of this library's collate (13 radius searches), if it built the dict
-        head = torch.stack([x[0] for x in lengths])
-        if cflags is not None:
-            head = torch.cat([head, cflags[:, 1].to(torch.int64)])
-        head = head.cpu().tolist()  # the one synchronisation of this wrapper
-        n_ref = head[:5]
-        if any(head[5:]):
-            raise RuntimeError('radius search: a search of the collate reported an internal error (status word set)')
+        n_ref = data_dict.get('_level_ref_sizes')  # host copies left by Engine.collate: no synchronisation needed here
+        if n_ref is None:
+            cflags = data_dict.get('_flags')  # status words of this library's collate (13 radius searches), if it built the dict
+            head = torch.stack([x[0] for x in lengths])
+            if cflags is not None:
+                head = torch.cat([head, cflags[:, 1].to(torch.int64)])
+            head = head.cpu().tolist()  # the one synchronisation of this wrapper
+            n_ref = head[:5]
+            if any(head[5:]):
+                raise RuntimeError('radius search: a search of the collate reported an internal error (status word set)')
         widths = data_dict.get('_widths', {})
         feats = dev_t(data_dict['features'], torch.float32)
         if feats.dim() != 2 or feats.stride(1) != 1:
