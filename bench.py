@@ -260,7 +260,7 @@ def main():
         data = collate.registration_collate_fn_stack_mode([item], cfg.backbone.num_stages, cfg.backbone.init_voxel_size,
                                                           cfg.backbone.init_radius, cfg.neighbor_limits, device=dev)
         data['testing'] = True
-        out = net(data)
+        out = net(data, {})  # a taps dictionary selects the per-op mirror (without one forward() is the native call)
         return out['estimated_transform'].cpu().numpy(), out['corr_scores'].shape[0]
 
     def fence():
