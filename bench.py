@@ -274,6 +274,25 @@ def main():
     n_high = int(os.environ.get('RDM_BENCH_HIGH_PRIORITY_STREAMS', '0'))
     streams = ([torch.cuda.Stream(device=dev, priority=-1 if k < n_high else 0) for k in range(args.streams)]
                if args.streams > 1 else [None])
+    # (RDM_BENCH_CU_MASK=interleave|blocks, developer experiment: every stream gets its own 1/streams of the CUs through
+    # hipExtStreamCreateWithCUMask -- spatial partitioning instead of contention for the same CUs)
+    cu_mode = os.environ.get('RDM_BENCH_CU_MASK')
+    if cu_mode and args.streams > 1:
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        streams = []
+        for k in range(args.streams):
+            bits = [0] * ((n_cu + 31) // 32)
+            for cu in range(n_cu):
+                mine = (cu % args.streams == k) if cu_mode == 'interleave' else (cu * args.streams // n_cu == k)
+                if mine:
+                    bits[cu // 32] |= 1 << (cu % 32)
+            arr = (ctypes.c_uint32 * len(bits))(*bits)
+            h = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(bits), arr)
+            assert rc == 0, rc
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
 
     # spinning waits need a core per pair in flight on every rank; poll + sleep when the budget is smaller
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
