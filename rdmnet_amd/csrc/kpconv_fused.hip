@@ -5,19 +5,20 @@
 //   WF[m, k, c] = sum_h max(0, 1 - |s[idx[m,h]] - q[m] - kp[k]| / sigma) * feats[idx[m,h], c]      :91-105
 //   out[m, c']  = (sum_k sum_c WF[m, k, c] W[k, c, c']) / max(1, #{h : sum_c feats[idx[m,h], c] > 0}) + bias[c']   :107-121
 // The two-kernel form (kpconv.hip + gemm.hip) writes WF -- 15*C floats per query, 61 MB for the 32 k-point level at
-// C = 32 -- and reads it back; at C <= 64 that round trip costs as much as the gather itself.  Here a workgroup of
-// eight wavefronts aggregates QB queries (one wavefront per query at a time, the 16x16x4 MFMA formulation of
-// kpconv.hip), parks the QB x 15C block in LDS, and multiplies it by W on the same matrix cores: the A operand of
-// v_mfma_f32_16x16x4_f32 is a 16-B LDS read (16 queries x 4 consecutive k per instruction), the B operand one
-// coalesced 16-B global read per lane from a copy of W stored in operand order (rdm_kpconv_pack_weights).  The
-// epilogue divides by the neighbour count, adds the bias, writes the [M, C'] output and accumulates the fp64 column
-// sums GroupNorm needs (same partial layout as the GEMM epilogue, gemm.hip).
-//   C = 32: QB = 32 (2 row tiles x 2 column tiles x 2 K halves = 8 wavefronts), W = 61 KB read once per 32 queries
-//   C = 64: QB = 16 (1 row tile  x 4 column tiles x 2 K halves),                W = 245 KB read once per 16 queries
-//   LDS 78 KB per workgroup (62 KB block + per-wavefront neighbour staging): two workgroups per CU, so one gathers
-//   while the other multiplies.
+// C = 32 -- and reads it back.  Here a workgroup aggregates 16 queries (one wavefront per query at a time, the 16x16x4
+// MFMA formulation of kpconv.hip), parks the 16 x 15C block in LDS, and multiplies it by W on the same matrix cores:
+// the A operand of v_mfma_f32_16x16x4_f32 is a 16-B LDS read (16 queries x 4 consecutive k per instruction), the B
+// operand one coalesced 16-B global read per lane from a copy of W stored in operand order
+// (rdm_kpconv_pack_weights); the K range is split over the wavefronts and the slices meet in LDS in a fixed order.
+// The epilogue divides by the neighbour count, adds the bias, writes the [M, C'] output and accumulates the fp64
+// column sums GroupNorm needs (same partial layout as the GEMM epilogue, gemm.hip).
+//   C = 32: 16 wavefronts x 1 query, 2 column tiles x 8 K slices; 31 KB block + 32 KB staging -> 2 workgroups per CU
+//   C = 64:  8 wavefronts x 2 queries, 4 column tiles x 2 K slices; 62 KB block + 16 KB staging -> 2 workgroups per CU
 //   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
-//   channel.
+//   channel, 16 wavefronts x 4 queries per workgroup.
+// Measured (profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
+// scan pair, the time does not (the LDS block caps a CU at 16-32 queries in flight in lock-step phases), so the engine
+// uses it only when RDM_FUSED_KPCONV=1.
 #include <atomic>
 #include <cstdlib>
 
