@@ -54,7 +54,8 @@ class RDMNet(torch.nn.Module):
         self._np_state = None  # name -> numpy float32 (what the kernels' weight preparation reads)
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
         self.attention_bf16 = bool(getattr(cfg.thdroformer, 'attention_bf16', False))
-        self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py); .engine
+        self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py)
+        self._engines, self._engines_state, self._engines_lock = {}, None, threading.Lock()  # native engines by stream
         self.fast_path = True          # forward(data_dict) as one native call; False = the per-op mirror
         self.device = None
         if device is not None:
@@ -295,17 +296,25 @@ class RDMNet(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _engine(self):
-        """The native engine of the calling thread (an engine is not re-entrant; bench.py drives one forward per
-        host thread and stream), built from this module's state dict on first use."""
+        """The native engine of the CURRENT STREAM (an engine is not re-entrant and its work is ordered by the stream it
+        runs on; bench.py drives one forward per host thread, each on its own stream), built from this module's state
+        dict on first use and kept for the life of the module."""
         from . import engine as engine_mod
-        eng = getattr(self._tls, 'engine', None)
-        if eng is None or getattr(self._tls, 'engine_state', None) is not self._state:
-            if self.device is None:
-                self.cuda()
-            with torch.cuda.device(self.device):
-                eng = engine_mod.Engine(self.cfg, self._state, device=self.device)
-            eng.keep_taps(True)
-            self._tls.engine, self._tls.engine_state = eng, self._state
+        if self.device is None:
+            self.cuda()
+        key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
+        with self._engines_lock:
+            eng = self._engines.get(key)
+            if eng is not None and self._engines_state is self._state:
+                return eng
+            if self._engines_state is not self._state:  # parameters changed (load_state_dict / .to()): rebuild lazily
+                self._engines.clear()
+                self._engines_state = self._state
+        with torch.cuda.device(self.device):
+            eng = engine_mod.Engine(self.cfg, self._state, device=self.device)
+        eng.keep_taps(True)
+        with self._engines_lock:
+            self._engines[key] = eng
         return eng
 
     def engine(self):
