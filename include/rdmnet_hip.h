@@ -48,6 +48,11 @@ size_t rdm_grid_subsample_workspace_bytes(int64_t n_points, int batch);
 int rdm_grid_subsample(const float* points, int64_t n_points, const int64_t* lengths, int batch,
                        float voxel_size, float* out_points, int64_t* out_lengths, void* ws,
                        size_t ws_bytes, void* stream);
+/* The same with the kernel form chosen by the caller: 0 = by size (what rdm_grid_subsample does: from 16 384 stacked points
+ * the phases before the hash-map order replay run as separate launches over many workgroups), 1 = one workgroup per cloud
+ * for every phase, 2 = the multi-launch form.  Identical output bit for bit (tests/test_native_gpu.py).                  */
+int rdm_grid_subsample_form(const float* points, int64_t n_points, const int64_t* lengths, int batch, float voxel_size,
+                            float* out_points, int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream, int form);
 
 /* ---- a2: radius neighbours -----------------------------------------------------------------
  * Replaces rdmnet.ext.radius_neighbors

@@ -20,6 +20,8 @@ SIGNATURES = {
     'rdm_grid_subsample_workspace_bytes': (c_size, [c_i64, c_int]),
     'rdm_grid_subsample': (c_int, [c_void, c_i64, c_void, c_int, c_f32, c_void, c_void, c_void, c_size,
                                    c_void]),
+    'rdm_grid_subsample_form': (c_int, [c_void, c_i64, c_void, c_int, c_f32, c_void, c_void, c_void, c_size,
+                                        c_void, c_int]),
     'rdm_radius_neighbors_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_radius_neighbors': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_int, c_f32, c_int,
                                      c_void, c_void, c_void, c_void, c_void, c_size, c_void]),

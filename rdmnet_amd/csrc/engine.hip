@@ -795,8 +795,10 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     lv[i].pts = e->alloc<float>(3 * cap);
     lv[i].lengths = all_len + 2 * (i - 1);
     ENG_ALLOC(lv[i].pts);
-    ENG_CHECK(rdm_grid_subsample(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
-                                 r.st));
+    // level 0 -> 1 (16-20 k points per cloud): phases spread over the GPU when the clouds are large; the later levels run at
+    // capacity `cap` with a few thousand real points: the single-workgroup kernel
+    ENG_CHECK(grid_subsample_mode(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
+                                  r.st, i == 1 ? 0 : 1));
     // capacity of the next level is unknown on the host until the read-back; run it at full capacity
   }
   int64_t host_len[8];

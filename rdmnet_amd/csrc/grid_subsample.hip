@@ -20,10 +20,13 @@
 // order, output = sum * (float)(1.0 / count).
 #pragma clang fp contract(off)
 
+#include <atomic>
+#include <cstdlib>
 #include <unordered_map>  // std::__detail::_Prime_rehash_policy
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -36,6 +39,7 @@ constexpr int kLdsM = 10304, kLdsB = 10304;
 constexpr int kOwn = (kLdsM + kT - 1) / kT;  // stage elements owned by one thread
 constexpr size_t kLdsBytes = 3 * sizeof(unsigned short) * kLdsM + 2 * sizeof(unsigned) * kLdsB;
 constexpr int kMaxStages = 40;
+constexpr int64_t kMultiMinPoints = 16384;  // stacked points from which rdm_grid_subsample uses the multi-launch form
 constexpr unsigned long long kEmpty = ~0ull;
 
 struct Schedule {
@@ -44,7 +48,18 @@ struct Schedule {
   int buckets[kMaxStages];
 };
 
+// per-cloud record of the multi-launch form (below): grid geometry, voxel count, crowded-voxel counter, per-block counts
+constexpr int kMultiMaxBlocks = 256;   // 1024-point blocks per cloud
+struct GsMeta {
+  float org[3];
+  int M;
+  unsigned long long nx, ny;
+  int nbig, pad;
+  int blk[kMultiMaxBlocks];
+};
+
 struct GridArgs {
+  GsMeta* meta;          // [batch] (multi-launch form only)
   const float* points;
   const int64_t* lengths;
   int batch;
@@ -228,6 +243,60 @@ __device__ unsigned short* replay_lds(const GridArgs& a, const unsigned long lon
   return cur;
 }
 
+// One crowded voxel (more than 8 points) by one wavefront: rank sort of the point indices (lane = list entry), then the sums
+// in ascending point order from registers (the order fixes the fp32 result).  sorted64: 64 ints of LDS private to the wavefront.
+__device__ __forceinline__ void crowded_voxel(const float* P, const int* list, int* cur, const int* ecnt, const int* ebase,
+                                              float* epts, int e, int lane, int* sorted64) {
+  const int c = ld_agent(&ecnt[e]), base = ebase[e];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (c <= 64) {
+    const int mine = lane < c ? list[base + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
+    if (lane < c) sorted64[rank] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane < c ? sorted64[lane] : 0;
+    const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+    for (int j = 0; j < c; ++j) {
+      sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
+      sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
+      sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+    }
+  } else {
+    // more than a wavefront of points in one voxel (a degenerate cloud can put ALL its points there): the same
+    // rank sort in chunks of 64 against chunks of 64 -- c^2/64 wavefront steps instead of one thread's c^2/4
+    // memory round trips -- with the sorted indices in `cur` (a P7 array, free until then)
+    for (int m0 = 0; m0 < c; m0 += 64) {
+      const int mine = m0 + lane < c ? list[base + m0 + lane] : 0x7fffffff;
+      int rank = 0;
+      for (int o0 = 0; o0 < c; o0 += 64) {
+        const int other = o0 + lane < c ? list[base + o0 + lane] : 0x7fffffff;
+        const int cnt = min(64, c - o0);
+        for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(other, j) < mine ? 1 : 0;
+      }
+      if (m0 + lane < c) cur[base + rank] = mine;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the sorted list was written by other lanes
+    for (int m0 = 0; m0 < c; m0 += 64) {
+      const int i = m0 + lane < c ? ld_agent(&cur[base + m0 + lane]) : 0;
+      const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+      const int cnt = min(64, c - m0);
+      for (int j = 0; j < cnt; ++j) {
+        sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
+        sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
+        sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
+      }
+    }
+  }
+  if (lane == 0) {
+    const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
+    epts[3 * e] = sx * wgt;
+    epts[3 * e + 1] = sy * wgt;
+    epts[3 * e + 2] = sz * wgt;
+  }
+}
+
 constexpr int kMaskChunks = 64;  // 64-point chunks per wavefront whose ballots P2 keeps in LDS
 constexpr int kBigCap = 2048;  // work list of crowded voxels; beyond it the owning thread sorts serially
 #ifdef RDM_GS_TIMING
@@ -236,6 +305,99 @@ __device__ unsigned long long rdm_gs_clk[16];  // tools/gs_phase_lab.hip: shader
 #else
 #define GS_STAMP(k) do { } while (0)
 #endif
+// P7 + P8 of one cloud by one 1024-thread workgroup: replay of the hash map's growth stages (in LDS when the cloud fits,
+// through the per-cloud global arrays otherwise), then the voxel barycentres in the container's iteration order
+// (grid_subsampling_cpu.cpp:44-47).  s_dyn: the kLdsBytes of dynamic LDS; s_scan: kT/64 + 2 ints.
+__device__ void replay_and_emit(const GridArgs& a, int64_t start, int M, const unsigned long long* ekey, const float* epts, int* cur,
+                                int* nxt, int* bt, int* off, int* tmp, int* bf, int* bc, int* bl, unsigned char* s_dyn,
+                                int* s_scan) {
+  const int tid = threadIdx.x;
+  // ---- P7: replay the container's growth stages to obtain its iteration order
+  int last_b = 0;
+  for (int j = 0; j < a.sched.n && a.sched.at[j] < M; ++j) last_b = a.sched.buckets[j];
+  const bool in_lds = M <= kLdsM && last_b <= kLdsB;  // uniform over the block
+  const unsigned short* lds_order = nullptr;
+  if (in_lds) {
+    unsigned short* l_cur = reinterpret_cast<unsigned short*>(s_dyn);
+    unsigned short* l_nxt = l_cur + kLdsM;
+    unsigned short* l_tmp = l_nxt + kLdsM;
+    unsigned* l_bf = reinterpret_cast<unsigned*>(l_tmp + kLdsM);
+    unsigned* l_bcl = l_bf + kLdsB;
+    lds_order = replay_lds(a, ekey, M, l_cur, l_nxt, l_tmp, l_bf, l_bcl, s_scan);
+  } else {
+    for (int j = 0; j < a.sched.n; ++j) {
+      const int k0 = a.sched.at[j];
+      if (k0 >= M) break;
+      int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
+      if (k1 > M) k1 = M;
+      const int B = a.sched.buckets[j];
+      const int n = k1;  // every element ranked < k0 is already in `cur`
+      for (int x = tid; x < B; x += kT) {
+        bf[x] = 0x7fffffff;
+        bc[x] = 0;
+        bl[x] = 0;
+      }
+      __syncthreads();
+      for (int t = tid; t < n; t += kT) {
+        const int e = t < k0 ? cur[t] : t;
+        const int bkt = static_cast<int>(ekey[e] % static_cast<unsigned long long>(B));
+        bt[t] = bkt;
+        atomicMin(&bf[bkt], t);
+        atomicAdd(&bc[bkt], 1);
+      }
+      __syncthreads();
+      block_scan(
+          n,
+          [&](int t) {
+            const int bkt = bt[t];
+            return ld_agent(&bf[bkt]) == t ? ld_agent(&bc[bkt]) : 0;
+          },
+          off, s_scan, true);
+      for (int t = tid; t < n; t += kT) {
+        const int bkt = bt[t];
+        const int base = off[ld_agent(&bf[bkt])];
+        const int slot = atomicAdd(&bl[bkt], 1);
+        tmp[base + slot] = t;
+      }
+      __syncthreads();
+      for (int t = tid; t < n; t += kT) {
+        const int bkt = bt[t];
+        if (ld_agent(&bf[bkt]) != t) continue;
+        const int c = ld_agent(&bc[bkt]);
+        int* L = tmp + off[t];
+        for (int x = 1; x < c; ++x) {  // newest first inside a bucket
+          const int val = L[x];
+          int y = x - 1;
+          while (y >= 0 && L[y] < val) {
+            L[y + 1] = L[y];
+            --y;
+          }
+          L[y + 1] = val;
+        }
+      }
+      __syncthreads();
+      for (int pos = tid; pos < n; pos += kT) {
+        const int t = tmp[pos];
+        nxt[pos] = t < k0 ? cur[t] : t;
+      }
+      __syncthreads();
+      int* sw = cur;
+      cur = nxt;
+      nxt = sw;
+    }
+  }
+
+  GS_STAMP(5);
+  // ---- P8: emit in list order (grid_subsampling_cpu.cpp:44-47)
+  float* out = a.tmp_points + 3 * start;
+  for (int pos = tid; pos < M; pos += kT) {
+    const int e = in_lds ? static_cast<int>(lds_order[pos]) : cur[pos];
+    out[3 * pos] = epts[3 * e];
+    out[3 * pos + 1] = epts[3 * e + 1];
+    out[3 * pos + 2] = epts[3 * e + 2];
+  }
+}
+
 __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __shared__ int s_scan[kT / 64 + 2];
   // scratch tables of P2 and P6 live in the dynamic LDS that P7's replay uses afterwards (144 KB, always allocated)
@@ -578,55 +740,7 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
     const int lane = tid & 63, w = tid >> 6;
     const int nbig = min(s_nbig, kBigCap);
     for (int k = w; k < nbig; k += kT / 64) {
-      const int e = s_big[k];
-      const int c = ld_agent(&ecnt[e]), base = ebase[e];
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-      if (c <= 64) {
-        const int mine = lane < c ? list[base + lane] : 0x7fffffff;
-        int rank = 0;
-        for (int j = 0; j < c; ++j) rank += __builtin_amdgcn_readlane(mine, j) < mine ? 1 : 0;
-        if (lane < c) s_sorted[w][rank] = mine;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int i = lane < c ? s_sorted[w][lane] : 0;
-        const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
-        for (int j = 0; j < c; ++j) {
-          sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
-          sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
-          sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
-        }
-      } else {
-        // more than a wavefront of points in one voxel (a degenerate cloud can put ALL its points there): the same
-        // rank sort in chunks of 64 against chunks of 64 -- c^2/64 wavefront steps instead of one thread's c^2/4
-        // memory round trips -- with the sorted indices in `cur` (a P7 array, free until then)
-        for (int m0 = 0; m0 < c; m0 += 64) {
-          const int mine = m0 + lane < c ? list[base + m0 + lane] : 0x7fffffff;
-          int rank = 0;
-          for (int o0 = 0; o0 < c; o0 += 64) {
-            const int other = o0 + lane < c ? list[base + o0 + lane] : 0x7fffffff;
-            const int cnt = min(64, c - o0);
-            for (int j = 0; j < cnt; ++j) rank += __builtin_amdgcn_readlane(other, j) < mine ? 1 : 0;
-          }
-          if (m0 + lane < c) cur[base + rank] = mine;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // the sorted list was written by other lanes
-        for (int m0 = 0; m0 < c; m0 += 64) {
-          const int i = m0 + lane < c ? ld_agent(&cur[base + m0 + lane]) : 0;
-          const float px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
-          const int cnt = min(64, c - m0);
-          for (int j = 0; j < cnt; ++j) {
-            sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), j));
-            sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), j));
-            sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), j));
-          }
-        }
-      }
-      if (lane == 0) {
-        const float wgt = static_cast<float>(1.0 / static_cast<double>(c));
-        epts[3 * e] = sx * wgt;
-        epts[3 * e + 1] = sy * wgt;
-        epts[3 * e + 2] = sz * wgt;
-      }
+      crowded_voxel(P, list, cur, ecnt, ebase, epts, s_big[k], lane, s_sorted[w]);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
@@ -634,92 +748,312 @@ __global__ __launch_bounds__(kT) void grid_subsample_kernel(GridArgs a) {
   __syncthreads();
 
   GS_STAMP(4);
-  // ---- P7: replay the container's growth stages to obtain its iteration order
-  int last_b = 0;
-  for (int j = 0; j < a.sched.n && a.sched.at[j] < M; ++j) last_b = a.sched.buckets[j];
-  const bool in_lds = M <= kLdsM && last_b <= kLdsB;  // uniform over the block
-  const unsigned short* lds_order = nullptr;
-  if (in_lds) {
-    unsigned short* l_cur = reinterpret_cast<unsigned short*>(s_dyn);
-    unsigned short* l_nxt = l_cur + kLdsM;
-    unsigned short* l_tmp = l_nxt + kLdsM;
-    unsigned* l_bf = reinterpret_cast<unsigned*>(l_tmp + kLdsM);
-    unsigned* l_bcl = l_bf + kLdsB;
-    lds_order = replay_lds(a, ekey, M, l_cur, l_nxt, l_tmp, l_bf, l_bcl, s_scan);
-  } else {
-    for (int j = 0; j < a.sched.n; ++j) {
-      const int k0 = a.sched.at[j];
-      if (k0 >= M) break;
-      int k1 = (j + 1 < a.sched.n) ? a.sched.at[j + 1] : 0x7fffffff;
-      if (k1 > M) k1 = M;
-      const int B = a.sched.buckets[j];
-      const int n = k1;  // every element ranked < k0 is already in `cur`
-      for (int x = tid; x < B; x += kT) {
-        bf[x] = 0x7fffffff;
-        bc[x] = 0;
-        bl[x] = 0;
-      }
-      __syncthreads();
-      for (int t = tid; t < n; t += kT) {
-        const int e = t < k0 ? cur[t] : t;
-        const int bkt = static_cast<int>(ekey[e] % static_cast<unsigned long long>(B));
-        bt[t] = bkt;
-        atomicMin(&bf[bkt], t);
-        atomicAdd(&bc[bkt], 1);
-      }
-      __syncthreads();
-      block_scan(
-          n,
-          [&](int t) {
-            const int bkt = bt[t];
-            return ld_agent(&bf[bkt]) == t ? ld_agent(&bc[bkt]) : 0;
-          },
-          off, s_scan, true);
-      for (int t = tid; t < n; t += kT) {
-        const int bkt = bt[t];
-        const int base = off[ld_agent(&bf[bkt])];
-        const int slot = atomicAdd(&bl[bkt], 1);
-        tmp[base + slot] = t;
-      }
-      __syncthreads();
-      for (int t = tid; t < n; t += kT) {
-        const int bkt = bt[t];
-        if (ld_agent(&bf[bkt]) != t) continue;
-        const int c = ld_agent(&bc[bkt]);
-        int* L = tmp + off[t];
-        for (int x = 1; x < c; ++x) {  // newest first inside a bucket
-          const int val = L[x];
-          int y = x - 1;
-          while (y >= 0 && L[y] < val) {
-            L[y + 1] = L[y];
-            --y;
-          }
-          L[y + 1] = val;
-        }
-      }
-      __syncthreads();
-      for (int pos = tid; pos < n; pos += kT) {
-        const int t = tmp[pos];
-        nxt[pos] = t < k0 ? cur[t] : t;
-      }
-      __syncthreads();
-      int* sw = cur;
-      cur = nxt;
-      nxt = sw;
-    }
-  }
-
-  GS_STAMP(5);
-  // ---- P8: emit in list order (grid_subsampling_cpu.cpp:44-47)
-  float* out = a.tmp_points + 3 * start;
-  for (int pos = tid; pos < M; pos += kT) {
-    const int e = in_lds ? static_cast<int>(lds_order[pos]) : cur[pos];
-    out[3 * pos] = epts[3 * e];
-    out[3 * pos + 1] = epts[3 * e + 1];
-    out[3 * pos + 2] = epts[3 * e + 2];
-  }
+  // ---- P7 + P8: replay the container's growth stages to obtain its iteration order, emit in that order
+  replay_and_emit(a, start, M, ekey, epts, cur, nxt, bt, off, tmp, bf, bc, bl, s_dyn, s_scan);
   if (tid == 0) a.out_lengths[b] = M;
   GS_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-launch form for large clouds (the first pyramid level: 16-20 k points per cloud).  The single-workgroup kernel
+// above spends three quarters of such a call in phases P0-P6 -- keys, de-duplication, first-occurrence ranks, per-voxel
+// lists and sums -- all of them bound by ONE CU's rate for scattered accesses.  Here each phase is its own launch over
+// as many workgroups as the cloud has 1024-point blocks (kernel boundaries are the grid-wide barriers), and only the
+// inherently ordered tail -- the hash-map order replay and the emit, replay_and_emit() -- stays on one workgroup per
+// cloud.  Same arithmetic, same tables, same output bit for bit (tests/test_native_gpu.py compares both forms).
+struct CloudView {
+  int64_t start;
+  int N;
+  const float* P;
+  unsigned ht_mask, ht_cap;
+  unsigned long long* ht_keys;
+  unsigned* ht_first;
+  unsigned* ht_rank;
+  unsigned* pt_slot;
+  unsigned long long* ekey;
+  int *ecnt, *ebase, *efill, *list, *cur, *nxt, *bt, *off, *tmp, *bf, *bc, *bl;
+  float* epts;
+};
+__device__ __forceinline__ CloudView cloud_view(const GridArgs& a, int b) {
+  CloudView v;
+  int64_t start = 0;
+  for (int i = 0; i < b; ++i) start += a.lengths[i];
+  v.start = start;
+  v.N = static_cast<int>(a.lengths[b]);
+  v.P = a.points + 3 * start;
+  unsigned cap = 64;
+  while (cap < 2u * static_cast<unsigned>(v.N > 0 ? v.N : 0)) cap <<= 1;
+  v.ht_cap = cap;
+  v.ht_mask = cap - 1;
+  const size_t ht_off = 4 * static_cast<size_t>(start) + 64 * static_cast<size_t>(b);
+  v.ht_keys = a.ht_keys + ht_off;
+  v.ht_first = a.ht_first + ht_off;
+  v.ht_rank = a.ht_rank + ht_off;
+  v.pt_slot = a.pt_slot + start;
+  v.ekey = a.ekey + start;
+  v.ecnt = a.ecnt + start;
+  v.ebase = a.ebase + start;
+  v.efill = a.efill + start;
+  v.list = a.list + start;
+  v.epts = a.epts + 3 * start;
+  v.cur = a.order_a + start;
+  v.nxt = a.order_b + start;
+  v.bt = a.bt + start;
+  v.off = a.off + start;
+  v.tmp = a.tmp + start;
+  const size_t b_off = 3 * static_cast<size_t>(start) + 64 * static_cast<size_t>(b);
+  v.bf = a.bf + b_off;
+  v.bc = a.bc + b_off;
+  v.bl = a.bl + b_off;
+  return v;
+}
+
+// M0: bounding box, origin, nX, nY (P0 of the single-workgroup kernel) and the empty tables; one workgroup per cloud
+__global__ __launch_bounds__(kT) void gs_prepare_kernel(GridArgs a) {
+  __shared__ float s_red[2 * 3 * (kT / 64)];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const CloudView c = cloud_view(a, b);
+  GsMeta* meta = a.meta + b;
+  if (c.N <= 0) {
+    if (tid == 0) {
+      a.out_lengths[b] = 0;
+      meta->M = 0;
+      meta->nbig = 0;
+    }
+    return;
+  }
+  const float* P = c.P;
+  const float v = a.voxel;
+  float lo[3] = {P[0], P[1], P[2]}, hi[3] = {P[0], P[1], P[2]};
+  for (int i = tid; i < c.N; i += kT)
+    for (int d = 0; d < 3; ++d) {
+      const float x = P[3 * i + d];
+      if (x < lo[d]) lo[d] = x;
+      if (x > hi[d]) hi[d] = x;
+    }
+  for (int d = 0; d < 3; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], o, 64));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o, 64));
+    }
+  const int w = tid >> 6;
+  if ((tid & 63) == 0)
+    for (int d = 0; d < 3; ++d) {
+      s_red[w * 6 + d] = lo[d];
+      s_red[w * 6 + 3 + d] = hi[d];
+    }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < kT / 64; ++k)
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = fminf(lo[d], s_red[k * 6 + d]);
+        hi[d] = fmaxf(hi[d], s_red[k * 6 + 3 + d]);
+      }
+    const float inv = static_cast<float>(1.0 / static_cast<double>(v));
+    float org[3];
+    for (int d = 0; d < 3; ++d) org[d] = floorf(lo[d] * inv) * v;
+    const double fx = floor(static_cast<double>((hi[0] - org[0]) / v)) + 1.0;
+    const double fy = floor(static_cast<double>((hi[1] - org[1]) / v)) + 1.0;
+    for (int d = 0; d < 3; ++d) meta->org[d] = org[d];
+    meta->nx = static_cast<unsigned long long>(static_cast<long long>(fx));
+    meta->ny = static_cast<unsigned long long>(static_cast<long long>(fy));
+    meta->M = 0;
+    meta->nbig = 0;
+  }
+  for (unsigned x = tid; x < c.ht_cap; x += kT) {
+    c.ht_keys[x] = kEmpty;
+    c.ht_first[x] = 0xFFFFFFFFu;
+  }
+  for (int i = tid; i < c.N; i += kT) c.ecnt[i] = 0;
+}
+
+// M1: voxel key per point + de-duplication (P1); grid = (1024-point blocks, clouds)
+__global__ __launch_bounds__(kT) void gs_keys_kernel(GridArgs a) {
+  const CloudView c = cloud_view(a, blockIdx.y);
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= c.N) return;
+  const GsMeta* meta = a.meta + blockIdx.y;
+  const float v = a.voxel, ox = meta->org[0], oy = meta->org[1], oz = meta->org[2];
+  const unsigned long long nx = meta->nx, ny = meta->ny;
+  const float px = c.P[3 * i], py = c.P[3 * i + 1], pz = c.P[3 * i + 2];
+  const unsigned long long ix = static_cast<unsigned long long>(static_cast<long long>(floorf((px - ox) / v)));
+  const unsigned long long iy = static_cast<unsigned long long>(static_cast<long long>(floorf((py - oy) / v)));
+  const unsigned long long iz = static_cast<unsigned long long>(static_cast<long long>(floorf((pz - oz) / v)));
+  const unsigned long long key = ix + nx * iy + nx * ny * iz;
+  unsigned slot = static_cast<unsigned>((key * 0x9E3779B97F4A7C15ull) >> 40) & c.ht_mask;
+  for (;;) {  // linear probing
+    const unsigned long long prev = atomicCAS(&c.ht_keys[slot], kEmpty, key);
+    if (prev == kEmpty || prev == key) break;
+    slot = (slot + 1) & c.ht_mask;
+  }
+  atomicMin(&c.ht_first[slot], static_cast<unsigned>(i));
+  c.pt_slot[i] = slot;
+}
+
+// M2: how many points of this block are the first of their voxel
+__global__ __launch_bounds__(kT) void gs_first_count_kernel(GridArgs a) {
+  __shared__ int s_cnt[kT / 64];
+  const CloudView c = cloud_view(a, blockIdx.y);
+  if (static_cast<int>(blockIdx.x) * kT >= c.N) return;  // (whole workgroup)
+  const int i = blockIdx.x * kT + threadIdx.x;
+  const bool first = i < c.N && c.ht_first[c.pt_slot[i]] == static_cast<unsigned>(i);
+  const unsigned long long m = __ballot(first);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < kT / 64; ++k) t += s_cnt[k];
+    a.meta[blockIdx.y].blk[blockIdx.x] = t;
+  }
+}
+
+// M3: rank of every distinct key by first occurrence (= insertion order into the reference's map) and the key list (P2)
+__global__ __launch_bounds__(kT) void gs_rank_kernel(GridArgs a) {
+  __shared__ int s_cnt[kT / 64 + 1];
+  __shared__ int s_base;
+  const CloudView c = cloud_view(a, blockIdx.y);
+  if (static_cast<int>(blockIdx.x) * kT >= c.N) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const GsMeta* meta = a.meta + blockIdx.y;
+  // voxels first seen in earlier blocks (at most kMultiMaxBlocks = 256 counts: one per thread of the first four wavefronts)
+  int part = tid < static_cast<int>(blockIdx.x) ? meta->blk[tid] : 0;
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) s_cnt[w] = part;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < kT / 64; ++k) t += s_cnt[k];
+    s_base = t;
+  }
+  __syncthreads();
+  const int base = s_base;
+  __syncthreads();
+  const int i = blockIdx.x * kT + tid;
+  unsigned slot = 0;
+  bool first = false;
+  if (i < c.N) {
+    slot = c.pt_slot[i];
+    first = c.ht_first[slot] == static_cast<unsigned>(i);
+  }
+  const unsigned long long m = __ballot(first);
+  if (lane == 0) s_cnt[w] = __popcll(m);
+  __syncthreads();
+  int before = 0;
+  for (int k = 0; k < w; ++k) before += s_cnt[k];
+  if (first) {
+    const int r = base + before + __popcll(m & ((1ull << lane) - 1ull));
+    c.ht_rank[slot] = static_cast<unsigned>(r);
+    c.ekey[r] = c.ht_keys[slot];
+  }
+}
+
+// M4: points per voxel, voxel rank of every point (first half of P3..P6)
+__global__ __launch_bounds__(kT) void gs_count_kernel(GridArgs a) {
+  const CloudView c = cloud_view(a, blockIdx.y);
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= c.N) return;
+  const int rk = static_cast<int>(c.ht_rank[c.pt_slot[i]]);
+  atomicAdd(&c.ecnt[rk], 1);
+  c.tmp[i] = rk;
+}
+
+// M5: voxel count, list bases (exclusive scan of the counts), fill cursors; one workgroup per cloud
+__global__ __launch_bounds__(kT) void gs_scan_kernel(GridArgs a) {
+  __shared__ int s_scan[kT / 64 + 2];
+  __shared__ int s_m;
+  const CloudView c = cloud_view(a, blockIdx.x);
+  if (c.N <= 0) return;
+  GsMeta* meta = a.meta + blockIdx.x;
+  const int nblk = (c.N + kT - 1) / kT;
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < nblk; ++k) t += meta->blk[k];
+    s_m = t;
+    meta->M = t;
+  }
+  __syncthreads();
+  const int M = s_m;
+  block_scan(M, [&](int e) { return c.ecnt[e]; }, c.ebase, s_scan, false);
+  for (int e = threadIdx.x; e < M; e += kT) c.efill[e] = c.ebase[e];
+}
+
+// M6: per-voxel point lists (one returning atomic per point gives the list position)
+__global__ __launch_bounds__(kT) void gs_fill_kernel(GridArgs a) {
+  const CloudView c = cloud_view(a, blockIdx.y);
+  const int i = blockIdx.x * kT + threadIdx.x;
+  if (i >= c.N) return;
+  const int pos = atomicAdd(&c.efill[c.tmp[i]], 1);
+  c.list[pos] = i;
+}
+
+// M7: per-voxel sums in ascending point order (SampledData::update, grid_subsampling_cpu.h:17-20); one thread per voxel, the
+// crowded voxels (more than 8 points) go to a work list for M8
+__global__ __launch_bounds__(256) void gs_sum_kernel(GridArgs a) {
+  const CloudView c = cloud_view(a, blockIdx.y);
+  GsMeta* meta = a.meta + blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= meta->M) return;
+  const int cnt = c.ecnt[e], base = c.ebase[e];
+  if (cnt > 8) {
+    c.off[atomicAdd(&meta->nbig, 1)] = e;  // (at most M entries; `off` is a replay array, free until then)
+    return;
+  }
+  int id[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) id[x] = x < cnt ? c.list[base + x] : 0x7fffffff;
+#pragma unroll
+  for (int pass = 0; pass < 7; ++pass)
+#pragma unroll
+    for (int x = 0; x < 7 - pass; ++x) {
+      const int lo = min(id[x], id[x + 1]), hi = max(id[x], id[x + 1]);
+      id[x] = lo;
+      id[x + 1] = hi;
+    }
+  float px[8], py[8], pz[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    const int i = x < cnt ? id[x] : 0;
+    px[x] = c.P[3 * i];
+    py[x] = c.P[3 * i + 1];
+    pz[x] = c.P[3 * i + 2];
+  }
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+    if (x < cnt) {
+      sx += px[x];
+      sy += py[x];
+      sz += pz[x];
+    }
+  const float wgt = static_cast<float>(1.0 / static_cast<double>(cnt));
+  c.epts[3 * e] = sx * wgt;
+  c.epts[3 * e + 1] = sy * wgt;
+  c.epts[3 * e + 2] = sz * wgt;
+}
+
+// M8: the crowded voxels, one wavefront each
+__global__ __launch_bounds__(256) void gs_crowded_kernel(GridArgs a) {
+  __shared__ int s_sorted[4][64];
+  const CloudView c = cloud_view(a, blockIdx.y);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nbig = ld_agent(&a.meta[blockIdx.y].nbig);
+  for (int k = blockIdx.x * 4 + w; k < nbig; k += gridDim.x * 4) {
+    crowded_voxel(c.P, c.list, c.cur, c.ecnt, c.ebase, c.epts, c.off[k], lane, s_sorted[w]);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// M9: hash-map order replay + emit (P7, P8); one workgroup per cloud, the replay's tables in dynamic LDS
+__global__ __launch_bounds__(kT) void gs_replay_kernel(GridArgs a) {
+  __shared__ int s_scan[kT / 64 + 2];
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  const int b = blockIdx.x;
+  const CloudView c = cloud_view(a, b);
+  if (c.N <= 0) return;  // (out_lengths was written by gs_prepare_kernel)
+  const int M = a.meta[b].M;
+  replay_and_emit(a, c.start, M, c.ekey, c.epts, c.cur, c.nxt, c.bt, c.off, c.tmp, c.bf, c.bc, c.bl, s_dyn, s_scan);
+  if (threadIdx.x == 0) a.out_lengths[b] = M;
 }
 
 // Stack the per-cloud results contiguously (grid_subsampling_cpu.cpp:67-68).
@@ -795,12 +1129,25 @@ extern "C" size_t rdm_grid_subsample_workspace_bytes(int64_t n_points, int batch
   a.take<float>(3 * n);
   for (int i = 0; i < 5; ++i) a.take<int>(n);
   for (int i = 0; i < 3; ++i) a.take<int>(bk);
+  a.take<GsMeta>(static_cast<size_t>(batch > 0 ? batch : 1));
   return a.off;
 }
 
 extern "C" int rdm_grid_subsample(const float* points, int64_t n_points, const int64_t* lengths,
                                   int batch, float voxel_size, float* out_points,
                                   int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream) {
+  return rdm::grid_subsample_mode(points, n_points, lengths, batch, voxel_size, out_points, out_lengths, ws, ws_bytes, stream, 0);
+}
+
+extern "C" int rdm_grid_subsample_form(const float* points, int64_t n_points, const int64_t* lengths, int batch,
+                                       float voxel_size, float* out_points, int64_t* out_lengths, void* ws, size_t ws_bytes,
+                                       void* stream, int form) {
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_grid_subsample_form: form must be 0 (by size), 1 (one workgroup per cloud) or 2 (multi-launch)");
+  return rdm::grid_subsample_mode(points, n_points, lengths, batch, voxel_size, out_points, out_lengths, ws, ws_bytes, stream, form);
+}
+
+int rdm::grid_subsample_mode(const float* points, int64_t n_points, const int64_t* lengths, int batch, float voxel_size,
+                             float* out_points, int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream, int mode) {
   using namespace rdm;
   RDM_REQUIRE(points && lengths && out_points && out_lengths, "rdm_grid_subsample: null pointer");
   RDM_REQUIRE(batch > 0 && n_points >= 0 && n_points < (1ll << 30),
@@ -841,11 +1188,36 @@ extern "C" int rdm_grid_subsample(const float* points, int64_t n_points, const i
   a.bf = ar.take<int>(bk);
   a.bc = ar.take<int>(bk);
   a.bl = ar.take<int>(bk);
+  a.meta = ar.take<GsMeta>(static_cast<size_t>(batch));
   if (!ar.ok) {
     set_error("rdm_grid_subsample: workspace too small (%zu < %zu bytes)", ws_bytes, ar.off);
     return RDM_ERR_WORKSPACE;
   }
   fill_schedule(n_points + 1, &a.sched);
+  // large clouds (the first pyramid level): phases P0-P6 as separate launches over many workgroups, see gs_*_kernel.
+  // mode: 0 = choose by size, 1 = single-workgroup kernel, 2 = multi-launch form
+  static const bool force_single = getenv("RDM_GS_SINGLE") != nullptr;  // developer knob (A/B runs)
+  const bool multi = mode == 2 || (mode == 0 && !force_single && n_points >= kMultiMinPoints);
+  if (multi && n_points <= static_cast<int64_t>(kMultiMaxBlocks) * kT) {
+    static std::atomic<uint64_t> replay_attr{0};
+    RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(gs_replay_kernel), static_cast<int>(kLdsBytes), replay_attr));
+    const dim3 pts(static_cast<unsigned>(ceil_div<int64_t>(n_points, kT)), batch), vox(static_cast<unsigned>(ceil_div<int64_t>(n_points, 256)), batch);
+    hipLaunchKernelGGL(gs_prepare_kernel, dim3(batch), dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_keys_kernel, pts, dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_first_count_kernel, pts, dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_rank_kernel, pts, dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_count_kernel, pts, dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_scan_kernel, dim3(batch), dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_fill_kernel, pts, dim3(kT), 0, st, a);
+    hipLaunchKernelGGL(gs_sum_kernel, vox, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gs_crowded_kernel, dim3(32, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gs_replay_kernel, dim3(batch), dim3(kT), kLdsBytes, st, a);
+    if (int e = launch_status("grid subsample (multi-launch)")) return e;
+    const int cblocks = static_cast<int>(ceil_div<int64_t>(3 * n_points, 256 * 4));
+    hipLaunchKernelGGL(compact_clouds_kernel, dim3(cblocks > 0 ? cblocks : 1, batch), dim3(256), 0, st,
+                       a.tmp_points, lengths, out_lengths, batch, out_points);
+    return launch_status("compact_clouds_kernel");
+  }
   static std::atomic<uint64_t> lds_attr{0};
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(grid_subsample_kernel), static_cast<int>(kLdsBytes), lds_attr));
   hipLaunchKernelGGL(grid_subsample_kernel, dim3(batch), dim3(kT), kLdsBytes, st, a);

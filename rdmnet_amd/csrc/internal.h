@@ -23,6 +23,11 @@ int gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0, floa
 // (64-row tiles without split-K; the split-K reduce uses as few as 8 rows per block)
 inline int64_t gemm_stats_max_blocks(int64_t m) { return (m + 7) / 8 + 1; }
 
+// rdm_grid_subsample with the form chosen by the caller: mode 0 = by size (rdm_grid_subsample), 1 = the single-workgroup
+// kernel, 2 = the multi-launch form (phases spread over the GPU, large clouds).  Same output bit for bit.
+int grid_subsample_mode(const float* points, int64_t n_points, const int64_t* lengths, int batch, float voxel_size,
+                        float* out_points, int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream, int mode);
+
 // GroupNorm given (optional) precomputed partials: nblk > 0 uses them, nblk == 0 computes them.
 int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
                       const float* gamma, const float* beta, float eps, const float* residual, int64_t ldr, int act,

@@ -321,15 +321,17 @@ def radius_search_device(q, s, q_lengths, s_lengths, radius, width, flags):
     return out[:nq]
 
 
-def grid_subsample_device(points, lengths, voxel):
-    """-> (out_points [n,3] capacity buffer, out_lengths int64[batch]) without synchronising."""
+def grid_subsample_device(points, lengths, voxel, form=0):
+    """-> (out_points [n,3] capacity buffer, out_lengths int64[batch]) without synchronising.  form: 0 = kernel form by size,
+    1 = one workgroup per cloud, 2 = multi-launch (rdm_grid_subsample_form; same output)."""
     L = _lib.lib()
     n, batch = points.shape[0], lengths.shape[0]
     out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=points.device)
     out_len = torch.empty((batch,), dtype=torch.int64, device=points.device)
     ws = scratch(points.device, L.rdm_grid_subsample_workspace_bytes(n, batch))
-    _lib.check(L.rdm_grid_subsample(points.data_ptr(), n, lengths.data_ptr(), batch, float(voxel), out.data_ptr(),
-                                    out_len.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_grid_subsample')
+    _lib.check(L.rdm_grid_subsample_form(points.data_ptr(), n, lengths.data_ptr(), batch, float(voxel), out.data_ptr(),
+                                         out_len.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(), int(form)),
+               'rdm_grid_subsample')
     return out, out_len
 
 

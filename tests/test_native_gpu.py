@@ -158,3 +158,36 @@ def test_dense_neighbourhoods_use_the_large_buffer_pass(ext, oracle_native):
     io = o.radius_neighbors(g, g, lens, lens, np.float32(2.0))
     assert io.shape[1] > 1024
     assert np.array_equal(io, gpu_radius(ext, g, g, lens, lens, 2.0))
+
+
+def test_multi_launch_subsampling_equals_single_workgroup_form_and_oracle(scans, oracle_native):
+    """rdm_grid_subsample_form: the multi-launch form (keys / ranks / lists / sums spread over the GPU, only the hash-map order
+    replay on one workgroup per cloud) returns the SAME points in the SAME order as the one-workgroup-per-cloud kernel and as
+    the reference's C++ (grid_subsampling_cpu.cpp:3-75) -- bundled scans at full size, random clouds, crowded voxels (one voxel
+    holding thousands of points), a batch with a tiny and an empty cloud, capacity larger than the stacked rows."""
+    from rdmnet_amd import ops
+    o = oracle_native.reference() or oracle_native.restatement()
+    rng = np.random.default_rng(11)
+    cases = []
+    a, b = scans['s000000'], scans['s000004']
+    cases.append((np.concatenate([a, b]), np.array([len(a), len(b)], np.int64), 0.6, 0))
+    cases.append((np.concatenate([a, b]), np.array([len(a), len(b)], np.int64), 0.3, 5000))       # capacity rows beyond the clouds
+    big = (rng.uniform(-1, 1, (60000, 3)) * np.array([80, 80, 4])).astype(np.float32)
+    cases.append((big, np.array([30000, 0, 29993, 7], np.int64), 0.9, 0))                      # empty and tiny clouds in the batch
+    crowded = np.concatenate([rng.normal(0, 0.05, (5000, 3)), rng.uniform(-30, 30, (20000, 3))]).astype(np.float32)
+    cases.append((crowded[rng.permutation(len(crowded))], np.array([12000, 13000], np.int64), 1.2, 0))
+    cases.append(((rng.uniform(-1, 1, (200000, 3)) * np.array([100, 100, 10])).astype(np.float32), np.array([200000], np.int64), 0.45, 0))
+    for pts, lens, voxel, extra in cases:
+        dev = torch.from_numpy(np.concatenate([pts, np.zeros((extra, 3), np.float32)])).cuda()
+        dl = torch.from_numpy(lens).cuda()
+        outs = []
+        for form in (1, 2, 0):
+            p, l = ops.grid_subsample_device(dev, dl, voxel, form=form)
+            l = l.cpu().numpy()
+            outs.append((p[:int(l.sum())].cpu().numpy(), l))
+        # (the reference's C++ reads the first point of an empty cloud: the restatement checks the batch that has one)
+        chk = oracle_native.restatement() if (lens == 0).any() else o
+        rp, rl = chk.grid_subsampling(pts, lens, np.float32(voxel))
+        for p, l in outs:
+            assert np.array_equal(l, rl), (lens, voxel)
+            assert np.array_equal(p, rp), (lens, voxel)
