@@ -764,6 +764,13 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   static const Cand cands[3] = {{T128, 128, 128, 4.0, 2.6, 3.4, 3, 0.0}, {T64, 64, 64, 1.5, 2.2, 0.86, 4, 0.2},
                                 {T128x32, 128, 32, 3.0, 1.3, 0.86, 3, 0.0}};
   static const int split_set[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+  // CUs the model plans for.  (RDM_GEMM_CUS, developer knob: with four pairs in flight a product effectively owns a
+  // quarter of the chip, tools/exp_cumask.sh.)
+  static const long long model_cus = [] {
+    const char* v = getenv("RDM_GEMM_CUS");
+    const long long n = v ? atoll(v) : 256;
+    return n >= 8 && n <= 256 ? n : 256ll;
+  }();
   Tile tile = T64;
   int best_s = 1;
   {
@@ -780,11 +787,11 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
         if (sp > 1 && static_cast<size_t>(m) * n * sp * batches * sizeof(float) > ws_cap) break;
         const long long blocks = tiles * sp;
         const double k_per = static_cast<double>(k) / sp / 64.0;
-        const long long per_round = 256ll * c.resident;
+        const long long per_round = model_cus * c.resident;
         const long long full = blocks / per_round, rem = blocks % per_round;
         auto per_k64 = [&](double r) { return std::max(c.lat_k64_us * (1.0 + c.alpha * (r - 1.0)), c.mfma_k64_us * r); };
         double t = full * (c.fixed_us + k_per * per_k64(c.resident));
-        if (rem) t += c.fixed_us + k_per * per_k64(static_cast<double>(ceil_div<long long>(rem, 256)));
+        if (rem) t += c.fixed_us + k_per * per_k64(static_cast<double>(ceil_div<long long>(rem, model_cus)));
         if (sp > 1) t += 3.0 + static_cast<double>(m) * n * sp * 8.0 / 1.5e6;  // reduce launch + partial write/read
         if (t < best) {
           best = t;
