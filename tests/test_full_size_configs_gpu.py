@@ -129,3 +129,30 @@ def test_config4_low_overlap_full_size(oracle_native):
     T64, S = ofw.procrustes_fp64(scp, rcp, w * (res < fm.acceptance_radius))
     rre, rte = ofw.rre_rte(T, T64)
     assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)
+
+
+@pytest.mark.parametrize('seed', [1, 7])
+def test_other_weight_seeds_float_stages_match_oracle(oracle_native, golden_dir, seed):
+    """The goldens and every other parity test use the seed-0 synthetic weights; the float stages must agree with the oracle
+    for any weights.  Bench pair 3 at full size, seeds 1 and 7: pyramid bit-exact, encoder / transformer / decoder / vote taps
+    <= 2e-5 of their maximum, NMS mask equal."""
+    from oracle import forward as ofw
+    from rdmnet_amd import collate, config, model, weights
+    cfg = config.make_cfg()
+    state = weights.synthetic_state_dict(cfg, seed=seed)
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    ref, src = z['ref3'], z['src3']
+    odata = ofw.pyramid(np.concatenate([ref, src]), np.array([len(ref), len(src)], np.int64), cfg)
+    otaps = {}
+    ofw.forward(ofw.to_torch(state), cfg, odata, otaps)
+    net = model.create_model(cfg).cuda()
+    net.load_state_dict(state)
+    taps = {}
+    net(collate.collate_pair(ref, src, cfg), taps)
+    for k in taps:
+        if k.startswith('encoder.'):
+            assert rel(taps[k], otaps[k]) <= 2e-5, k
+    for k in ('t1_ref', 't1_src', 'decoder', 'vote_feats'):
+        assert rel(taps[k], otaps[k]) <= 2e-5, k
+    assert rel(taps['vote_xyz'], otaps['vote_xyz']) <= 1e-6
+    assert torch.equal(taps['nms_mask'].cpu().bool(), otaps['nms_mask'])
