@@ -19,6 +19,8 @@ def gather_records(records, world, dist=None):
     counts = [torch.zeros_like(k) for _ in range(world)]
     dist.all_gather(counts, k)
     kmax = int(max(int(c) for c in counts))
+    if kmax == 0:  # nothing to exchange (a collective on zero-size tensors is backend-dependent)
+        return [records[:0].clone() for _ in range(world)]
     block = torch.zeros((kmax, records.shape[1]), dtype=records.dtype, device=records.device)
     block[:records.shape[0]] = records
     blocks = [torch.zeros_like(block) for _ in range(world)]
