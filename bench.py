@@ -13,6 +13,7 @@ one all_gather of result records at the end (RCCL).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -341,15 +342,23 @@ def main():
     errors = []
 
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
-        jobs = [[] for _ in streams]
-        for slot in range(count):
-            jobs[slot % len(streams)].append((slot, first + slot))
         if len(streams) == 1:
-            run_range(jobs[0], streams[0], rec, lat_out, prof_lists[0], engines[0] if engines else None, events_every)
+            run_range([(slot, first + slot) for slot in range(count)], streams[0], rec, lat_out, prof_lists[0],
+                      engines[0] if engines else None, events_every)
             if errors:
                 raise errors[0]
             return
-        threads = [threading.Thread(target=run_range, args=(jobs[k], streams[k], rec, lat_out, prof_lists[k],
+        # the in-flight pairs draw their steps from one queue (a stream that falls behind -- its pairs met the fat kernels
+        # of three others -- takes fewer), so that all streams drain together at the end of a K-step region
+        queue = collections.deque((slot, first + slot) for slot in range(count))
+
+        def draw():
+            while True:
+                try:
+                    yield queue.popleft()  # atomic under the GIL
+                except IndexError:
+                    return
+        threads = [threading.Thread(target=run_range, args=(draw(), streams[k], rec, lat_out, prof_lists[k],
                                                             engines[k] if engines else None, events_every))
                    for k in range(len(streams))]
         for t in threads:

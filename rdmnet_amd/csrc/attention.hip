@@ -285,6 +285,7 @@ static int attention_launch(const float* q, int64_t ldq, const float* k, int64_t
   a.inv_scale = sqrtf(static_cast<float>(head_dim));
   a.seg0_blocks = 0; a.row1 = 0; a.nq1 = 0; a.nk1 = 0;
   const dim3 grid(ceil_div<int64_t>(n_q, 16), heads);
+  RDM_DUP_LOOP("attn")
   if (bf16)
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else
@@ -323,6 +324,7 @@ extern "C" int rdm_attention_self_pair(const float* q, int64_t ldq, const float*
   a.seg0_blocks = static_cast<int>(ceil_div<int64_t>(n0, 16));
   a.row1 = static_cast<int>(n0); a.nq1 = static_cast<int>(n1); a.nk1 = static_cast<int>(n1);
   const dim3 grid(a.seg0_blocks + ceil_div<int64_t>(n1, 16), heads);
+  RDM_DUP_LOOP("attn")
   if (bf16)
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else

@@ -6,6 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace rdm {
 
@@ -46,6 +48,21 @@ inline int launch_status(const char* what) {
   }
   return RDM_OK;
 }
+
+// Developer knob for marginal-cost measurements (tools/exp_dup.sh): RDM_DUP="<class>[:<n>]" launches every kernel of
+// that class n times (default 2) in a row -- the launches are idempotent, results do not change -- so the drop in pairs/s
+// is what that class costs with several pairs in flight.  Unset: one launch, the call sites cache the answer.
+inline int dup_reps(const char* cls) {
+  const char* e = getenv("RDM_DUP");
+  if (!e) return 1;
+  const size_t n = strlen(cls);
+  if (strncmp(e, cls, n) != 0 || (e[n] != 0 && e[n] != ':')) return 1;
+  const int r = e[n] == ':' ? atoi(e + n + 1) : 2;
+  return r >= 0 && r <= 16 ? r : 1;
+}
+#define RDM_DUP_LOOP(cls) \
+  static const int _dup_reps = ::rdm::dup_reps(cls); \
+  for (int _dup = 0; _dup < _dup_reps; ++_dup)
 
 template <typename T>
 inline T ceil_div(T a, T b) {

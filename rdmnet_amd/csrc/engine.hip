@@ -797,6 +797,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(lv[i].pts);
     // level 0 -> 1 (16-20 k points per cloud): phases spread over the GPU when the clouds are large; the later levels run at
     // capacity `cap` with a few thousand real points: the single-workgroup kernel
+    RDM_DUP_LOOP("gs")
     ENG_CHECK(grid_subsample_mode(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
                                   r.st, i == 1 ? 0 : 1));
     // capacity of the next level is unknown on the host until the read-back; run it at full capacity

@@ -750,6 +750,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
       m * n <= 1536 * 512 && !(tune_env && tune_env[0] != '0')) {
     if (stat_blocks) *stat_blocks = 0;
+    RDM_DUP_LOOP("gemmsmall")
     hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
@@ -837,6 +838,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
                            : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, stat_rows_per_block(n))) : 0);
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
+  RDM_DUP_LOOP("gemm") {
   if (exp_tile == 4) launch<128, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 5) launch<64, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 6) launch<128, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
@@ -854,6 +856,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       if (k >= 32) launch<128, 32, 4, 1, 32, 2>(g, batches, trans_b, st);
       else launch<128, 32, 4, 1, 16>(g, batches, trans_b, st);
       break;
+  }
   }
   if (int e = launch_status("gemm_kernel")) return e;
   if (g.splits > 1 && reduce_stats) {
@@ -1016,6 +1019,7 @@ extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const 
   a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
   a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
   a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
+  RDM_DUP_LOOP("tail")
   hipLaunchKernelGGL(attention_tail128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
                      static_cast<hipStream_t>(stream), a);
   return launch_status("attention_tail128_kernel");

@@ -84,10 +84,15 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   // ---- phase 1: neighbour rows, relative positions, positive-row count
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
   int positives = 0;
-  for (int h = lane; h < H; h += 64) {
-    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+  int Hq = 0;  // slots up to the last real neighbour: shadow neighbours contribute exact zeros, and the searches pad at the end
+  for (int hb = 0; hb < H; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
+    const int h = hb + lane;
+    const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+    const bool real = id >= 0 && id < a.Ns;
+    const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
+    if (rm) Hq = hb + 64 - __builtin_clzll(rm);
     float4 v;
-    if (id >= 0 && id < a.Ns) {
+    if (real) {
       v.x = a.s_points[3 * id] - qx;
       v.y = a.s_points[3 * id + 1] - qy;
       v.z = a.s_points[3 * id + 2] - qz;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
       v.z = 1.0e6f - qz;
       v.w = __int_as_float(-1);
     }
-    nb[wave][h] = v;
+    if (h < H) nb[wave][h] = v;
   }
   positives = wave_sum_i(positives);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- phase 2: PF groups of four neighbours per trip
+  H = Hq;
   for (int h0 = 0; h0 < H; h0 += 4 * PF) {
     float w[PF];
     float f[PF][U][VEC];
@@ -193,9 +199,13 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
   if (a.width) H = min(H, *a.width);
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
   int positives = 0;
-  for (int h = lane; h < H; h += 64) {
-    const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+  int Hq = 0;  // slots up to the last real neighbour (the rest are shadow neighbours: zero feature)
+  for (int hb = 0; hb < H; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
+    const int h = hb + lane;
+    const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+    if (rm) Hq = hb + 64 - __builtin_clzll(rm);
     if (id >= 0 && id < a.Ns) {
       v.x = a.s_points[3 * id] - qx;
       v.y = a.s_points[3 * id + 1] - qy;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
       v.w = a.s_feats[id * a.ldf];
       positives += a.s_pos[id];
     }
-    nb[wave][h] = v;
+    if (h < H) nb[wave][h] = v;
   }
   positives = wave_sum_i(positives);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
               kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
   float acc = 0.f;
-  for (int h = g; h < H; h += 4) {
+  for (int h = g; h < Hq; h += 4) {
     const float4 v = nb[wave][h];
     const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
     const float d2 = (dx * dx + dy * dy) + dz * dz;
@@ -288,6 +298,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   // 64 channels (32 for C = 32) per wavefront, four neighbour groups prefetched per trip.  Measured on
   // MI355X: deeper prefetch (24 groups, 3 waves/SIMD) is SLOWER -- the kernel is bound by 128-B line
   // fills from L2 (feature row + point + flag per neighbour), not by the dependent-load chain.
+  RDM_DUP_LOOP("gather")
   switch (c) {
     case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, kWaves)), block, 0, st, a); break;
     case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 4>), grid(1), block, 0, st, a); break;

@@ -341,11 +341,15 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     use = partial;
     nblk = own_blk;
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
-                     static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
+  {
+    RDM_DUP_LOOP("gnfin")
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
+                       static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
+  }
   const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+  RDM_DUP_LOOP("gnapply")
   if (!positive && vec_ok && c >= 256)
     hipLaunchKernelGGL(gn_apply_wide_kernel, dim3(ceil_div<int64_t>(n * (c / 4), 256)), dim3(256), 0, st, x, static_cast<int>(n),
                        static_cast<int>(c / 4), static_cast<int>(ldx), ss, ss + c, residual, static_cast<int>(ldr), act, y,
@@ -391,6 +395,7 @@ extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ld
   RDM_REQUIRE(x && idx && y, "rdm_gather_max: null pointer");
   RDM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && h > 0, "rdm_gather_max: bad sizes");
   if (m == 0) return RDM_OK;
+  RDM_DUP_LOOP("pool")
   hipLaunchKernelGGL(gather_max_kernel, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)),
                      dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n_s),
                      static_cast<int>(c), static_cast<int>(ldx), idx, static_cast<int>(m),

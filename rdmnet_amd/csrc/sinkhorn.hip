@@ -201,6 +201,7 @@ extern "C" int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64
   // the 129 x 129 fp32 tile (66.5 KB) needs more than the default 64 KB of dynamic LDS (set once per device)
   static std::atomic<uint64_t> attr_set{0};
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_kernel), 160 * 1024 - 4096, attr_set));
+  RDM_DUP_LOOP("sinkhorn")
   hipLaunchKernelGGL(sinkhorn_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), lds,
                      static_cast<hipStream_t>(stream), scores, static_cast<int>(m), static_cast<int>(n), row_mask,
                      col_mask, alpha, iters, out);
