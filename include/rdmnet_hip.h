@@ -259,6 +259,47 @@ int rdm_attention_self_pair(const float* q, int64_t ldq, const float* k, int64_t
                             float* out, int64_t ldo, int64_t n0, int64_t n1, int heads, int head_dim, int bf16,
                             void* stream);
 
+/* rdm_attention_layer: ONE application of an attention layer to blocks of 16 query rows as one launch
+ * (rdmnet/thdroformer/thdroformer.py:142-202 RPEAttentionLayer + RPETransformerLayer, :204-251 the self / cross schedule of
+ * RPEConditionalTransformer; geotransformer/modules/transformer/vanilla_transformer.py:15-129, output_layer.py:6-21):
+ *   hid = softmax(q k^T / sqrt(head_dim)) v                      per head, the attention of rdm_attention
+ *   y   = LayerNorm(hid Wo^T + bo + x);  out = LayerNorm(relu(y W1^T + b1) W2^T + b2 + y)        = rdm_attention_tail
+ *   dst_p = out Wp^T + bp  [+ rotary embedding of its leading rope_cols columns, as rdm_rope]   for up to two
+ *           projections p -- the q|k|v (self), q and k|v (cross) inputs of the layers that follow, or the transformer's
+ *           output projection -- so that the only launch boundaries of a transformer are the ones attention itself needs.
+ * Rows are "stacked" row indices ([ref; src]); a segment is a range of query rows with its own keys/values (self layer:
+ * two segments, each cloud attends to itself; cross layer: one segment per step).  Width 128 = 4 heads x 32 with a 256-wide
+ * FFN; weights as nn.Linear stores them ([out, in], in contiguous), 16-byte aligned, row strides multiples of 4.
+ * projections_only != 0: no attention and no tail, the rows of `out` are projected (the first layer's q|k|v). */
+typedef struct rdm_layer_projection {
+  const float* w;      /* [ncols, 128], row stride ldw */
+  const float* bias;   /* [ncols] or NULL */
+  float* dst;          /* [stacked rows, ncols], row stride ldd */
+  int32_t ncols;       /* multiple of 128 */
+  int32_t ldw, ldd;
+  int32_t rope_cols;   /* 0, 128 or 256: leading columns rotated by theta = 2 pi sigmoid(emb[row, (col % 128) / 2]) */
+  int32_t segments;    /* bit s: the projection applies to the rows of segment s */
+} rdm_layer_projection;
+typedef struct rdm_attention_layer_args {
+  const float* q;      /* [stacked rows, >= 128] projected (and rotated) queries */
+  const float* x;      /* [stacked rows, >= 128] layer input (residual) */
+  float* out;          /* [stacked rows, >= 128] layer output */
+  int64_t ldq, ldx, ldo;
+  int32_t n_segments;  /* 1 or 2 */
+  int32_t heads, head_dim, bf16, projections_only, n_projections;
+  int64_t row0[2], n_q[2];  /* query rows [row0, row0 + n_q) of each segment */
+  const float* k[2];        /* keys of each segment [n_k, >= 128], row stride ldk */
+  const float* v[2];
+  int64_t ldk[2], ldv[2], n_k[2];
+  const float *wo, *bo, *gamma1, *beta1, *w1, *b1, *w2, *b2, *gamma2, *beta2;  /* as rdm_attention_tail */
+  int64_t ld_wo, ld_w1, ld_w2;
+  float eps;
+  rdm_layer_projection proj[2];
+  const float* emb;    /* [stacked rows, 64] rotary embedding input (embedding.proj output); needed when rope_cols > 0 */
+  int64_t lde;
+} rdm_attention_layer_args;
+int rdm_attention_layer(const rdm_attention_layer_args* args, void* stream);
+
 /* ---- a8/a9 helpers ------------------------------------------------------------------------------
  * rdm_vote_shift: xyz + clamp(offset[:, :3], +-limit) (rdmnet/vote/vote.py:98-108).
  * rdm_sigmoid_column: clamp(sigmoid(x[:, 0]), 0, 1) of a strided column (experiments/model_infer.py:161-162).

@@ -60,9 +60,11 @@ inline int dup_reps(const char* cls) {
   const int r = e[n] == ':' ? atoi(e + n + 1) : 2;
   return r >= 0 && r <= 16 ? r : 1;
 }
+#define RDM_DUP_CAT2(a, b) a##b
+#define RDM_DUP_CAT(a, b) RDM_DUP_CAT2(a, b)
 #define RDM_DUP_LOOP(cls) \
-  static const int _dup_reps = ::rdm::dup_reps(cls); \
-  for (int _dup = 0; _dup < _dup_reps; ++_dup)
+  static const int RDM_DUP_CAT(_dup_reps_, __LINE__) = ::rdm::dup_reps(cls); \
+  for (int _dup = 0; _dup < RDM_DUP_CAT(_dup_reps_, __LINE__); ++_dup)
 
 template <typename T>
 inline T ceil_div(T a, T b) {

@@ -40,7 +40,7 @@ struct HostParam {
 
 struct Linear {  // B operand [K_pad, N_pad] + bias
   float* b = nullptr;
-  float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused transformer kernels, out == 128 / 256 only
+  float* wt = nullptr;  // [out, kpad] (checkpoint layout, k contiguous) for the fused transformer kernels, out % 128 == 0 only
   float* bias = nullptr;
   float* packed = nullptr;  // KPConv weights in the operand order of the fused kernel (c_in = 1, 32, 64), else null
   int64_t in = 0, out = 0, kpad = 0, ldb = 0;
@@ -359,8 +359,117 @@ int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, M
 // are shared by both clouds (embedding, in/out projections, and in self layers the q|k|v projection,
 // rotary embedding and the whole tail) runs once on all rows; only the attention itself is per cloud.
 // Cross layers keep the reference's order: src attends to the UPDATED ref features (:244-245).
+// The same with one launch per attention application (rdm_attention_layer: attention + tail + the projections the
+// following layers need): 3 launches per (self, cross) layer pair instead of 10.  Needs the transformer width 128 =
+// 4 heads x 32 with a 256-wide FFN; returns 1 when the configuration does not fit (the caller then runs the per-op
+// sequence below).
+int thdroformer_fused(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
+  rdm_engine* e = r.e;
+  const int64_t N = x.rows, n1 = N - n0;
+  auto find = [&](const std::string& key) -> const Linear* {
+    auto it = e->lin.find(key);
+    return it == e->lin.end() ? nullptr : &it->second;
+  };
+  if (e->cfg.num_heads != 4 || num_layers < 1 || n0 <= 0 || n1 <= 0) return 1;
+  const Linear* op = find(name + ".out_proj");
+  if (!op || !op->wt || op->kpad != 128 || op->out % 128 != 0 || out.ld < op->out) return 1;
+  for (int i = 0; i < 2 * num_layers; ++i) {
+    const std::string p = name + ".transformer.layers." + std::to_string(i);
+    const Linear *lo = find(p + ".attention.linear"), *l1 = find(p + ".output.expand"), *l2 = find(p + ".output.squeeze");
+    if (!lo || !l1 || !l2 || !lo->wt || !l1->wt || !l2->wt || lo->out != 128 || lo->kpad != 128 || l1->out != 256 ||
+        l1->kpad != 128 || l2->out != 128 || l2->kpad != 256)
+      return 1;
+    const Linear *a = find(p + (i % 2 == 0 ? ".qkv" : ".q")), *b = i % 2 == 0 ? a : find(p + ".kv");
+    if (!a || !b || !a->wt || !b->wt || a->kpad != 128 || b->kpad != 128 || a->out != (i % 2 == 0 ? 384 : 128) ||
+        b->out != (i % 2 == 0 ? 384 : 256))
+      return 1;
+  }
+  Mat emb, f;
+  ENG_CHECK(linear(r, name + ".embedding.proj", pts4, emb));
+  ENG_CHECK(linear(r, name + ".in_proj", x, f));
+  if (f.cols != 128 || emb.cols < 64) return 1;
+  Mat qkv = e->mat(N, 384), q2 = e->mat(N, 128), kv = e->mat(N, 256);
+  ENG_ALLOC(qkv.p); ENG_ALLOC(q2.p); ENG_ALLOC(kv.p);
+  auto projection = [&](const Linear& L, float* dst, int64_t ldd, int rope_cols, int segments) {
+    rdm_layer_projection P;
+    P.w = L.wt; P.bias = L.bias; P.dst = dst; P.ncols = static_cast<int32_t>(L.out); P.ldw = static_cast<int32_t>(L.kpad);
+    P.ldd = static_cast<int32_t>(ldd); P.rope_cols = rope_cols; P.segments = segments;
+    return P;
+  };
+  rdm_attention_layer_args a;
+  std::memset(&a, 0, sizeof(a));
+  a.heads = 4; a.head_dim = 32; a.bf16 = e->cfg.attention_bf16 ? 1 : 0; a.eps = 1e-5f;
+  a.emb = emb.p; a.lde = emb.ld;
+  // the first self layer's q|k|v (+ rotary embedding) from the in_proj rows
+  a.projections_only = 1;
+  a.out = f.p; a.ldo = f.ld;
+  a.n_segments = 1; a.row0[0] = 0; a.n_q[0] = N;
+  a.n_projections = 1;
+  a.proj[0] = projection(*find(name + ".transformer.layers.0.qkv"), qkv.p, qkv.ld, 256, 1);
+  ENG_CHECK(rdm_attention_layer(&a, r.st));
+  a.projections_only = 0;
+  for (int i = 0; i < 2 * num_layers; ++i) {
+    const std::string p = name + ".transformer.layers." + std::to_string(i);
+    const std::string pn = name + ".transformer.layers." + std::to_string(i + 1);
+    const bool last = i + 1 == 2 * num_layers;
+    Mat fnew = e->mat(N, 128);
+    ENG_ALLOC(fnew.p);
+    const Linear &Lo = *find(p + ".attention.linear"), &L1 = *find(p + ".output.expand"), &L2 = *find(p + ".output.squeeze");
+    a.x = f.p; a.ldx = f.ld; a.out = fnew.p; a.ldo = fnew.ld;
+    a.wo = Lo.wt; a.ld_wo = Lo.kpad; a.bo = Lo.bias; a.gamma1 = vecp(r, p + ".attention.norm.weight");
+    a.beta1 = vecp(r, p + ".attention.norm.bias");
+    a.w1 = L1.wt; a.ld_w1 = L1.kpad; a.b1 = L1.bias; a.w2 = L2.wt; a.ld_w2 = L2.kpad; a.b2 = L2.bias;
+    a.gamma2 = vecp(r, p + ".output.norm.weight"); a.beta2 = vecp(r, p + ".output.norm.bias");
+    if (!a.gamma1 || !a.beta1 || !a.gamma2 || !a.beta2) {
+      set_error("rdm_engine: missing LayerNorm parameters of %s", p.c_str());
+      return RDM_ERR_ARG;
+    }
+    // what the layers after this one need from the new rows
+    auto next_inputs = [&](int first_slot, int segments) {  // the next SELF layer's q|k|v, or the output projection
+      a.proj[first_slot] = last ? projection(*find(name + ".out_proj"), out.p, out.ld, 0, segments)
+                                : projection(*find(pn + ".qkv"), qkv.p, qkv.ld, 256, segments);
+      a.n_projections = first_slot + 1;
+    };
+    if (i % 2 == 0) {  // self layer: each cloud attends to itself; then q (all rows) and k|v (src rows) of the cross layer
+      a.q = qkv.p; a.ldq = qkv.ld;
+      a.n_segments = 2;
+      a.row0[0] = 0; a.n_q[0] = n0; a.k[0] = qkv.p + 128; a.v[0] = qkv.p + 256; a.ldk[0] = a.ldv[0] = qkv.ld; a.n_k[0] = n0;
+      a.row0[1] = n0; a.n_q[1] = n1; a.k[1] = qkv.p + n0 * qkv.ld + 128; a.v[1] = qkv.p + n0 * qkv.ld + 256;
+      a.ldk[1] = a.ldv[1] = qkv.ld; a.n_k[1] = n1;
+      a.proj[0] = projection(*find(pn + ".q"), q2.p, q2.ld, 0, 3);
+      a.proj[1] = projection(*find(pn + ".kv"), kv.p, kv.ld, 0, 2);
+      a.n_projections = 2;
+      ENG_CHECK(rdm_attention_layer(&a, r.st));
+    } else {  // cross layer, the reference's order: ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
+      a.q = q2.p; a.ldq = q2.ld;
+      a.n_segments = 1;
+      a.row0[0] = 0; a.n_q[0] = n0; a.k[0] = kv.p + n0 * kv.ld; a.v[0] = kv.p + n0 * kv.ld + 128; a.ldk[0] = a.ldv[0] = kv.ld;
+      a.n_k[0] = n1;
+      a.proj[0] = projection(*find(p + ".kv"), kv.p, kv.ld, 0, 1);  // k|v of the updated ref rows for the second step
+      next_inputs(1, 1);
+      ENG_CHECK(rdm_attention_layer(&a, r.st));
+      a.row0[0] = n0; a.n_q[0] = n1; a.k[0] = kv.p; a.v[0] = kv.p + 128; a.n_k[0] = n0;
+      next_inputs(0, 1);
+      ENG_CHECK(rdm_attention_layer(&a, r.st));
+    }
+    f = fnew;
+  }
+  return RDM_OK;
+}
+
 int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
   rdm_engine* e = r.e;
+  // RDM_FUSED_LAYER=1: one launch per attention application (86 -> 28 launches per pair).  Measured: +1.3 %
+  // pairs/s with four pairs in flight, but 6 % slower with one -- a 16-row block then pulls all four heads' keys/values and
+  // the following layers' projection weights through ONE CU's ~20 B/clk L2 port (40-46 us per launch against 9 + 14 + 5 us
+  // for the attention (212 workgroups), the tail and the projections as separate launches) -- hence opt-in.
+  static const bool fused_layer = [] { const char* v = getenv("RDM_FUSED_LAYER"); return v && v[0] == '1'; }();
+  if (fused_layer) {
+    const size_t mark = e->arena_off;
+    const int rc = thdroformer_fused(r, name, pts4, x, n0, num_layers, out);
+    if (rc != 1) return rc;
+    e->arena_off = mark;  // configuration outside the fused kernel's shapes
+  }
   const int heads = e->cfg.num_heads;
   const int64_t N = x.rows, n1 = N - n0;
   Mat emb, f;
@@ -409,6 +518,39 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n) p[i] = v;
 }
+// features = 1 (dataset.py:187-188) and the "row sum > 0" flag the first KPConv needs (kpconv.py:113-114), one launch
+__global__ void unit_features_kernel(float* x, int64_t n, int64_t ld, uint8_t* positive) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  for (int64_t c = 0; c < ld; ++c) x[i * ld + c] = 1.0f;  // (the pad columns as the separate fill wrote them)
+  positive[i] = 1;
+}
+// The NMS survivors' rows (vote.py:36-40 boolean-mask selects; model_infer.py:206-216): nodes, their zero-padded [n,4]
+// copy for the positional Linear, features and the (n2p, n2n) score pairs -- one launch instead of seven gathers.
+struct SelectNodesArgs {
+  const int32_t* order;   // compacted indices: ref survivors from 0, src survivors from nc_ref
+  int nc_ref, m_r, m_n;
+  const float *xyz, *feats, *n2p, *n2n;
+  int d, ldf, ldo;
+  float *nodes, *nodes4, *out_feats, *scores;
+};
+__global__ __launch_bounds__(64) void select_nodes_kernel(SelectNodesArgs a) {
+  const int j = blockIdx.x;
+  const int src = j < a.m_r ? a.order[j] : a.order[a.nc_ref + (j - a.m_r)];
+  const int t = threadIdx.x;
+  if (t < 3) {
+    const float v = a.xyz[3 * src + t];
+    a.nodes[3 * j + t] = v;
+    a.nodes4[4 * j + t] = v;
+  } else if (t == 3) {
+    a.nodes4[4 * j + 3] = 0.f;
+  } else if (t == 4) {
+    a.scores[2 * j] = a.n2p[src];
+  } else if (t == 5) {
+    a.scores[2 * j + 1] = a.n2n[src];
+  }
+  for (int c = t; c < a.ldo; c += 64) a.out_feats[static_cast<int64_t>(j) * a.ldo + c] = c < a.d ? a.feats[static_cast<int64_t>(src) * a.ldf + c] : 0.f;
+}
 __global__ void concat_points_kernel(const float* a, int64_t na, const float* b, int64_t nb, float* out, int64_t* lengths) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i == 0) {
@@ -417,17 +559,6 @@ __global__ void concat_points_kernel(const float* a, int64_t na, const float* b,
   }
   if (i < 3 * na) out[i] = a[i];
   else if (i < 3 * (na + nb)) out[i] = b[i - 3 * na];
-}
-__global__ void widen_index_kernel(const int32_t* in, int64_t n, int64_t* out) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i < n) out[i] = in[i];
-}
-__global__ void pack2_kernel(const float* a, const float* b, int64_t n, float* out) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i < n) {
-    out[2 * i] = a[i];
-    out[2 * i + 1] = b[i];
-  }
 }
 
 template <typename K, typename... A>
@@ -542,10 +673,14 @@ int make_linear(rdm_engine* e, const std::string& key, const std::vector<const H
   for (auto* bb : bs) bias.insert(bias.end(), bb->data.begin(), bb->data.end());
   ENG_CHECK(upload(e, b, &L.b));
   ENG_CHECK(upload(e, bias, &L.bias));
-  if (ws.size() == 1 && (out == 128 || out == 256) && L.kpad % 16 == 0) {
+  if (out % 128 == 0 && out <= 512 && L.kpad % 16 == 0) {  // checkpoint layout ([out, in], stacked blocks below each other)
     std::vector<float> wt(static_cast<size_t>(out) * L.kpad, 0.f);
-    for (int64_t o = 0; o < out; ++o)
-      for (int64_t i = 0; i < in; ++i) wt[o * L.kpad + i] = ws[0]->data[o * in + i];
+    int64_t r0 = 0;
+    for (auto* w : ws) {
+      for (int64_t o = 0; o < w->shape[0]; ++o)
+        for (int64_t i = 0; i < in; ++i) wt[(r0 + o) * L.kpad + i] = w->data[o * in + i];
+      r0 += w->shape[0];
+    }
     ENG_CHECK(upload(e, wt, &L.wt));
   }
   e->lin[key] = L;
@@ -603,6 +738,11 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
       ENG_CHECK(upload(e, p.data, &d));
       e->vec[name] = d;
     }
+  }
+  {
+    float* d = nullptr;
+    ENG_CHECK(upload(e, std::vector<float>(static_cast<size_t>(e->cfg.points_in_patch), std::sqrt(static_cast<float>(e->cfg.out_dim))), &d));
+    e->vec["__sqrt_out_dim"] = d;
   }
   e->finalized = true;
   return RDM_OK;
@@ -831,7 +971,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       ENG_ALLOC(grids[i].ws);
       gp[i] = lv[i].pts; gn[i] = lv[i].n; gl[i] = lv[i].lengths; gr[i] = rad; gw[i] = grids[i].ws; gb[i] = grids[i].bytes;
     }
-    ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
+    RDM_DUP_LOOP("rnbuild")
+  ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
   }
   for (int i = 0; i < 5; ++i) {
     ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i]));
@@ -877,11 +1018,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   } else {
     x = e->mat(n0, 1);
     ENG_ALLOC(x.p);
-    ENG_CHECK(launch1d("fill", fill_kernel, n0 * x.ld, r.st, x.p, n0 * x.ld, 1.0f));  // features = 1 (dataset.py:187-188)
   }
   uint8_t* x_pos = e->alloc<uint8_t>(n0);
   ENG_ALLOC(x_pos);
-  ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, r.st));
+  if (dd) ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, r.st));
+  else ENG_CHECK(launch1d("unit_features", unit_features_kernel, n0, r.st, x.p, n0, x.ld, x_pos));
   Mat feats[5];
   {
     const char* names[14] = {"encoder1_1", "encoder1_2", "encoder2_1", "encoder2_2", "encoder2_3", "encoder3_1", "encoder3_2",
@@ -1018,10 +1159,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     int32_t* order = e->alloc<int32_t>(Nc > 0 ? Nc : 1);
     int32_t* kept = flags + 60;  // [2]
     ENG_ALLOC(order);
-    ENG_CHECK(rdm_compact_indices(keep, 0, nc_ref, order, kept, r.st));
-    ENG_CHECK(rdm_compact_indices(keep, nc_ref, Nc, order + nc_ref, kept + 1, r.st));
+    // both clouds' compactions in one launch, which also stores the status words into the mapped read-back buffer
+    ENG_CHECK(compact_indices_pair(keep, nc_ref, Nc, order, kept, flags, static_cast<int32_t*>(e->pinned_dev), 64, r.st));
     int32_t host_flags[64];
-    ENG_CHECK(d2h(r, flags, sizeof(host_flags), host_flags));
+    ENG_CHECK(wait_stream(r));
+    std::memcpy(host_flags, e->pinned, sizeof(host_flags));
     for (int i = 0; i < 2 * call; i += 2)
       if (host_flags[i + 1] != 0) {
         set_error("rdm_engine_run: a radius search failed (status %d: 2 = grid built for a smaller radius)", host_flags[i + 1]);
@@ -1029,28 +1171,27 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       }
     m_r = host_flags[60]; m_s = host_flags[61]; Mn = m_r + m_s;
     RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
-    int64_t* sel = e->alloc<int64_t>(Mn);
-    ENG_ALLOC(sel);
-    ENG_CHECK(launch1d("widen", widen_index_kernel, m_r, r.st, order, m_r, sel));
-    ENG_CHECK(launch1d("widen", widen_index_kernel, m_s, r.st, order + nc_ref, m_s, sel + m_r));
     nodes = e->alloc<float>(3 * Mn);
     ENG_ALLOC(nodes);
-    ENG_CHECK(rdm_gather_rows(shifted, Nc, 3, 3, sel, Mn, nodes, 3, r.st));
     Mat sel_feats = e->mat(Mn, D);
     ENG_ALLOC(sel_feats.p);
-    ENG_CHECK(rdm_gather_rows(vfeats.p, Nc, D, vfeats.ld, sel, Mn, sel_feats.p, sel_feats.ld, r.st));
-    float* packed = e->alloc<float>(2 * Nc);
     float* sel_scores = e->alloc<float>(2 * Mn);
-    ENG_ALLOC(packed); ENG_ALLOC(sel_scores);
-    ENG_CHECK(launch1d("pack2", pack2_kernel, Nc, r.st, n2p, n2n, Nc, packed));
-    ENG_CHECK(rdm_gather_rows(packed, Nc, 2, 2, sel, Mn, sel_scores, 2, r.st));
+    ENG_ALLOC(sel_scores);
+    Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
+    ENG_ALLOC(nodes4.p);
+    {  // the survivors' rows of every per-superpoint tensor with one launch
+      SelectNodesArgs sa;
+      sa.order = order; sa.nc_ref = static_cast<int>(nc_ref); sa.m_r = static_cast<int>(m_r); sa.m_n = static_cast<int>(Mn);
+      sa.xyz = shifted; sa.feats = vfeats.p; sa.n2p = n2p; sa.n2n = n2n;
+      sa.d = static_cast<int>(D); sa.ldf = static_cast<int>(vfeats.ld); sa.ldo = static_cast<int>(sel_feats.ld);
+      sa.nodes = nodes; sa.nodes4 = nodes4.p; sa.out_feats = sel_feats.p; sa.scores = sel_scores;
+      hipLaunchKernelGGL(select_nodes_kernel, dim3(static_cast<unsigned>(Mn)), dim3(64), 0, r.st, sa);
+      ENG_CHECK(launch_status("select_nodes_kernel"));
+    }
     tap(r, "nodes", nodes, Mn, 3, 3, 0);
     tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
 
     // ---------------------------------------------------------------- transformer #2, normalise
-    Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
-    ENG_ALLOC(nodes4.p);
-    ENG_CHECK(launch1d("pad_points", pad_points_kernel, Mn, r.st, nodes, Mn, nodes4.p));
     buf2 = e->mat(Mn, D);
     ENG_ALLOC(buf2.p);
     ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2));
@@ -1089,6 +1230,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   uint8_t* s_nm = e->alloc<uint8_t>(m_s);
   ENG_ALLOC(r_knn); ENG_ALLOC(s_knn); ENG_ALLOC(r_km); ENG_ALLOC(s_km); ENG_ALLOC(r_nm); ENG_ALLOC(s_nm);
   int32_t* p2n_status = flags + 62;
+  RDM_DUP_LOOP("p2n")
   ENG_CHECK(rdm_point_to_node_pair(pf_ref, nf_ref, nodes, m_r, pf_src, nf_src, nodes + 3 * m_r, m_s, K, r_knn, r_km, r_nm, s_knn,
                                    s_km, s_nm, p2n_status, r.ws, r.ws_bytes, r.st));  // both clouds, one set of launches
   const int kc = c.num_correspondences;
@@ -1106,7 +1248,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     } else {
       cm_bytes = r.ws_bytes;
     }
-    ENG_CHECK(rdm_coarse_matching_features(fn.p, fn.ld, m_r, fn.p + m_r * fn.ld, fn.ld, m_s, D, r_nm, s_nm,
+    RDM_DUP_LOOP("coarse")
+  ENG_CHECK(rdm_coarse_matching_features(fn.p, fn.ld, m_r, fn.p + m_r * fn.ld, fn.ld, m_s, D, r_nm, s_nm,
                                            c.dual_normalization, kc, r_sel, s_sel, node_sc, n_sel, cm_ws, cm_bytes, r.st));
   }
   int32_t tail[2];
@@ -1137,19 +1280,20 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     const int64_t ns1[4] = {m_r, m_s, m_r, m_s}, w1[4] = {2 * K, 2 * K, K / 4, K / 4}, mm1[4] = {B, B, B, B};
     const int64_t* i1[4] = {r_sel, s_sel, r_sel, s_sel};
     void* y1[4] = {r_idx, s_idx, r_pm, s_pm};
-    ENG_CHECK(gather_rows_multi(4, x1, ns1, w1, w1, i1, mm1, y1, w1, r.st));
+    RDM_DUP_LOOP("rows")
+  ENG_CHECK(gather_rows_multi(4, x1, ns1, w1, w1, i1, mm1, y1, w1, r.st));
     const void* x2[4] = {pf_ref, pf_src, feats_f.p, feats_f.p + nf_ref * feats_f.ld};
     const int64_t ns2[4] = {nf_ref, nf_src, nf_ref, nf_src}, w2[4] = {3, 3, D, D}, lx2[4] = {3, 3, feats_f.ld, feats_f.ld};
     const int64_t mm2[4] = {B * K, B * K, B * K, B * K};
     const int64_t* i2[4] = {r_idx, s_idx, r_idx, s_idx};
     void* y2[4] = {r_pts, s_pts, r_pf, s_pf};
-    ENG_CHECK(gather_rows_multi(4, x2, ns2, w2, lx2, i2, mm2, y2, w2, r.st));
+    RDM_DUP_LOOP("rows")
+  ENG_CHECK(gather_rows_multi(4, x2, ns2, w2, lx2, i2, mm2, y2, w2, r.st));
   }
-  float* sqrt_c = e->alloc<float>(K);
+  float* sqrt_c = vecp(r, "__sqrt_out_dim");  // [K] x sqrt(D): the einsum's divisor (model_infer.py:311), uploaded at finalize
   float* scores = e->alloc<float>(B * K * K);
   float* ms = e->alloc<float>(B * (K + 1) * (K + 1));
   ENG_ALLOC(sqrt_c); ENG_ALLOC(scores); ENG_ALLOC(ms);
-  ENG_CHECK(launch1d("fill", fill_kernel, K, r.st, sqrt_c, static_cast<int64_t>(K), std::sqrt(static_cast<float>(D))));
   ENG_CHECK(rdm_gemm(r_pf, D, K * D, s_pf, D, K * D, 1, scores, K, static_cast<int64_t>(K) * K, K, K, D, static_cast<int>(B),
                      nullptr, sqrt_c, 0, nullptr, 0, r.st));
   ENG_CHECK(rdm_sinkhorn(scores, B, K, K, r_pm, s_pm, vecp(r, "optimal_transport.alpha"), c.sinkhorn_iterations, ms, r.st));
@@ -1164,17 +1308,17 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float* rc = e->alloc<float>(3 * ccap);
   float* sc = e->alloc<float>(3 * ccap);
   float* cs = e->alloc<float>(ccap);
-  float* T = e->alloc<float>(16);
-  int32_t* counts = e->alloc<int32_t>(4);
-  ENG_ALLOC(rc); ENG_ALLOC(sc); ENG_ALLOC(cs); ENG_ALLOC(T); ENG_ALLOC(counts);
+  float* T = e->alloc<float>(16 + 4);  // pose and the three counters behind it: one read-back copy
+  ENG_ALLOC(rc); ENG_ALLOC(sc); ENG_ALLOC(cs); ENG_ALLOC(T);
+  int32_t* counts = reinterpret_cast<int32_t*>(T + 16);
+  RDM_DUP_LOOP("lgr")
   ENG_CHECK(rdm_lgr(ms, r_pts, s_pts, r_pm, s_pm, B, K, c.acceptance_radius, c.correspondence_threshold,
                     c.num_refinement_steps, rc, sc, cs, T, counts, r.ws, r.ws_bytes, r.st));
   struct {
     float T[16];
     int32_t counts[4];
   } tailbuf;
-  copy_words(T, r.e->pinned_dev, 16, r.st);
-  copy_words(counts, static_cast<char*>(r.e->pinned_dev) + 64, 3, r.st);
+  copy_words(T, r.e->pinned_dev, 16 + 3, r.st);
   ENG_CHECK(wait_stream(r));
   std::memcpy(tailbuf.T, r.e->pinned, 64);
   std::memcpy(tailbuf.counts, static_cast<char*>(r.e->pinned) + 64, 12);

@@ -860,6 +860,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   }
   if (int e = launch_status("gemm_kernel")) return e;
   if (g.splits > 1 && reduce_stats) {
+    RDM_DUP_LOOP("splitk")
     hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(ceil_div<long long>(m, stat_rows_per_block(n)), ceil_div<long long>(n, 256)), dim3(256),
                        0, st, g, reduce_stats);
     return launch_status("splitk_reduce_stats_kernel");

@@ -306,11 +306,13 @@ __global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, c
 constexpr int kRefineStage = 4608;  // correspondences staged in LDS: 4608 * 29 B = 131 KB
 __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
                                                           const float* scores, float radius, int steps,
-                                                          LgrBuffers w, unsigned char* gate, float* out_T) {
+                                                          LgrBuffers w, unsigned char* gate, float* out_T,
+                                                          int32_t* counts) {
   __shared__ double red[9 * 16];
   __shared__ float Tf[12];
   extern __shared__ float stage[];
   const int C = w.meta[0], chunks = w.meta[1];
+  int best_out = w.meta[2];  // (the layout kernel's value when no patch reaches the threshold)
   // The refinement makes 4 passes over the correspondences per step; one workgroup, so every pass is a chain of
   // dependent L2 round trips.  Up to kRefineStage correspondences are copied into LDS once (7 words each + the gate).
   if (C <= kRefineStage) {
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, 
     const unsigned long long all = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
     const int best = 0x7fffffff - static_cast<int>(all & 0xffffffffull);
     if (threadIdx.x == 0) w.meta[2] = best;
+    best_out = best;
     if (threadIdx.x < 12) Tf[threadIdx.x] = w.chunk_T[12 * best + threadIdx.x];
   } else {  // degenerate: no patch reaches the threshold -> start from all correspondences (:189-194)
     block_procrustes(src_corr, ref_corr, scores, nullptr, 0, C, red, T);
@@ -359,6 +362,11 @@ __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, 
   if (threadIdx.x < 16) {
     const int r = threadIdx.x / 4, c = threadIdx.x % 4;
     out_T[threadIdx.x] = r < 3 ? Tf[4 * r + c] : (c == 3 ? 1.f : 0.f);
+  }
+  if (threadIdx.x == 0) {  // {n_correspondences, n_hypotheses, best_hypothesis} for the caller (no separate copy launch)
+    counts[0] = C;
+    counts[1] = chunks;
+    counts[2] = best_out;
   }
 }
 
@@ -416,7 +424,6 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
                      src_corr, corr_scores);
   hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
   hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), kRefineStage * 29 + 64, st, ref_corr, src_corr, corr_scores,
-                     acceptance_radius, num_refinement_steps, w, gate, transform);
-  copy_words(w.meta, counts, 3, st);
+                     acceptance_radius, num_refinement_steps, w, gate, transform, counts);
   return launch_status("lgr kernels");
 }

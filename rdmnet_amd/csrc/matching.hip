@@ -10,6 +10,7 @@
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -88,6 +89,56 @@ __global__ __launch_bounds__(1024) void compact_index_kernel(const unsigned char
     __syncthreads();
   }
   if (threadIdx.x == 0) *count = base;
+}
+
+// Both clouds' compactions in one launch (workgroup b: rows [b ? n_ref : 0, b ? n : n_ref), indices from order + begin,
+// count in counts[b]), and -- for the engine's size read-back -- a copy of the `mirror_words` status words at mirror_src
+// into mirror_dst (mapped host memory) with the two counts stored directly into their slots: no separate copy launch.
+__global__ __launch_bounds__(1024) void compact_index_pair_kernel(const unsigned char* keep, int n_ref, int n, int32_t* order,
+                                                                  int32_t* counts, const int32_t* mirror_src,
+                                                                  int32_t* mirror_dst, int mirror_words) {
+  __shared__ int wsum[17];
+  __shared__ int base;
+  const int begin = blockIdx.x ? n_ref : 0, end = blockIdx.x ? n : n_ref;
+  int32_t* out = order + begin;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = begin; i0 < end; i0 += blockDim.x) {
+    const int i = i0 + threadIdx.x;
+    const int flag = (i < end && keep[i]) ? 1 : 0;
+    int inc = flag;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0;
+      for (int k = 0; k < 16; ++k) {
+        const int t = wsum[k];
+        wsum[k] = acc;
+        acc += t;
+      }
+      wsum[16] = acc;
+    }
+    __syncthreads();
+    if (flag) out[base + wsum[w] + inc - 1] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[16];
+    __syncthreads();
+  }
+  const int slot = static_cast<int>(counts - mirror_src) + blockIdx.x;  // where this count lives among the status words
+  if (threadIdx.x == 0) {
+    counts[blockIdx.x] = base;
+    if (mirror_dst) mirror_dst[slot] = base;
+  }
+  if (mirror_dst && blockIdx.x == 0) {
+    const int s0 = static_cast<int>(counts - mirror_src);
+    for (int t = threadIdx.x; t < mirror_words; t += blockDim.x)
+      if (t != s0 && t != s0 + 1) mirror_dst[t] = mirror_src[t];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,6 +619,16 @@ extern "C" int rdm_compact_indices(const uint8_t* keep, int64_t begin, int64_t e
   hipLaunchKernelGGL(compact_index_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), keep,
                      static_cast<int>(begin), static_cast<int>(end), order, count);
   return launch_status("compact_index_kernel");
+}
+
+int rdm::compact_indices_pair(const uint8_t* keep, int64_t n_ref, int64_t n, int32_t* order, int32_t* counts,
+                              const int32_t* mirror_src, int32_t* mirror_dst, int mirror_words, void* stream) {
+  RDM_REQUIRE(keep && order && counts && n_ref >= 0 && n >= n_ref, "compact_indices_pair: bad arguments");
+  RDM_REQUIRE(!mirror_dst || (mirror_src && counts >= mirror_src && counts + 2 <= mirror_src + mirror_words),
+              "compact_indices_pair: the counts must lie inside the mirrored words");
+  hipLaunchKernelGGL(compact_index_pair_kernel, dim3(2), dim3(1024), 0, static_cast<hipStream_t>(stream), keep,
+                     static_cast<int>(n_ref), static_cast<int>(n), order, counts, mirror_src, mirror_dst, mirror_words);
+  return launch_status("compact_index_pair_kernel");
 }
 
 extern "C" size_t rdm_point_to_node_workspace_bytes(int64_t n_points, int64_t n_nodes) {

@@ -381,6 +381,7 @@ extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
   RDM_REQUIRE(x && gamma && beta && y, "rdm_layer_norm: null pointer");
   RDM_REQUIRE(n >= 0 && c > 0 && c <= 2048, "rdm_layer_norm: bad sizes");
   if (n == 0) return RDM_OK;
+  RDM_DUP_LOOP("ln")
   hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
                      static_cast<int>(ldx), residual, static_cast<int>(ldr), gamma, beta, eps, act, y,
@@ -403,6 +404,30 @@ extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ld
   return launch_status("gather_max_kernel");
 }
 
+// The same with 16-byte accesses (c1, c2 and every row stride multiples of 4, 16-byte aligned bases): one wavefront per row.
+__global__ __launch_bounds__(256) void upsample_concat_vec_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+                                                                  const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
+                                                                  int m_total, float* y, int ldy) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= m_total) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t id = idx[static_cast<int64_t>(m) * ldi];
+  const bool ok = id >= 0 && id < n_coarse;
+  const float4* src1 = reinterpret_cast<const float4*>(coarse + (ok ? id : 0) * ld1);
+  const float4* src2 = reinterpret_cast<const float4*>(skip + static_cast<int64_t>(m) * ld2);
+  float4* dst = reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy);
+  const int q1 = c1 / 4, q2 = c2 / 4, qy = ldy / 4;
+  for (int q = lane; q < qy; q += 64) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < q1) {
+      if (ok) v = src1[q];
+    } else if (q < q1 + q2) {
+      v = src2[q - q1];
+    }
+    dst[q] = v;
+  }
+}
+
 extern "C" int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1,
                                    const int64_t* idx, int64_t ldi, const float* skip, int64_t c2,
                                    int64_t ld2, int64_t m, float* y, int64_t ldy, void* stream) {
@@ -410,6 +435,15 @@ extern "C" int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_
   RDM_REQUIRE(coarse && idx && skip && y, "rdm_upsample_concat: null pointer");
   RDM_REQUIRE(ldy >= c1 + c2, "rdm_upsample_concat: ldy too small");
   if (m == 0) return RDM_OK;
+  const bool vec = c1 % 4 == 0 && c2 % 4 == 0 && ld1 % 4 == 0 && ld2 % 4 == 0 && ldy % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(coarse) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  RDM_DUP_LOOP("ups")
+  if (vec)
+    hipLaunchKernelGGL(upsample_concat_vec_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 4))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse), static_cast<int>(c1),
+                       static_cast<int>(ld1), idx, static_cast<int>(ldi), skip, static_cast<int>(c2), static_cast<int>(ld2),
+                       static_cast<int>(m), y, static_cast<int>(ldy));
+  else
   hipLaunchKernelGGL(upsample_concat_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse),
                      static_cast<int>(c1), static_cast<int>(ld1), idx, static_cast<int>(ldi), skip,

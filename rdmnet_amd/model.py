@@ -5,6 +5,7 @@ Same operator API as the reference (experiments/model_infer.py:26-107, 109-354, 
 keys, `model(data_dict) -> output_dict` with the reference's keys.  Every tensor op runs in
 librdmnet_hip.so through rdmnet_amd.ops; torch provides device memory and the stream.
 """
+import os
 import threading
 from collections import OrderedDict
 
@@ -133,6 +134,9 @@ class RDMNet(torch.nn.Module):
             W[p + '.qkv'] = _dev_linear(np.concatenate([wq, wk, wv], 0), np.concatenate([bq, bk, bv]), dev)[:2]
             W[p + '.q'] = _dev_linear(wq, bq, dev)[:2]
             W[p + '.kv'] = _dev_linear(np.concatenate([wk, wv], 0), np.concatenate([bk, bv]), dev)[:2]
+            if wq.shape == (128, 128):  # checkpoint layout ([out, in]) for rdm_attention_layer's projections
+                for key, ws in (('.qkv', [wq, wk, wv]), ('.q', [wq]), ('.kv', [wk, wv])):
+                    W[p + key + '.wt'] = torch.from_numpy(np.ascontiguousarray(np.concatenate(ws, 0), dtype=np.float32)).to(dev)
         self._w = W
         return W
 
@@ -264,6 +268,8 @@ class RDMNet(torch.nn.Module):
         W, heads = self._w, self.cfg.thdroformer.num_heads
         N = x.shape[0]
         n1 = N - n0
+        if self._fused_layers_ok(name, num_layers, heads, n0, n1):
+            return self._thdroformer_fused(name, pts4, x, n0, num_layers, out)
         emb = self._linear(name + '.embedding.proj', pts4)
         f = self._linear(name + '.in_proj', x)
         d = f.shape[1]
@@ -286,6 +292,60 @@ class RDMNet(torch.nn.Module):
                 self._attention_tail(p, hid[n0:], f[n0:], fnew[n0:])
             f = fnew
         self._linear(name + '.out_proj', f, out=out)
+
+    def _fused_layers_ok(self, name, num_layers, heads, n0, n1):
+        """rdm_attention_layer (opt-in, RDM_FUSED_LAYER=1, as in the native engine) covers the transformer width
+        128 = 4 heads x 32 with a 256-wide FFN."""
+        W = self._w
+        if os.environ.get('RDM_FUSED_LAYER') != '1' or heads != 4 or num_layers < 1 or n0 <= 0 or n1 <= 0:
+            return False
+        if tuple(getattr(W.get(name + '.out_proj.wt'), 'shape', ())) != (256, 128):
+            return False
+        for i in range(2 * num_layers):
+            p = f'{name}.transformer.layers.{i}'
+            shapes = [tuple(getattr(W.get(p + k + '.wt'), 'shape', ())) for k in ('.attention.linear', '.output.expand', '.output.squeeze')]
+            if shapes != [(128, 128), (256, 128), (128, 256)] or (p + '.qkv.wt') not in W:
+                return False
+        return True
+
+    def _thdroformer_fused(self, name, pts4, x, n0, num_layers, out):
+        """The same transformer with ONE launch per attention application (ops.attention_layer: attention + tail + the
+        projections the following layers need) -- the sequence of the native engine (engine.hip: thdroformer_fused)."""
+        W = self._w
+        N, dev = x.shape[0], x.device
+        n1 = N - n0
+        emb = self._linear(name + '.embedding.proj', pts4)
+        f = self._linear(name + '.in_proj', x)
+        qkv, q2, kv = ops.feat_empty(N, 384, dev), ops.feat_empty(N, 128, dev), ops.feat_empty(N, 256, dev)
+        L = lambda i: f'{name}.transformer.layers.{i}'
+        last = 2 * num_layers - 1
+
+        def proj(key, dst, rope_cols, seg_bits):
+            return (W[key + '.wt'], W[key][1], dst, rope_cols, seg_bits)
+
+        def next_inputs(i, seg_bits):  # the next self layer's q|k|v (with the rotary embedding), or the output projection
+            return proj(name + '.out_proj', out, 0, seg_bits) if i == last else proj(L(i + 1) + '.qkv', qkv, 256, seg_bits)
+
+        ops.attention_layer(out=f, segments=[(0, N, None, None)], projections=[proj(L(0) + '.qkv', qkv, 256, 1)], emb=emb,
+                            projections_only=True)
+        for i in range(2 * num_layers):
+            p = L(i)
+            lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
+            tail = (W[lo + '.wt'], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], W[l1 + '.wt'], W[l1][1],
+                    W[l2 + '.wt'], W[l2][1], W[p + '.output.norm.weight'], W[p + '.output.norm.bias'])
+            fnew = ops.feat_empty(N, 128, dev)
+            common = dict(out=fnew, x=f, tail=tail, emb=emb, bf16=self.attention_bf16)
+            if i % 2 == 0:  # self: each cloud attends to itself; then the cross layer's q (all rows) and k|v (src rows)
+                ops.attention_layer(q=qkv, segments=[(0, n0, qkv[:n0, 128:256], qkv[:n0, 256:384]),
+                                                     (n0, n1, qkv[n0:, 128:256], qkv[n0:, 256:384])],
+                                    projections=[proj(L(i + 1) + '.q', q2, 0, 3), proj(L(i + 1) + '.kv', kv, 0, 2)], **common)
+            else:  # cross: ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
+                ops.attention_layer(q=q2, segments=[(0, n0, kv[n0:, :128], kv[n0:, 128:256])],
+                                    projections=[proj(p + '.kv', kv, 0, 1), next_inputs(i, 1)], **common)
+                ops.attention_layer(q=q2, segments=[(n0, n1, kv[:n0, :128], kv[:n0, 128:256])],
+                                    projections=[next_inputs(i, 1)], **common)
+            f = fnew
+        return out
 
     @staticmethod
     def _pts4(pts):

@@ -77,6 +77,38 @@ def test_kpconv_gather_matches_reference_formula(ops, c, h, m, ns):
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('c,h', [(1, 40), (32, 65), (64, 100), (128, 70)])
+def test_kpconv_gather_shadow_slots_anywhere(ops, c, h):
+    """The gather stops at a query's LAST real neighbour (the searches pad at the end of a row), so rows whose shadow slots sit
+    at the front or in the middle, rows of shadow slots only and rows without any give what the row with its real
+    neighbours packed to the front gives, bit for bit (each query accumulates its neighbours in slot order)."""
+    g = torch.Generator().manual_seed(c * 1000 + h)
+    ns, m = 500, 257
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_pts = s_pts[torch.randint(0, ns, (m,), generator=g)] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g) if c > 1 else torch.ones(ns, 1)
+    idx = torch.randint(0, ns, (m, h), generator=g)
+    keep = torch.rand(m, h, generator=g) < 0.6
+    keep[0] = False          # no neighbour at all
+    keep[1] = True           # a full row
+    keep[2, :-1] = False     # only the last slot
+    keep[2, -1] = True
+    scattered = torch.where(keep, idx, torch.full_like(idx, ns))
+    order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)   # real neighbours first, order kept
+    packed = torch.gather(scattered, 1, order)
+    kp = torch.randn(15, 3, generator=g)
+    args = (q_pts.cuda(), s_pts.cuda(), padded(feats), ops.row_positive(padded(feats)))
+    wf_a, nn_a = ops.kpconv_gather(*args, scattered.cuda(), kp.cuda(), 1.3)
+    wf_b, nn_b = ops.kpconv_gather(*args, packed.cuda(), kp.cuda(), 1.3)
+    assert torch.equal(nn_a, nn_b)
+    kdim = wf_a.shape[1] if c > 1 else 15
+    if c > 1:  # (the four neighbours of an MFMA step are summed inside the instruction: groups shift when slots move)
+        assert (wf_a - wf_b).abs().max() <= 1e-5 * wf_b.abs().max()
+    else:
+        assert (wf_a[:, :kdim] - wf_b[:, :kdim]).abs().max() <= 1e-5 * wf_b.abs().max()
+    assert torch.count_nonzero(wf_a[0, :15 * c]) == 0
+
+
 def test_kpconv_gather_width_cap(ops):
     g = torch.Generator().manual_seed(3)
     ns, m, h, c = 200, 64, 20, 32
@@ -125,6 +157,10 @@ def test_pooling_ops_are_exact(ops):
     cp = torch.cat([coarse, torch.zeros(1, 257)])
     assert torch.equal(y.cpu(), torch.cat([cp[idx[:, 0]], skip], 1))
     assert y.stride(0) == 1284 and torch.count_nonzero(torch.as_strided(y, (m, 3), (1284, 1), 1281)) == 0
+    # widths that are multiples of 4 take the 16-byte kernel (decoder3 / decoder2 of the path)
+    coarse4, skip4 = torch.randn(ns, 512, generator=g), torch.randn(m, 256, generator=g)
+    y4 = ops.upsample_concat(padded(coarse4), idx.cuda(), padded(skip4))
+    assert torch.equal(y4.cpu(), torch.cat([torch.cat([coarse4, torch.zeros(1, 512)])[idx[:, 0]], skip4], 1))
 
 
 @pytest.mark.parametrize('m,k,n', [(5000, 64, 32), (13795, 128, 256), (700, 1024, 512), (77, 36, 64)])
@@ -223,6 +259,82 @@ def test_attention_self_pair_equals_two_launches(ops, n0, n1):
             assert torch.equal(both[:n0], ops.attention(q[:n0], k[:n0], v[:n0], 4, bf16=bf16))
         if n1:
             assert torch.equal(both[n0:], ops.attention(q[n0:], k[n0:], v[n0:], 4, bf16=bf16))
+
+
+@pytest.mark.parametrize('n0,n1,cross', [(350, 301, False), (17, 5, False), (431, 411, True), (16, 33, True)])
+def test_attention_layer_one_launch_matches_the_separate_launches_and_torch(ops, n0, n1, cross):
+    """rdm_attention_layer (attention + tail + the following layers' projections with the rotary embedding, one launch)
+    against (a) the launches it replaces (rdm_attention / rdm_attention_tail / rdm_gemm / rdm_rope): 2e-5 of the output range
+    -- the key split and the contraction order differ -- and (b) torch fp64 of the reference formulas
+    (thdroformer.py:56-85, 112-139, 142-173; output_layer.py:6-21): 5e-5 of the output range."""
+    rng = np.random.default_rng(n0 * 3 + n1)
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.normal(size=s) * scale).astype(np.float32))
+    N = n0 + n1
+    q, x = t(N, 128), t(N, 128)
+    kv = t(N, 256)
+    emb = t(N, 64)
+    wo, w1, w2 = t(128, 128, scale=128 ** -0.5), t(256, 128, scale=128 ** -0.5), t(128, 256, scale=256 ** -0.5)
+    bo, b1, b2 = t(128), t(256), t(128)
+    g1, g2 = (torch.from_numpy(rng.uniform(0.5, 1.5, 128).astype(np.float32)) for _ in range(2))
+    be1, be2 = t(128), t(128)
+    wp, bp = t(384, 128, scale=128 ** -0.5), t(384)        # q|k|v of a following self layer (rotary embedding on q, k)
+    wq, bq = t(256, 128, scale=128 ** -0.5), t(256)        # a second projection of some rows only
+    c = lambda v: v.cuda().contiguous()
+    qd, xd, kvd, embd = c(q), c(x), c(kv), c(emb)
+    tail = tuple(c(v) for v in (wo, bo, g1, be1, w1, b1, w2, b2, g2, be2))
+    out, dst0, dst1 = (torch.full((N, w), 7.0, device='cuda') for w in (128, 384, 256))
+    if cross:   # one segment: rows [0, n0) attend to rows [n0, N)
+        segs = [(0, n0, kvd[n0:, :128], kvd[n0:, 128:])]
+        rows, keys = [slice(0, n0)], [slice(n0, N)]
+        bits1 = 1
+    else:       # two segments: each range attends to itself
+        segs = [(0, n0, kvd[:n0, :128], kvd[:n0, 128:]), (n0, n1, kvd[n0:, :128], kvd[n0:, 128:])]
+        rows, keys = [slice(0, n0), slice(n0, N)], [slice(0, n0), slice(n0, N)]
+        bits1 = 2
+    ops.attention_layer(out=out, q=qd, x=xd, segments=segs, tail=tail, emb=embd,
+                        projections=[(c(wp), c(bp), dst0, 256, 3), (c(wq), c(bq), dst1, 0, bits1)])
+    # (a) the separate launches
+    for r, kk in zip(rows, keys):
+        hid = ops.attention(qd[r], kvd[kk, :128], kvd[kk, 128:], 4)
+        o = ops.attention_tail(hid, xd[r], *tail)
+        scale = o.abs().max()
+        assert (out[r] - o).abs().max() <= 2e-5 * scale
+        p0 = ops.gemm(o, c(wp.t()), 128, 384, bias=c(bp))
+        ops.rope(p0[:, :128], p0[:, 128:256], embd[r])
+        assert (dst0[r] - p0).abs().max() <= 2e-5 * p0.abs().max()
+    sel = rows[-1] if not cross else rows[0]
+    p1 = ops.gemm(out[sel].contiguous(), c(wq.t()), 128, 256, bias=c(bq))
+    assert (dst1[sel] - p1).abs().max() <= 2e-5 * p1.abs().max()
+    if not cross:  # rows of the segment the second projection skips stay untouched, rows outside every segment too
+        assert (dst1[:n0] == 7.0).all()
+    else:
+        assert (out[n0:] == 7.0).all() and (dst0[n0:] == 7.0).all() and (dst1[n0:] == 7.0).all()
+    # (b) torch fp64
+    for r, kk in zip(rows, keys):
+        Q = q[r].double().reshape(-1, 4, 32).transpose(0, 1)
+        K = kv[kk, :128].double().reshape(-1, 4, 32).transpose(0, 1)
+        V = kv[kk, 128:].double().reshape(-1, 4, 32).transpose(0, 1)
+        hid = (torch.softmax(Q @ K.transpose(1, 2) / np.sqrt(32.0), -1) @ V).transpose(0, 1).reshape(-1, 128)
+        y = F.layer_norm(hid @ wo.double().t() + bo.double() + x[r].double(), (128,), g1.double(), be1.double(), 1e-5)
+        z = torch.relu(y @ w1.double().t() + b1.double())
+        want = F.layer_norm(z @ w2.double().t() + b2.double() + y, (128,), g2.double(), be2.double(), 1e-5)
+        assert (out[r].cpu().double() - want).abs().max() <= 5e-5 * want.abs().max()
+        p0 = want @ wp.double().t() + bp.double()
+        theta = 2 * np.pi * torch.sigmoid(emb[r].double())
+        cs, sn = torch.cos(theta), torch.sin(theta)
+        for base in (0, 128):
+            x0, x1 = p0[:, base:base + 128:2].clone(), p0[:, base + 1:base + 128:2].clone()
+            p0[:, base:base + 128:2] = x0 * cs - x1 * sn
+            p0[:, base + 1:base + 128:2] = x1 * cs + x0 * sn
+        assert (dst0[r].cpu().double() - p0).abs().max() <= 5e-5 * p0.abs().max()
+    # projections only: the rows of `out` through a projection
+    dst2 = torch.zeros((N, 384), device='cuda')
+    ops.attention_layer(out=out, segments=[(0, N, None, None)], projections=[(c(wp), c(bp), dst2, 256, 1)], emb=embd,
+                        projections_only=True)
+    if not cross:
+        assert torch.equal(dst2, dst0)
+    else:
+        assert torch.equal(dst2[:n0], dst0[:n0])
 
 
 def test_point_to_node_pair_equals_two_calls(ops):
