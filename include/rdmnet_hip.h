@@ -206,6 +206,17 @@ int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t l
                           const float* beta, float eps, const float* residual, int64_t ldr, int act, float* lin_out,
                           int64_t ld_lin, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
                           void* stream);
+/* rdm_decoder_stage: one stage of the decoder (experiments/backbone.py:118-151; nearest_upsample =
+ * geotransformer/modules/kpconv/functional.py:6-22, UnaryBlock / LastUnaryBlock = modules.py:53-101):
+ *   y = act(GroupNorm([coarse[idx[:, 0]] | skip] W + bias))        gamma != NULL (lin_out: scratch for the pre-norm rows)
+ *   lin_out = [coarse[idx[:, 0]] | skip] W + bias                  gamma == NULL
+ * idx [m, ldi] is the upsampling table (column 0 used; an index outside [0, n_coarse) gives a zero row); W [pad4(c1+c2), n pad]
+ * as rdm_gemm's B.  When c1 is a multiple of 32 the concatenated rows exist only inside the GEMM's operand tiles. */
+size_t rdm_decoder_stage_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1, const int64_t* idx, int64_t ldi,
+                      const float* skip, int64_t c2, int64_t ld2, int64_t m, const float* w, int64_t ldw, const float* bias,
+                      int64_t n, int groups, const float* gamma, const float* beta, float eps, int act, float* lin_out,
+                      int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
 int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
                    int64_t ldr, const float* gamma, const float* beta, float eps, int act, float* y,
                    int64_t ldy, void* stream);

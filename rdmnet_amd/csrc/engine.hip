@@ -193,6 +193,47 @@ int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const 
                                r.ws_bytes, r.st);
 }
 
+// Decoder stage (backbone.py:118-151): Linear [+ GroupNorm + LeakyReLU] of [nearest_upsample(coarse) | skip]; the GEMM forms the
+// concatenated rows in its A-tile loads when the widths allow it (rdm_decoder_stage) -- the [M, c1 + c2] tensor (33 MB at the
+// finest decoder level) is then neither written nor re-read.
+int decoder_stage(Run& r, const std::string& lin_name, const std::string* norm_name, const Mat& coarse, const int64_t* up_idx,
+                  int64_t up_ld, const Mat& skip, int64_t m, Mat& y) {
+  rdm_engine* e = r.e;
+  auto it = e->lin.find(lin_name);
+  if (it == e->lin.end()) {
+    set_error("rdm_engine: missing parameter %s", lin_name.c_str());
+    return RDM_ERR_ARG;
+  }
+  const Linear& L = it->second;
+  RDM_REQUIRE(coarse.cols + skip.cols == L.in, "rdm_engine: %s expects %lld input columns", lin_name.c_str(), (long long)L.in);
+  Mat t = e->mat(m, L.out);
+  ENG_ALLOC(t.p);
+  float *g = nullptr, *b = nullptr;
+  if (norm_name) {
+    y = e->mat(m, L.out);
+    ENG_ALLOC(y.p);
+    g = vecp(r, *norm_name + ".weight");
+    b = vecp(r, *norm_name + ".bias");
+    if (!g || !b) {
+      set_error("rdm_engine: missing parameter %s.*", norm_name->c_str());
+      return RDM_ERR_ARG;
+    }
+  } else {
+    y = t;
+  }
+  const size_t need = rdm_decoder_stage_workspace_bytes(m, L.out, L.in);
+  void* ws = r.ws;
+  size_t ws_bytes = r.ws_bytes;
+  if (need > ws_bytes) {
+    ws = e->alloc<char>(need);
+    ENG_ALLOC(ws);
+    ws_bytes = need;
+  }
+  return rdm_decoder_stage(coarse.p, coarse.rows, coarse.cols, coarse.ld, up_idx, up_ld, skip.p, skip.cols, skip.ld, m, L.b, L.ldb,
+                           L.bias, L.out, r.groups, g, b, 1e-5f, 2, t.p, t.ld, norm_name ? y.p : nullptr, norm_name ? y.ld : 0, ws,
+                           ws_bytes, r.st);
+}
+
 int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, int act, Mat& y, bool alloc_out = true) {
   rdm_engine* e = r.e;
   if (alloc_out) {
@@ -1092,23 +1133,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // ---------------------------------------------------------------- decoder (backbone.py:118-151)
   Mat dec;
   {
-    Mat c4 = e->mat(lv[3].n, buf_c.cols + feats[3].cols);
-    ENG_ALLOC(c4.p);
-    ENG_CHECK(rdm_upsample_concat(buf_c.p, Nc, buf_c.cols, buf_c.ld, up[3].idx, up[3].stride(), feats[3].p, feats[3].cols,
-                                  feats[3].ld, lv[3].n, c4.p, c4.ld, r.st));
-    Mat l4;
-    ENG_CHECK(unary(r, "decoder.decoder4", c4, l4, 2, nullptr, nullptr));
-    Mat c3 = e->mat(lv[2].n, l4.cols + feats[2].cols);
-    ENG_ALLOC(c3.p);
-    ENG_CHECK(rdm_upsample_concat(l4.p, l4.rows, l4.cols, l4.ld, up[2].idx, up[2].stride(), feats[2].p, feats[2].cols,
-                                  feats[2].ld, lv[2].n, c3.p, c3.ld, r.st));
-    Mat l3;
-    ENG_CHECK(unary(r, "decoder.decoder3", c3, l3, 2, nullptr, nullptr));
-    Mat c2 = e->mat(lv[1].n, l3.cols + feats[1].cols);
-    ENG_ALLOC(c2.p);
-    ENG_CHECK(rdm_upsample_concat(l3.p, l3.rows, l3.cols, l3.ld, up[1].idx, up[1].stride(), feats[1].p, feats[1].cols,
-                                  feats[1].ld, lv[1].n, c2.p, c2.ld, r.st));
-    ENG_CHECK(linear(r, "decoder.decoder2.mlp", c2, dec));
+    const std::string n4 = "decoder.decoder4.norm.norm", n3 = "decoder.decoder3.norm.norm";
+    Mat l4, l3;
+    ENG_CHECK(decoder_stage(r, "decoder.decoder4.mlp", &n4, buf_c, up[3].idx, up[3].stride(), feats[3], lv[3].n, l4));
+    ENG_CHECK(decoder_stage(r, "decoder.decoder3.mlp", &n3, l4, up[2].idx, up[2].stride(), feats[2], lv[2].n, l3));
+    ENG_CHECK(decoder_stage(r, "decoder.decoder2.mlp", nullptr, l3, up[1].idx, up[1].stride(), feats[1], lv[1].n, dec));
   }
   tap(r, "decoder", dec);
   Mat feats_f = dec.cols_from(0, D);

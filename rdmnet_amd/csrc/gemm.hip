@@ -39,6 +39,12 @@ struct GemmArgs {
   int splits;            // split-K factor (partials go to `part`)
   float* part;           // [batch*splits, M, N] when splits > 1
   double* stats;         // optional GroupNorm partials [grid.y][2][N] (non split-K only)
+  // CAT kernels only -- A is the decoder's [nearest_upsample(coarse) | skip] (backbone.py:118-151, functional.py:6-22)
+  // without materialising it: columns k < c1 of row m are coarse[aidx[m * ldi]] (row index out of range: zeros), the rest
+  // skip[m]; A = coarse, lda its row stride; c1 a multiple of the k-tile depth
+  const float* A2;
+  const int64_t* aidx;
+  int lda2, ldi, c1, n_coarse;
 #ifdef RDM_GEMM_TIMING
   unsigned long long* clk;  // tools/gemm_phase_lab.hip: shader-clock stamps of workgroup (0,0,0), thread 0
 #endif
@@ -58,7 +64,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // PF = global->register prefetch depth in K tiles (the loop barriers order LDS only, so the stages really stay in
 // flight): the skinny products of this path run a handful of blocks per CU and a block covers part of the load
 // latency itself.
-template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF>
+template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF, bool CAT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
@@ -101,6 +107,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   static_assert(PF == 1 || PF == 2, "one or two register stages");
   // named stages (an array of stages indexed in a loop ended up in scratch memory)
   float4 ra0[A_V], rb0[B_V], ra1[PF == 2 ? A_V : 1], rb1[PF == 2 ? B_V : 1];
+  // CAT: the gathered coarse row of each A row this thread stages (fixed over the K loop), -1 = shadow row (zeros)
+  long long cat_row[CAT ? A_V : 1];
+  if constexpr (CAT) {
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      const int row = (tid + i * 256) / (BK / 4);
+      const long long id = g.aidx[static_cast<long long>(min(m0 + row, g.M - 1)) * g.ldi];
+      cat_row[i] = (id >= 0 && id < g.n_coarse) ? id : -1;
+    }
+  }
 
   // Loads are unconditional from clamped (always valid) addresses, the out-of-range parts are zeroed when the stage is
   // written to LDS, and the K loop issues and stores a stage on every trip: no control flow in the loop body, so that
@@ -113,7 +129,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int i = 0; i < A_V; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
+      if constexpr (CAT) {  // (a k-tile lies on one side of c1: the choice is workgroup-uniform)
+        const float* src = k0 < g.c1 ? A + max(cat_row[i], 0ll) * g.lda + (k0 + kc)
+                                     : g.A2 + static_cast<long long>(min(m0 + row, g.M - 1)) * g.lda2 + min(k0 - g.c1 + kc, g.K - g.c1 - 4);
+        ra[i] = *reinterpret_cast<const float4*>(src);
+      } else {
       ra[i] = *reinterpret_cast<const float4*>(A + static_cast<long long>(min(m0 + row, g.M - 1)) * g.lda + min(k0 + kc, g.K - 4));
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_V; ++i) {
@@ -136,7 +158,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
       if (A_N4 % 256 != 0 && idx >= A_N4) continue;
-      const float4 v = masked(ra[i], m0 + row < g.M && k0 + kc < g.K);
+      bool a_ok = m0 + row < g.M && k0 + kc < g.K;
+      if constexpr (CAT) a_ok = a_ok && (k0 >= g.c1 || cat_row[i] >= 0);
+      const float4 v = masked(ra[i], a_ok);
       As[buf][kc + 0][row] = v.x;
       As[buf][kc + 1][row] = v.y;
       As[buf][kc + 2][row] = v.z;
@@ -726,6 +750,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, do
 template <int BM, int BN, int WM, int WN, int BK, int PF = 1>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
+  if constexpr (BM == 64 && BN == 64 && BK == 32 && PF == 2) {
+    if (g.aidx) {  // virtual [upsample | skip] A operand
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>), grid, dim3(256), 0, st, g);
+      return;
+    }
+  }
   if (trans_b)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF>), grid, dim3(256), 0, st, g);
   else
@@ -747,7 +777,7 @@ namespace {
 int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
   const long long m = g.M, n = g.N, k = g.K;
   const char* tune_env = getenv("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
-  if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
+  if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && !g.aidx && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
       m * n <= 1536 * 512 && !(tune_env && tune_env[0] != '0')) {
     if (stat_blocks) *stat_blocks = 0;
     RDM_DUP_LOOP("gemmsmall")
@@ -778,6 +808,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     double best = 1e30;
     const size_t ws_cap = ws ? ws_bytes : 0;
     for (const Cand& c : cands) {
+      if (g.aidx && c.tile != T64) continue;
       if (c.tile == T128x32 && n > 64) continue;
       if (c.tile != T128x32 && n <= 32) continue;  // a 64-wide tile would be half empty
       if (c.tile == T128 && n < 128) continue;
@@ -814,6 +845,17 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       force_splits = sp;
       if (t >= 1 && t <= 7 && sp == 0) best_s = 1;
     }
+  }
+  // developer experiment: RDM_GEMM_BIG="<min M>[,<tile 4..7>]" runs the un-split products with at least that many rows and
+  // n >= 128 on a larger tile (default 6 = 128x128x32) -- fewer operand bytes per flop through the CU's L2 port, which is what
+  // co-limits the 64x64 tile when several pairs share the GPU
+  static const int big_min_m = [] { const char* v = getenv("RDM_GEMM_BIG"); return v ? atoi(v) : 0; }();
+  static const int big_tile = [] { const char* v = getenv("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
+  if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && best_s == 1 && force_splits == 0 && batches == 1)
+    exp_tile = big_tile;
+  if (g.aidx) {  // the concatenating A operand exists for the 64x64x32 tile only
+    tile = T64;
+    exp_tile = 0;
   }
   int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   if (exp_tile == 4) { bm = 128; bn = 64; }
@@ -885,6 +927,28 @@ int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ld
   g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
   g.sa = g.sb = g.sc = 0;
   g.act = 0; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
+  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0;
+  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
+}
+
+// C = [nearest_upsample(coarse)[idx[:, 0]] | skip] B + bias (decoder, backbone.py:118-151) without materialising the
+// concatenation: the GEMM's A tiles come from the two sources directly.  c1 (columns of coarse) must be a multiple of 32
+// and c1 + c2 the padded K of B; otherwise returns 1 and the caller concatenates (rdm_upsample_concat) as before.
+int rdm::gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, int64_t n_coarse, const int64_t* idx, int64_t ldi,
+                                const float* skip, int64_t ld2, int64_t c2, const float* b, int64_t ldb, float* c, int64_t ldc,
+                                int64_t m, int64_t n, const float* bias, int act, void* ws, size_t ws_bytes, double* gn_partial,
+                                int* gn_blocks, void* stream) {
+  if (c1 % 32 != 0 || c2 % 4 != 0 || c2 < 4 || ld1 % 4 != 0 || ld2 % 4 != 0 || ldb % 4 != 0 || m <= 0 ||
+      ((reinterpret_cast<uintptr_t>(coarse) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(b)) & 15) != 0)
+    return 1;
+  GemmArgs g;
+  g.A = coarse; g.B = b; g.C = c; g.bias = bias; g.rowdiv = nullptr;
+  g.M = static_cast<int>(m); g.N = static_cast<int>(n); g.K = static_cast<int>(c1 + c2);
+  g.lda = static_cast<int>(ld1); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
+  g.sa = g.sb = g.sc = 0;
+  g.act = act; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
+  g.A2 = skip; g.aidx = idx; g.lda2 = static_cast<int>(ld2); g.ldi = static_cast<int>(ldi); g.c1 = static_cast<int>(c1);
+  g.n_coarse = static_cast<int>(n_coarse);
   return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -908,6 +972,7 @@ int rdm::gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0,
       g[i].M = static_cast<int>(M[i]); g[i].N = static_cast<int>(N[i]); g[i].K = static_cast<int>(K[i]);
       g[i].lda = static_cast<int>(LA[i]); g[i].ldb = static_cast<int>(LB[i]); g[i].ldc = static_cast<int>(LC[i]);
       g[i].sa = g[i].sb = g[i].sc = 0; g[i].act = 0; g[i].splits = 1; g[i].part = nullptr; g[i].stats = nullptr;
+      g[i].A2 = nullptr; g[i].aidx = nullptr; g[i].lda2 = g[i].ldi = g[i].c1 = g[i].n_coarse = 0;
     }
     const long long gx = ceil_div<long long>(std::max(n0, n1), 32), gy = ceil_div<long long>(std::max(m0, m1), 32);
     hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(gx, gy, 2), dim3(256), 0, static_cast<hipStream_t>(stream), g[0], g[1]);
@@ -939,6 +1004,7 @@ extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const flo
   g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
   g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
   g.act = act; g.splits = 1; g.part = nullptr; g.stats = nullptr;
+  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0;
   return gemm_dispatch(g, batches, trans_b != 0, ws, ws_bytes, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -974,6 +1040,51 @@ extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w
     return e;
   return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, residual, ldr, act, y, ldy,
                            positive, nws, gn_ws, stream);
+}
+
+// Decoder stage (experiments/backbone.py:118-151): y = act(GroupNorm([nearest_upsample(coarse) | skip] W + b)), or the plain
+// Linear into lin_out when gamma is null (decoder2).  The concatenated rows are formed inside the GEMM's A-tile loads when
+// c1 is a multiple of 32 (gemm_concat_with_stats); other widths (the 257-column coarse tensor of decoder4) go through
+// rdm_upsample_concat into the workspace first.
+extern "C" size_t rdm_decoder_stage_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  return rdm_linear_group_norm_workspace_bytes(m, n) + rdm::align_up(static_cast<size_t>(m > 0 ? m : 1) * ((k + 3) / 4 * 4) * sizeof(float));
+}
+
+extern "C" int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1, const int64_t* idx, int64_t ldi,
+                                 const float* skip, int64_t c2, int64_t ld2, int64_t m, const float* w, int64_t ldw,
+                                 const float* bias, int64_t n, int groups, const float* gamma, const float* beta, float eps,
+                                 int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(coarse && idx && skip && w && lin_out && (!gamma || (beta && y)), "rdm_decoder_stage: null pointer");
+  RDM_REQUIRE(c1 > 0 && c2 > 0 && n > 0 && m >= 0 && ldw % 4 == 0, "rdm_decoder_stage: bad sizes");
+  if (m == 0) return RDM_OK;
+  const int64_t k = c1 + c2, kpad = (k + 3) / 4 * 4;
+  static const bool no_virtual = getenv("RDM_NO_VIRTUAL_CONCAT") != nullptr;  // developer knob: always materialise
+  Arena ar(ws, ws_bytes);
+  const size_t gemm_ws = rdm_gemm_workspace_bytes(m, n, 1);
+  char* gws = ar.take<char>(gemm_ws);
+  double* partial = ar.take<double>(static_cast<size_t>(gemm_stats_max_blocks(m)) * 2 * n);
+  const size_t gn_ws = rdm_group_norm_workspace_bytes(m, n);
+  char* nws = ar.take<char>(gn_ws);
+  float* cat = ar.take<float>(static_cast<size_t>(m) * kpad);
+  if (!ar.ok) {
+    set_error("rdm_decoder_stage: workspace too small (%zu < %zu)", ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  int nblk = 0;
+  int rc = 1;
+  if (!no_virtual && k == kpad)
+    rc = gemm_concat_with_stats(coarse, ld1, c1, n_coarse, idx, ldi, skip, ld2, c2, w, ldw, lin_out, ld_lin, m, n, bias, 0, gws,
+                                gemm_ws, gamma ? partial : nullptr, &nblk, stream);
+  if (rc == 1) {
+    if (int e = rdm_upsample_concat(coarse, n_coarse, c1, ld1, idx, ldi, skip, c2, ld2, m, cat, kpad, stream)) return e;
+    rc = gemm_with_stats(cat, kpad, w, ldw, lin_out, ld_lin, m, n, kpad, bias, nullptr, gws, gemm_ws, gamma ? partial : nullptr,
+                         &nblk, stream);
+  }
+  if (rc != 0 || !gamma) return rc;
+  return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, nullptr, 0, act, y, ldy, nullptr, nws,
+                           gn_ws, stream);
 }
 
 // y = act(LayerNorm(x W^T + bias [+ residual]) * gamma + beta) with W [128, k] (nn.Linear weight as stored): the

@@ -231,10 +231,16 @@ class RDMNet(torch.nn.Module):
 
     def run_decoder(self, feats, data):
         """experiments/backbone.py:118-151."""
-        up = data['upsampling']
-        l4 = self._unary('decoder.decoder4', ops.upsample_concat(feats[4], up[3], feats[3]))
-        l3 = self._unary('decoder.decoder3', ops.upsample_concat(l4, up[2], feats[2]))
-        return self._linear('decoder.decoder2.mlp', ops.upsample_concat(l3, up[1], feats[1]))
+        up, W, groups = data['upsampling'], self._w, self.cfg.backbone.group_norm
+
+        def stage(name, coarse, idx, skip, norm=True):
+            b, bias, in_f, out_f = W[name + '.mlp']
+            g, be = (W[name + '.norm.norm.weight'], W[name + '.norm.norm.bias']) if norm else (None, None)
+            return ops.decoder_stage(coarse, idx, skip, b, out_f, bias, g, be, groups, act=ACT_LEAKY)
+
+        l4 = stage('decoder.decoder4', feats[4], up[3], feats[3])
+        l3 = stage('decoder.decoder3', l4, up[2], feats[2])
+        return stage('decoder.decoder2', l3, up[1], feats[1], norm=False)
 
     # ------------------------------------------------------------------ 3DRoFormer
     def _attention_tail(self, p, hid, x, out):

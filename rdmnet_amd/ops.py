@@ -184,6 +184,21 @@ def linear_group_norm(x, b, k, n, bias, gamma, beta, groups, *, rowdiv=None, act
     return (y, pos) if want_positive else y
 
 
+def decoder_stage(coarse, idx, skip, b, n, bias, gamma=None, beta=None, groups=32, *, act=ACT_NONE, eps=1e-5):
+    """One decoder stage (backbone.py:118-151): act(GroupNorm([coarse[idx[:, 0]] | skip] @ b + bias)), or the plain Linear when
+    gamma is None.  b: [pad4(c1 + c2), pad4(n)] as for gemm."""
+    L = _lib.lib()
+    m, c1, c2 = skip.shape[0], coarse.shape[1], skip.shape[1]
+    lin = feat_empty(m, n, skip.device)
+    y = feat_empty(m, n, skip.device) if gamma is not None else None
+    ws = scratch(skip.device, L.rdm_decoder_stage_workspace_bytes(m, n, c1 + c2))
+    _lib.check(L.rdm_decoder_stage(coarse.data_ptr(), coarse.shape[0], c1, _ld(coarse), idx.data_ptr(), _ld(idx), skip.data_ptr(),
+                                   c2, _ld(skip), m, b.data_ptr(), _ld(b), _lib.ptr(bias), n, groups, _lib.ptr(gamma),
+                                   _lib.ptr(beta), eps, act, lin.data_ptr(), _ld(lin), _lib.ptr(y), _ld(y) if y is not None else 0,
+                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_decoder_stage')
+    return y if gamma is not None else lin
+
+
 def layer_norm(x, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=None):
     L = _lib.lib()
     n, c = x.shape

@@ -163,6 +163,33 @@ def test_pooling_ops_are_exact(ops):
     assert torch.equal(y4.cpu(), torch.cat([torch.cat([coarse4, torch.zeros(1, 512)])[idx[:, 0]], skip4], 1))
 
 
+@pytest.mark.parametrize('ns,m,c1,c2,n,norm', [(300, 1000, 64, 36, 128, True), (563, 1310, 257, 1024, 1024, True),
+                                              (1310, 3879, 1024, 512, 512, True), (900, 2500, 512, 256, 257, False)])
+def test_decoder_stage_matches_torch(ops, ns, m, c1, c2, n, norm):
+    """Decoder stage (backbone.py:118-151: nearest_upsample + cat + UnaryBlock / Linear) against torch fp64, 2e-5 of the output
+    range; c1 % 32 == 0 takes the GEMM whose A tiles read the two sources directly, other widths the materialised rows --
+    both must agree with the separate launches (upsample_concat + linear_group_norm / gemm) to the same tolerance."""
+    g = torch.Generator().manual_seed(m + c1)
+    coarse, skip = torch.randn(ns, c1, generator=g), torch.randn(m, c2, generator=g)
+    idx = torch.randint(0, ns + 1, (m, 5), generator=g)  # includes the shadow index ns
+    k = c1 + c2
+    w, bias = torch.randn(k, n, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    gamma, beta = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    a = torch.cat([torch.cat([coarse, torch.zeros(1, c1)])[idx[:, 0]], skip], 1).double()
+    lin = a @ w.double() + bias.double()
+    want = F.leaky_relu(F.group_norm(lin.t()[None], 32, gamma.double(), beta.double(), 1e-5)[0].t(), 0.1) if norm else lin
+    kp = (k + 3) // 4 * 4
+    wp = torch.zeros(kp, n)
+    wp[:k] = w
+    args = (padded(coarse), idx.cuda(), padded(skip), padded(wp), n, bias.cuda())
+    got = ops.decoder_stage(*args, gamma.cuda(), beta.cuda(), 32, act=ops.ACT_LEAKY) if norm else ops.decoder_stage(*args)
+    assert (got.cpu().double() - want).abs().max() <= 2e-5 * want.abs().max()
+    cat = ops.upsample_concat(padded(coarse), idx.cuda(), padded(skip))
+    sep = (ops.linear_group_norm(cat, padded(wp), kp, n, bias.cuda(), gamma.cuda(), beta.cuda(), 32, act=ops.ACT_LEAKY) if norm
+           else ops.gemm(cat, padded(wp), kp, n, bias=bias.cuda()))
+    assert (got - sep).abs().max() <= 2e-5 * want.abs().max()
+
+
 @pytest.mark.parametrize('m,k,n', [(5000, 64, 32), (13795, 128, 256), (700, 1024, 512), (77, 36, 64)])
 def test_linear_group_norm_fused_matches_torch(ops, m, k, n):
     g = torch.Generator().manual_seed(m + n)
