@@ -206,6 +206,13 @@ int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t l
                           const float* beta, float eps, const float* residual, int64_t ldr, int act, float* lin_out,
                           int64_t ld_lin, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
                           void* stream);
+/* rdm_patch_scores: the patch score matrices of the fine matching (experiments/model_infer.py:291-311: index_select of the
+ * patch features + einsum('bnd,bmd->bnm') / sqrt(d)): scores[b, i, j] = <ref_feats[ref_idx[b, i]], src_feats[src_idx[b, j]]>
+ * / rowdiv[i], ref_idx / src_idx [batch, side] int64 with the reference's padded gather (an index outside the tensor selects a
+ * zero row).  scores [batch, side, side] contiguous.  The gathered [batch, side, d] tensors are never materialised. */
+int rdm_patch_scores(const float* ref_feats, int64_t ld_ref, int64_t n_ref, const int64_t* ref_idx, const float* src_feats,
+                     int64_t ld_src, int64_t n_src, const int64_t* src_idx, int64_t batch, int64_t side, int64_t d,
+                     const float* rowdiv, float* scores, void* stream);
 /* rdm_decoder_stage: one stage of the decoder (experiments/backbone.py:118-151; nearest_upsample =
  * geotransformer/modules/kpconv/functional.py:6-22, UnaryBlock / LastUnaryBlock = modules.py:53-101):
  *   y = act(GroupNorm([coarse[idx[:, 0]] | skip] W + bias))        gamma != NULL (lin_out: scratch for the pre-norm rows)

@@ -62,6 +62,8 @@ SIGNATURES = {
     'rdm_linear_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_linear_group_norm': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void,
                                       c_f32, c_void, c_i64, c_int, c_void, c_i64, c_void, c_i64, c_void, c_void, c_size, c_void]),
+    'rdm_patch_scores': (c_int, [c_void, c_i64, c_i64, c_void, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void,
+                                 c_void]),
     'rdm_decoder_stage_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),
     'rdm_decoder_stage': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void,
                                   c_i64, c_int, c_void, c_void, c_f32, c_int, c_void, c_i64, c_void, c_i64, c_void, c_size, c_void]),

@@ -1300,31 +1300,40 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   uint8_t* s_pm = e->alloc<uint8_t>(B * K);
   float* r_pts = e->alloc<float>(B * K * 3);
   float* s_pts = e->alloc<float>(B * K * 3);
-  float* r_pf = e->alloc<float>(B * K * D);
-  float* s_pf = e->alloc<float>(B * K * D);
   ENG_ALLOC(r_idx); ENG_ALLOC(s_idx); ENG_ALLOC(r_pm); ENG_ALLOC(s_pm); ENG_ALLOC(r_pts); ENG_ALLOC(s_pts);
-  ENG_ALLOC(r_pf); ENG_ALLOC(s_pf);
-  {  // the eight patch gathers as two launches: (knn indices, knn masks) x (ref, src), then (points, features) x (ref, src)
+  {  // the patch gathers as two launches: (knn indices, knn masks) x (ref, src), then the points x (ref, src); the patch
+     // FEATURES are gathered inside the score GEMM's operand loads (rdm_patch_scores)
     const void* x1[4] = {r_knn, s_knn, r_km, s_km};
     const int64_t ns1[4] = {m_r, m_s, m_r, m_s}, w1[4] = {2 * K, 2 * K, K / 4, K / 4}, mm1[4] = {B, B, B, B};
     const int64_t* i1[4] = {r_sel, s_sel, r_sel, s_sel};
     void* y1[4] = {r_idx, s_idx, r_pm, s_pm};
     RDM_DUP_LOOP("rows")
   ENG_CHECK(gather_rows_multi(4, x1, ns1, w1, w1, i1, mm1, y1, w1, r.st));
-    const void* x2[4] = {pf_ref, pf_src, feats_f.p, feats_f.p + nf_ref * feats_f.ld};
-    const int64_t ns2[4] = {nf_ref, nf_src, nf_ref, nf_src}, w2[4] = {3, 3, D, D}, lx2[4] = {3, 3, feats_f.ld, feats_f.ld};
-    const int64_t mm2[4] = {B * K, B * K, B * K, B * K};
-    const int64_t* i2[4] = {r_idx, s_idx, r_idx, s_idx};
-    void* y2[4] = {r_pts, s_pts, r_pf, s_pf};
+    const void* x2[2] = {pf_ref, pf_src};
+    const int64_t ns2[2] = {nf_ref, nf_src}, w2[2] = {3, 3}, lx2[2] = {3, 3};
+    const int64_t mm2[2] = {B * K, B * K};
+    const int64_t* i2[2] = {r_idx, s_idx};
+    void* y2[2] = {r_pts, s_pts};
     RDM_DUP_LOOP("rows")
-  ENG_CHECK(gather_rows_multi(4, x2, ns2, w2, lx2, i2, mm2, y2, w2, r.st));
+  ENG_CHECK(gather_rows_multi(2, x2, ns2, w2, lx2, i2, mm2, y2, w2, r.st));
   }
   float* sqrt_c = vecp(r, "__sqrt_out_dim");  // [K] x sqrt(D): the einsum's divisor (model_infer.py:311), uploaded at finalize
   float* scores = e->alloc<float>(B * K * K);
   float* ms = e->alloc<float>(B * (K + 1) * (K + 1));
   ENG_ALLOC(sqrt_c); ENG_ALLOC(scores); ENG_ALLOC(ms);
-  ENG_CHECK(rdm_gemm(r_pf, D, K * D, s_pf, D, K * D, 1, scores, K, static_cast<int64_t>(K) * K, K, K, D, static_cast<int>(B),
-                     nullptr, sqrt_c, 0, nullptr, 0, r.st));
+  static const bool materialise_patches = getenv("RDM_NO_PATCH_GATHER") != nullptr;  // developer knob (A/B): gather, then GEMM
+  if (materialise_patches) {
+    float* r_pf = e->alloc<float>(B * K * D);
+    float* s_pf = e->alloc<float>(B * K * D);
+    ENG_ALLOC(r_pf); ENG_ALLOC(s_pf);
+    ENG_CHECK(rdm_gather_rows(feats_f.p, nf_ref, D, feats_f.ld, r_idx, B * K, r_pf, D, r.st));
+    ENG_CHECK(rdm_gather_rows(feats_f.p + nf_ref * feats_f.ld, nf_src, D, feats_f.ld, s_idx, B * K, s_pf, D, r.st));
+    ENG_CHECK(rdm_gemm(r_pf, D, K * D, s_pf, D, K * D, 1, scores, K, static_cast<int64_t>(K) * K, K, K, D, static_cast<int>(B),
+                       nullptr, sqrt_c, 0, nullptr, 0, r.st));
+  } else {
+    ENG_CHECK(rdm_patch_scores(feats_f.p, feats_f.ld, nf_ref, r_idx, feats_f.p + nf_ref * feats_f.ld, feats_f.ld, nf_src, s_idx, B,
+                               K, D, sqrt_c, scores, r.st));
+  }
   ENG_CHECK(rdm_sinkhorn(scores, B, K, K, r_pm, s_pm, vecp(r, "optimal_transport.alpha"), c.sinkhorn_iterations, ms, r.st));
   tap(r, "patch_scores", scores, B * K, K, K, 0);
   tap(r, "matching_scores", ms, B * (K + 1), K + 1, K + 1, 0);

@@ -45,6 +45,11 @@ struct GemmArgs {
   const float* A2;
   const int64_t* aidx;
   int lda2, ldi, c1, n_coarse;
+  // CAT + TRANS_B ("patch scores", model_infer.py:291-311): row m of batch b of A is A[aidx[b * M + m]] and row n of B is
+  // B[bidx[b * N + n]] (an index outside [0, n_coarse) / [0, n_b): a zero row, as the reference's padded gather gives); tiles
+  // whose rows or columns are all shadow rows are written as zeros without touching the features
+  const int64_t* bidx;
+  int n_b;
 #ifdef RDM_GEMM_TIMING
   unsigned long long* clk;  // tools/gemm_phase_lab.hip: shader-clock stamps of workgroup (0,0,0), thread 0
 #endif
@@ -108,13 +113,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // named stages (an array of stages indexed in a loop ended up in scratch memory)
   float4 ra0[A_V], rb0[B_V], ra1[PF == 2 ? A_V : 1], rb1[PF == 2 ? B_V : 1];
   // CAT: the gathered coarse row of each A row this thread stages (fixed over the K loop), -1 = shadow row (zeros)
-  long long cat_row[CAT ? A_V : 1];
-  if constexpr (CAT) {
+  long long cat_row[CAT ? A_V : 1], cat_brow[CAT && TRANS_B ? B_V : 1];
+  if constexpr (CAT && !TRANS_B) {
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
       const int row = (tid + i * 256) / (BK / 4);
       const long long id = g.aidx[static_cast<long long>(min(m0 + row, g.M - 1)) * g.ldi];
       cat_row[i] = (id >= 0 && id < g.n_coarse) ? id : -1;
+    }
+  }
+  if constexpr (CAT && TRANS_B) {
+    A = g.A;  // gathered rows: no batch stride
+    B = g.B;
+    int any_a = 0, any_b = 0;
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+      const int row = (tid + i * 256) / (BK / 4);
+      const long long id = (m0 + row < g.M && (A_N4 % 256 == 0 || tid + i * 256 < A_N4)) ? g.aidx[static_cast<long long>(batch) * g.M + m0 + row] : -1;
+      cat_row[i] = (id >= 0 && id < g.n_coarse) ? id : -1;
+      any_a |= cat_row[i] >= 0;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+      const int row = (tid + i * 256) / (BK / 4);
+      const long long id = (n0 + row < g.N && (B_N4 % 256 == 0 || tid + i * 256 < B_N4)) ? g.bidx[static_cast<long long>(batch) * g.N + n0 + row] : -1;
+      cat_brow[i] = (id >= 0 && id < g.n_b) ? id : -1;
+      any_b |= cat_brow[i] >= 0;
+    }
+    any_a = __syncthreads_or(any_a);
+    any_b = __syncthreads_or(any_b);
+    if (!any_a || !any_b) {  // workgroup-uniform: a tile of zero rows (or zero columns) is zero
+      float* Cz = g.C + batch * g.sc;
+      for (int e = tid; e < BM * BN; e += 256) {
+        const int r = m0 + e / BN, cc = n0 + e % BN;
+        if (r < g.M && cc < g.N) Cz[static_cast<long long>(r) * g.ldc + cc] = 0.f;
+      }
+      return;
     }
   }
 
@@ -129,7 +163,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int i = 0; i < A_V; ++i) {
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
-      if constexpr (CAT) {  // (a k-tile lies on one side of c1: the choice is workgroup-uniform)
+      if constexpr (CAT && TRANS_B) {
+        ra[i] = *reinterpret_cast<const float4*>(A + max(cat_row[i], 0ll) * g.lda + min(k0 + kc, g.K - 4));
+      } else if constexpr (CAT) {  // (a k-tile lies on one side of c1: the choice is workgroup-uniform)
         const float* src = k0 < g.c1 ? A + max(cat_row[i], 0ll) * g.lda + (k0 + kc)
                                      : g.A2 + static_cast<long long>(min(m0 + row, g.M - 1)) * g.lda2 + min(k0 - g.c1 + kc, g.K - g.c1 - 4);
         ra[i] = *reinterpret_cast<const float4*>(src);
@@ -142,7 +178,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int idx = tid + i * 256;
       if (TRANS_B) {
         const int row = idx / KC4, kc = (idx % KC4) * 4;
+        if constexpr (CAT) {
+          rb[i] = *reinterpret_cast<const float4*>(B + max(cat_brow[i], 0ll) * g.ldb + min(k0 + kc, g.K - 4));
+        } else {
         rb[i] = *reinterpret_cast<const float4*>(B + static_cast<long long>(min(n0 + row, g.N - 1)) * g.ldb + min(k0 + kc, g.K - 4));
+        }
       } else {
         const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
         rb[i] = *reinterpret_cast<const float4*>(B + static_cast<long long>(min(k0 + k, g.K - 1)) * g.ldb + min(n0 + n4, g.ldb - 4));
@@ -159,7 +199,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int row = idx / KC4, kc = (idx % KC4) * 4;
       if (A_N4 % 256 != 0 && idx >= A_N4) continue;
       bool a_ok = m0 + row < g.M && k0 + kc < g.K;
-      if constexpr (CAT) a_ok = a_ok && (k0 >= g.c1 || cat_row[i] >= 0);
+      if constexpr (CAT && TRANS_B) a_ok = a_ok && cat_row[i] >= 0;
+      else if constexpr (CAT) a_ok = a_ok && (k0 >= g.c1 || cat_row[i] >= 0);
       const float4 v = masked(ra[i], a_ok);
       As[buf][kc + 0][row] = v.x;
       As[buf][kc + 1][row] = v.y;
@@ -172,7 +213,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int idx = tid + i * 256;
         const int row = idx / KC4, kc = (idx % KC4) * 4;
         if (B_N4 % 256 != 0 && idx >= B_N4) continue;
-        const float4 v = masked(rb[i], n0 + row < g.N && k0 + kc < g.K);
+        bool b_ok = n0 + row < g.N && k0 + kc < g.K;
+        if constexpr (CAT) b_ok = b_ok && cat_brow[i] >= 0;
+        const float4 v = masked(rb[i], b_ok);
         Bs[buf][kc + 0][row] = v.x;
         Bs[buf][kc + 1][row] = v.y;
         Bs[buf][kc + 2][row] = v.z;
@@ -751,6 +794,10 @@ template <int BM, int BN, int WM, int WN, int BK, int PF = 1>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
   if constexpr (BM == 64 && BN == 64 && BK == 32 && PF == 2) {
+    if (g.aidx && g.bidx) {  // gathered rows on both sides (patch scores)
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>), grid, dim3(256), 0, st, g);
+      return;
+    }
     if (g.aidx) {  // virtual [upsample | skip] A operand
       hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>), grid, dim3(256), 0, st, g);
       return;
@@ -853,9 +900,10 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   static const int big_tile = [] { const char* v = getenv("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
   if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && best_s == 1 && force_splits == 0 && batches == 1)
     exp_tile = big_tile;
-  if (g.aidx) {  // the concatenating A operand exists for the 64x64x32 tile only
+  if (g.aidx) {  // the concatenating / gathering operands exist for the 64x64x32 tile only
     tile = T64;
     exp_tile = 0;
+    if (g.bidx) best_s = 1, force_splits = 0;  // (256 batches fill the chip; the zero-tile shortcut writes C directly)
   }
   int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   if (exp_tile == 4) { bm = 128; bn = 64; }
@@ -927,7 +975,7 @@ int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ld
   g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
   g.sa = g.sb = g.sc = 0;
   g.act = 0; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
-  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0;
+  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0; g.bidx = nullptr; g.n_b = 0;
   return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -949,6 +997,7 @@ int rdm::gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, in
   g.act = act; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
   g.A2 = skip; g.aidx = idx; g.lda2 = static_cast<int>(ld2); g.ldi = static_cast<int>(ldi); g.c1 = static_cast<int>(c1);
   g.n_coarse = static_cast<int>(n_coarse);
+  g.bidx = nullptr; g.n_b = 0;
   return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
 }
 
@@ -972,7 +1021,7 @@ int rdm::gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0,
       g[i].M = static_cast<int>(M[i]); g[i].N = static_cast<int>(N[i]); g[i].K = static_cast<int>(K[i]);
       g[i].lda = static_cast<int>(LA[i]); g[i].ldb = static_cast<int>(LB[i]); g[i].ldc = static_cast<int>(LC[i]);
       g[i].sa = g[i].sb = g[i].sc = 0; g[i].act = 0; g[i].splits = 1; g[i].part = nullptr; g[i].stats = nullptr;
-      g[i].A2 = nullptr; g[i].aidx = nullptr; g[i].lda2 = g[i].ldi = g[i].c1 = g[i].n_coarse = 0;
+      g[i].A2 = nullptr; g[i].aidx = nullptr; g[i].lda2 = g[i].ldi = g[i].c1 = g[i].n_coarse = 0; g[i].bidx = nullptr; g[i].n_b = 0;
     }
     const long long gx = ceil_div<long long>(std::max(n0, n1), 32), gy = ceil_div<long long>(std::max(m0, m1), 32);
     hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(gx, gy, 2), dim3(256), 0, static_cast<hipStream_t>(stream), g[0], g[1]);
@@ -1004,7 +1053,7 @@ extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const flo
   g.lda = static_cast<int>(lda); g.ldb = static_cast<int>(ldb); g.ldc = static_cast<int>(ldc);
   g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
   g.act = act; g.splits = 1; g.part = nullptr; g.stats = nullptr;
-  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0;
+  g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0; g.bidx = nullptr; g.n_b = 0;
   return gemm_dispatch(g, batches, trans_b != 0, ws, ws_bytes, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -1040,6 +1089,30 @@ extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w
     return e;
   return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, residual, ldr, act, y, ldy,
                            positive, nws, gn_ws, stream);
+}
+
+// Patch score matrices (experiments/model_infer.py:291-311): scores[b, i, j] = <ref_feats[ref_idx[b, i]], src_feats[src_idx[b, j]]>
+// / divisor[i] with the reference's padded gather (index outside the tensor: zero row) folded into the operand loads -- the
+// [B, K, D] patch feature tensors (2 x 33 MB) are never written, and tiles made of shadow rows only are stored as zeros.
+extern "C" int rdm_patch_scores(const float* ref_feats, int64_t ld_ref, int64_t n_ref, const int64_t* ref_idx,
+                                const float* src_feats, int64_t ld_src, int64_t n_src, const int64_t* src_idx, int64_t batch,
+                                int64_t side, int64_t d, const float* rowdiv, float* scores, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(ref_feats && src_feats && ref_idx && src_idx && scores, "rdm_patch_scores: null pointer");
+  RDM_REQUIRE(batch >= 0 && side > 0 && d > 0 && d % 4 == 0 && ld_ref % 4 == 0 && ld_src % 4 == 0 && n_ref > 0 && n_src > 0,
+              "rdm_patch_scores: bad sizes");
+  RDM_REQUIRE(((reinterpret_cast<uintptr_t>(ref_feats) | reinterpret_cast<uintptr_t>(src_feats)) & 15) == 0,
+              "rdm_patch_scores: features must be 16-byte aligned");
+  if (batch == 0) return RDM_OK;
+  GemmArgs g;
+  g.A = ref_feats; g.B = src_feats; g.C = scores; g.bias = nullptr; g.rowdiv = rowdiv;
+  g.M = static_cast<int>(side); g.N = static_cast<int>(side); g.K = static_cast<int>(d);
+  g.lda = static_cast<int>(ld_ref); g.ldb = static_cast<int>(ld_src); g.ldc = static_cast<int>(side);
+  g.sa = g.sb = 0; g.sc = side * side;
+  g.act = 0; g.splits = 1; g.part = nullptr; g.stats = nullptr;
+  g.A2 = nullptr; g.aidx = ref_idx; g.lda2 = g.ldi = g.c1 = 0; g.n_coarse = static_cast<int>(n_ref);
+  g.bidx = src_idx; g.n_b = static_cast<int>(n_src);
+  return gemm_dispatch(g, static_cast<int>(batch), true, nullptr, 0, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // Decoder stage (experiments/backbone.py:118-151): y = act(GroupNorm([nearest_upsample(coarse) | skip] W + b)), or the plain

@@ -542,11 +542,11 @@ class RDMNet(torch.nn.Module):
         r_pts = ops.gather_rows(pts_f[:n_f], r_idx.view(-1)).view(B, k_pts, 3)
         s_pts = ops.gather_rows(pts_f[n_f:], s_idx.view(-1)).view(B, k_pts, 3)
         c_f = cfg.backbone.output_dim
-        r_pf = ops.gather_rows(feats_f[:n_f], r_idx.view(-1), out=torch.empty((B * k_pts, c_f), dtype=torch.float32, device=dev))
-        s_pf = ops.gather_rows(feats_f[n_f:], s_idx.view(-1), out=torch.empty((B * k_pts, c_f), dtype=torch.float32, device=dev))
         out.update(ref_node_corr_knn_points=r_pts, src_node_corr_knn_points=s_pts,
                    ref_node_corr_knn_masks=r_pm.bool(), src_node_corr_knn_masks=s_pm.bool())
-        patch_scores = ops.gemm_batched(r_pf.view(B, k_pts, c_f), s_pf.view(B, k_pts, c_f), c_f, rowdiv=self._sqrt_c(c_f, k_pts))
+        # index_select of the patch features + einsum / sqrt(c) (model_infer.py:291-311) as one call: the gathers happen in the
+        # GEMM's operand loads
+        patch_scores = ops.patch_scores(feats_f[:n_f], r_idx, feats_f[n_f:], s_idx, rowdiv=self._sqrt_c(c_f, k_pts))
         taps['patch_scores'] = patch_scores
         ms = ops.sinkhorn(patch_scores, r_pm, s_pm, W['optimal_transport.alpha'], cfg.model.num_sinkhorn_iterations)
         out['matching_scores'] = ms

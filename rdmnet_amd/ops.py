@@ -79,6 +79,18 @@ def gemm_batched(a, b, k, *, trans_b=True, out=None, rowdiv=None):
     return out
 
 
+def patch_scores(ref_feats, ref_idx, src_feats, src_idx, rowdiv=None):
+    """scores[b, i, j] = <ref_feats[ref_idx[b, i]], src_feats[src_idx[b, j]]> / rowdiv[i] (model_infer.py:291-311); an index
+    outside the tensor selects a zero row.  ref_idx / src_idx: [B, k] int64 -> [B, k, k]."""
+    L = _lib.lib()
+    B, k = ref_idx.shape
+    out = torch.empty((B, k, k), dtype=torch.float32, device=ref_feats.device)
+    _lib.check(L.rdm_patch_scores(ref_feats.data_ptr(), _ld(ref_feats), ref_feats.shape[0], ref_idx.data_ptr(), src_feats.data_ptr(),
+                                  _ld(src_feats), src_feats.shape[0], src_idx.data_ptr(), B, k, ref_feats.shape[1], _lib.ptr(rowdiv),
+                                  out.data_ptr(), _lib.stream_ptr()), 'rdm_patch_scores')
+    return out
+
+
 def row_positive(x):
     L = _lib.lib()
     out = torch.empty((max(x.shape[0], 1),), dtype=torch.uint8, device=x.device)

@@ -50,6 +50,34 @@ def test_gemm_batched_patch_scores(ops):
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize('B,k,n_r,n_s', [(256, 128, 8000, 7500), (3, 128, 50, 40), (17, 64, 300, 300)])
+def test_patch_scores_gathers_inside_the_gemm(ops, B, k, n_r, n_s):
+    """rdm_patch_scores (model_infer.py:291-311: padded index_select of the patch features + einsum / sqrt(d)) against the
+    separate launches (gather_rows + batched GEMM: same tile, same summation order -> same bits) and torch fp64 (1e-5 of the
+    range).  Patches hold their real points first and shadow indices behind (point_to_node_partition), some none at all."""
+    g = torch.Generator().manual_seed(B + k)
+    d = 256
+    rf, sf = torch.randn(n_r, d, generator=g), torch.randn(n_s, d, generator=g)
+
+    def indices(n):
+        idx = torch.randint(0, n, (B, k), generator=g)
+        valid = torch.randint(0, k + 1, (B,), generator=g)
+        valid[0] = 0
+        valid[-1] = k
+        return torch.where(torch.arange(k)[None] < valid[:, None], idx, torch.full_like(idx, n))
+    ri, si = indices(n_r), indices(n_s)
+    div = torch.full((k,), float(np.sqrt(d)))
+    got = ops.patch_scores(padded(rf), ri.cuda(), padded(sf), si.cuda(), rowdiv=div.cuda())
+    a = ops.gather_rows(padded(rf), ri.view(-1).cuda(), out=torch.empty((B * k, d), device='cuda')).view(B, k, d)
+    b = ops.gather_rows(padded(sf), si.view(-1).cuda(), out=torch.empty((B * k, d), device='cuda')).view(B, k, d)
+    sep = ops.gemm_batched(a, b, d, rowdiv=div.cuda())
+    assert torch.equal(got, sep)
+    rp, sp = torch.cat([rf, torch.zeros(1, d)]).double(), torch.cat([sf, torch.zeros(1, d)]).double()
+    want = torch.einsum('bnd,bmd->bnm', rp[ri], sp[si]) / np.sqrt(d)
+    assert (got.cpu().double() - want).abs().max() <= 1e-5 * want.abs().max()
+    assert torch.count_nonzero(got[0]) == 0
+
+
 @pytest.mark.parametrize('c,h,m,ns', [(1, 65, 500, 700), (32, 65, 400, 900), (64, 63, 300, 500), (128, 69, 200, 300),
                                       (256, 70, 150, 200), (512, 81, 90, 100), (32, 3, 50, 60)])
 def test_kpconv_gather_matches_reference_formula(ops, c, h, m, ns):
