@@ -291,8 +291,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     if (pool_src) {
       *pool_out = e->mat(q.n, pool_src->cols);
       ENG_ALLOC(pool_out->p);
-      ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
-                               t.flags, pool_out->p, pool_out->ld, r.st));
+      ENG_CHECK(gather_max_ordered(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
+                                   t.flags, pool_out->p, pool_out->ld, order, r.st));
     }
     if (prof) {
       RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
@@ -328,8 +328,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   if (pool_src) {  // strided block: the shortcut max-pool over the same neighbour table (functional.py:54-67)
     *pool_out = e->mat(q.n, pool_src->cols);
     ENG_ALLOC(pool_out->p);
-    ENG_CHECK(rdm_gather_max(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
-                             t.flags, pool_out->p, pool_out->ld, r.st));
+    ENG_CHECK(gather_max_ordered(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
+                                   t.flags, pool_out->p, pool_out->ld, order, r.st));
   }
   if (prof) {
     RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));

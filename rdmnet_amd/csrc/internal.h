@@ -58,6 +58,11 @@ int radius_grid_build_multi(int n, const float* const* s_points, const int64_t* 
 int compact_indices_pair(const uint8_t* keep, int64_t n_ref, int64_t n, int32_t* order, int32_t* counts,
                          const int32_t* mirror_src, int32_t* mirror_dst, int mirror_words, void* stream);
 
+// rdm_gather_max visiting the queries in the order of `order_records` (the cell-sorted float4 records of the query level's
+// search grid, rdm_radius_grid_records; null = row order): same output, better L2 locality of the gathered rows.
+int gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m, int64_t h, int64_t ldi,
+                       const int32_t* width, float* y, int64_t ldy, const float* order_records, void* stream);
+
 size_t radius_redo_queue_bytes();
 void radius_redo_queue_reset(void* queue);
 int radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,

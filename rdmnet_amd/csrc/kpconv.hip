@@ -38,6 +38,7 @@ struct KpArgs {
   const int32_t* width;    // optional device int: effective row width (min(limit, max_count))
   const float4* order;     // optional processing order: query row = int bits of order[unit].w
   int units_per_block;     // work units (query x channel slice) per workgroup
+  int xcd_remap;           // 1: workgroups re-mapped so that each XCD owns a contiguous range of the (cell-ordered) units
   float* wf;               // [M, ldw] (>= 15*C)
   float* nn;               // [M]
   int M, Ns, H, C;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   const int qpb = a.units_per_block;
   const int nblk = gridDim.x;
   int blk = blockIdx.x;
-  if (qpb > kWaves && nblk >= 16) {  // bijective XCD remap (8 XCDs, round-robin dispatch)
+  if ((qpb > kWaves || a.xcd_remap) && nblk >= 16) {  // bijective XCD remap (8 XCDs, round-robin dispatch)
     const int q = nblk / 8, rr = nblk % 8, xcd = blk % 8, within = blk / 8;
     blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + within;
   }
@@ -287,6 +288,8 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
   a.ldw = static_cast<int>(ldw); a.sigma = sigma;
+  static const bool xcd_env = getenv("RDM_GATHER_XCD") != nullptr;  // developer knob (A/B)
+  a.xcd_remap = (xcd_env && order_records) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(64 * kWaves);
   // one work unit per wavefront.  Measured on MI355X: letting a workgroup own 16 or 64 consecutive

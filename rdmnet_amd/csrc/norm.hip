@@ -198,11 +198,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, i
 }
 
 // out[m, c] = max_h x[idx[m,h], c], pad rows count as zeros.  One wavefront per (row, 256 channels).
+// `order` (optional): cell-sorted query records of the level's search grid (query row = int bits of .w).  Queries are
+// then visited in cell order and workgroups re-mapped so that each XCD (workgroup b runs on XCD b % 8, own 4 MB L2) owns a
+// contiguous range of them -- a slab of space, whose support rows (one eighth of the tensor plus a halo) stay in that L2;
+// in row order (hash-map order, spatially random) every XCD streams the whole tensor from the fabric.
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
                                                          const int64_t* idx, int m_total, int h, int ldi,
-                                                         const int32_t* width, float* y, int ldy) {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= m_total) return;
+                                                         const int32_t* width, float* y, int ldy, const float4* order) {
+  int blk = blockIdx.x;
+  if (order && gridDim.x >= 16) {  // bijective: XCD x takes logical workgroups [start_x, start_x + count_x)
+    const int nblk = gridDim.x, q = nblk / 8, rr = nblk % 8, xcd = blk % 8, within = blk / 8;
+    blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + within;
+  }
+  const int unit = blk * 4 + (threadIdx.x >> 6);
+  if (unit >= m_total) return;
+  const int m = order ? __float_as_int(order[unit].w) : unit;
   const int lane = threadIdx.x & 63;
   const int c0 = blockIdx.y * 256 + lane * 4;
   if (c0 >= c) return;
@@ -389,19 +399,26 @@ extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
   return launch_status("layernorm_kernel");
 }
 
-extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx,
-                              int64_t m, int64_t h, int64_t ldi, const int32_t* width, float* y,
-                              int64_t ldy, void* stream) {
-  using namespace rdm;
+int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m, int64_t h,
+                            int64_t ldi, const int32_t* width, float* y, int64_t ldy, const float* order_records, void* stream) {
   RDM_REQUIRE(x && idx && y, "rdm_gather_max: null pointer");
   RDM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && h > 0, "rdm_gather_max: bad sizes");
   if (m == 0) return RDM_OK;
+  static const bool no_order = getenv("RDM_NO_POOL_ORDER") != nullptr;  // developer knob (A/B): row order
+  if (no_order) order_records = nullptr;
   RDM_DUP_LOOP("pool")
   hipLaunchKernelGGL(gather_max_kernel, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)),
                      dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n_s),
                      static_cast<int>(c), static_cast<int>(ldx), idx, static_cast<int>(m),
-                     static_cast<int>(h), static_cast<int>(ldi), width, y, static_cast<int>(ldy));
+                     static_cast<int>(h), static_cast<int>(ldi), width, y, static_cast<int>(ldy),
+                     reinterpret_cast<const float4*>(order_records));
   return launch_status("gather_max_kernel");
+}
+
+extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx,
+                              int64_t m, int64_t h, int64_t ldi, const int32_t* width, float* y,
+                              int64_t ldy, void* stream) {
+  return rdm::gather_max_ordered(x, n_s, c, ldx, idx, m, h, ldi, width, y, ldy, nullptr, stream);
 }
 
 // The same with 16-byte accesses (c1, c2 and every row stride multiples of 4, 16-byte aligned bases): one wavefront per row.
