@@ -50,6 +50,7 @@ struct GemmArgs {
   // whose rows or columns are all shadow rows are written as zeros without touching the features
   const int64_t* bidx;
   int n_b;
+  int xcd_tiles;  // 1: output tiles re-mapped so that an XCD (workgroup id % 8) owns whole row tiles with all their column tiles
 #ifdef RDM_GEMM_TIMING
   unsigned long long* clk;  // tools/gemm_phase_lab.hip: shader-clock stamps of workgroup (0,0,0), thread 0
 #endif
@@ -93,7 +94,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_x = blockIdx.x, tile_y = blockIdx.y;
+  if (g.xcd_tiles) {  // (workgroups are dispatched x-fastest, round-robin over the 8 XCDs)
+    const int nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nblk / 8, rr = nblk % 8, xcd = lin % 8, within = lin / 8;
+    const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + within;
+    tile_x = logical % gridDim.x;
+    tile_y = logical / gridDim.x;
+  }
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
   GEMM_STAMP(0);
   const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
   const float* A = g.A + batch * g.sa;
@@ -387,8 +396,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         a += stat_red[w * BN + cl][0][0];
         b += stat_red[w * BN + cl][0][1];
       }
-      g.stats[(static_cast<long long>(blockIdx.y) * 2 + 0) * g.N + col] = a;
-      g.stats[(static_cast<long long>(blockIdx.y) * 2 + 1) * g.N + col] = b;
+      g.stats[(static_cast<long long>(tile_y) * 2 + 0) * g.N + col] = a;
+      g.stats[(static_cast<long long>(tile_y) * 2 + 1) * g.N + col] = b;
     }
   }
   GEMM_STAMP(3);
@@ -900,6 +909,8 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   static const int big_tile = [] { const char* v = getenv("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
   if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && best_s == 1 && force_splits == 0 && batches == 1)
     exp_tile = big_tile;
+  static const bool xcd_env = getenv("RDM_GEMM_XCD") != nullptr;  // developer knob (A/B)
+  g.xcd_tiles = (xcd_env && ceil_div<long long>(n, 64) > 1 && ceil_div<long long>(m, 64) * ceil_div<long long>(n, 64) >= 64) ? 1 : 0;
   if (g.aidx) {  // the concatenating / gathering operands exist for the 64x64x32 tile only
     tile = T64;
     exp_tile = 0;

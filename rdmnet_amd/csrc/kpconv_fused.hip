@@ -90,8 +90,12 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
       if (m >= a.M) break;
       const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
       int positives = 0;
-      for (int h = lane; h < H; h += 64) {
-        const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+      int Hq = 0;  // slots up to the last real neighbour (kpconv.hip: shadow slots contribute exact zeros)
+      for (int hb = 0; hb < H; hb += 64) {
+        const int h = hb + lane;
+        const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+        const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+        if (rm) Hq = hb + 64 - __builtin_clzll(rm);
         float4 v;
         if (id >= 0 && id < a.Ns) {
           v.x = a.s_points[3 * id] - qx;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
           v.z = 1.0e6f - qz;
           v.w = __int_as_float(-1);
         }
-        nb[h] = v;
+        if (h < H) nb[h] = v;
       }
       positives = wave_sum_i(positives);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
       f32x4 acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int h0 = 0; h0 < H; h0 += 4 * PF) {
+      for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {
         float w[PF];
         float f[PF][VEC];
 #pragma unroll
@@ -251,8 +255,12 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
     if (m >= a.M) break;
     const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
     int positives = 0;
-    for (int h = lane; h < H; h += 64) {
-      const int64_t id = a.idx[static_cast<int64_t>(m) * a.ldi + h];
+    int Hq = 0;  // slots up to the last real neighbour
+    for (int hb = 0; hb < H; hb += 64) {
+      const int h = hb + lane;
+      const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+      const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+      if (rm) Hq = hb + 64 - __builtin_clzll(rm);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (id >= 0 && id < a.Ns) {
         v.x = a.s_points[3 * id] - qx;
@@ -261,13 +269,13 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
         v.w = a.s_feats[id * a.ldf];
         positives += a.s_pos[id];
       }
-      nb[h] = v;
+      if (h < H) nb[h] = v;
     }
     positives = wave_sum_i(positives);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
-    for (int h = g; h < H; h += 4) {
+    for (int h = g; h < Hq; h += 4) {
       const float4 v = nb[h];
       const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
       const float d2 = (dx * dx + dy * dy) + dz * dz;
