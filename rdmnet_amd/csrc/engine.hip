@@ -971,6 +971,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   ENG_ALLOC(all_len);
   float voxel = c.init_voxel_size;
   int64_t cap = n0;
+  // levels whose subsampling runs as the multi-launch pipeline (RDM_GS_MULTI_LEVELS, developer knob; default: the first)
+  static const int gs_multi_levels = [] { const char* v = getenv("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
   for (int i = 1; i < 5; ++i) {
     voxel *= 2.f;  // data.py:23-28
     lv[i].pts = e->alloc<float>(3 * cap);
@@ -980,7 +982,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     // capacity `cap` with a few thousand real points: the single-workgroup kernel
     RDM_DUP_LOOP("gs")
     ENG_CHECK(grid_subsample_mode(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
-                                  r.st, i == 1 ? 0 : 1));
+                                  r.st, i <= gs_multi_levels ? 2 : 1));
     // capacity of the next level is unknown on the host until the read-back; run it at full capacity
   }
   int64_t host_len[8];

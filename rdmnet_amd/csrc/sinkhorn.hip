@@ -32,12 +32,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // [HALF*(t&1), HALF*(t&1) + HALF) with HALF = 2 * PAIRS, as float2 pairs in registers.  Three size classes (68, 100,
 // 132) are instantiated: a patch with 60 valid points per side does half the work of a full one, and most patches
 // are not full (the register arrays need static indexing, so the trip count cannot simply be a run-time bound).
-template <int PAIRS>
+// T threads share a line (row / column): T = 2 for the three large classes; small blocks -- most patches hold a few dozen
+// real points -- use T = 4 (sides up to 64) and T = 8 (up to 32), so that all 256 threads work on the 64 / 32 lines there are
+// instead of three quarters of them evaluating lines outside the block.
+template <int PAIRS, int T = 2>
 __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr, int nc, float norm, int iters, float* u, float* v,
                                                  const int* rows, const int* cols, int m, int n, float* O) {
   constexpr int HALF = 2 * PAIRS;
+  static_assert(T == 2 || T == 4 || T == 8, "threads per line");
   const int tid = threadIdx.x, R = nr + 1, C = nc + 1;
-  const int own = tid >> 1, half = tid & 1, base = half * HALF;
+  const int own = tid / T, half = tid % T, base = half * HALF;
   const float log_mu = own < nr ? norm : logf(static_cast<float>(nc)) + norm;
   const float log_nu = own < nc ? norm : logf(static_cast<float>(nr)) + norm;
   f32x2 zr[PAIRS], zc[PAIRS];  // -inf marks "outside the block": contributes exp(-inf) = 0
@@ -57,7 +61,8 @@ __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr
       t[i] = z[i] + p2[i];
       mx = fmaxf(mx, fmaxf(t[i].x, t[i].y));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+#pragma unroll
+    for (int o = 1; o < T; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     const f32x2 mx2 = {mx, mx}, l2e = {1.4426950408889634f, 1.4426950408889634f};
     f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
@@ -69,7 +74,8 @@ __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr
       sum2 += e;
     }
     float sum = sum2.x + sum2.y;
-    sum += __shfl_xor(sum, 1, 64);
+#pragma unroll
+    for (int o = 1; o < T; o <<= 1) sum += __shfl_xor(sum, o, 64);
     return log_m - (mx + logf(sum));
   };
 
@@ -183,7 +189,9 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   __syncthreads();
 
   const int side = R > C ? R : C;
-  if (side <= 68) sinkhorn_iterate<17>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
+  if (side <= 32) sinkhorn_iterate<2, 8>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
+  else if (side <= 64) sinkhorn_iterate<8, 4>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
+  else if (side <= 68) sinkhorn_iterate<17>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
   else if (side <= 100) sinkhorn_iterate<25>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
   else sinkhorn_iterate<33>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
 }

@@ -406,7 +406,8 @@ def test_point_to_node_pair_equals_two_calls(ops):
     assert int(st[0]) == 0
 
 
-@pytest.mark.parametrize('nr,nc', [(128, 128), (128, 40), (17, 128), (127, 128), (128, 1), (101, 100), (69, 68)])
+@pytest.mark.parametrize('nr,nc', [(128, 128), (128, 40), (17, 128), (127, 128), (128, 1), (101, 100), (69, 68),
+                                   (31, 31), (32, 31), (8, 20), (1, 1), (63, 63), (64, 33), (3, 60)])
 def test_sinkhorn_full_and_partial_patches_match_oracle(ops, nr, nc):
     """learnable_sinkhorn.py:13-66 on patches whose sides are FULL (128 valid points + dustbin = 129 lines, one more than the
     128 lines the kernel's thread pairs own) and at the size-class boundaries; scattered masks.  Dustbin row and column
