@@ -41,79 +41,98 @@ struct LgrBuffers {
 };
 
 // ------------------------------------------------------------------------------------------ extract
+// Only the block of REAL rows and columns (+ the dustbin line of each side) is staged: a masked line of the Sinkhorn output
+// holds fl(-1e12), i.e. exp() = 0 exactly, while a real row (column) of exp(scores) sums to 1, so its maximum is positive
+// and a masked entry never wins nor ties a top-1 -- the compacted search returns the indices of the full 129 x 129 one.  A
+// patch holds a few dozen real points of 128: 1-2 k exponentials per patch instead of 16.6 k.
 __global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_scores, int side,
                                                           const unsigned char* ref_mask,
                                                           const unsigned char* src_mask, LgrBuffers w) {
-  extern __shared__ float S[];  // [(side+1)][(side+1)] row-major, ld = side + 2 (odd for side = 128? 130 even)
+  extern __shared__ float S[];  // compacted [(nr+1)][(nc+1)], row stride ldc (odd)
+  __shared__ int rows[kSide + 1], cols[kSide + 1];  // original index of every compacted line, dustbin (= side) last
   __shared__ int rowarg[kSide + 1], colarg[kSide + 1];
   __shared__ unsigned char rowok[kSide + 1], colok[kSide + 1];
   __shared__ int rowcnt[kSide + 1];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int n1 = side + 1, ld = n1 | 1;
+  __shared__ int s_n[2];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n1 = side + 1;
   const float* L = log_scores + static_cast<int64_t>(b) * n1 * n1;
-  for (int t = tid; t < n1 * n1; t += 256) S[(t / n1) * ld + (t % n1)] = expf(L[t]);
-  __syncthreads();
-  if (tid < side) {  // top-1 of row tid over all columns (first maximum), must beat the dustbin column
-    const int i = tid;
-    float best = S[i * ld];
-    int arg = 0;
-    for (int j = 1; j < n1; ++j) {
-      const float v = S[i * ld + j];
-      if (v > best) {
-        best = v;
-        arg = j;
-      }
+  if (wave < 2) {  // wavefront 0: the real rows, wavefront 1: the real columns, ascending (ballot compaction)
+    const unsigned char* mk = (wave == 0 ? ref_mask : src_mask) + static_cast<int64_t>(b) * side;
+    int* list = wave == 0 ? rows : cols;
+    int cnt = 0;
+    for (int i0 = 0; i0 < side; i0 += 64) {
+      const int i = i0 + lane;
+      const bool on = i < side && mk[i] != 0;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(on);
+      if (on) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+      cnt += __popcll(bal);
     }
-    rowarg[i] = arg;
-    rowok[i] = (arg < side && best > S[i * ld + side]) ? 1 : 0;
-  } else if (tid >= 128 && tid < 128 + side) {  // top-1 of column over all rows, must beat the dustbin row
-    const int j = tid - 128;
-    float best = S[j];
-    int arg = 0;
-    for (int i = 1; i < n1; ++i) {
-      const float v = S[i * ld + j];
-      if (v > best) {
-        best = v;
-        arg = i;
-      }
+    if (lane == 0) {
+      list[cnt] = side;
+      s_n[wave] = cnt;
     }
-    colarg[j] = arg;
-    colok[j] = (arg < side && best > S[side * ld + j]) ? 1 : 0;
   }
   __syncthreads();
-  // masks staged in LDS: the two loops below test side^2 (row, column) pairs per patch
-  __shared__ unsigned char rm[kSide], cm[kSide];
-  if (tid < side) rm[tid] = ref_mask[static_cast<int64_t>(b) * side + tid];
-  else if (tid >= 128 && tid < 128 + side) cm[tid - 128] = src_mask[static_cast<int64_t>(b) * side + tid - 128];
+  const int nr = s_n[0], nc = s_n[1], R = nr + 1, C = nc + 1, ldc = C | 1;
+  for (int t = tid; t < R * C; t += 256) {
+    const int r = t / C, c = t % C;
+    S[r * ldc + c] = expf(L[static_cast<int64_t>(rows[r]) * n1 + cols[c]]);
+  }
   __syncthreads();
-  auto is_corr = [&](int i, int j) {
-    return rm[i] && cm[j] && ((rowok[i] && rowarg[i] == j) || (colok[j] && colarg[j] == i));
-  };
-  if (tid < side) {
-    int c = 0;
-    if (rm[tid])
-      for (int j = 0; j < side; ++j) c += is_corr(tid, j) ? 1 : 0;
-    rowcnt[tid] = c;
+  if (tid < nr) {  // top-1 of a real row over the real columns + dustbin (first maximum), must beat the dustbin column
+    const int r = tid;
+    float best = S[r * ldc];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = S[r * ldc + c];
+      if (v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    rowarg[r] = arg;  // compacted column (nc = dustbin)
+    rowok[r] = (arg < nc && best > S[r * ldc + nc]) ? 1 : 0;
+  } else if (tid >= 128 && tid < 128 + nc) {  // top-1 of a real column over the real rows + dustbin
+    const int c = tid - 128;
+    float best = S[c];
+    int arg = 0;
+    for (int r = 1; r < R; ++r) {
+      const float v = S[r * ldc + c];
+      if (v > best) {
+        best = v;
+        arg = r;
+      }
+    }
+    colarg[c] = arg;
+    colok[c] = (arg < nr && best > S[nr * ldc + c]) ? 1 : 0;
+  }
+  __syncthreads();
+  auto is_corr = [&](int r, int c) { return (rowok[r] && rowarg[r] == c) || (colok[c] && colarg[c] == r); };
+  if (tid < nr) {
+    int cn = 0;
+    for (int c = 0; c < nc; ++c) cn += is_corr(tid, c) ? 1 : 0;
+    rowcnt[tid] = cn;
   }
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
-    for (int i = 0; i < side; ++i) {
-      const int c = rowcnt[i];
-      rowcnt[i] = acc;
-      acc += c;
+    for (int r = 0; r < nr; ++r) {
+      const int cn = rowcnt[r];
+      rowcnt[r] = acc;
+      acc += cn;
     }
     w.patch_count[b] = acc;
   }
   __syncthreads();
-  if (tid < side) {
+  if (tid < nr) {  // row-major over the original indices (the order of torch.nonzero): the lists are ascending
     int pos = rowcnt[tid];
-    for (int j = 0; rm[tid] && j < side; ++j)
-      if (is_corr(tid, j)) {
+    for (int c = 0; c < nc; ++c)
+      if (is_corr(tid, c)) {
         const int64_t o = static_cast<int64_t>(b) * kPerPatch + pos++;
-        w.local_i[o] = tid;
-        w.local_j[o] = j;
-        w.local_s[o] = S[tid * ld + j];
+        w.local_i[o] = rows[tid];
+        w.local_j[o] = cols[c];
+        w.local_s[o] = S[tid * ldc + c];
       }
   }
 }
