@@ -134,12 +134,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, in
 
 // Same without the row flag, for wide matrices with few rows (coarse levels: 800 x 2048): one thread per
 // float4, grid over (rows, column quads) so that the launch has enough wavefronts to cover the latency.
+// `positive` (optional, needs c4 a power of two <= 64 so that a row lies inside one wavefront): the row-sum flag of
+// gn_apply_kernel with the SAME summation tree (column index bits from high to low: gn_apply_kernel's lane-strided partial
+// sums and xor-butterfly), so both kernels set the same flags bit for bit.
 __global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int n, int c4, int ldx, const float* scale,
                                                             const float* shift, const float* res, int ldr, int act,
-                                                            float* y, int ldy) {
+                                                            float* y, int ldy, unsigned char* positive) {
   const int64_t t = blockIdx.x * 256ll + threadIdx.x;
-  if (t >= static_cast<int64_t>(n) * c4) return;
-  const int row = static_cast<int>(t / c4), col = static_cast<int>(t % c4) * 4;
+  const bool live = t < static_cast<int64_t>(n) * c4;
+  if (!live && !positive) return;
+  float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+  const int row = live ? static_cast<int>(t / c4) : 0, col = live ? static_cast<int>(t % c4) * 4 : 0;
+  if (live) {
   const float4 xv = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(row) * ldx + col);
   const float4 sc = *reinterpret_cast<const float4*>(scale + col), sh = *reinterpret_cast<const float4*>(shift + col);
   float v[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
@@ -153,6 +159,16 @@ __global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int 
     else if (act == 1) v[k] = v[k] > 0.f ? v[k] : 0.f;
   }
   *reinterpret_cast<float4*>(y + static_cast<int64_t>(row) * ldy + col) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rs4[k] = v[k];
+  }
+  if (positive) {  // (every lane of the wavefront takes part in the exchanges; rows never straddle wavefronts)
+    for (int o = c4 >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs4[k] += __shfl_xor(rs4[k], o, 64);
+    const float rs = (rs4[0] + rs4[2]) + (rs4[1] + rs4[3]);
+    if (live && col == 0) positive[row] = rs > 0.f ? 1 : 0;
+  }
 }
 
 // y = act(LayerNorm(x (+ res)) * gamma + beta); one wavefront per row, c <= 2048
@@ -359,11 +375,17 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+  // 16-byte accesses whenever the layout allows; with the positive-row flag only where a row lies inside one wavefront AND
+  // gn_apply_kernel's summation tree can be reproduced (up to 128 columns: at most two values per lane there)
+  static const bool narrow_rows = getenv("RDM_GN_APPLY_ROWS") != nullptr;  // developer knob (A/B): one wavefront per row below 256 columns
+  const int64_t c4 = c / 4;
+  const bool flag_ok = c4 == 8 || c4 == 16 || c4 == 32;
+  const bool wide = vec_ok && (narrow_rows ? (!positive && c >= 256) : (!positive || flag_ok));
   RDM_DUP_LOOP("gnapply")
-  if (!positive && vec_ok && c >= 256)
+  if (wide)
     hipLaunchKernelGGL(gn_apply_wide_kernel, dim3(ceil_div<int64_t>(n * (c / 4), 256)), dim3(256), 0, st, x, static_cast<int>(n),
                        static_cast<int>(c / 4), static_cast<int>(ldx), ss, ss + c, residual, static_cast<int>(ldr), act, y,
-                       static_cast<int>(ldy));
+                       static_cast<int>(ldy), positive);
   else
     hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
                        static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
