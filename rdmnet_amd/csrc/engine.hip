@@ -1400,10 +1400,20 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(CopyBatch b) {
   const int base = (blockIdx.x - b.first_block[it]) * 1024;
   const uint32_t* s = b.src[it];
   uint32_t* d = b.dst[it];
+  const int n = b.words[it];
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {  // workgroup-uniform: 16 bytes per thread
+    const int i = base + 4 * threadIdx.x;
+    if (i + 3 < n) {
+      *reinterpret_cast<uint4*>(d + i) = *reinterpret_cast<const uint4*>(s + i);
+    } else {
+      for (int k = i; k < n && k < i + 4; ++k) d[k] = s[k];
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int i = base + u * 256 + threadIdx.x;
-    if (i < b.words[it]) d[i] = s[i];
+    if (i < n) d[i] = s[i];
   }
 }
 }  // namespace
