@@ -54,20 +54,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, 
 
 // One block per 64 columns (whole groups: C/groups divides 64): 16 lanes per column add the row-block
 // partials in a fixed order, then scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma.
+// COLS = 64: the layout above.  COLS = 16 (64 lanes per column) for the fine levels, whose GEMMs leave hundreds of partial
+// rows for 32-128 columns: four times the workgroups and a quarter of the dependent load rounds per lane.  The per-column
+// sums differ between the two only in the (fixed) order of fp64 additions.
+template <int COLS>
 __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
                                                             int c, int groups, const float* gamma,
                                                             const float* beta, float eps, float* scale,
                                                             float* shift) {
-  __shared__ double sh[2][16][64];
-  const int ci = threadIdx.x & 63, lane = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + ci;
+  constexpr int LANES = 1024 / COLS;
+  __shared__ double sh[2][LANES][COLS];
+  const int ci = threadIdx.x % COLS, lane = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + ci;
   double s = 0.0, ss = 0.0;
   if (col < c)
-    for (int b0 = lane; b0 < nblk; b0 += 64) {  // four partial rows in flight, added in ascending order
+    for (int b0 = lane; b0 < nblk; b0 += 4 * LANES) {  // four partial rows in flight, added in ascending order
       double p0[4], p1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int b = b0 + 16 * u;
+        const int b = b0 + LANES * u;
         p0[u] = b < nblk ? partial[(static_cast<int64_t>(b) * 2 + 0) * c + col] : 0.0;
         p1[u] = b < nblk ? partial[(static_cast<int64_t>(b) * 2 + 1) * c + col] : 0.0;
       }
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial
   __syncthreads();
   if (lane == 0) {
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < LANES; ++k) {
       a += sh[0][k][ci];
       b += sh[1][k][ci];
     }
@@ -368,8 +373,14 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     nblk = own_blk;
   }
   {
+    static const bool fin64 = getenv("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
+    const bool narrow = !fin64 && nblk >= 128 && c / groups <= 16 && 16 % (c / groups) == 0;
     RDM_DUP_LOOP("gnfin")
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
+    if (narrow)
+      hipLaunchKernelGGL(gn_finalize_kernel<16>, dim3(ceil_div<int64_t>(c, 16)), dim3(1024), 0, st, use, nblk,
+                         static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
+    else
+    hipLaunchKernelGGL(gn_finalize_kernel<64>, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
                        static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
   }
   const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
