@@ -3,7 +3,7 @@
 // rdm_engine_run = collate (geotransformer/utils/data.py:13-77) + RDMNet.forward
 // (experiments/model_infer.py:109-354) expressed as a sequence of this library's own C-ABI kernels
 // on one HIP stream, with activations bump-allocated from an engine-owned device arena.  It exists
-// because the path is ~700 short launches per pair: issued from Python they cost ~15 us each, issued
+// because the path is hundreds of short launches per pair (~700 at first, ~340 now): issued from Python they cost ~15 us each, issued
 // from here ~2 us.  The op sequence is identical to rdmnet_amd/model.py (the per-op mirror used by
 // the stage tests), so both produce bit-identical results.
 //
