@@ -244,6 +244,23 @@ int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, i
                        const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
                        const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
                        const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out, void* stream);
+/* rdm_attention_tail_proj: rdm_attention_tail, whose workgroups also compute up to two Linear layers of the rows they have just
+ * produced -- the projections the FOLLOWING attention layers need (cross layer: q of all rows and k|v of the src rows; the
+ * k|v of the updated ref rows; the next self layer's q|k|v; the transformer's output projection), i.e. the rdm_gemm launches
+ * that would otherwise follow the tail:  dst[row, :ncols] = out[row, :] b + bias  for rows [row_lo, row_hi) of the call
+ * (b [128, ld_b] as rdm_gemm's B operand).  Same arithmetic as that rdm_gemm launch, hence the same bits. */
+typedef struct rdm_tail_projection {
+  const float* b;      /* [128, ldb] */
+  const float* bias;   /* [ncols] or NULL */
+  float* dst;          /* [m, ldd] (row 0 = the call's first row) */
+  int64_t ncols, ldb, ldd;
+  int64_t row_lo, row_hi;
+} rdm_tail_projection;
+int rdm_attention_tail_proj(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                            const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
+                            const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
+                            const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out,
+                            const rdm_tail_projection* proj, int n_proj, void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
 /* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the

@@ -73,6 +73,9 @@ SIGNATURES = {
                                       c_f32, c_int, c_void, c_i64, c_void]),
     'rdm_attention_tail': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void, c_i64,
                                    c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void]),
+    'rdm_attention_tail_proj': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void,
+                                        c_i64, c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void, c_int,
+                                        c_void]),
     'rdm_gather_max': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_i64,
                                c_void]),
     'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,
@@ -123,6 +126,12 @@ SIGNATURES = {
     'rdm_copy_device': (c_int, [c_void, c_void, c_size, c_void]),
 }
 
+
+
+class TailProjection(ctypes.Structure):
+    """rdm_tail_projection (include/rdmnet_hip.h)"""
+    _fields_ = [('b', c_void), ('bias', c_void), ('dst', c_void), ('ncols', c_i64), ('ldb', c_i64), ('ldd', c_i64),
+                ('row_lo', c_i64), ('row_hi', c_i64)]
 
 
 class LayerProjection(ctypes.Structure):

@@ -498,6 +498,96 @@ int thdroformer_fused(Run& r, const std::string& name, const Mat& pts4, const Ma
   return RDM_OK;
 }
 
+// The per-op sequence with the projections of a layer's NEW rows computed by the tail's own launch (rdm_attention_tail_proj:
+// same bits as the rdm_gemm launches they replace): per (self, cross) layer pair 7 launches instead of 10 -- rotary embedding,
+// self attention, tail [+ the cross layer's q and k|v]; attention ref <- src, tail [+ k|v of the updated ref rows + the next
+// self layer's q|k|v of those rows]; attention src <- ref, tail [+ the next q|k|v of the src rows] (the last layer: the output
+// projection instead).  Returns 1 when the configuration does not fit (width 128, 256-wide FFN).
+int thdroformer_tail_proj(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
+  rdm_engine* e = r.e;
+  const int heads = e->cfg.num_heads;
+  const int64_t N = x.rows, n1 = N - n0;
+  auto find = [&](const std::string& key) -> const Linear* {
+    auto it = e->lin.find(key);
+    return it == e->lin.end() ? nullptr : &it->second;
+  };
+  if (num_layers < 1 || n0 <= 0 || n1 <= 0 || N > 1536) return 1;  // (rdm_gemm takes its 32x32 K-split kernel up to 1536 rows)
+  const Linear* op = find(name + ".out_proj");
+  if (!op || op->kpad != 128 || out.ld < op->out || N * op->out > 1536 * 512) return 1;
+  for (int i = 0; i < 2 * num_layers; ++i) {
+    const std::string p = name + ".transformer.layers." + std::to_string(i);
+    const Linear *lo = find(p + ".attention.linear"), *l1 = find(p + ".output.expand"), *l2 = find(p + ".output.squeeze");
+    if (!lo || !l1 || !l2 || !lo->wt || !l1->wt || !l2->wt || lo->out != 128 || lo->kpad != 128 || l1->out != 256 ||
+        l1->kpad != 128 || l2->out != 128 || l2->kpad != 256)
+      return 1;
+    const Linear *a = find(p + (i % 2 == 0 ? ".qkv" : ".q")), *b = i % 2 == 0 ? a : find(p + ".kv");
+    if (!a || !b || a->kpad != 128 || b->kpad != 128 || a->out != (i % 2 == 0 ? 384 : 128) || b->out != (i % 2 == 0 ? 384 : 256))
+      return 1;
+  }
+  Mat emb, f;
+  ENG_CHECK(linear(r, name + ".embedding.proj", pts4, emb));
+  ENG_CHECK(linear(r, name + ".in_proj", x, f));
+  if (f.cols != 128) return 1;
+  const int64_t d = 128;
+  const int hd = static_cast<int>(d / heads);
+  const auto attend = e->cfg.attention_bf16 ? rdm_attention_bf16 : rdm_attention;
+  Mat qkv, q2 = e->mat(N, d), kv = e->mat(N, 2 * d);
+  ENG_ALLOC(q2.p); ENG_ALLOC(kv.p);
+  ENG_CHECK(linear(r, name + ".transformer.layers.0.qkv", f, qkv));
+  auto tail = [&](const std::string& p, const Mat& hid, const Mat& xin, Mat fout, const rdm_tail_projection* pr, int npr) -> int {
+    const Linear &Lo = *find(p + ".attention.linear"), &L1 = *find(p + ".output.expand"), &L2 = *find(p + ".output.squeeze");
+    return rdm_attention_tail_proj(hid.p, hid.ld, xin.p, xin.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias,
+                                   vecp(r, p + ".attention.norm.weight"), vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias,
+                                   L2.wt, L2.kpad, L2.bias, vecp(r, p + ".output.norm.weight"), vecp(r, p + ".output.norm.bias"), 1e-5f,
+                                   fout.p, fout.ld, pr, npr, r.st);
+  };
+  auto proj = [&](const Linear& L, float* dst, int64_t ldd, int64_t lo, int64_t hi) {
+    rdm_tail_projection P;
+    P.b = L.b; P.bias = L.bias; P.dst = dst; P.ncols = L.out; P.ldb = L.ldb; P.ldd = ldd; P.row_lo = lo; P.row_hi = hi;
+    return P;
+  };
+  for (int i = 0; i < 2 * num_layers; ++i) {
+    const std::string p = name + ".transformer.layers." + std::to_string(i);
+    const std::string pn = name + ".transformer.layers." + std::to_string(i + 1);
+    const bool last = i + 1 == 2 * num_layers;
+    Mat fnew = e->mat(N, d), hid = e->mat(N, d);
+    ENG_ALLOC(fnew.p); ENG_ALLOC(hid.p);
+    if (i % 2 == 0) {
+      Mat q = qkv.cols_from(0, d), k = qkv.cols_from(d, d), v = qkv.cols_from(2 * d, d);
+      ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb.p, emb.ld, N, d, r.st));
+      ENG_CHECK(rdm_attention_self_pair(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n1, heads, hd,
+                                        e->cfg.attention_bf16 ? 1 : 0, r.st));
+      // the cross layer's q (all rows) and k|v of the src rows (its first step attends ref <- src)
+      const rdm_tail_projection pr[2] = {proj(*find(pn + ".q"), q2.p, q2.ld, 0, N), proj(*find(pn + ".kv"), kv.p, kv.ld, n0, N)};
+      ENG_CHECK(tail(p, hid, f, fnew, pr, 2));
+    } else {
+      Mat qkv_next;
+      if (!last) {
+        qkv_next = e->mat(N, 3 * d);
+        ENG_ALLOC(qkv_next.p);
+      }
+      auto next_inputs = [&](int64_t row0, int64_t rows) {  // for the rows of one cloud (the call's rows start at row0)
+        return last ? proj(*op, out.p + row0 * out.ld, out.ld, 0, rows)
+                    : proj(*find(pn + ".qkv"), qkv_next.p + row0 * qkv_next.ld, qkv_next.ld, 0, rows);
+      };
+      // ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
+      ENG_CHECK(attend(q2.p, q2.ld, kv.p + n0 * kv.ld, kv.ld, kv.p + n0 * kv.ld + d, kv.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
+      {
+        const rdm_tail_projection pr[2] = {proj(*find(p + ".kv"), kv.p, kv.ld, 0, n0), next_inputs(0, n0)};
+        ENG_CHECK(tail(p, hid.rows_from(0, n0), f.rows_from(0, n0), fnew.rows_from(0, n0), pr, 2));
+      }
+      ENG_CHECK(attend(q2.p + n0 * q2.ld, q2.ld, kv.p, kv.ld, kv.p + d, kv.ld, hid.p + n0 * hid.ld, hid.ld, n1, n0, heads, hd, r.st));
+      {
+        const rdm_tail_projection pr[1] = {next_inputs(n0, n1)};
+        ENG_CHECK(tail(p, hid.rows_from(n0, n1), f.rows_from(n0, n1), fnew.rows_from(n0, n1), pr, 1));
+      }
+      qkv = qkv_next;
+    }
+    f = fnew;
+  }
+  return RDM_OK;
+}
+
 int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
   rdm_engine* e = r.e;
   // RDM_FUSED_LAYER=1: one launch per attention application (86 -> 28 launches per pair).  Measured: +1.3 %
@@ -510,6 +600,17 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
     const int rc = thdroformer_fused(r, name, pts4, x, n0, num_layers, out);
     if (rc != 1) return rc;
     e->arena_off = mark;  // configuration outside the fused kernel's shapes
+  }
+  // RDM_TAIL_PROJ=1: the projections of a layer's new rows inside the tail's launch (7 launches per layer pair instead of
+  // 10, same bits).  Measured slower -- 485 against 494 pairs/s at four in flight, 4.39 against 4.12 ms with one: the 53
+  // workgroups of a tail then stream up to 320 KB more weights through their CU's L2 port each and run half-empty 32-row
+  // tiles, where the separate rdm_gemm spreads the same product over ~300 workgroups -- hence opt-in.
+  static const bool tail_proj = [] { const char* v = getenv("RDM_TAIL_PROJ"); return v && v[0] == '1'; }();
+  if (tail_proj) {
+    const size_t mark = e->arena_off;
+    const int rc = thdroformer_tail_proj(r, name, pts4, x, n0, num_layers, out);
+    if (rc != 1) return rc;
+    e->arena_off = mark;
   }
   const int heads = e->cfg.num_heads;
   const int64_t N = x.rows, n1 = N - n0;

@@ -566,11 +566,23 @@ __global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
 // L2 latency for the kernel instead of one per product; what bounds the kernel is the ~20 B/clk a CU gets from L2 for
 // its 320 KB of weights, so the barriers order LDS only (lds_barrier) and the later products' weights keep streaming
 // under the earlier products -- and y, z travel through LDS.  Replaces three launches.
+// A Linear of the NEW rows computed by the tail's workgroup itself (rdm_attention_tail_proj): dst[row, :] = out[row, :] B + bias
+// for the rows [row_lo, row_hi) of the call, B [128, ncols] as rdm_gemm's B operand.  The arithmetic is gemm_small_kernel's --
+// 32 x 32 x 2 MFMA tiles, K split over four wavefronts, the four partial tiles added in the same order -- so the result has
+// the bits the separate rdm_gemm launch produces (the 16 rows of a workgroup fill half of a 32-row tile).
+struct TailProj {
+  const float* b;
+  const float* bias;
+  float* dst;
+  int ncols, ldb, ldd, row_lo, row_hi;
+};
 struct TailArgs {
   const float *hid, *x, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
   float* out;
   int M, ldh, ldx, ldo, ldwo, ldw1, ldw2;
   float eps;
+  int nproj;
+  TailProj proj[2];
 #ifdef RDM_TAIL_TIMING
   unsigned long long* clk;  // tools/tail_lab.hip: shader-clock stamps of workgroup 0, wavefront 0
 #endif
@@ -580,6 +592,7 @@ struct TailArgs {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
+template <bool PROJ>
 __global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
   __shared__ __attribute__((aligned(16))) float ys[16][132];
   __shared__ __attribute__((aligned(16))) float zs[16][260];
@@ -721,6 +734,59 @@ __global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + 4 * kb + r;
     if (row < a.M) a.out[static_cast<long long>(row) * a.ldo + c] = o[r];
+  }
+  if constexpr (PROJ) {
+    // ---- projections of the new rows for the layers that follow (gemm_small_body's arithmetic, see TailProj)
+    __shared__ float pred[2][4][32][33];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ys[4 * kb + r][c] = o[r];  // (every wavefront is past its reads of ys: barriers of the FFN)
+    lds_barrier();
+    const int li = lane & 31, lk = lane >> 5;
+    const int slot = w >> 2, kbeg = (w & 3) * 32 + lk * 16;  // two 32-column tiles per round, K = 128 split four ways
+    float av[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(&ys[li & 15][kbeg + 4 * q]);
+      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+    }
+    for (int pi = 0; pi < a.nproj; ++pi) {
+      const TailProj P = a.proj[pi];
+      if (m0 >= P.row_hi || m0 + 16 <= P.row_lo) continue;  // workgroup-uniform
+      const int ntiles = (P.ncols + 31) / 32;
+      for (int t0 = 0; t0 < ntiles; t0 += 2) {
+        const int tile = t0 + slot;
+        if (tile < ntiles) {  // wavefront-uniform
+          const int col = tile * 32 + li;
+          const bool col_ok = col < P.ldb;
+          float bv[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) bv[t] = col_ok ? P.b[static_cast<long long>(kbeg + t) * P.ldb + col] : 0.f;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pred[slot][w & 3][(r & 3) + 8 * (r >> 2) + 4 * lk][li] = acc[r];
+        }
+        __syncthreads();
+        {
+          const int sl = tid >> 8, e0 = tid & 255;
+          const int tl = t0 + sl;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {  // rows 0..15 of the 32-row tile are this workgroup's
+            const int e = e0 + 256 * q, rr = e >> 5, cc = e & 31;
+            const int row = m0 + rr, ocol = tl * 32 + cc;
+            if (tl < ntiles && row < a.M && row >= P.row_lo && row < P.row_hi && ocol < P.ncols) {
+              float v = ((pred[sl][0][rr][cc] + pred[sl][1][rr][cc]) + pred[sl][2][rr][cc]) + pred[sl][3][rr][cc];
+              if (P.bias) v += P.bias[ocol];
+              P.dst[static_cast<long long>(row) * P.ldd + ocol] = v;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
 }
 
@@ -1195,11 +1261,11 @@ extern "C" int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w
 
 // The tail of an attention layer (output projection + residual LayerNorm + FFN + residual LayerNorm) in one launch;
 // see attention_tail128_kernel.  Weights in checkpoint layout (k contiguous): wo [128,128], w1 [256,128], w2 [128,256].
-extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
-                                  const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
-                                  const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
-                                  const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
-                                  int64_t ld_out, void* stream) {
+extern "C" int rdm_attention_tail_proj(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                                       const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
+                                       const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
+                                       const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
+                                       int64_t ld_out, const rdm_tail_projection* proj, int n_proj, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(hidden && x && wo && w1 && w2 && gamma1 && beta1 && gamma2 && beta2 && out, "rdm_attention_tail: null pointer");
   RDM_REQUIRE(d == 128 && m >= 0, "rdm_attention_tail: supports d = 128 with a 256-wide FFN (d=%lld)", (long long)d);
@@ -1215,8 +1281,35 @@ extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const 
   a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
   a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
   a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
+  a.nproj = 0;
+  if (n_proj > 0) {
+    RDM_REQUIRE(n_proj <= 2 && proj, "rdm_attention_tail_proj: at most two projections");
+    for (int i = 0; i < n_proj; ++i) {
+      const rdm_tail_projection& P = proj[i];
+      RDM_REQUIRE(P.b && P.dst && P.ncols > 0 && P.ldb >= P.ncols && P.ldb % 4 == 0 && P.ldd >= P.ncols && P.row_lo >= 0 &&
+                      P.row_hi >= P.row_lo && P.row_hi <= m,
+                  "rdm_attention_tail_proj: projection %d: bad shape", i);
+      a.proj[i].b = P.b; a.proj[i].bias = P.bias; a.proj[i].dst = P.dst; a.proj[i].ncols = static_cast<int>(P.ncols);
+      a.proj[i].ldb = static_cast<int>(P.ldb); a.proj[i].ldd = static_cast<int>(P.ldd);
+      a.proj[i].row_lo = static_cast<int>(P.row_lo); a.proj[i].row_hi = static_cast<int>(P.row_hi);
+    }
+    a.nproj = n_proj;
+  }
   RDM_DUP_LOOP("tail")
-  hipLaunchKernelGGL(attention_tail128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
-                     static_cast<hipStream_t>(stream), a);
+  if (a.nproj > 0)
+    hipLaunchKernelGGL(attention_tail128_kernel<true>, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(attention_tail128_kernel<false>, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), a);
   return launch_status("attention_tail128_kernel");
+}
+
+extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                                  const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
+                                  const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
+                                  const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
+                                  int64_t ld_out, void* stream) {
+  return rdm_attention_tail_proj(hidden, ld_hidden, x, ldx, m, d, wo, ld_wo, bo, gamma1, beta1, w1, ld_w1, b1, w2, ld_w2, b2, gamma2,
+                                 beta2, eps, out, ld_out, nullptr, 0, stream);
 }

@@ -276,6 +276,8 @@ class RDMNet(torch.nn.Module):
         n1 = N - n0
         if self._fused_layers_ok(name, num_layers, heads, n0, n1):
             return self._thdroformer_fused(name, pts4, x, n0, num_layers, out)
+        if self._tail_proj_ok(name, num_layers, n0, n1):
+            return self._thdroformer_tail_proj(name, pts4, x, n0, num_layers, out)
         emb = self._linear(name + '.embedding.proj', pts4)
         f = self._linear(name + '.in_proj', x)
         d = f.shape[1]
@@ -298,6 +300,69 @@ class RDMNet(torch.nn.Module):
                 self._attention_tail(p, hid[n0:], f[n0:], fnew[n0:])
             f = fnew
         self._linear(name + '.out_proj', f, out=out)
+
+    def _tail_proj_ok(self, name, num_layers, n0, n1):
+        """Opt-in (RDM_TAIL_PROJ=1; measured slower): the projections of a layer's new rows inside the tail's launch
+        (ops.attention_tail(projections=...)): width 128,
+        256-wide FFN, at most 1536 stacked rows (the sizes at which rdm_gemm runs the kernel whose arithmetic the tail
+        reproduces) -- the conditions of the native engine's thdroformer_tail_proj."""
+        W = self._w
+        if os.environ.get('RDM_TAIL_PROJ') != '1' or num_layers < 1 or n0 <= 0 or n1 <= 0 or n0 + n1 > 1536:
+            return False
+        op = W.get(name + '.out_proj')
+        if op is None or op[2] != 128 or (n0 + n1) * op[3] > 1536 * 512:
+            return False
+        for i in range(2 * num_layers):
+            p = f'{name}.transformer.layers.{i}'
+            shapes = [tuple(getattr(W.get(p + k + '.wt'), 'shape', ())) for k in ('.attention.linear', '.output.expand', '.output.squeeze')]
+            if shapes != [(128, 128), (256, 128), (128, 256)] or (p + '.qkv') not in W or W[p + '.qkv'][0].shape[0] != 128:
+                return False
+        return True
+
+    def _thdroformer_tail_proj(self, name, pts4, x, n0, num_layers, out):
+        """The per-op sequence of the native engine (engine.hip: thdroformer_tail_proj): 7 launches per (self, cross) layer pair."""
+        W, heads = self._w, self.cfg.thdroformer.num_heads
+        N, dev = x.shape[0], x.device
+        n1 = N - n0
+        emb = self._linear(name + '.embedding.proj', pts4)
+        f = self._linear(name + '.in_proj', x)
+        d = 128
+        L = lambda i: f'{name}.transformer.layers.{i}'
+        last = 2 * num_layers - 1
+        q2, kv = ops.feat_empty(N, d, dev), ops.feat_empty(N, 2 * d, dev)
+        qkv = ops.gemm(f, W[L(0) + '.qkv'][0], d, 3 * d, bias=W[L(0) + '.qkv'][1])
+
+        def tail(p, hid, xin, fout, projections):
+            lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
+            return ops.attention_tail(hid, xin, W[lo + '.wt'], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'],
+                                      W[l1 + '.wt'], W[l1][1], W[l2 + '.wt'], W[l2][1], W[p + '.output.norm.weight'],
+                                      W[p + '.output.norm.bias'], out=fout, projections=projections)
+
+        def proj(key, dst, n, lo, hi):
+            return (W[key][0], W[key][1], dst, n, lo, hi)
+
+        for i in range(2 * num_layers):
+            p = L(i)
+            fnew, hid = ops.feat_empty(N, d, dev), ops.feat_empty(N, d, dev)
+            if i % 2 == 0:
+                q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+                ops.rope(q, k, emb)
+                ops.attention_self_pair(q, k, v, n0, heads, out=hid, bf16=self.attention_bf16)
+                tail(p, hid, f, fnew, [proj(L(i + 1) + '.q', q2, d, 0, N), proj(L(i + 1) + '.kv', kv, 2 * d, n0, N)])
+            else:
+                qkv_next = ops.feat_empty(N, 3 * d, dev) if i != last else None
+
+                def next_inputs(row0, rows):
+                    if i == last:
+                        return (W[name + '.out_proj'][0], W[name + '.out_proj'][1], out[row0:], W[name + '.out_proj'][3], 0, rows)
+                    return proj(L(i + 1) + '.qkv', qkv_next[row0:], 3 * d, 0, rows)
+                ops.attention(q2[:n0], kv[n0:, :d], kv[n0:, d:], heads, out=hid[:n0], bf16=self.attention_bf16)
+                tail(p, hid[:n0], f[:n0], fnew[:n0], [proj(p + '.kv', kv, 2 * d, 0, n0), next_inputs(0, n0)])
+                ops.attention(q2[n0:], kv[:n0, :d], kv[:n0, d:], heads, out=hid[n0:], bf16=self.attention_bf16)
+                tail(p, hid[n0:], f[n0:], fnew[n0:], [next_inputs(n0, n1)])
+                qkv = qkv_next
+            f = fnew
+        return out
 
     def _fused_layers_ok(self, name, num_layers, heads, n0, n1):
         """rdm_attention_layer (opt-in, RDM_FUSED_LAYER=1, as in the native engine) covers the transformer width

@@ -221,16 +221,24 @@ def layer_norm(x, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=Non
     return y
 
 
-def attention_tail(hidden, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, *, eps=1e-5, out=None):
+def attention_tail(hidden, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, *, eps=1e-5, out=None, projections=()):
     """The tail of an attention layer in one launch: y = LN(hidden @ wo.T + bo + x); out = LN(relu(y @ w1.T + b1) @ w2.T
-    + b2 + y).  Width 128, FFN 256; weights as nn.Linear stores them (wo [128,128], w1 [256,128], w2 [128,256])."""
+    + b2 + y).  Width 128, FFN 256; weights as nn.Linear stores them (wo [128,128], w1 [256,128], w2 [128,256]).
+    projections: up to two (b [128, pad4(n)], bias, dst [m, >= n] view, n, row_lo, row_hi) -- Linear layers of the new rows
+    [row_lo, row_hi) computed by the same launch with rdm_gemm's arithmetic (rdm_attention_tail_proj)."""
     L = _lib.lib()
     m = hidden.shape[0]
     y = out if out is not None else feat_empty(m, 128, hidden.device)
-    _lib.check(L.rdm_attention_tail(hidden.data_ptr(), _ld(hidden), x.data_ptr(), _ld(x), m, wo.shape[0], wo.data_ptr(), _ld(wo),
-                                    _lib.ptr(bo), gamma1.data_ptr(), beta1.data_ptr(), w1.data_ptr(), _ld(w1), _lib.ptr(b1),
-                                    w2.data_ptr(), _ld(w2), _lib.ptr(b2), gamma2.data_ptr(), beta2.data_ptr(), eps,
-                                    y.data_ptr(), _ld(y), _lib.stream_ptr()), 'rdm_attention_tail')
+    import ctypes
+    arr = (_lib.TailProjection * max(len(projections), 1))()
+    for i, (b, bias, dst, n, lo, hi) in enumerate(projections):
+        P = arr[i]
+        P.b, P.bias, P.dst, P.ncols, P.ldb, P.ldd, P.row_lo, P.row_hi = b.data_ptr(), _lib.ptr(bias), dst.data_ptr(), n, _ld(b), _ld(dst), lo, hi
+    _lib.check(L.rdm_attention_tail_proj(hidden.data_ptr(), _ld(hidden), x.data_ptr(), _ld(x), m, wo.shape[0], wo.data_ptr(), _ld(wo),
+                                         _lib.ptr(bo), gamma1.data_ptr(), beta1.data_ptr(), w1.data_ptr(), _ld(w1), _lib.ptr(b1),
+                                         w2.data_ptr(), _ld(w2), _lib.ptr(b2), gamma2.data_ptr(), beta2.data_ptr(), eps,
+                                         y.data_ptr(), _ld(y), ctypes.addressof(arr) if projections else None, len(projections),
+                                         _lib.stream_ptr()), 'rdm_attention_tail_proj')
     return y
 
 

@@ -303,6 +303,28 @@ def test_attention_tail_fused_matches_torch(ops, m):
     assert (got - o3).abs().max() <= 3e-5 * want.abs().max()
 
 
+@pytest.mark.parametrize('m,lo,hi', [(431, 0, 431), (842, 431, 842), (17, 3, 9), (700, 0, 700)])
+def test_attention_tail_projections_have_the_bits_of_the_separate_gemm(ops, m, lo, hi):
+    """rdm_attention_tail_proj: the Linear layers of the new rows computed by the tail's own launch equal, bit for bit, the
+    rdm_gemm launches they replace (same MFMA tiles, K split and summation order), rows outside [row_lo, row_hi) stay
+    untouched, and the tail's own output does not change."""
+    rng = np.random.default_rng(m + lo)
+    t = lambda *s, scale=1.0: torch.from_numpy((rng.normal(size=s) * scale).astype(np.float32)).cuda()
+    hid, x = t(m, 128), t(m, 128)
+    tail = (t(128, 128, scale=.09), t(128), t(128).abs() + .5, t(128), t(256, 128, scale=.09), t(256), t(128, 256, scale=.06), t(128),
+            t(128).abs() + .5, t(128))
+    b_qkv, bias_qkv = t(128, 384, scale=.09), t(384)
+    b_kv, bias_kv = t(128, 256, scale=.09), t(256)
+    plain = ops.attention_tail(hid, x, *tail)
+    d0, d1 = torch.full((m, 384), 7.0, device='cuda'), torch.full((m, 256), 7.0, device='cuda')
+    out = ops.attention_tail(hid, x, *tail, projections=[(b_qkv, bias_qkv, d0, 384, 0, m), (b_kv, bias_kv, d1, 256, lo, hi)])
+    assert torch.equal(out, plain)
+    assert torch.equal(d0, ops.gemm(plain, b_qkv, 128, 384, bias=bias_qkv))
+    want1 = ops.gemm(plain, b_kv, 128, 256, bias=bias_kv)
+    assert torch.equal(d1[lo:hi], want1[lo:hi])
+    assert (d1[:lo] == 7.0).all() and (d1[hi:] == 7.0).all()
+
+
 @pytest.mark.parametrize('n0,n1', [(350, 301), (16, 1), (0, 40), (33, 0)])
 def test_attention_self_pair_equals_two_launches(ops, n0, n1):
     """Both clouds' self-attention in one launch (thdroformer.py:225-236) gives the bits of the two separate launches."""
