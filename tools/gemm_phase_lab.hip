@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
   g.A = dev(size_t(M) * K); g.B = dev(size_t(K) * N); g.C = dev(size_t(M) * N); g.bias = dev(N); g.rowdiv = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = N; g.ldc = N; g.sa = g.sb = g.sc = 0; g.act = 0; g.splits = splits;
   g.part = splits > 1 ? dev(size_t(M) * N * splits) : nullptr; g.stats = nullptr;
+  g.A2 = nullptr; g.aidx = nullptr; g.bidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = g.n_b = 0; g.xcd_tiles = 0;
   if (with_stats) { double* st; (void)hipMalloc(&st, size_t((M + 63) / 64) * 2 * N * 8); g.stats = st; g.rowdiv = dev(M); }
   (void)hipMalloc(&g.clk, 64);
   unsigned long long h[8];
