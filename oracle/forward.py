@@ -332,8 +332,10 @@ def correspondence_matrix(score, ref_mask, src_mask):
     return corr & (ref_mask[:, :, None] & src_mask[:, None, :])
 
 
-def lgr(ref_knn, src_knn, ref_mask, src_mask, log_scores, cfg):
-    """modules/geotransformer/local_global_registration.py:145-243."""
+def lgr(ref_knn, src_knn, ref_mask, src_mask, log_scores, cfg, force_best=None):
+    """modules/geotransformer/local_global_registration.py:145-243.  `force_best` (test probe, not in the
+    reference): refine from that local hypothesis instead of the argmax of the inlier counts -- used to enumerate
+    the poses the reference would return if a near-tie between hypotheses fell the other way."""
     fm = cfg.fine_matching
     score = torch.exp(log_scores)
     corr = correspondence_matrix(score, ref_mask, src_mask)
@@ -352,7 +354,7 @@ def lgr(ref_knn, src_knn, ref_mask, src_mask, log_scores, cfg):
         Ts = procrustes(bs, br, bw)
         res = torch.linalg.norm(ref_c[None] - _apply(Ts, src_c[None]), dim=2)
         inl = res < fm.acceptance_radius
-        best = inl.sum(1).argmax()
+        best = inl.sum(1).argmax() if force_best is None else torch.tensor(int(force_best))
         cur = sc * inl[best].float()
         info.update(hypotheses=Ts, inlier_counts=inl.sum(1), best=int(best))
     else:

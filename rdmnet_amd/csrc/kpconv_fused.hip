@@ -321,14 +321,13 @@ constexpr int kQb32 = 16, kNw32 = 16, kIters32 = 2, kQb64 = 16, kNw64 = 8, kIter
 
 }  // namespace
 
-// Whether the engine and the per-op path route the fine levels through the fused kernel.  OFF by default: measured on
-// MI355X the fused form is throughput-neutral and 15-25 % slower per layer with one pair in
-// flight -- the 15*C floats per query it parks in LDS cap a CU at 16-32 queries in flight in lock-step phases, where the
-// stand-alone gather keeps 32 independent wavefronts busy.  RDM_FUSED_KPCONV=1 switches it on (both paths read this).
+// Whether the engine and the per-op path route the fine levels (C_in = 1, 32, 64) through the fused kernel.  ON by
+// default since round 3: the [M, 15*C] tensor between gather and weight product was a 13x write amplification of
+// these layers (profiles/r02_pmc_fetch_write.md); RDM_FUSED_KPCONV=0 selects the two-kernel form for A/B runs.
 extern "C" int rdm_kpconv_fused_enabled(void) {
   static const bool on = [] {
     const char* v = getenv("RDM_FUSED_KPCONV");
-    return v != nullptr && v[0] != '\0' && v[0] != '0';
+    return !(v != nullptr && v[0] == '0');
   }();
   return on ? 1 : 0;
 }

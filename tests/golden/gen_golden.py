@@ -61,6 +61,16 @@ def run_reference(cfg, model, ref_pts, src_pts):
     return data, out, taps
 
 
+def corr_rows(out):
+    a = np.concatenate([np_(out['ref_corr_points']), np_(out['src_corr_points'])], 1).astype(np.float64)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def corr_symmetric_difference(out_a, out_b):
+    a, b = (set(map(tuple, corr_rows(o).tolist())) for o in (out_a, out_b))
+    return len(a ^ b)
+
+
 def np_(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
@@ -77,24 +87,51 @@ def main():
     np.random.seed(0)
     model = create_model(cfg)
     model.eval()
-    state = weights.synthetic_state_dict(my_cfg, seed=0)
-    ref_sd = model.state_dict()
-    assert list(ref_sd.keys()) == list(state.keys()), 'schema order differs from the reference state_dict'
-    for k in ref_sd:
-        assert tuple(ref_sd[k].shape) == tuple(state[k].shape), k
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
-    W = ofw.to_torch(state)
+
+    def load_seed(seed):
+        state = weights.synthetic_state_dict(my_cfg, seed=seed)
+        ref_sd = model.state_dict()
+        assert list(ref_sd.keys()) == list(state.keys()), 'schema order differs from the reference state_dict'
+        for k in ref_sd:
+            assert tuple(ref_sd[k].shape) == tuple(state[k].shape), k
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        return ofw.to_torch(state)
 
     scans = np.load(os.path.join(HERE, 'scans.npz'))
+    synth = np.load(os.path.join(HERE, 'synthetic_pairs.npz'))
+    # tag -> (ref scan, src scan, weight seed).  The reference's `infer` subset is the two bundled pairs 0<->4 and
+    # 0<->7 (rdmnet/datasets/registration/kitti/dataset.py:56-64).  `small` is the 10 m crop of 0<->4: its best local
+    # hypothesis leads the runner-up by >= 5 inliers in the reference's own LGR (8 and 1 thread), so summation-order
+    # noise upstream cannot change the pose.  `crop9` (the 9 m crop, rounds 1-2's `small`) is kept as the documented
+    # near-tie case: best and second-best hypothesis are 6 vs 5 inliers; the file carries the poses of every hypothesis
+    # within one inlier of the best (`lgr/alt_transforms`) for a tie-aware assertion.
     cases = {
-        'small': (crop(scans['s000000'], 9.0), crop(scans['s000004'], 9.0)),
-        'pair04': (scans['s000000'], scans['s000004']),
+        'small': (crop(scans['s000000'], 10.0), crop(scans['s000004'], 10.0), 0),
+        'crop9': (crop(scans['s000000'], 9.0), crop(scans['s000004'], 9.0), 0),
+        'pair04': (scans['s000000'], scans['s000004'], 0),
+        'pair07': (scans['s000000'], scans['s000007'], 0),
+        'pair04_seed1': (scans['s000000'], scans['s000004'], 1),
+        'synth0': (synth['ref0'], synth['src0'], 0),   # BASELINE configs[1] shape; the reference's own 8- and 1-thread
+        'synth3': (synth['ref3'], synth['src3'], 0),   # runs differ in a few point correspondences on 0, in nothing on 3
     }
+    for i in os.environ.get('RDM_GOLDEN_EXTRA_SYNTH', '').split():  # probing other synthetic pairs, not committed
+        cases[f'synth{i}'] = (synth[f'ref{i}'], synth[f'src{i}'], 0)
+    only = [a for a in sys.argv[1:] if a in cases]
+    assert len(only) == len(sys.argv) - 1, sys.argv
     report = {}
-    for tag, (rp, sp) in cases.items():
+    rep_path = os.path.join(HERE, 'oracle_vs_reference.json')
+    if only and os.path.exists(rep_path):
+        report = json.load(open(rep_path))
+    loaded_seed = None
+    for tag, (rp, sp, seed) in cases.items():
+        if only and tag not in only:
+            continue
+        if seed != loaded_seed:
+            W = load_seed(seed)
+            loaded_seed = seed
         torch.set_num_threads(8)
         data, out, taps = run_reference(cfg, model, rp, sp)
-        fx = {'ref_points_in': rp, 'src_points_in': sp}
+        fx = {'ref_points_in': rp, 'src_points_in': sp, 'weight_seed': np.int64(seed)}
         for i in range(5):
             fx[f'lengths{i}'] = np_(data['lengths'][i])
         for n, v in taps.items():
@@ -124,7 +161,6 @@ def main():
                                                                 my_cfg.model.num_points_in_patch)[1])
         fx['full/src_node_masks'] = np_(point_to_node_partition(data['points'][1][n_f0:], out['src_points_c'],
                                                                 my_cfg.model.num_points_in_patch)[1])
-        np.savez_compressed(os.path.join(HERE, f'forward_{tag}.npz'), **fx)
 
         # ---- pin the oracle: replay the restatement on the same inputs, record deviations
         odata = ofw.pyramid(np.concatenate([rp, sp]), np.array([len(rp), len(sp)], np.int64), my_cfg)
@@ -180,9 +216,20 @@ def main():
         ms = ofw.sinkhorn(pscores, out['ref_node_corr_knn_masks'], out['src_node_corr_knn_masks'],
                           W['optimal_transport.alpha'], my_cfg.model.num_sinkhorn_iterations)
         tf['sinkhorn/matching_scores'] = dev(ms, out['matching_scores'])
-        rc, sc2, cs, T, _ = ofw.lgr(out['ref_node_corr_knn_points'], out['src_node_corr_knn_points'],
-                                    out['ref_node_corr_knn_masks'], out['src_node_corr_knn_masks'],
-                                    out['matching_scores'], my_cfg)
+        lgr_in = (out['ref_node_corr_knn_points'], out['src_node_corr_knn_points'], out['ref_node_corr_knn_masks'],
+                  out['src_node_corr_knn_masks'], out['matching_scores'], my_cfg)
+        rc, sc2, cs, T, linfo = ofw.lgr(*lgr_in)
+        # margin of the reference's own hypothesis selection (local_global_registration.py:204-221), and the poses it
+        # would return if a near-tie (within one inlier of the best) fell the other way
+        if 'inlier_counts' in linfo:
+            counts = linfo['inlier_counts'].numpy()
+            near = [int(i) for i in np.nonzero(counts >= counts.max() - 1)[0]]
+            fx['lgr/inlier_counts'] = counts.astype(np.int64)
+            fx['lgr/best'] = np.int64(linfo['best'])
+            fx['lgr/alt_hypotheses'] = np.asarray(near, np.int64)
+            fx['lgr/alt_transforms'] = np.stack([np_(ofw.lgr(*lgr_in, force_best=i)[3]) for i in near])
+            top = np.sort(counts)[::-1]
+            tf['lgr/inlier_margin'] = int(top[0] - top[1]) if len(top) > 1 else int(top[0])
         tf['lgr/corr_points_equal'] = bool(torch.equal(rc, out['ref_corr_points']) and torch.equal(sc2, out['src_corr_points']))
         tf['lgr/corr_scores'] = dev(cs, out['corr_scores'])
         rre_t, rte_t = ofw.rre_rte(np_(T), np_(out['estimated_transform']))
@@ -193,19 +240,30 @@ def main():
                        'n_hypotheses': len(otaps['lgr']['chunks'])}
         # the reference against itself at another thread count: its own fp32 noise floor
         torch.set_num_threads(1)
-        _, out1, _ = run_reference(cfg, model, rp, sp)
+        _, out1, taps1 = run_reference(cfg, model, rp, sp)
         rre1, rte1 = ofw.rre_rte(np_(out1['estimated_transform']), np_(out['estimated_transform']))
+        pairs8 = set(zip(np_(out['ref_node_corr_indices']).tolist(), np_(out['src_node_corr_indices']).tolist()))
+        pairs1 = set(zip(np_(out1['ref_node_corr_indices']).tolist(), np_(out1['src_node_corr_indices']).tolist()))
+        # what the reference decides differently against ITSELF at another thread count bounds what an end-to-end
+        # comparison can demand of the discrete outputs of this case (tests read these flags; nothing is skipped silently)
+        fx['self/node_corr_symmetric_difference'] = np.int64(len(pairs8 ^ pairs1))
+        fx['self/nms_mask_equal'] = np.bool_(np.array_equal(np_(taps['nms']), np_(taps1['nms'])))
+        fx['self/transform_1_thread'] = np_(out1['estimated_transform'])
+        fx['self/n_corr_1_thread'] = np.int64(out1['corr_scores'].shape[0])
+        fx['self/corr_symmetric_difference'] = np.int64(corr_symmetric_difference(out1, out))
         rep['reference_8_vs_1_thread'] = {
-            'rre_deg': rre1, 'rte_m': rte1,
+            'rre_deg': rre1, 'rte_m': rte1, 'node_corr_symmetric_difference': len(pairs8 ^ pairs1),
             'corr_equal': bool(out1['ref_corr_points'].shape == out['ref_corr_points'].shape
                                and torch.equal(out1['ref_corr_points'], out['ref_corr_points'])),
+            'corr_symmetric_difference': corr_symmetric_difference(out1, out),
             'feats_f_max_abs': float((out1['ref_feats_f'] - out['ref_feats_f']).abs().max()),
             'matching_scores': dev(out1['matching_scores'], out['matching_scores'])}
         torch.set_num_threads(8)
+        np.savez_compressed(os.path.join(HERE, f'forward_{tag}.npz'), **fx)
         report[tag] = rep
         print(tag, json.dumps(rep['pose']), json.dumps(rep['reference_8_vs_1_thread']))
         print('  teacher-forced:', json.dumps(tf))
-    with open(os.path.join(HERE, 'oracle_vs_reference.json'), 'w') as f:
+    with open(rep_path, 'w') as f:
         json.dump(report, f, indent=1, sort_keys=True)
 
 

@@ -1,12 +1,21 @@
 """GPU: the HIP path against vectors captured from the REFERENCE ITSELF (tests/golden/forward_*.npz, produced by
 tests/golden/gen_golden.py importing /root/reference: experiments/model_infer.py:109-354 behind the reference's own
-collate) -- no oracle in between.  Full size: the bundled pair (000000, 000004), 20 524 + 19 085 points
-(BASELINE.json configs[0]); and the 5 k-point crop.
+collate) -- no oracle in between.  Seven cases: both bundled pairs of the reference's `infer` subset at full size
+(0<->4: 20 524 + 19 085 points, 0<->7; kitti/dataset.py:56-64 = BASELINE.json configs[0]), pair 0<->4 with a second
+weight seed, two 2 x 16 k-point synthetic pairs (configs[1]'s workload), the 10 m crop of 0<->4 (`small`) and the
+9 m crop (`crop9`, the documented near-tie case).
 
-Integer / index outputs must be EQUAL (NMS mask, superpoint correspondences, patch masks, point correspondences);
-float outputs within the stated relative bounds; the pose within twice the spread the reference shows against itself
-between 8-thread and 1-thread CPU runs (tests/golden/oracle_vs_reference.json: reference_8_vs_1_thread) and, on the
-crop, within the north star's RRE <= 1e-3 deg / RTE <= 1e-3 cm.  The measured deviations are written to
+Integer / index outputs must be EQUAL (NMS mask, superpoint correspondences, patch masks, point correspondences as a
+set -- except where the golden file records that the reference differs from ITSELF between its 8- and 1-thread CPU
+runs, `self/*` entries: synth0's correspondences differ by one row there, and then at most that many rows may differ
+here); float outputs within the stated relative bounds.  Pose: with random weights the reference's local-to-global
+registration picks among hypotheses whose inlier counts tie within one (local_global_registration.py:204-221; margins
+recorded per case in oracle_vs_reference.json: 0-2 everywhere but `small`, and on 0<->7 the reference's own two runs
+return poses 121 deg apart).  The assertion is therefore tie-aware: the HIP pose must match ONE of the poses the
+reference returns from the hypotheses within one inlier of its best (`lgr/alt_transforms`, entry of the reference's own
+choice first) -- within the north star's RRE <= 1e-3 deg / RTE <= 1e-3 cm on the crops, RRE <= 1e-3 deg / RTE <= 1e-2 cm
+at full size (64-80 m coordinates: one fp32 ulp is 8e-4 cm, the reference against itself moves by 2e-3 ... 5e-3 cm).
+On `small` (margin 7) only the reference's own hypothesis is accepted.  The measured deviations are written to
 gpurun_out/hip_vs_reference.json; a copy of a run is tracked as tests/golden/hip_vs_reference.json."""
 import json
 import os
@@ -41,26 +50,37 @@ def rre_rte(T, G):
     return float(np.degrees(ang)), float(np.linalg.norm(T[:3, 3] - G[:3, 3]))
 
 
+TAGS = ['pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'small', 'crop9']
+
+
 @pytest.fixture(scope='module')
 def setup():
     from rdmnet_amd import collate, config, engine, model, weights
     cfg = config.make_cfg()
-    state = weights.synthetic_state_dict(cfg, seed=0)  # the weights the goldens were generated with
-    net = model.create_model(cfg).cuda()
-    net.load_state_dict(state)
-    eng = engine.Engine(cfg, state)
-    eng.keep_taps(True)
-    yield cfg, net, eng, collate
+    built = {}
+
+    def for_seed(seed):  # the weights the golden case was generated with (`weight_seed` in the file)
+        if seed not in built:
+            state = weights.synthetic_state_dict(cfg, seed=seed)
+            net = model.create_model(cfg).cuda()
+            net.load_state_dict(state)
+            eng = engine.Engine(cfg, state)
+            eng.keep_taps(True)
+            built[seed] = (net, eng)
+        return built[seed]
+
+    yield cfg, for_seed, collate
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'hip_vs_reference.json'), 'w') as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize('tag', ['pair04', 'small'])
+@pytest.mark.parametrize('tag', TAGS)
 def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
-    cfg, net, eng, collate = setup
+    cfg, for_seed, collate = setup
     g = np.load(os.path.join(golden_dir, f'forward_{tag}.npz'))
-    spread = json.load(open(os.path.join(golden_dir, 'oracle_vs_reference.json')))[tag]['reference_8_vs_1_thread']
+    net, eng = for_seed(int(g['weight_seed']))
+    full_size = tag not in ('small', 'crop9')
     rp, sp = g['ref_points_in'], g['src_points_in']
     data = collate.collate_pair(rp, sp, cfg, exact_shapes=True)
     for i in range(5):
@@ -102,53 +122,76 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     hip_pairs = list(zip(npy(out['ref_node_corr_indices']).tolist(), npy(out['src_node_corr_indices']).tolist()))
     rep['node_corr_set_symmetric_difference'] = len(set(ref_pairs) ^ set(hip_pairs))
     rep['node_corr_same_position_fraction'] = float(np.mean([a == b for a, b in zip(ref_pairs, hip_pairs)]))
-    sets_equal = rep['node_corr_set_symmetric_difference'] == 0 and len(hip_pairs) == len(ref_pairs)
-    if tag == 'pair04':
-        assert sets_equal, rep['node_corr_set_symmetric_difference']
-    if sets_equal:
-        pos = {p: i for i, p in enumerate(ref_pairs)}
-        perm = np.array([pos[p] for p in hip_pairs])  # HIP position -> reference position
-        rs = g['tap/node_corr_scores'].astype(np.float64)
-        rep['node_corr_max_tie_gap'] = float(np.abs(rs[perm] - rs).max() / rs.max())
-        assert rep['node_corr_max_tie_gap'] <= 1e-5                      # moved only inside near-tie groups
-        rep['tap/node_corr_scores'] = rel(npy(taps['node_corr_scores']), rs[perm])
-        assert rep['tap/node_corr_scores'] <= 1e-5
-        rmask, smask = g['out/ref_node_corr_knn_masks'][perm], g['out/src_node_corr_knn_masks'][perm]
-        assert np.array_equal(npy(out['ref_node_corr_knn_masks']).astype(bool), rmask)
-        assert np.array_equal(npy(out['src_node_corr_knn_masks']).astype(bool), smask)
-        assert np.array_equal(npy(out['ref_node_corr_knn_points']), g['out/ref_node_corr_knn_points'][perm])
-        assert np.array_equal(npy(out['src_node_corr_knn_points']), g['out/src_node_corr_knn_points'][perm])
-        gold_ms = expand_scores(g['out/matching_scores'], g['out/ref_node_corr_knn_masks'], g['out/src_node_corr_knn_masks'])[perm]
-        hip_ms = npy(out['matching_scores'])
-        valid = gold_ms > -1e11
-        assert np.array_equal(hip_ms > -1e11, valid)
-        rep['out/matching_scores'] = rel(hip_ms[valid], gold_ms[valid])
-        # (the crop's patches are fuller and its log-scores 10x smaller: the reference against itself, 8 vs 1 thread,
-        # moves by 4e-7 of the maximum there)
-        assert rep['out/matching_scores'] <= (1e-6 if tag == 'pair04' else 3e-6)
-        # point correspondences: the same set of (ref point, src point) rows, scores attached
-        def rows(rc, sc, cs):
-            a = np.concatenate([npy(rc), npy(sc), npy(cs)[:, None]], 1).astype(np.float64)
-            return a[np.lexsort(a[:, :6].T[::-1])]
-        hr = rows(out['ref_corr_points'], out['src_corr_points'], out['corr_scores'])
-        gr = rows(g['out/ref_corr_points'], g['out/src_corr_points'], g['out/corr_scores'])
-        corr_equal = hr.shape == gr.shape and np.array_equal(hr[:, :6], gr[:, :6])
-        rep['corr_points_equal_as_set'] = bool(corr_equal)
-        rep['n_corr'] = [int(hr.shape[0]), int(gr.shape[0])]
-        if tag == 'pair04':
-            assert corr_equal
-        if corr_equal:
-            rep['out/corr_scores'] = rel(hr[:, 6], gr[:, 6])
-            assert rep['out/corr_scores'] <= 2e-5
+    assert int(g['self/node_corr_symmetric_difference']) == 0  # the reference agrees with itself on every case
+    assert rep['node_corr_set_symmetric_difference'] == 0 and len(hip_pairs) == len(ref_pairs)
+    pos = {p: i for i, p in enumerate(ref_pairs)}
+    perm = np.array([pos[p] for p in hip_pairs])  # HIP position -> reference position
+    rs = g['tap/node_corr_scores'].astype(np.float64)
+    rep['node_corr_max_tie_gap'] = float(np.abs(rs[perm] - rs).max() / rs.max())
+    assert rep['node_corr_max_tie_gap'] <= 1e-5                      # moved only inside near-tie groups
+    rep['tap/node_corr_scores'] = rel(npy(taps['node_corr_scores']), rs[perm])
+    assert rep['tap/node_corr_scores'] <= 1e-5
+    rmask, smask = g['out/ref_node_corr_knn_masks'][perm], g['out/src_node_corr_knn_masks'][perm]
+    assert np.array_equal(npy(out['ref_node_corr_knn_masks']).astype(bool), rmask)
+    assert np.array_equal(npy(out['src_node_corr_knn_masks']).astype(bool), smask)
+    assert np.array_equal(npy(out['ref_node_corr_knn_points']), g['out/ref_node_corr_knn_points'][perm])
+    assert np.array_equal(npy(out['src_node_corr_knn_points']), g['out/src_node_corr_knn_points'][perm])
+    gold_ms = expand_scores(g['out/matching_scores'], g['out/ref_node_corr_knn_masks'], g['out/src_node_corr_knn_masks'])[perm]
+    hip_ms = npy(out['matching_scores'])
+    valid = gold_ms > -1e11
+    assert np.array_equal(hip_ms > -1e11, valid)
+    rep['out/matching_scores'] = rel(hip_ms[valid], gold_ms[valid])
+    # (the crop's patches are fuller and its log-scores 10x smaller: the reference against itself, 8 vs 1 thread,
+    # moves by 4e-7 of the maximum there)
+    assert rep['out/matching_scores'] <= (1e-6 if full_size else 3e-6)
+    # point correspondences: the same set of (ref point, src point) rows, scores attached
+    def rows(rc, sc, cs):
+        a = np.concatenate([npy(rc), npy(sc), npy(cs)[:, None]], 1).astype(np.float64)
+        return a[np.lexsort(a[:, :6].T[::-1])]
+    hr = rows(out['ref_corr_points'], out['src_corr_points'], out['corr_scores'])
+    gr = rows(g['out/ref_corr_points'], g['out/src_corr_points'], g['out/corr_scores'])
+    hs, gs = ({tuple(r[:6]): r[6] for r in a.tolist()} for a in (hr, gr))
+    rep['corr_points_symmetric_difference'] = len(set(hs) ^ set(gs))
+    rep['n_corr'] = [int(hr.shape[0]), int(gr.shape[0])]
+    # equal as a set; where the reference's own 8- and 1-thread runs differ in k rows (synth0: k = 2, one
+    # correspondence at the top-1-versus-dustbin threshold), at most k rows may differ here
+    assert rep['corr_points_symmetric_difference'] <= int(g['self/corr_symmetric_difference']), rep['n_corr']
+    common = sorted(set(hs) & set(gs))
+    rep['out/corr_scores'] = rel([hs[k] for k in common], [gs[k] for k in common])
+    assert rep['out/corr_scores'] <= 2e-5
 
-    # ---- pose
-    rre, rte = rre_rte(npy(out['estimated_transform']), g['out/estimated_transform'])
-    rep['pose'] = {'rre_deg': rre, 'rte_m': rte, 'reference_8_vs_1_thread': {'rre_deg': spread['rre_deg'], 'rte_m': spread['rte_m']}}
-    if tag == 'pair04':
-        # 64-80 m coordinates: one fp32 ulp is 8e-6 m, the reference against itself moves by 2.0e-5 m
-        assert rre <= max(2.0 * spread['rre_deg'], 1e-4) and rte <= 2.0 * spread['rte_m'] + 1e-5, (rre, rte, spread)
-    else:
-        assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)  # the north star's bound: 1e-3 deg, 1e-3 cm
+    # ---- pose (tie-aware, see the module docstring)
+    T = npy(out['estimated_transform'])
+    margin = int(np.sort(g['lgr/inlier_counts'])[::-1][:2] @ [1, -1])
+    own = int(np.nonzero(g['lgr/alt_hypotheses'] == g['lgr/best'])[0][0])
+    errs = [rre_rte(T, A) for A in g['lgr/alt_transforms']]
+    pick = int(np.argmin([e[0] for e in errs]))
+    rre, rte = errs[pick]
+    rre_own, rte_own = rre_rte(T, g['out/estimated_transform'])
+    rep['pose'] = {'rre_deg': rre, 'rte_m': rte, 'reference_inlier_margin': margin, 'n_near_tie_hypotheses': len(errs),
+                   'matched_the_references_own_hypothesis': pick == own,
+                   'vs_reference_pose': {'rre_deg': rre_own, 'rte_m': rte_own},
+                   'reference_8_vs_1_thread': dict(zip(('rre_deg', 'rte_m'), rre_rte(g['self/transform_1_thread'],
+                                                                                    g['out/estimated_transform'])))}
+    # 0<->7 is the one case whose pose the reference does not reproduce itself (a handful of inliers at the 0.6 m
+    # acceptance radius: its 8- and 1-thread runs return poses 121 deg apart); the bar there is the next block
+    self_pose = rep['pose']['reference_8_vs_1_thread']
+    assert (self_pose['rre_deg'] <= 1e-3 and self_pose['rte_m'] <= 1e-4) == (tag != 'pair07')
+    if tag != 'pair07':
+        assert rre <= 1e-3 and rte <= (1e-4 if full_size else 1e-5), (rre, rte, margin)
+    if margin >= 3:
+        assert pick == own and len(errs) == 1
+    # the pose is the reference's local-to-global registration OF THIS RUN'S OWN matching scores: the restated LGR
+    # (oracle.forward.lgr, bit-exact against the reference on all seven golden cases, test_oracle_forward.py) fed the
+    # HIP patch points / masks / Sinkhorn output returns the same correspondences and the same pose
+    from oracle import forward as ofw
+    orc, osc, ocs, oT, _ = ofw.lgr(out['ref_node_corr_knn_points'].cpu(), out['src_node_corr_knn_points'].cpu(),
+                                   out['ref_node_corr_knn_masks'].cpu().bool(), out['src_node_corr_knn_masks'].cpu().bool(),
+                                   out['matching_scores'].cpu(), cfg)
+    assert torch.equal(orc, out['ref_corr_points'].cpu()) and torch.equal(osc, out['src_corr_points'].cpu())
+    rep['pose']['vs_reference_lgr_on_own_scores'] = dict(zip(('rre_deg', 'rte_m'), rre_rte(T, oT.numpy())))
+    assert rep['pose']['vs_reference_lgr_on_own_scores']['rre_deg'] <= 1e-3
+    assert rep['pose']['vs_reference_lgr_on_own_scores']['rte_m'] <= (1e-4 if full_size else 1e-5)
 
     # ---- the native engine (what bench.py measures) returns the same result bit for bit at this size
     eng.run(torch.from_numpy(rp).cuda(), torch.from_numpy(sp).cuda())
@@ -159,7 +202,7 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     assert torch.equal(eng.tensor('ref_node_corr_indices')[:, 0], out['ref_node_corr_indices'])
 
 
-@pytest.mark.parametrize('tag', ['pair04', 'small'])
+@pytest.mark.parametrize('tag', TAGS)
 def test_coarse_matching_reproduces_reference_indices_teacher_forced(golden_dir, tag):
     """Fed the REFERENCE's own superpoint features and non-empty-node masks (the un-sampled `full/*` entries of the
     golden file), the HIP stage returns the reference's captured ref/src_node_corr_indices -- the same pairs in the same
