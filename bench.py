@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
 
 
 def make_pairs(n_pairs, cache_dir):
@@ -198,6 +199,9 @@ def main():
                     help='engine: one native call per pair (rdm_engine_run); python: per-op mirror (rdmnet_amd.model)')
     ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL) in production; gloo only to exercise the\n'
                     'multi-process logic on a single GPU (with RDM_BENCH_SHARE_DEVICE=1)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with --gpus 1: initialise the process group anyway (world size 1, backend --dist-backend) and send the\n'
+                         'record gather, the barriers and the timing reduction through it -- the RCCL path on a single GPU')
     ap.add_argument('--layer-events-every', type=int, default=8,
                     help='record the per-KPConv-layer HIP events (roofline) on every N-th pair of a stream: 42 event\n'
                          'records per pair cost ~13 %% of the throughput with 4 pairs in flight; 0 = never')
@@ -213,6 +217,9 @@ def main():
                     help='collate of the drop-in-API pass: native = rdm_engine_collate (one call), python = 17 launches from Python')
     ap.add_argument('--api-steps', type=int, default=192,
                     help='pairs of the drop-in-API pass (Python collate + model(data_dict)) after the timed region (0 = skip)')
+    ap.add_argument('--real-slots', choices=['on', 'off'], default='on',
+                    help='on: count the real (non-padding) neighbour slots of every distinct pair before the run (8 untimed\n'
+                         'collates) for the real-slot variant of the roofline; off: profile runs that should contain bench pairs only')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -228,9 +235,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    force = args.force_dist and world == 1
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:  # --force-dist without a launcher: a free rendezvous port
+            import socket
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -307,6 +320,17 @@ def main():
             eng.set_wait(wait_us)
             engines.append(eng)
 
+    # Slots of every KPConv layer's neighbour table that hold a real neighbour (the rest is padding behind them), per
+    # distinct pair: the `real_slots` variant of the roofline.  Untimed; layer order = Encoder.forward (backbone.py:72-107).
+    real_slots = {}
+    if engines and args.real_slots == 'on':
+        for pid, (r_, s_) in enumerate(dev_pairs):
+            dd = engines[0].collate(r_, s_)
+            nb = [int((dd['neighbors'][l] < dd['points'][l].shape[0]).sum()) for l in range(5)]
+            sub = [int((dd['subsampling'][l] < dd['points'][l].shape[0]).sum()) for l in range(4)]
+            real_slots[pid] = [nb[0], nb[0], sub[0], nb[1], nb[1], sub[1], nb[2], nb[2], sub[2], nb[3], nb[3], sub[3], nb[4], nb[4]]
+        del dd
+
     def run_range(indices, stream, rec, lat_out, prof_out, eng, events_every=None):
         events_every = args.layer_events_every if events_every is None else events_every
         ctx = torch.cuda.stream(stream) if stream is not None else None
@@ -321,10 +345,14 @@ def main():
                 if eng is not None:
                     sampled = prof_out is not None and events_every > 0 and (slot // max(len(streams), 1)) % events_every == 0
                     eng.enable_profile(sampled)
-                    res = eng.run(*dev_pairs[pid])  # returns after the pose has been read back
+                    res = eng.run(*dev_pairs[pid])  # returns with pose AND correspondences in host memory
                     T, n_corr = eng.transform(), res.n_correspondences
+                    rc_h, sc_h, cs_h = eng.host_corr()  # "... to estimated_transform + correspondences on the host"
+                    assert rc_h.shape[0] == n_corr
                     if sampled:
-                        prof_out.extend(eng.kpconv_profile())
+                        for li, layer_rec in enumerate(eng.kpconv_profile()):
+                            layer_rec['pid'], layer_rec['layer'] = pid, li
+                            prof_out.append(layer_rec)
                 else:
                     T, n_corr = step(i)
                 if rec is not None:
@@ -386,12 +414,12 @@ def main():
     run_all(args.warmup, args.steps, records, lat, prof_lists)
     # the path's only collective: one gather of per-pair result records (RCCL)
     comm_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')  # gloo gathers CPU tensors
-    gathered = sharding.gather_records(records.to(comm_dev), world, dist)
+    gathered = sharding.gather_records(records.to(comm_dev), world, dist, force)
     fence()
     elapsed = time.perf_counter() - t0
     if os.environ.get('RDM_BENCH_DUMP_LAT'):  # developer: per-pair latencies in completion order
         json.dump(lat, open(os.environ['RDM_BENCH_DUMP_LAT'], 'w'))
-    elapsed, lat = sharding.reduce_timing(elapsed, lat, world, dist, comm_dev)  # max over ranks; all ranks' latencies
+    elapsed, lat = sharding.reduce_timing(elapsed, lat, world, dist, comm_dev, force)  # max over ranks; all ranks' latencies
 
     # ---- host-to-host rate (SURVEY §8d's definition of a pair: two clouds in HOST memory -> transform + correspondences
     # in HOST memory).  Never `value`: a second, shorter region after the timed one.  Each in-flight pair copies its scans
@@ -409,9 +437,8 @@ def main():
                 for i in indices:
                     pr, ps = pinned[(rank + i * world) % len(pinned)]
                     res = eng.run(pr.to(dev, non_blocking=True), ps.to(dev, non_blocking=True))
-                    rc, sc, cs = eng.corr()
-                    host_out = torch.cat([rc, sc, cs[:, None]], 1).cpu()  # [n_corr, 7] on the host; the pose already is
-                    assert host_out.shape[0] == res.n_correspondences
+                    rc, sc, cs = eng.host_corr()  # written to pinned host memory by the run's last kernel; the pose too
+                    assert rc.shape[0] == res.n_correspondences and cs.shape[0] == res.n_correspondences
             except BaseException as exc:
                 errors.append(exc)
             finally:
@@ -430,7 +457,7 @@ def main():
             for t in threads:
                 t.join()
         fence()
-        h_elapsed, _ = sharding.reduce_timing(time.perf_counter() - th0, [], world, dist, comm_dev)
+        h_elapsed, _ = sharding.reduce_timing(time.perf_counter() - th0, [], world, dist, comm_dev, force)
         if errors:
             raise errors[0]
         host_to_host = {'value': args.host_steps * world / h_elapsed, 'unit': 'pairs/s', 'steps': args.host_steps,
@@ -481,7 +508,7 @@ def main():
             for t in threads:
                 t.join()
             fence()
-            a_elapsed, _ = sharding.reduce_timing(time.perf_counter() - ta0, [], world, dist, comm_dev)
+            a_elapsed, _ = sharding.reduce_timing(time.perf_counter() - ta0, [], world, dist, comm_dev, force)
             if errors:
                 raise errors[0]
         # forward only, one pair in flight: model(data_dict) (output_dict assembled) against the bare native call
@@ -507,30 +534,63 @@ def main():
                        '8 pairs, one in flight'}
 
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
+    # Layer forms (rdm_kpconv_profile.fused): c_in = 1 / 32 / 64 run as ONE kernel (kpconv_fused*: neighbourhood gather + weight
+    # contraction, no [M, 15 C] tensor in HBM; 6 launches per pair), c_in >= 128 as kpconv_gather_kernel + gemm_kernel (8).
+    # `gather_ms` of a record is the neighbourhood kernel alone in both forms.
     def kp_totals(prof):
-        t_total = t_gather = b_total = b_gather = 0.0
+        tot = {'t_total': 0.0, 'b_total': 0.0, 'n': 0}
+        forms = {f: {'t': 0.0, 'b': 0.0, 'b_real': 0.0, 'flops': 0.0, 'n': 0} for f in ('fused', 'gather')}
         per_layer = {}
         for rec in prof:
-            if 'events' in rec:
-                e0, e1, e2 = rec['events']
-                tg, tt = e0.elapsed_time(e1) * 1e-3, e0.elapsed_time(e2) * 1e-3
-                rec['gather_ms'], rec['total_ms'] = tg * 1e3, tt * 1e3
-            else:
-                tg, tt = rec['gather_ms'] * 1e-3, rec['total_ms'] * 1e-3
-            t_total += tt
-            t_gather += tg
-            b_total += rec['bytes']
-            b_gather += rec['gather_bytes']
+            if 'events' in rec:  # per-op Python mirror: the events themselves
+                e0, e1, e2 = rec.pop('events')
+                rec['gather_ms'], rec['total_ms'] = e0.elapsed_time(e1), e0.elapsed_time(e2)
+            tg, tt = rec['gather_ms'] * 1e-3, rec['total_ms'] * 1e-3
+            tot['t_total'] += tt
+            tot['b_total'] += rec['bytes']
+            tot['n'] += 1
+            f = forms['fused' if rec.get('fused') else 'gather']
+            f['t'] += tg
+            f['b'] += rec['gather_bytes']
+            f['b_real'] += rec.get('real_bytes', 0.0)
+            f['flops'] += 2.0 * rec['m'] * (16 if rec['cin'] == 1 else 15 * rec['cin']) * rec['cout'] if rec.get('fused') else 0.0
+            f['n'] += 1
             key = rec.get('name') or f"kpconv M={rec['m']} H={rec['h']} C={rec['cin']}->{rec['cout']}"
-            d = per_layer.setdefault(key, {'t': 0.0, 'tg': 0.0, 'bytes': rec['bytes'], 'n': 0, 'm': rec['m'],
-                                           'h': rec['h'], 'cin': rec['cin'], 'cout': rec['cout']})
+            d = per_layer.setdefault(key, {'t': 0.0, 'tg': 0.0, 'bytes': rec['bytes'], 'n': 0, 'm': rec['m'], 'fused': rec.get('fused', 0),
+                                           'h': rec['h'], 'cin': rec['cin'], 'cout': rec['cout'], 'real_bytes': rec.get('real_bytes')})
             d['t'] += tt
             d['tg'] += tg
             d['n'] += 1
-        return t_total, t_gather, b_total, b_gather, per_layer
+        return tot, forms, per_layer
+
+    def form_line(f):
+        if f['n'] == 0 or f['t'] <= 0:
+            return None
+        gbs = f['b'] / f['t'] / 1e9
+        out = {'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS, 'launches': f['n'], 'us_per_launch': f['t'] / f['n'] * 1e6,
+               'bytes_per_launch': f['b'] / f['n']}
+        if f['b_real'] > 0:
+            out['real_slots'] = {'achieved': f['b_real'] / f['t'] / 1e9, 'frac': f['b_real'] / f['t'] / 1e9 / HBM_PEAK_GBS,
+                                 'bytes_per_launch': f['b_real'] / f['n'], 'fill': f['b_real'] / f['b']}
+        if f['flops'] > 0:  # the fused kernels also do the weight contraction: the bound of one launch is max(bytes / HBM, flops / MFMA)
+            t_bound = max(f['b'] / (HBM_PEAK_GBS * 1e9), f['flops'] / (MFMA_F32_PEAK_TF * 1e12))
+            out['mfma_tflops'] = f['flops'] / f['t'] / 1e12
+            out['frac_of_max_hbm_mfma_bound'] = t_bound / f['t']
+        return out
+
+    def roofline_of(forms):
+        both = {k: forms['fused'][k] + forms['gather'][k] for k in ('t', 'b', 'b_real', 'flops', 'n')}
+        both['flops'] = 0.0
+        line = form_line(both) or {'achieved': 0.0, 'frac': 0.0, 'launches': 0, 'us_per_launch': 0.0, 'bytes_per_launch': 0.0}
+        line['by_form'] = {'one_kernel_layers (c_in 1/32/64: kpconv_fused*, gather + weight contraction)': form_line(forms['fused']),
+                           'gather_kernel_layers (c_in >= 128: kpconv_gather_kernel alone, as round 2 reported all 14)': form_line(forms['gather'])}
+        return line
 
     prof = [r for pl in prof_lists for r in pl]
-    t_total, t_gather, b_total, b_gather, per_layer = kp_totals(prof)
+    for rec in prof:
+        if 'pid' in rec and real_slots.get(rec['pid']):
+            rec['real_bytes'] = real_slots[rec['pid']][rec['layer']] * (8 + 12 + 4 * rec['cin'])
+    tot, forms, per_layer = kp_totals(prof)
     # With several pairs in flight the event-bracketed durations above include the time a KPConv kernel
     # shares the CUs with other pairs' kernels.  A short single-stream pass after the timed region gives the
     # same kernels' durations when they own the GPU (reported beside, never instead of, the timed-region figure).
@@ -540,16 +600,20 @@ def main():
         fence()
         if errors:
             raise errors[0]
-    it, ig, ib, ibg, per_layer_iso = kp_totals(iso_prof)
+    for rec in iso_prof:
+        if 'pid' in rec and real_slots.get(rec['pid']):
+            rec['real_bytes'] = real_slots[rec['pid']][rec['layer']] * (8 + 12 + 4 * rec['cin'])
+    itot, iforms, per_layer_iso = kp_totals(iso_prof)
     if iso_prof:
         per_layer = per_layer_iso
 
     def mfma_totals(records):
-        """fp32 FLOPs and seconds of the KPConv weight contractions [M, 15 C] x [15 C, C'] of the non-strided layers
-        (the strided layers' second event interval also holds the shortcut max-pool)."""
+        """fp32 FLOPs and seconds of the KPConv weight contractions [M, 15 C] x [15 C, C'] that run on gemm_kernel: the
+        non-strided two-kernel layers (the strided layers' second event interval also holds the shortcut max-pool; the
+        one-kernel layers contract inside kpconv_fused*)."""
         fl = tt = 0.0
         for rec in records:
-            if rec.get('pooled'):
+            if rec.get('pooled') or rec.get('fused'):
                 continue
             fl += 2.0 * rec['m'] * 15 * rec['cin'] * rec['cout']
             tt += (rec['total_ms'] - rec['gather_ms']) * 1e-3
@@ -557,43 +621,43 @@ def main():
 
     n_layers = max(len(prof), 1)
     traffic, traffic_note = None, None
-    for tag in ('r02', 'r01'):  # HBM bytes per gather dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
+    for tag in ('r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
         pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_kpconv_gather.json')
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             traffic, traffic_note = pmc['traffic_bytes_per_dispatch'], pmc['kernel'] + '; ' + pmc['source']
             break
-    achieved = b_gather / t_gather / 1e9 if t_gather > 0 else 0.0
-    # `roofline`: the kernel the north star names -- the KPConv neighbourhood gather (kpconv_gather_kernel<*> +
-    # kpconv_gather_c1_kernel, 14 launches per pair).  achieved = SURVEY §8d gather bytes M*H*(8 + 12 + 4*C_in) per launch /
-    # the launch's duration (HIP events on its stream); `achieved`/`frac` are the TIMED REGION's (several pairs share the
-    # GPU), `one_pair_in_flight` the same kernels with the GPU to themselves; `traffic` (PMC) covers the same kernels.
-    roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+    # `roofline`: the kernels the north star names -- the KPConv neighbourhood kernels, 14 launches per pair.  achieved =
+    # SURVEY 8d gather bytes M*H*(8 + 12 + 4*C_in) per launch (padded slots counted: the contract figure) / the launch's
+    # duration (HIP events on its stream); `real_slots` = the same with the slots that hold a neighbour only (the kernels
+    # stop at a row's last real neighbour).  `achieved`/`frac` are the TIMED REGION's (several pairs share the GPU),
+    # `one_pair_in_flight` the same kernels with the GPU to themselves; `traffic` (PMC) covers the same kernels.
+    roofline = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', **roofline_of(forms),
                 'traffic': traffic, 'traffic_scope': traffic_note,
-                'kernel': 'kpconv_gather_kernel<*> + kpconv_gather_c1_kernel (KPConv neighbourhood gather, 14 launches/pair)',
+                'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_fused_kernel<32|64> (6) and '
+                          'kpconv_gather_kernel<*> (8)',
                 'region': f'timed region, {len(streams)} pair(s) in flight',
-                'bytes_per_launch': b_gather / n_layers, 'us_per_launch': t_gather / n_layers * 1e6,
                 'pairs_with_layer_events': len(prof) // 14,
-                'one_pair_in_flight': ({'achieved': ibg / ig / 1e9, 'frac': ibg / ig / 1e9 / HBM_PEAK_GBS,
-                                        'us_per_launch': ig / max(len(iso_prof), 1) * 1e6,
-                                        'note': 'same kernels, 8 pairs on one stream after the timed region'} if ig > 0 else None),
-                # the whole KPConv layer (gather + weight GEMM + shortcut pool) against the same HBM peak, as round 1 reported it
-                'kpconv_layer': {'kernels': 'gather + gemm_kernel (weights) + gather_max (strided layers)',
-                                 'bytes_per_launch': b_total / n_layers,
-                                 'timed_region': {'achieved': b_total / t_total / 1e9 if t_total > 0 else 0.0,
-                                                  'frac': b_total / t_total / 1e9 / HBM_PEAK_GBS if t_total > 0 else 0.0,
-                                                  'us_per_launch': t_total / n_layers * 1e6},
-                                 'one_pair_in_flight': ({'achieved': ib / it / 1e9, 'frac': ib / it / 1e9 / HBM_PEAK_GBS,
-                                                         'us_per_launch': it / max(len(iso_prof), 1) * 1e6} if it > 0 else None),
-                                 'ms_per_pair_timed_region': t_total / max(len(prof) / 14.0, 1.0) * 1e3}}
+                'one_pair_in_flight': ({**roofline_of(iforms), 'note': 'same kernels, 8 pairs on one stream after the timed region'}
+                                       if iso_prof else None),
+                # the whole KPConv layer (+ weight GEMM / GroupNorm passes + shortcut pool) against the same HBM peak, as round 1 reported it
+                'kpconv_layer': {'kernels': 'neighbourhood kernel + gemm_kernel (weights, two-kernel layers) + GroupNorm passes (one-kernel layers) + gather_max (strided layers)',
+                                 'bytes_per_launch': tot['b_total'] / n_layers,
+                                 'timed_region': {'achieved': tot['b_total'] / tot['t_total'] / 1e9 if tot['t_total'] > 0 else 0.0,
+                                                  'frac': tot['b_total'] / tot['t_total'] / 1e9 / HBM_PEAK_GBS if tot['t_total'] > 0 else 0.0,
+                                                  'us_per_launch': tot['t_total'] / n_layers * 1e6},
+                                 'one_pair_in_flight': ({'achieved': itot['b_total'] / itot['t_total'] / 1e9,
+                                                         'frac': itot['b_total'] / itot['t_total'] / 1e9 / HBM_PEAK_GBS,
+                                                         'us_per_launch': itot['t_total'] / max(len(iso_prof), 1) * 1e6} if itot['t_total'] > 0 else None),
+                                 'ms_per_pair_timed_region': tot['t_total'] / max(len(prof) / 14.0, 1.0) * 1e3}}
     # `roofline_mfma`: the kernel family that dominates the kernel time (gemm_kernel, fp32 MFMA): the KPConv weight
     # contractions, from the same per-layer events; peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md)
     mf, mt = mfma_totals(prof)
     imf, imt = mfma_totals(iso_prof)
-    roofline_mfma = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> on the KPConv weight contractions [M,15C]x[15C,C\'] (9 non-strided layers/pair)',
-                     'achieved': mf / mt / 1e12 if mt > 0 else 0.0, 'peak': 157.3, 'unit': 'TFLOP/s',
-                     'frac': mf / mt / 1e12 / 157.3 if mt > 0 else 0.0, 'region': f'timed region, {len(streams)} pair(s) in flight',
-                     'one_pair_in_flight': ({'achieved': imf / imt / 1e12, 'frac': imf / imt / 1e12 / 157.3} if imt > 0 else None)}
+    roofline_mfma = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> on the KPConv weight contractions [M,15C]x[15C,C\'] (6 non-strided two-kernel layers/pair, c_in >= 128)',
+                     'achieved': mf / mt / 1e12 if mt > 0 else 0.0, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                     'frac': mf / mt / 1e12 / MFMA_F32_PEAK_TF if mt > 0 else 0.0, 'region': f'timed region, {len(streams)} pair(s) in flight',
+                     'one_pair_in_flight': ({'achieved': imf / imt / 1e12, 'frac': imf / imt / 1e12 / MFMA_F32_PEAK_TF} if imt > 0 else None)}
 
     if rank == 0:
         result = {
@@ -611,6 +675,10 @@ def main():
             'records': {'gathered': int(sum(g.shape[0] for g in gathered)),
                         'distinct_steps': len({int(x) for g in gathered for x in g[:, 4].tolist()}),
                         'distinct_pairs': len({int(x) for g in gathered for x in g[:, 0].tolist()})},
+            'collective': ({'backend': args.dist_backend, 'world': world, 'forced_single_rank': bool(force),
+                            'library': ('RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version())) if args.dist_backend == 'nccl' else 'gloo',
+                            'ops': 'barrier x2 per region, all_gather (counts + records), all_reduce(MAX) of the elapsed time'}
+                           if dist is not None else None),
             'host_to_host': host_to_host,
             'drop_in_api': api,
             'roofline': roofline,

@@ -144,7 +144,7 @@ int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int6
  * and nn[m] = max(1, #neighbours whose feature row sums to > 0) (as float).  Pad indices (>= n_s)
  * are the reference's shadow point/zero row.  s_positive[i] = (sum_c feats[i,c] > 0), see
  * rdm_row_positive / rdm_group_norm.  width (optional device int32) caps the row width like the
- * reference's `[:, :min(limit, max_count)]`.  c in {1, 32, 64, 128, 256, 512}; h <= 128.
+ * reference's `[:, :min(limit, max_count)]`.  c in {1, 32, 64, 128, 256, 512}; any h (rows wider than the 128 slots a wavefront stages in LDS run in chunks).
  * The second half of the convolution is rdm_gemm(wf, W[15*c, c'], rowdiv = nn, bias).          */
 int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
                       const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
@@ -244,23 +244,6 @@ int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, i
                        const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
                        const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
                        const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out, void* stream);
-/* rdm_attention_tail_proj: rdm_attention_tail, whose workgroups also compute up to two Linear layers of the rows they have just
- * produced -- the projections the FOLLOWING attention layers need (cross layer: q of all rows and k|v of the src rows; the
- * k|v of the updated ref rows; the next self layer's q|k|v; the transformer's output projection), i.e. the rdm_gemm launches
- * that would otherwise follow the tail:  dst[row, :ncols] = out[row, :] b + bias  for rows [row_lo, row_hi) of the call
- * (b [128, ld_b] as rdm_gemm's B operand).  Same arithmetic as that rdm_gemm launch, hence the same bits. */
-typedef struct rdm_tail_projection {
-  const float* b;      /* [128, ldb] */
-  const float* bias;   /* [ncols] or NULL */
-  float* dst;          /* [m, ldd] (row 0 = the call's first row) */
-  int64_t ncols, ldb, ldd;
-  int64_t row_lo, row_hi;
-} rdm_tail_projection;
-int rdm_attention_tail_proj(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
-                            const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
-                            const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
-                            const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out,
-                            const rdm_tail_projection* proj, int n_proj, void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
 /* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the
@@ -293,47 +276,6 @@ int rdm_attention_bf16(const float* q, int64_t ldq, const float* k, int64_t ldk,
 int rdm_attention_self_pair(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                             float* out, int64_t ldo, int64_t n0, int64_t n1, int heads, int head_dim, int bf16,
                             void* stream);
-
-/* rdm_attention_layer: ONE application of an attention layer to blocks of 16 query rows as one launch
- * (rdmnet/thdroformer/thdroformer.py:142-202 RPEAttentionLayer + RPETransformerLayer, :204-251 the self / cross schedule of
- * RPEConditionalTransformer; geotransformer/modules/transformer/vanilla_transformer.py:15-129, output_layer.py:6-21):
- *   hid = softmax(q k^T / sqrt(head_dim)) v                      per head, the attention of rdm_attention
- *   y   = LayerNorm(hid Wo^T + bo + x);  out = LayerNorm(relu(y W1^T + b1) W2^T + b2 + y)        = rdm_attention_tail
- *   dst_p = out Wp^T + bp  [+ rotary embedding of its leading rope_cols columns, as rdm_rope]   for up to two
- *           projections p -- the q|k|v (self), q and k|v (cross) inputs of the layers that follow, or the transformer's
- *           output projection -- so that the only launch boundaries of a transformer are the ones attention itself needs.
- * Rows are "stacked" row indices ([ref; src]); a segment is a range of query rows with its own keys/values (self layer:
- * two segments, each cloud attends to itself; cross layer: one segment per step).  Width 128 = 4 heads x 32 with a 256-wide
- * FFN; weights as nn.Linear stores them ([out, in], in contiguous), 16-byte aligned, row strides multiples of 4.
- * projections_only != 0: no attention and no tail, the rows of `out` are projected (the first layer's q|k|v). */
-typedef struct rdm_layer_projection {
-  const float* w;      /* [ncols, 128], row stride ldw */
-  const float* bias;   /* [ncols] or NULL */
-  float* dst;          /* [stacked rows, ncols], row stride ldd */
-  int32_t ncols;       /* multiple of 128 */
-  int32_t ldw, ldd;
-  int32_t rope_cols;   /* 0, 128 or 256: leading columns rotated by theta = 2 pi sigmoid(emb[row, (col % 128) / 2]) */
-  int32_t segments;    /* bit s: the projection applies to the rows of segment s */
-} rdm_layer_projection;
-typedef struct rdm_attention_layer_args {
-  const float* q;      /* [stacked rows, >= 128] projected (and rotated) queries */
-  const float* x;      /* [stacked rows, >= 128] layer input (residual) */
-  float* out;          /* [stacked rows, >= 128] layer output */
-  int64_t ldq, ldx, ldo;
-  int32_t n_segments;  /* 1 or 2 */
-  int32_t heads, head_dim, bf16, projections_only, n_projections;
-  int64_t row0[2], n_q[2];  /* query rows [row0, row0 + n_q) of each segment */
-  const float* k[2];        /* keys of each segment [n_k, >= 128], row stride ldk */
-  const float* v[2];
-  int64_t ldk[2], ldv[2], n_k[2];
-  const float *wo, *bo, *gamma1, *beta1, *w1, *b1, *w2, *b2, *gamma2, *beta2;  /* as rdm_attention_tail */
-  int64_t ld_wo, ld_w1, ld_w2;
-  float eps;
-  rdm_layer_projection proj[2];
-  const float* emb;    /* [stacked rows, 64] rotary embedding input (embedding.proj output); needed when rope_cols > 0 */
-  int64_t lde;
-} rdm_attention_layer_args;
-int rdm_attention_layer(const rdm_attention_layer_args* args, void* stream);
 
 /* ---- a8/a9 helpers ------------------------------------------------------------------------------
  * rdm_vote_shift: xyz + clamp(offset[:, :3], +-limit) (rdmnet/vote/vote.py:98-108).
@@ -463,6 +405,13 @@ typedef struct rdm_engine_result {
   const float* corr_scores;
   const float* transform_dev;
   size_t arena_used;
+  /* the same correspondences on the HOST (engine-owned pinned memory, written by the run's last kernel; valid until the
+   * next call on this engine): what infer.py:70-101 reads after `.cpu()`.  n_host_correspondences == n_correspondences
+   * (the buffer holds the path's upper bound, num_correspondences x 2 x points_in_patch).                             */
+  const float* host_ref_corr_points;  /* [n, 3] */
+  const float* host_src_corr_points;  /* [n, 3] */
+  const float* host_corr_scores;      /* [n] */
+  int32_t n_host_correspondences;
 } rdm_engine_result;
 
 typedef struct rdm_tensor_view {
@@ -473,8 +422,12 @@ typedef struct rdm_tensor_view {
 
 typedef struct rdm_kpconv_profile {   /* one KPConv layer of the last run (HIP events on the run's stream) */
   int64_t m, h, c_in, c_out, pooled_channels;
-  float gather_ms;            /* rdm_kpconv_gather alone */
-  float total_ms;             /* gather + weight GEMM (+ the shortcut max-pool of strided blocks) */
+  float gather_ms;            /* the neighbourhood kernel alone: rdm_kpconv_gather, or rdm_kpconv_fused (gather + weight
+                                 contraction in one kernel) when `fused` */
+  float total_ms;             /* whole layer: + weight GEMM (two-kernel form) or + GroupNorm passes (fused form), + the
+                                 shortcut max-pool of strided blocks */
+  int32_t fused;              /* 1: the layer ran as ONE kernel (c_in = 1, 32, 64) */
+  int32_t reserved;
 } rdm_kpconv_profile;
 
 int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out);
@@ -499,6 +452,10 @@ typedef struct rdm_data_dict {
   const int64_t* neighbors[5];   int64_t neighbors_width[5],   neighbors_ld[5];   const int32_t* neighbors_count[5];
   const int64_t* subsampling[4]; int64_t subsampling_width[4], subsampling_ld[4]; const int32_t* subsampling_count[4];
   const int64_t* upsampling[4];  int64_t upsampling_width[4],  upsampling_ld[4];  const int32_t* upsampling_count[4];
+  /* optional: the {max count, status} words of the searches that built the tables (rdm_engine_collate's "search_flags",
+   * device int32 [n_collate_status, 2]).  A non-zero status word makes rdm_engine_forward return RDM_ERR_CAPACITY at its
+   * first read-back instead of computing on a broken table; null / 0 for tables from another collate.              */
+  const int32_t* collate_status; int64_t n_collate_status;
 } rdm_data_dict;
 
 /* rdm_engine_collate = the collate alone (registration_collate_fn_stack_mode / precompute_data_stack_mode,

@@ -11,9 +11,21 @@ def per_kernel(db, counter):
     return {r[0]: (r[1], r[2], r[3]) for r in rows}
 
 
+def pairs_in(db, counter):
+    """Scan pairs the profiled process ran = dispatches of a once-per-pair kernel (nms_kernel)."""
+    cur = sqlite3.connect(db).cursor()
+    return cur.execute("select count(*) from pmc_events where counter_name=? and name like '%nms_kernel%'", (counter,)).fetchone()[0]
+
+
 def main(fetch_db, write_db, steps):
     f, w = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
-    print('| kernel | dispatches/step | FETCH_SIZE KB/dispatch (raw) | WRITE_SIZE KB/dispatch (raw) | fetch MB/step | write MB/step |')
+    if steps <= 0:  # count them (round 2 passed a constant that did not match the run: 14 against 10 pairs)
+        steps = pairs_in(fetch_db, 'FETCH_SIZE')
+        assert steps == pairs_in(write_db, 'WRITE_SIZE'), 'the two passes ran different numbers of pairs'
+    print(f'pairs in each pass: {steps}; whole run per pair: FETCH_SIZE {sum(v[2] for v in f.values()) / steps / 1024:.1f} MB raw '
+          f'(x2 on gfx950 for wide reads = {2 * sum(v[2] for v in f.values()) / steps / 1024:.1f} MB), WRITE_SIZE '
+          f'{sum(v[2] for v in w.values()) / steps / 1024:.1f} MB\n')
+    print('| kernel | dispatches/pair | FETCH_SIZE KB/dispatch (raw) | WRITE_SIZE KB/dispatch (raw) | fetch MB/pair | write MB/pair |')
     print('|---|---|---|---|---|---|')
     names = sorted(f, key=lambda k: -(f[k][2] + w.get(k, (0, 0, 0))[2]))
     for k in names[:30]:

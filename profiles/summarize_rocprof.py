@@ -10,6 +10,8 @@ def main(db_path, steps):
     rows = cur.execute('select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) '
                        'from kernels group by name order by 3 desc').fetchall()
     tot = sum(r[2] for r in rows)
+    if steps <= 0:  # pairs the process ran = dispatches of a once-per-pair kernel
+        steps = max(1, sum(r[1] for r in rows if 'nms_kernel' in r[0]))
     print(f'total kernel time {tot / 1e6:.3f} ms over {steps} steps = {tot / steps / 1e6:.3f} ms/step\n')
     print('| kernel | calls/step | total ms | avg us | min us | max us | % |')
     print('|---|---|---|---|---|---|---|')

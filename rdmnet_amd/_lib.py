@@ -73,9 +73,6 @@ SIGNATURES = {
                                       c_f32, c_int, c_void, c_i64, c_void]),
     'rdm_attention_tail': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void, c_i64,
                                    c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void]),
-    'rdm_attention_tail_proj': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void,
-                                        c_i64, c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void, c_int,
-                                        c_void]),
     'rdm_gather_max': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_i64,
                                c_void]),
     'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,
@@ -88,7 +85,6 @@ SIGNATURES = {
                               c_void]),
     'rdm_attention_self_pair': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_int, c_int,
                                         c_int, c_void]),
-    'rdm_attention_layer': (c_int, [c_void, c_void]),
     'rdm_vote_shift': (c_int, [c_void, c_void, c_i64, c_i64, c_f32, c_f32, c_f32, c_void, c_void]),
     'rdm_sigmoid_column': (c_int, [c_void, c_i64, c_i64, c_void, c_void]),
     'rdm_l2_normalize': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void]),
@@ -126,31 +122,6 @@ SIGNATURES = {
     'rdm_copy_device': (c_int, [c_void, c_void, c_size, c_void]),
 }
 
-
-
-class TailProjection(ctypes.Structure):
-    """rdm_tail_projection (include/rdmnet_hip.h)"""
-    _fields_ = [('b', c_void), ('bias', c_void), ('dst', c_void), ('ncols', c_i64), ('ldb', c_i64), ('ldd', c_i64),
-                ('row_lo', c_i64), ('row_hi', c_i64)]
-
-
-class LayerProjection(ctypes.Structure):
-    """rdm_layer_projection (include/rdmnet_hip.h)"""
-    _fields_ = [('w', c_void), ('bias', c_void), ('dst', c_void), ('ncols', ctypes.c_int32), ('ldw', ctypes.c_int32),
-                ('ldd', ctypes.c_int32), ('rope_cols', ctypes.c_int32), ('segments', ctypes.c_int32)]
-
-
-class AttentionLayerArgs(ctypes.Structure):
-    """rdm_attention_layer_args (include/rdmnet_hip.h)"""
-    _fields_ = [('q', c_void), ('x', c_void), ('out', c_void), ('ldq', c_i64), ('ldx', c_i64), ('ldo', c_i64),
-                ('n_segments', ctypes.c_int32), ('heads', ctypes.c_int32), ('head_dim', ctypes.c_int32), ('bf16', ctypes.c_int32),
-                ('projections_only', ctypes.c_int32), ('n_projections', ctypes.c_int32),
-                ('row0', c_i64 * 2), ('n_q', c_i64 * 2), ('k', c_void * 2), ('v', c_void * 2),
-                ('ldk', c_i64 * 2), ('ldv', c_i64 * 2), ('n_k', c_i64 * 2),
-                ('wo', c_void), ('bo', c_void), ('gamma1', c_void), ('beta1', c_void), ('w1', c_void), ('b1', c_void),
-                ('w2', c_void), ('b2', c_void), ('gamma2', c_void), ('beta2', c_void),
-                ('ld_wo', c_i64), ('ld_w1', c_i64), ('ld_w2', c_i64), ('eps', c_f32),
-                ('proj', LayerProjection * 2), ('emb', c_void), ('lde', c_i64)]
 
 
 _lib = None

@@ -49,16 +49,25 @@ inline int launch_status(const char* what) {
   return RDM_OK;
 }
 
-// Developer knob for marginal-cost measurements (tools/exp_dup.sh): RDM_DUP="<class>[:<n>]" launches every kernel of
-// that class n times (default 2) in a row -- the launches are idempotent, results do not change -- so the drop in pairs/s
-// is what that class costs with several pairs in flight.  Unset: one launch, the call sites cache the answer.
+// Developer knobs (A/B switches and tuning overrides behind the measurements in DESIGN.md 5) exist in the LAB build only
+// (`make lab` -> librdmnet_hip_lab.so, compiled with -DRDM_DEV_KNOBS; tools/*.sh select it with RDM_LIB_PATH): the
+// product library never reads the environment.
+#ifdef RDM_DEV_KNOBS
+inline const char* dev_knob(const char* name) { return getenv(name); }
+#else
+inline const char* dev_knob(const char*) { return nullptr; }
+#endif
+
+// Developer knob for marginal-cost measurements (tools/exp_dup.sh, lab build): RDM_DUP="<class>[:<n>]" launches every
+// kernel of that class n times (default 2) in a row -- the launches are idempotent, results do not change -- so the drop in
+// pairs/s is what that class costs with several pairs in flight.  Unset (and in the product build): one launch.
 inline int dup_reps(const char* cls) {
-  const char* e = getenv("RDM_DUP");
+  const char* e = dev_knob("RDM_DUP");
   if (!e) return 1;
   const size_t n = strlen(cls);
   if (strncmp(e, cls, n) != 0 || (e[n] != 0 && e[n] != ':')) return 1;
   const int r = e[n] == ':' ? atoi(e + n + 1) : 2;
-  return r >= 0 && r <= 16 ? r : 1;
+  return r >= 1 && r <= 16 ? r : 1;  // (0 would skip the kernel and corrupt the results)
 }
 #define RDM_DUP_CAT2(a, b) a##b
 #define RDM_DUP_CAT(a, b) RDM_DUP_CAT2(a, b)

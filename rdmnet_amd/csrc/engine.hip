@@ -61,6 +61,7 @@ struct rdm_engine {
   bool arena_exhausted = false, arena_fixed = false;  // fixed: the caller chose arena_bytes, never regrown
   void* pinned = nullptr;     // small host staging buffer for the size read-backs (mapped: kernels write it)
   void* pinned_dev = nullptr; // its device address
+  int64_t host_corr_cap = 0;  // correspondences the mapped buffer holds behind its first 4 KB
   int wait_sleep_us = 0;      // 0: hipStreamSynchronize (spins a core); > 0: poll hipStreamQuery and sleep in between
   bool finalized = false;
   std::map<std::string, rdm_tensor_view> taps;
@@ -284,10 +285,15 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     const int li = e->prof_layers;
     const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
-    ENG_CHECK(rdm_kpconv_fused_group_norm(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
-                                          vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, r.groups, gam, bet,
-                                          1e-5f, 2, conv.p, conv.ld, y.p, y.ld, r.ws, r.ws_bytes, r.st));
+    // (rdm_kpconv_fused_group_norm's two halves, so that the layer events bracket the convolution kernel alone)
+    const int nblk = static_cast<int>(ceil_div<int64_t>(q.n, rdm_kpconv_fused_rows_per_block(cin)));
+    double* gn_partial = static_cast<double*>(r.ws);
+    const size_t stat_bytes = align_up(static_cast<size_t>(nblk) * 2 * W.out * sizeof(double));
+    ENG_CHECK(rdm_kpconv_fused(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
+                               vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, r.st));
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
+    ENG_CHECK(group_norm_finish(gn_partial, nblk, conv.p, q.n, W.out, conv.ld, r.groups, gam, bet, 1e-5f, nullptr, 0, 2, y.p, y.ld,
+                                nullptr, static_cast<char*>(r.ws) + stat_bytes, r.ws_bytes - stat_bytes, r.st));
     if (pool_src) {
       *pool_out = e->mat(q.n, pool_src->cols);
       ENG_ALLOC(pool_out->p);
@@ -299,6 +305,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
       rdm_kpconv_profile p;
       p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
       p.gather_ms = p.total_ms = 0.f;
+      p.fused = 1; p.reserved = 0;
       e->prof.push_back(p);
       e->prof_layers++;
     }
@@ -336,6 +343,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     rdm_kpconv_profile p;
     p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
     p.gather_ms = p.total_ms = 0.f;
+    p.fused = 0; p.reserved = 0;
     e->prof.push_back(p);
     e->prof_layers++;
   }
@@ -380,11 +388,10 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
 
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
   rdm_engine* e = r.e;
-  static const bool no_fused = getenv("RDM_NO_FUSED_TAIL") != nullptr;  // developer knob: the three separate launches
   auto lo = e->lin.find(p + ".attention.linear"), l1 = e->lin.find(p + ".output.expand"), l2 = e->lin.find(p + ".output.squeeze");
   if (lo != e->lin.end() && l1 != e->lin.end() && l2 != e->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&
       lo->second.out == 128 && lo->second.kpad == 128 && l1->second.out == 256 && l1->second.kpad == 128 &&
-      l2->second.out == 128 && l2->second.kpad == 256 && !no_fused) {
+      l2->second.out == 128 && l2->second.kpad == 256) {
     const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
     return rdm_attention_tail(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias, vecp(r, p + ".attention.norm.weight"),
                               vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias, L2.wt, L2.kpad, L2.bias,
@@ -400,218 +407,8 @@ int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, M
 // are shared by both clouds (embedding, in/out projections, and in self layers the q|k|v projection,
 // rotary embedding and the whole tail) runs once on all rows; only the attention itself is per cloud.
 // Cross layers keep the reference's order: src attends to the UPDATED ref features (:244-245).
-// The same with one launch per attention application (rdm_attention_layer: attention + tail + the projections the
-// following layers need): 3 launches per (self, cross) layer pair instead of 10.  Needs the transformer width 128 =
-// 4 heads x 32 with a 256-wide FFN; returns 1 when the configuration does not fit (the caller then runs the per-op
-// sequence below).
-int thdroformer_fused(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
-  rdm_engine* e = r.e;
-  const int64_t N = x.rows, n1 = N - n0;
-  auto find = [&](const std::string& key) -> const Linear* {
-    auto it = e->lin.find(key);
-    return it == e->lin.end() ? nullptr : &it->second;
-  };
-  if (e->cfg.num_heads != 4 || num_layers < 1 || n0 <= 0 || n1 <= 0) return 1;
-  const Linear* op = find(name + ".out_proj");
-  if (!op || !op->wt || op->kpad != 128 || op->out % 128 != 0 || out.ld < op->out) return 1;
-  for (int i = 0; i < 2 * num_layers; ++i) {
-    const std::string p = name + ".transformer.layers." + std::to_string(i);
-    const Linear *lo = find(p + ".attention.linear"), *l1 = find(p + ".output.expand"), *l2 = find(p + ".output.squeeze");
-    if (!lo || !l1 || !l2 || !lo->wt || !l1->wt || !l2->wt || lo->out != 128 || lo->kpad != 128 || l1->out != 256 ||
-        l1->kpad != 128 || l2->out != 128 || l2->kpad != 256)
-      return 1;
-    const Linear *a = find(p + (i % 2 == 0 ? ".qkv" : ".q")), *b = i % 2 == 0 ? a : find(p + ".kv");
-    if (!a || !b || !a->wt || !b->wt || a->kpad != 128 || b->kpad != 128 || a->out != (i % 2 == 0 ? 384 : 128) ||
-        b->out != (i % 2 == 0 ? 384 : 256))
-      return 1;
-  }
-  Mat emb, f;
-  ENG_CHECK(linear(r, name + ".embedding.proj", pts4, emb));
-  ENG_CHECK(linear(r, name + ".in_proj", x, f));
-  if (f.cols != 128 || emb.cols < 64) return 1;
-  Mat qkv = e->mat(N, 384), q2 = e->mat(N, 128), kv = e->mat(N, 256);
-  ENG_ALLOC(qkv.p); ENG_ALLOC(q2.p); ENG_ALLOC(kv.p);
-  auto projection = [&](const Linear& L, float* dst, int64_t ldd, int rope_cols, int segments) {
-    rdm_layer_projection P;
-    P.w = L.wt; P.bias = L.bias; P.dst = dst; P.ncols = static_cast<int32_t>(L.out); P.ldw = static_cast<int32_t>(L.kpad);
-    P.ldd = static_cast<int32_t>(ldd); P.rope_cols = rope_cols; P.segments = segments;
-    return P;
-  };
-  rdm_attention_layer_args a;
-  std::memset(&a, 0, sizeof(a));
-  a.heads = 4; a.head_dim = 32; a.bf16 = e->cfg.attention_bf16 ? 1 : 0; a.eps = 1e-5f;
-  a.emb = emb.p; a.lde = emb.ld;
-  // the first self layer's q|k|v (+ rotary embedding) from the in_proj rows
-  a.projections_only = 1;
-  a.out = f.p; a.ldo = f.ld;
-  a.n_segments = 1; a.row0[0] = 0; a.n_q[0] = N;
-  a.n_projections = 1;
-  a.proj[0] = projection(*find(name + ".transformer.layers.0.qkv"), qkv.p, qkv.ld, 256, 1);
-  ENG_CHECK(rdm_attention_layer(&a, r.st));
-  a.projections_only = 0;
-  for (int i = 0; i < 2 * num_layers; ++i) {
-    const std::string p = name + ".transformer.layers." + std::to_string(i);
-    const std::string pn = name + ".transformer.layers." + std::to_string(i + 1);
-    const bool last = i + 1 == 2 * num_layers;
-    Mat fnew = e->mat(N, 128);
-    ENG_ALLOC(fnew.p);
-    const Linear &Lo = *find(p + ".attention.linear"), &L1 = *find(p + ".output.expand"), &L2 = *find(p + ".output.squeeze");
-    a.x = f.p; a.ldx = f.ld; a.out = fnew.p; a.ldo = fnew.ld;
-    a.wo = Lo.wt; a.ld_wo = Lo.kpad; a.bo = Lo.bias; a.gamma1 = vecp(r, p + ".attention.norm.weight");
-    a.beta1 = vecp(r, p + ".attention.norm.bias");
-    a.w1 = L1.wt; a.ld_w1 = L1.kpad; a.b1 = L1.bias; a.w2 = L2.wt; a.ld_w2 = L2.kpad; a.b2 = L2.bias;
-    a.gamma2 = vecp(r, p + ".output.norm.weight"); a.beta2 = vecp(r, p + ".output.norm.bias");
-    if (!a.gamma1 || !a.beta1 || !a.gamma2 || !a.beta2) {
-      set_error("rdm_engine: missing LayerNorm parameters of %s", p.c_str());
-      return RDM_ERR_ARG;
-    }
-    // what the layers after this one need from the new rows
-    auto next_inputs = [&](int first_slot, int segments) {  // the next SELF layer's q|k|v, or the output projection
-      a.proj[first_slot] = last ? projection(*find(name + ".out_proj"), out.p, out.ld, 0, segments)
-                                : projection(*find(pn + ".qkv"), qkv.p, qkv.ld, 256, segments);
-      a.n_projections = first_slot + 1;
-    };
-    if (i % 2 == 0) {  // self layer: each cloud attends to itself; then q (all rows) and k|v (src rows) of the cross layer
-      a.q = qkv.p; a.ldq = qkv.ld;
-      a.n_segments = 2;
-      a.row0[0] = 0; a.n_q[0] = n0; a.k[0] = qkv.p + 128; a.v[0] = qkv.p + 256; a.ldk[0] = a.ldv[0] = qkv.ld; a.n_k[0] = n0;
-      a.row0[1] = n0; a.n_q[1] = n1; a.k[1] = qkv.p + n0 * qkv.ld + 128; a.v[1] = qkv.p + n0 * qkv.ld + 256;
-      a.ldk[1] = a.ldv[1] = qkv.ld; a.n_k[1] = n1;
-      a.proj[0] = projection(*find(pn + ".q"), q2.p, q2.ld, 0, 3);
-      a.proj[1] = projection(*find(pn + ".kv"), kv.p, kv.ld, 0, 2);
-      a.n_projections = 2;
-      ENG_CHECK(rdm_attention_layer(&a, r.st));
-    } else {  // cross layer, the reference's order: ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
-      a.q = q2.p; a.ldq = q2.ld;
-      a.n_segments = 1;
-      a.row0[0] = 0; a.n_q[0] = n0; a.k[0] = kv.p + n0 * kv.ld; a.v[0] = kv.p + n0 * kv.ld + 128; a.ldk[0] = a.ldv[0] = kv.ld;
-      a.n_k[0] = n1;
-      a.proj[0] = projection(*find(p + ".kv"), kv.p, kv.ld, 0, 1);  // k|v of the updated ref rows for the second step
-      next_inputs(1, 1);
-      ENG_CHECK(rdm_attention_layer(&a, r.st));
-      a.row0[0] = n0; a.n_q[0] = n1; a.k[0] = kv.p; a.v[0] = kv.p + 128; a.n_k[0] = n0;
-      next_inputs(0, 1);
-      ENG_CHECK(rdm_attention_layer(&a, r.st));
-    }
-    f = fnew;
-  }
-  return RDM_OK;
-}
-
-// The per-op sequence with the projections of a layer's NEW rows computed by the tail's own launch (rdm_attention_tail_proj:
-// same bits as the rdm_gemm launches they replace): per (self, cross) layer pair 7 launches instead of 10 -- rotary embedding,
-// self attention, tail [+ the cross layer's q and k|v]; attention ref <- src, tail [+ k|v of the updated ref rows + the next
-// self layer's q|k|v of those rows]; attention src <- ref, tail [+ the next q|k|v of the src rows] (the last layer: the output
-// projection instead).  Returns 1 when the configuration does not fit (width 128, 256-wide FFN).
-int thdroformer_tail_proj(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
-  rdm_engine* e = r.e;
-  const int heads = e->cfg.num_heads;
-  const int64_t N = x.rows, n1 = N - n0;
-  auto find = [&](const std::string& key) -> const Linear* {
-    auto it = e->lin.find(key);
-    return it == e->lin.end() ? nullptr : &it->second;
-  };
-  if (num_layers < 1 || n0 <= 0 || n1 <= 0 || N > 1536) return 1;  // (rdm_gemm takes its 32x32 K-split kernel up to 1536 rows)
-  const Linear* op = find(name + ".out_proj");
-  if (!op || op->kpad != 128 || out.ld < op->out || N * op->out > 1536 * 512) return 1;
-  for (int i = 0; i < 2 * num_layers; ++i) {
-    const std::string p = name + ".transformer.layers." + std::to_string(i);
-    const Linear *lo = find(p + ".attention.linear"), *l1 = find(p + ".output.expand"), *l2 = find(p + ".output.squeeze");
-    if (!lo || !l1 || !l2 || !lo->wt || !l1->wt || !l2->wt || lo->out != 128 || lo->kpad != 128 || l1->out != 256 ||
-        l1->kpad != 128 || l2->out != 128 || l2->kpad != 256)
-      return 1;
-    const Linear *a = find(p + (i % 2 == 0 ? ".qkv" : ".q")), *b = i % 2 == 0 ? a : find(p + ".kv");
-    if (!a || !b || a->kpad != 128 || b->kpad != 128 || a->out != (i % 2 == 0 ? 384 : 128) || b->out != (i % 2 == 0 ? 384 : 256))
-      return 1;
-  }
-  Mat emb, f;
-  ENG_CHECK(linear(r, name + ".embedding.proj", pts4, emb));
-  ENG_CHECK(linear(r, name + ".in_proj", x, f));
-  if (f.cols != 128) return 1;
-  const int64_t d = 128;
-  const int hd = static_cast<int>(d / heads);
-  const auto attend = e->cfg.attention_bf16 ? rdm_attention_bf16 : rdm_attention;
-  Mat qkv, q2 = e->mat(N, d), kv = e->mat(N, 2 * d);
-  ENG_ALLOC(q2.p); ENG_ALLOC(kv.p);
-  ENG_CHECK(linear(r, name + ".transformer.layers.0.qkv", f, qkv));
-  auto tail = [&](const std::string& p, const Mat& hid, const Mat& xin, Mat fout, const rdm_tail_projection* pr, int npr) -> int {
-    const Linear &Lo = *find(p + ".attention.linear"), &L1 = *find(p + ".output.expand"), &L2 = *find(p + ".output.squeeze");
-    return rdm_attention_tail_proj(hid.p, hid.ld, xin.p, xin.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias,
-                                   vecp(r, p + ".attention.norm.weight"), vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias,
-                                   L2.wt, L2.kpad, L2.bias, vecp(r, p + ".output.norm.weight"), vecp(r, p + ".output.norm.bias"), 1e-5f,
-                                   fout.p, fout.ld, pr, npr, r.st);
-  };
-  auto proj = [&](const Linear& L, float* dst, int64_t ldd, int64_t lo, int64_t hi) {
-    rdm_tail_projection P;
-    P.b = L.b; P.bias = L.bias; P.dst = dst; P.ncols = L.out; P.ldb = L.ldb; P.ldd = ldd; P.row_lo = lo; P.row_hi = hi;
-    return P;
-  };
-  for (int i = 0; i < 2 * num_layers; ++i) {
-    const std::string p = name + ".transformer.layers." + std::to_string(i);
-    const std::string pn = name + ".transformer.layers." + std::to_string(i + 1);
-    const bool last = i + 1 == 2 * num_layers;
-    Mat fnew = e->mat(N, d), hid = e->mat(N, d);
-    ENG_ALLOC(fnew.p); ENG_ALLOC(hid.p);
-    if (i % 2 == 0) {
-      Mat q = qkv.cols_from(0, d), k = qkv.cols_from(d, d), v = qkv.cols_from(2 * d, d);
-      ENG_CHECK(rdm_rope(q.p, q.ld, k.p, k.ld, emb.p, emb.ld, N, d, r.st));
-      ENG_CHECK(rdm_attention_self_pair(q.p, q.ld, k.p, k.ld, v.p, v.ld, hid.p, hid.ld, n0, n1, heads, hd,
-                                        e->cfg.attention_bf16 ? 1 : 0, r.st));
-      // the cross layer's q (all rows) and k|v of the src rows (its first step attends ref <- src)
-      const rdm_tail_projection pr[2] = {proj(*find(pn + ".q"), q2.p, q2.ld, 0, N), proj(*find(pn + ".kv"), kv.p, kv.ld, n0, N)};
-      ENG_CHECK(tail(p, hid, f, fnew, pr, 2));
-    } else {
-      Mat qkv_next;
-      if (!last) {
-        qkv_next = e->mat(N, 3 * d);
-        ENG_ALLOC(qkv_next.p);
-      }
-      auto next_inputs = [&](int64_t row0, int64_t rows) {  // for the rows of one cloud (the call's rows start at row0)
-        return last ? proj(*op, out.p + row0 * out.ld, out.ld, 0, rows)
-                    : proj(*find(pn + ".qkv"), qkv_next.p + row0 * qkv_next.ld, qkv_next.ld, 0, rows);
-      };
-      // ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
-      ENG_CHECK(attend(q2.p, q2.ld, kv.p + n0 * kv.ld, kv.ld, kv.p + n0 * kv.ld + d, kv.ld, hid.p, hid.ld, n0, n1, heads, hd, r.st));
-      {
-        const rdm_tail_projection pr[2] = {proj(*find(p + ".kv"), kv.p, kv.ld, 0, n0), next_inputs(0, n0)};
-        ENG_CHECK(tail(p, hid.rows_from(0, n0), f.rows_from(0, n0), fnew.rows_from(0, n0), pr, 2));
-      }
-      ENG_CHECK(attend(q2.p + n0 * q2.ld, q2.ld, kv.p, kv.ld, kv.p + d, kv.ld, hid.p + n0 * hid.ld, hid.ld, n1, n0, heads, hd, r.st));
-      {
-        const rdm_tail_projection pr[1] = {next_inputs(n0, n1)};
-        ENG_CHECK(tail(p, hid.rows_from(n0, n1), f.rows_from(n0, n1), fnew.rows_from(n0, n1), pr, 1));
-      }
-      qkv = qkv_next;
-    }
-    f = fnew;
-  }
-  return RDM_OK;
-}
-
 int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
   rdm_engine* e = r.e;
-  // RDM_FUSED_LAYER=1: one launch per attention application (86 -> 28 launches per pair).  Measured: +1.3 %
-  // pairs/s with four pairs in flight, but 6 % slower with one -- a 16-row block then pulls all four heads' keys/values and
-  // the following layers' projection weights through ONE CU's ~20 B/clk L2 port (40-46 us per launch against 9 + 14 + 5 us
-  // for the attention (212 workgroups), the tail and the projections as separate launches) -- hence opt-in.
-  static const bool fused_layer = [] { const char* v = getenv("RDM_FUSED_LAYER"); return v && v[0] == '1'; }();
-  if (fused_layer) {
-    const size_t mark = e->arena_off;
-    const int rc = thdroformer_fused(r, name, pts4, x, n0, num_layers, out);
-    if (rc != 1) return rc;
-    e->arena_off = mark;  // configuration outside the fused kernel's shapes
-  }
-  // RDM_TAIL_PROJ=1: the projections of a layer's new rows inside the tail's launch (7 launches per layer pair instead of
-  // 10, same bits).  Measured slower -- 485 against 494 pairs/s at four in flight, 4.39 against 4.12 ms with one: the 53
-  // workgroups of a tail then stream up to 320 KB more weights through their CU's L2 port each and run half-empty 32-row
-  // tiles, where the separate rdm_gemm spreads the same product over ~300 workgroups -- hence opt-in.
-  static const bool tail_proj = [] { const char* v = getenv("RDM_TAIL_PROJ"); return v && v[0] == '1'; }();
-  if (tail_proj) {
-    const size_t mark = e->arena_off;
-    const int rc = thdroformer_tail_proj(r, name, pts4, x, n0, num_layers, out);
-    if (rc != 1) return rc;
-    e->arena_off = mark;
-  }
   const int heads = e->cfg.num_heads;
   const int64_t N = x.rows, n1 = N - n0;
   Mat emb, f;
@@ -703,6 +500,25 @@ __global__ void concat_points_kernel(const float* a, int64_t na, const float* b,
   else if (i < 3 * (na + nb)) out[i] = b[i - 3 * na];
 }
 
+// The host half of a pair's result in one launch: pose + counters (19 words) and the first n correspondences
+// ([ref points 3n | src points 3n | scores n]) go straight into the mapped pinned buffer.
+__global__ __launch_bounds__(256) void export_result_kernel(const float* T, const float* rc, const float* sc, const float* cs,
+                                                            uint32_t* head, float* corr, int cap) {
+  const int n = min(reinterpret_cast<const int32_t*>(T)[16], cap);
+  const int tid = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+  if (tid < 19) head[tid] = reinterpret_cast<const uint32_t*>(T)[tid];
+  for (int i = tid; i < 7 * n; i += nt) corr[i] = i < 3 * n ? rc[i] : (i < 6 * n ? sc[i - 3 * n] : cs[i - 6 * n]);
+}
+
+// dst = OR of the status words of n {max count, status} pairs (one wavefront)
+__global__ __launch_bounds__(64) void or_status_kernel(const int32_t* pairs, int n, int32_t* dst) {
+  int v = 0;
+  for (int i = threadIdx.x; i < n; i += 64) v |= pairs[2 * i + 1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+  if (threadIdx.x == 0) *dst = v;
+}
+
 template <typename K, typename... A>
 int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
   if (n <= 0) return RDM_OK;
@@ -752,7 +568,11 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
     delete e;
     return RDM_ERR_HIP;
   }
-  err = hipHostMalloc(&e->pinned, 4096, hipHostMallocMapped);
+  // mapped pinned memory: 4 KB for the size / pose read-backs, then the correspondences of a run ([3n | 3n | n] floats, at
+  // most num_correspondences x 2 x points_in_patch of them: local_global_registration.py:145-202) -- the host half of a
+  // pair's result (transform + correspondences on the host) without a copy operation on the stream
+  e->host_corr_cap = static_cast<int64_t>(std::max(cfg->num_correspondences, 1)) * 2 * std::max(cfg->points_in_patch, 1);
+  err = hipHostMalloc(&e->pinned, 4096 + static_cast<size_t>(e->host_corr_cap) * 7 * sizeof(float), hipHostMallocMapped);
   if (err == hipSuccess) err = hipHostGetDevicePointer(&e->pinned_dev, e->pinned, 0);
   if (err != hipSuccess) {
     set_error("rdm_engine_create: hipHostMalloc failed: %s", hipGetErrorString(err));
@@ -965,15 +785,19 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
 
 // The collate alone (geotransformer/utils/data.py:13-77 on two clouds): the pyramid and its 13 searches stay in the engine's
 // arena as stage tensors ("points0".."points4", "lengths0".., "neighbors0".., "subsampling0".."subsampling3",
-// "upsampling0".., "search_flags") for rdm_engine_export; level sizes in result_host.  Taps are switched on by the call.
+// "upsampling0".., "search_flags") for rdm_engine_export; level sizes in result_host.  Stage tensors are kept for this call
+// whatever rdm_engine_keep_taps says (and the setting is restored afterwards).
 extern "C" int rdm_engine_collate(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points,
                                   int64_t n_src, rdm_engine_result* res, void* stream) {
   RDM_REQUIRE(e && ref_points && src_points && res, "rdm_engine_collate: null pointer");
   RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_collate: empty cloud");
+  RDM_REQUIRE(e->finalized, "rdm_engine_collate: call rdm_engine_finalize first");
+  const bool keep_before = e->keep_taps;  // the stage tensors of THIS call are kept; later runs keep what they kept before
   e->keep_taps = true;
   e->collate_only = true;
   const int rc = engine_run_growing(e, ref_points, n_ref, src_points, n_src, nullptr, res, stream);
   e->collate_only = false;
+  e->keep_taps = keep_before;
   return rc;
 }
 
@@ -1060,6 +884,12 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       up[i].rows = lv[i].n; up[i].width = dd->upsampling_width[i]; up[i].ld = dd->upsampling_ld[i];
       up[i].flags = const_cast<int32_t*>(dd->upsampling_count[i]);
     }
+    if (dd->collate_status && dd->n_collate_status > 0) {  // the collate's status words join the engine's own (checked below)
+      hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(64), 0, r.st, dd->collate_status, static_cast<int>(dd->n_collate_status),
+                         flags + 2 * call + 1);
+      ENG_CHECK(launch_status("or_status_kernel"));
+      call++;
+    }
   } else {
   // ---------------------------------------------------------------- collate (data.py:13-77)
   lv[0].n = n0; lv[0].n_ref = n_ref;
@@ -1073,7 +903,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float voxel = c.init_voxel_size;
   int64_t cap = n0;
   // levels whose subsampling runs as the multi-launch pipeline (RDM_GS_MULTI_LEVELS, developer knob; default: the first)
-  static const int gs_multi_levels = [] { const char* v = getenv("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
+  static const int gs_multi_levels = [] { const char* v = ::rdm::dev_knob("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
   for (int i = 1; i < 5; ++i) {
     voxel *= 2.f;  // data.py:23-28
     lv[i].pts = e->alloc<float>(3 * cap);
@@ -1424,7 +1254,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   float* scores = e->alloc<float>(B * K * K);
   float* ms = e->alloc<float>(B * (K + 1) * (K + 1));
   ENG_ALLOC(sqrt_c); ENG_ALLOC(scores); ENG_ALLOC(ms);
-  static const bool materialise_patches = getenv("RDM_NO_PATCH_GATHER") != nullptr;  // developer knob (A/B): gather, then GEMM
+  static const bool materialise_patches = ::rdm::dev_knob("RDM_NO_PATCH_GATHER") != nullptr;  // developer knob (A/B): gather, then GEMM
   if (materialise_patches) {
     float* r_pf = e->alloc<float>(B * K * D);
     float* s_pf = e->alloc<float>(B * K * D);
@@ -1459,7 +1289,10 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     float T[16];
     int32_t counts[4];
   } tailbuf;
-  copy_words(T, r.e->pinned_dev, 16 + 3, r.st);
+  float* host_corr = reinterpret_cast<float*>(static_cast<char*>(e->pinned) + 4096);
+  hipLaunchKernelGGL(export_result_kernel, dim3(16), dim3(256), 0, r.st, T, rc, sc, cs, static_cast<uint32_t*>(e->pinned_dev),
+                     reinterpret_cast<float*>(static_cast<char*>(e->pinned_dev) + 4096), static_cast<int>(e->host_corr_cap));
+  ENG_CHECK(launch_status("export_result_kernel"));
   ENG_CHECK(wait_stream(r));
   std::memcpy(tailbuf.T, r.e->pinned, 64);
   std::memcpy(tailbuf.counts, static_cast<char*>(r.e->pinned) + 64, 12);
@@ -1474,6 +1307,13 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   res->src_corr_points = sc;
   res->corr_scores = cs;
   res->transform_dev = T;
+  {  // host views of the correspondences (valid until the next call on this engine)
+    const int64_t nh = std::min<int64_t>(res->n_correspondences, e->host_corr_cap);
+    res->n_host_correspondences = static_cast<int32_t>(nh);
+    res->host_ref_corr_points = host_corr;
+    res->host_src_corr_points = host_corr + 3 * nh;
+    res->host_corr_scores = host_corr + 6 * nh;
+  }
   res->arena_used = e->arena_off;
   for (int i = 0; i < e->prof_layers; ++i) {  // the stream is idle here (read-back above synchronised it)
     RDM_HIP_CHECK(hipEventElapsedTime(&e->prof[i].gather_ms, e->events[3 * i], e->events[3 * i + 1]));

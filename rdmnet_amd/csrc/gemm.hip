@@ -566,23 +566,11 @@ __global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
 // L2 latency for the kernel instead of one per product; what bounds the kernel is the ~20 B/clk a CU gets from L2 for
 // its 320 KB of weights, so the barriers order LDS only (lds_barrier) and the later products' weights keep streaming
 // under the earlier products -- and y, z travel through LDS.  Replaces three launches.
-// A Linear of the NEW rows computed by the tail's workgroup itself (rdm_attention_tail_proj): dst[row, :] = out[row, :] B + bias
-// for the rows [row_lo, row_hi) of the call, B [128, ncols] as rdm_gemm's B operand.  The arithmetic is gemm_small_kernel's --
-// 32 x 32 x 2 MFMA tiles, K split over four wavefronts, the four partial tiles added in the same order -- so the result has
-// the bits the separate rdm_gemm launch produces (the 16 rows of a workgroup fill half of a 32-row tile).
-struct TailProj {
-  const float* b;
-  const float* bias;
-  float* dst;
-  int ncols, ldb, ldd, row_lo, row_hi;
-};
 struct TailArgs {
   const float *hid, *x, *wo, *bo, *g1, *be1, *w1, *b1, *w2, *b2, *g2, *be2;
   float* out;
   int M, ldh, ldx, ldo, ldwo, ldw1, ldw2;
   float eps;
-  int nproj;
-  TailProj proj[2];
 #ifdef RDM_TAIL_TIMING
   unsigned long long* clk;  // tools/tail_lab.hip: shader-clock stamps of workgroup 0, wavefront 0
 #endif
@@ -592,7 +580,6 @@ struct TailArgs {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
-template <bool PROJ>
 __global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
   __shared__ __attribute__((aligned(16))) float ys[16][132];
   __shared__ __attribute__((aligned(16))) float zs[16][260];
@@ -735,59 +722,6 @@ __global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
     const int row = m0 + 4 * kb + r;
     if (row < a.M) a.out[static_cast<long long>(row) * a.ldo + c] = o[r];
   }
-  if constexpr (PROJ) {
-    // ---- projections of the new rows for the layers that follow (gemm_small_body's arithmetic, see TailProj)
-    __shared__ float pred[2][4][32][33];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ys[4 * kb + r][c] = o[r];  // (every wavefront is past its reads of ys: barriers of the FFN)
-    lds_barrier();
-    const int li = lane & 31, lk = lane >> 5;
-    const int slot = w >> 2, kbeg = (w & 3) * 32 + lk * 16;  // two 32-column tiles per round, K = 128 split four ways
-    float av[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(&ys[li & 15][kbeg + 4 * q]);
-      av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-    }
-    for (int pi = 0; pi < a.nproj; ++pi) {
-      const TailProj P = a.proj[pi];
-      if (m0 >= P.row_hi || m0 + 16 <= P.row_lo) continue;  // workgroup-uniform
-      const int ntiles = (P.ncols + 31) / 32;
-      for (int t0 = 0; t0 < ntiles; t0 += 2) {
-        const int tile = t0 + slot;
-        if (tile < ntiles) {  // wavefront-uniform
-          const int col = tile * 32 + li;
-          const bool col_ok = col < P.ldb;
-          float bv[16];
-#pragma unroll
-          for (int t = 0; t < 16; ++t) bv[t] = col_ok ? P.b[static_cast<long long>(kbeg + t) * P.ldb + col] : 0.f;
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) pred[slot][w & 3][(r & 3) + 8 * (r >> 2) + 4 * lk][li] = acc[r];
-        }
-        __syncthreads();
-        {
-          const int sl = tid >> 8, e0 = tid & 255;
-          const int tl = t0 + sl;
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {  // rows 0..15 of the 32-row tile are this workgroup's
-            const int e = e0 + 256 * q, rr = e >> 5, cc = e & 31;
-            const int row = m0 + rr, ocol = tl * 32 + cc;
-            if (tl < ntiles && row < a.M && row >= P.row_lo && row < P.row_hi && ocol < P.ncols) {
-              float v = ((pred[sl][0][rr][cc] + pred[sl][1][rr][cc]) + pred[sl][2][rr][cc]) + pred[sl][3][rr][cc];
-              if (P.bias) v += P.bias[ocol];
-              P.dst[static_cast<long long>(row) * P.ldd + ocol] = v;
-            }
-          }
-        }
-        __syncthreads();
-      }
-    }
-  }
 }
 
 __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
@@ -898,7 +832,7 @@ namespace {
 
 int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
   const long long m = g.M, n = g.N, k = g.K;
-  const char* tune_env = getenv("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
+  const char* tune_env = ::rdm::dev_knob("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
   if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && !g.aidx && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
       m * n <= 1536 * 512 && !(tune_env && tune_env[0] != '0')) {
     if (stat_blocks) *stat_blocks = 0;
@@ -920,7 +854,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // CUs the model plans for.  (RDM_GEMM_CUS, developer knob: with four pairs in flight a product effectively owns a
   // quarter of the chip, tools/exp_cumask.sh.)
   static const long long model_cus = [] {
-    const char* v = getenv("RDM_GEMM_CUS");
+    const char* v = ::rdm::dev_knob("RDM_GEMM_CUS");
     const long long n = v ? atoll(v) : 256;
     return n >= 8 && n <= 256 ? n : 256ll;
   }();
@@ -957,7 +891,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   }
   // developer knob for tuning runs (tools/gemm_sweep*.py): RDM_GEMM_TUNE="<tile 1..3>,<splits>" overrides the model
   int force_splits = 0, exp_tile = 0;
-  if (const char* tune = getenv("RDM_GEMM_TUNE")) {
+  if (const char* tune = ::rdm::dev_knob("RDM_GEMM_TUNE")) {
     int t = 0, sp = 0;
     if (sscanf(tune, "%d,%d", &t, &sp) >= 1) {
       if (t == 1) tile = T128;
@@ -971,11 +905,11 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // developer experiment: RDM_GEMM_BIG="<min M>[,<tile 4..7>]" runs the un-split products with at least that many rows and
   // n >= 128 on a larger tile (default 6 = 128x128x32) -- fewer operand bytes per flop through the CU's L2 port, which is what
   // co-limits the 64x64 tile when several pairs share the GPU
-  static const int big_min_m = [] { const char* v = getenv("RDM_GEMM_BIG"); return v ? atoi(v) : 0; }();
-  static const int big_tile = [] { const char* v = getenv("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
+  static const int big_min_m = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_BIG"); return v ? atoi(v) : 0; }();
+  static const int big_tile = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
   if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && best_s == 1 && force_splits == 0 && batches == 1)
     exp_tile = big_tile;
-  static const bool xcd_env = getenv("RDM_GEMM_XCD") != nullptr;  // developer knob (A/B)
+  static const bool xcd_env = ::rdm::dev_knob("RDM_GEMM_XCD") != nullptr;  // developer knob (A/B)
   g.xcd_tiles = (xcd_env && ceil_div<long long>(n, 64) > 1 && ceil_div<long long>(m, 64) * ceil_div<long long>(n, 64) >= 64) ? 1 : 0;
   if (g.aidx) {  // the concatenating / gathering operands exist for the 64x64x32 tile only
     tile = T64;
@@ -1016,7 +950,8 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       // 32-deep k-tiles: 34 KB of LDS per block -> 4 blocks per CU (64-deep: 2); measured +2 % with 4 pairs in flight
       // (two k-tiles of register prefetch: -3 % over the path's shapes; four: no further gain -- what bounds these tiles
       // is the ~20 B/clk a CU draws from L2, see tools/tail_lab.hip, not the latency of one load)
-      if (k >= 48) launch<64, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
+      // (gathered / concatenated operands exist in the 32-deep instantiation only; its loads clamp k to K - 4)
+      if (k >= 48 || g.aidx) launch<64, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
       else launch<64, 64, 2, 2, 16>(g, batches, trans_b, st);
       break;
     case T128x32:
@@ -1080,7 +1015,7 @@ int rdm::gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, in
 
 namespace {
 bool small_kernel_ok(long long m, long long n, long long k) {
-  return m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 && m * n <= 1536 * 512 && !getenv("RDM_GEMM_TUNE");
+  return m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 && m * n <= 1536 * 512 && !::rdm::dev_knob("RDM_GEMM_TUNE");
 }
 }  // namespace
 
@@ -1210,7 +1145,7 @@ extern "C" int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t 
   RDM_REQUIRE(c1 > 0 && c2 > 0 && n > 0 && m >= 0 && ldw % 4 == 0, "rdm_decoder_stage: bad sizes");
   if (m == 0) return RDM_OK;
   const int64_t k = c1 + c2, kpad = (k + 3) / 4 * 4;
-  static const bool no_virtual = getenv("RDM_NO_VIRTUAL_CONCAT") != nullptr;  // developer knob: always materialise
+  static const bool no_virtual = ::rdm::dev_knob("RDM_NO_VIRTUAL_CONCAT") != nullptr;  // developer knob: always materialise
   Arena ar(ws, ws_bytes);
   const size_t gemm_ws = rdm_gemm_workspace_bytes(m, n, 1);
   char* gws = ar.take<char>(gemm_ws);
@@ -1261,11 +1196,11 @@ extern "C" int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w
 
 // The tail of an attention layer (output projection + residual LayerNorm + FFN + residual LayerNorm) in one launch;
 // see attention_tail128_kernel.  Weights in checkpoint layout (k contiguous): wo [128,128], w1 [256,128], w2 [128,256].
-extern "C" int rdm_attention_tail_proj(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
                                        const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
                                        const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
                                        const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
-                                       int64_t ld_out, const rdm_tail_projection* proj, int n_proj, void* stream) {
+                                       int64_t ld_out, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(hidden && x && wo && w1 && w2 && gamma1 && beta1 && gamma2 && beta2 && out, "rdm_attention_tail: null pointer");
   RDM_REQUIRE(d == 128 && m >= 0, "rdm_attention_tail: supports d = 128 with a 256-wide FFN (d=%lld)", (long long)d);
@@ -1281,35 +1216,9 @@ extern "C" int rdm_attention_tail_proj(const float* hidden, int64_t ld_hidden, c
   a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
   a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
   a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
-  a.nproj = 0;
-  if (n_proj > 0) {
-    RDM_REQUIRE(n_proj <= 2 && proj, "rdm_attention_tail_proj: at most two projections");
-    for (int i = 0; i < n_proj; ++i) {
-      const rdm_tail_projection& P = proj[i];
-      RDM_REQUIRE(P.b && P.dst && P.ncols > 0 && P.ldb >= P.ncols && P.ldb % 4 == 0 && P.ldd >= P.ncols && P.row_lo >= 0 &&
-                      P.row_hi >= P.row_lo && P.row_hi <= m,
-                  "rdm_attention_tail_proj: projection %d: bad shape", i);
-      a.proj[i].b = P.b; a.proj[i].bias = P.bias; a.proj[i].dst = P.dst; a.proj[i].ncols = static_cast<int>(P.ncols);
-      a.proj[i].ldb = static_cast<int>(P.ldb); a.proj[i].ldd = static_cast<int>(P.ldd);
-      a.proj[i].row_lo = static_cast<int>(P.row_lo); a.proj[i].row_hi = static_cast<int>(P.row_hi);
-    }
-    a.nproj = n_proj;
-  }
   RDM_DUP_LOOP("tail")
-  if (a.nproj > 0)
-    hipLaunchKernelGGL(attention_tail128_kernel<true>, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
-                       static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(attention_tail128_kernel<false>, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
-                       static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(attention_tail128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
+                     static_cast<hipStream_t>(stream), a);
   return launch_status("attention_tail128_kernel");
 }
 
-extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
-                                  const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
-                                  const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2,
-                                  const float* b2, const float* gamma2, const float* beta2, float eps, float* out,
-                                  int64_t ld_out, void* stream) {
-  return rdm_attention_tail_proj(hidden, ld_hidden, x, ldx, m, d, wo, ld_wo, bo, gamma1, beta1, w1, ld_w1, b1, w2, ld_w2, b2, gamma2,
-                                 beta2, eps, out, ld_out, nullptr, 0, stream);
-}

@@ -1196,7 +1196,7 @@ int rdm::grid_subsample_mode(const float* points, int64_t n_points, const int64_
   fill_schedule(n_points + 1, &a.sched);
   // large clouds (the first pyramid level): phases P0-P6 as separate launches over many workgroups, see gs_*_kernel.
   // mode: 0 = choose by size, 1 = single-workgroup kernel, 2 = multi-launch form
-  static const bool force_single = getenv("RDM_GS_SINGLE") != nullptr;  // developer knob (A/B runs)
+  static const bool force_single = ::rdm::dev_knob("RDM_GS_SINGLE") != nullptr;  // developer knob (A/B runs)
   const bool multi = mode == 2 || (mode == 0 && !force_single && n_points >= kMultiMinPoints);
   if (multi && n_points <= static_cast<int64_t>(kMultiMaxBlocks) * kT) {
     static std::atomic<uint64_t> replay_attr{0};

@@ -25,7 +25,7 @@ using namespace rdm;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKP = 15;          // kernel points (cfg.backbone.kernel_size)
-constexpr int kMaxH = 128;       // neighbour slots per query
+constexpr int kMaxH = 128;       // neighbour slots staged in LDS at a time (wider rows run in chunks)
 constexpr int kWaves = 4;
 
 struct KpArgs {
@@ -82,13 +82,20 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   if (a.width) H = min(H, *a.width);
   const int c_base = slice * (16 * VEC * U);  // first channel of this wavefront's slice
 
-  // ---- phase 1: neighbour rows, relative positions, positive-row count
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
   int positives = 0;
+  f32x4 acc[VEC * U];
+#pragma unroll
+  for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // neighbour slots in chunks of the LDS staging row (kMaxH = 128 slots: one chunk for every KITTI limit; the reference
+  // takes whatever calibrate_neighbors_stack_mode returns, utils/data.py:195-220)
+  for (int hc = 0; hc < H; hc += kMaxH) {
+  const int Hc = min(H - hc, kMaxH);
+  // ---- phase 1: neighbour rows, relative positions, positive-row count
   int Hq = 0;  // slots up to the last real neighbour: shadow neighbours contribute exact zeros, and the searches pad at the end
-  for (int hb = 0; hb < H; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
+  for (int hb = 0; hb < Hc; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
     const int h = hb + lane;
-    const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+    const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
     const bool real = id >= 0 && id < a.Ns;
     const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
     if (rm) Hq = hb + 64 - __builtin_clzll(rm);
@@ -105,19 +112,13 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
       v.z = 1.0e6f - qz;
       v.w = __int_as_float(-1);
     }
-    if (h < H) nb[wave][h] = v;
+    if (h < Hc) nb[wave][h] = v;
   }
-  positives = wave_sum_i(positives);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  f32x4 acc[VEC * U];
-#pragma unroll
-  for (int t = 0; t < VEC * U; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   // ---- phase 2: PF groups of four neighbours per trip
-  H = Hq;
-  for (int h0 = 0; h0 < H; h0 += 4 * PF) {
+  for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {
     float w[PF];
     float f[PF][U][VEC];
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
       const int h = h0 + 4 * p + g;
       int id = -1;
       w[p] = 0.f;
-      if (h < H) {
+      if (h < Hq) {
         const float4 v = nb[wave][h];
         id = __float_as_int(v.w);
         const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
         for (int e = 0; e < VEC; ++e)
           acc[u * VEC + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][u][e], acc[u * VEC + e], 0, 0, 0);
   }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb[wave] is rewritten by the next chunk / unit
+  __builtin_amdgcn_wave_barrier();
+  }  // chunk loop
+  positives = wave_sum_i(positives);
 
   // ---- store WF[m, k, c]: accumulator row = 4*g + r = kernel point, column j
   float* out = a.wf + static_cast<int64_t>(m) * a.ldw + c_base;
@@ -181,8 +186,6 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
     }
   }
   if (lane == 0 && slice == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb[wave] is rewritten by the next unit
-  __builtin_amdgcn_wave_barrier();
   }  // unit loop
 }
 
@@ -199,37 +202,42 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
-  int positives = 0;
-  int Hq = 0;  // slots up to the last real neighbour (the rest are shadow neighbours: zero feature)
-  for (int hb = 0; hb < H; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
-    const int h = hb + lane;
-    const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
-    if (rm) Hq = hb + 64 - __builtin_clzll(rm);
-    if (id >= 0 && id < a.Ns) {
-      v.x = a.s_points[3 * id] - qx;
-      v.y = a.s_points[3 * id + 1] - qy;
-      v.z = a.s_points[3 * id + 2] - qz;
-      v.w = a.s_feats[id * a.ldf];
-      positives += a.s_pos[id];
-    }
-    if (h < H) nb[wave][h] = v;
-  }
-  positives = wave_sum_i(positives);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   const int g = lane >> 4, j = lane & 15;
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f,
               kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
+  int positives = 0;
   float acc = 0.f;
-  for (int h = g; h < Hq; h += 4) {
-    const float4 v = nb[wave][h];
-    const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-    const float d2 = (dx * dx + dy * dy) + dz * dz;
-    acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
+  for (int hc = 0; hc < H; hc += kMaxH) {  // chunks of the staging row (one for every KITTI limit)
+    const int Hc = min(H - hc, kMaxH);
+    int Hq = 0;  // slots up to the last real neighbour (the rest are shadow neighbours: zero feature)
+    for (int hb = 0; hb < Hc; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
+      const int h = hb + lane;
+      const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+      if (rm) Hq = hb + 64 - __builtin_clzll(rm);
+      if (id >= 0 && id < a.Ns) {
+        v.x = a.s_points[3 * id] - qx;
+        v.y = a.s_points[3 * id + 1] - qy;
+        v.z = a.s_points[3 * id + 2] - qz;
+        v.w = a.s_feats[id * a.ldf];
+        positives += a.s_pos[id];
+      }
+      if (h < Hc) nb[wave][h] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int h = g; h < Hq; h += 4) {
+      const float4 v = nb[wave][h];
+      const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  positives = wave_sum_i(positives);
   acc += __shfl_xor(acc, 16, 64);
   acc += __shfl_xor(acc, 32, 64);
   float* out = a.wf + static_cast<int64_t>(m) * a.ldw;
@@ -274,8 +282,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   using namespace rdm;
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
               "rdm_kpconv_gather: null pointer");
-  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0 && h <= kMaxH, "rdm_kpconv_gather: bad sizes (h=%lld, max %d)",
-              (long long)h, kMaxH);
+  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0, "rdm_kpconv_gather: bad sizes (h=%lld)", (long long)h);
   RDM_REQUIRE(c == 1 || (c % 32 == 0 && c <= 512), "rdm_kpconv_gather: unsupported channel count %lld",
               (long long)c);
   RDM_REQUIRE(ldw >= kKP * c && (c == 1 || (ldf % 4 == 0 && ldw % 4 == 0)),
@@ -288,7 +295,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
   a.ldw = static_cast<int>(ldw); a.sigma = sigma;
-  static const bool xcd_env = getenv("RDM_GATHER_XCD") != nullptr;  // developer knob (A/B)
+  static const bool xcd_env = ::rdm::dev_knob("RDM_GATHER_XCD") != nullptr;  // developer knob (A/B)
   a.xcd_remap = (xcd_env && order_records) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(64 * kWaves);

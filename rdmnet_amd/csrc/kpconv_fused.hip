@@ -90,68 +90,73 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
       if (m >= a.M) break;
       const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
       int positives = 0;
-      int Hq = 0;  // slots up to the last real neighbour (kpconv.hip: shadow slots contribute exact zeros)
-      for (int hb = 0; hb < H; hb += 64) {
-        const int h = hb + lane;
-        const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
-        const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
-        if (rm) Hq = hb + 64 - __builtin_clzll(rm);
-        float4 v;
-        if (id >= 0 && id < a.Ns) {
-          v.x = a.s_points[3 * id] - qx;
-          v.y = a.s_points[3 * id + 1] - qy;
-          v.z = a.s_points[3 * id + 2] - qz;
-          v.w = __int_as_float(static_cast<int>(id));
-          positives += a.s_pos[id];
-        } else {  // shadow neighbour: point at 1e6, zero features
-          v.x = 1.0e6f - qx;
-          v.y = 1.0e6f - qy;
-          v.z = 1.0e6f - qz;
-          v.w = __int_as_float(-1);
-        }
-        if (h < H) nb[h] = v;
-      }
-      positives = wave_sum_i(positives);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       f32x4 acc[VEC];
 #pragma unroll
       for (int t = 0; t < VEC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {
-        float w[PF];
-        float f[PF][VEC];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-          const int h = h0 + 4 * p + g;
-          int id = -1;
-          w[p] = 0.f;
-          if (h < H) {
-            const float4 v = nb[h];
-            id = __float_as_int(v.w);
-            const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-            const float d2 = (dx * dx + dy * dy) + dz * dz;
-            w[p] = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma);
-            if (j >= kKP || id < 0) w[p] = 0.f;
+      for (int hc = 0; hc < H; hc += kMaxH) {  // chunks of the staging row (one for every KITTI limit), as in kpconv.hip
+        const int Hc = min(H - hc, kMaxH);
+        int Hq = 0;  // slots up to the last real neighbour (kpconv.hip: shadow slots contribute exact zeros)
+        for (int hb = 0; hb < Hc; hb += 64) {
+          const int h = hb + lane;
+          const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+          const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+          if (rm) Hq = hb + 64 - __builtin_clzll(rm);
+          float4 v;
+          if (id >= 0 && id < a.Ns) {
+            v.x = a.s_points[3 * id] - qx;
+            v.y = a.s_points[3 * id + 1] - qy;
+            v.z = a.s_points[3 * id + 2] - qz;
+            v.w = __int_as_float(static_cast<int>(id));
+            positives += a.s_pos[id];
+          } else {  // shadow neighbour: point at 1e6, zero features
+            v.x = 1.0e6f - qx;
+            v.y = 1.0e6f - qy;
+            v.z = 1.0e6f - qz;
+            v.w = __int_as_float(-1);
           }
-          const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
-          if (id >= 0) {
-            if constexpr (VEC == 4) {
-              const float4 t = *reinterpret_cast<const float4*>(row);
-              f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
-            } else {
-              const float2 t = *reinterpret_cast<const float2*>(row);
-              f[p][0] = t.x; f[p][1] = t.y;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) f[p][e] = 0.f;
-          }
+          if (h < Hc) nb[h] = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {
+          float w[PF];
+          float f[PF][VEC];
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
+          for (int p = 0; p < PF; ++p) {
+            const int h = h0 + 4 * p + g;
+            int id = -1;
+            w[p] = 0.f;
+            if (h < Hq) {
+              const float4 v = nb[h];
+              id = __float_as_int(v.w);
+              const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+              const float d2 = (dx * dx + dy * dy) + dz * dz;
+              w[p] = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma);
+              if (j >= kKP || id < 0) w[p] = 0.f;
+            }
+            const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
+            if (id >= 0) {
+              if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(row);
+                f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
+              } else {
+                const float2 t = *reinterpret_cast<const float2*>(row);
+                f[p][0] = t.x; f[p][1] = t.y;
+              }
+            } else {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][e], acc[e], 0, 0, 0);
+              for (int e = 0; e < VEC; ++e) f[p][e] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][e], acc[e], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next chunk / query
+        __builtin_amdgcn_wave_barrier();
       }
+      positives = wave_sum_i(positives);
       // park WF[ql, k, c]: accumulator row 4g + r = kernel point, lane j holds channels VEC*j .. VEC*j + VEC-1
       float* dst = WF + ql * LDW + VEC * j;
 #pragma unroll
@@ -162,8 +167,6 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
         else *reinterpret_cast<float2*>(dst + k * C) = make_float2(acc[0][r], acc[1][r]);
       }
       if (lane == 0) nn_s[ql] = static_cast<float>(positives > 1 ? positives : 1);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next query
-      __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
 
@@ -255,32 +258,37 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
     if (m >= a.M) break;
     const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
     int positives = 0;
-    int Hq = 0;  // slots up to the last real neighbour
-    for (int hb = 0; hb < H; hb += 64) {
-      const int h = hb + lane;
-      const int64_t id = h < H ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
-      const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
-      if (rm) Hq = hb + 64 - __builtin_clzll(rm);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (id >= 0 && id < a.Ns) {
-        v.x = a.s_points[3 * id] - qx;
-        v.y = a.s_points[3 * id + 1] - qy;
-        v.z = a.s_points[3 * id + 2] - qz;
-        v.w = a.s_feats[id * a.ldf];
-        positives += a.s_pos[id];
+    float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
+    for (int hc = 0; hc < H; hc += kMaxH) {  // chunks of the staging row
+      const int Hc = min(H - hc, kMaxH);
+      int Hq = 0;  // slots up to the last real neighbour
+      for (int hb = 0; hb < Hc; hb += 64) {
+        const int h = hb + lane;
+        const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+        const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+        if (rm) Hq = hb + 64 - __builtin_clzll(rm);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < a.Ns) {
+          v.x = a.s_points[3 * id] - qx;
+          v.y = a.s_points[3 * id + 1] - qy;
+          v.z = a.s_points[3 * id + 2] - qz;
+          v.w = a.s_feats[id * a.ldf];
+          positives += a.s_pos[id];
+        }
+        if (h < Hc) nb[h] = v;
       }
-      if (h < H) nb[h] = v;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int h = g; h < Hq; h += 4) {
+        const float4 v = nb[h];
+        const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next chunk / query
+      __builtin_amdgcn_wave_barrier();
     }
     positives = wave_sum_i(positives);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
-    for (int h = g; h < Hq; h += 4) {
-      const float4 v = nb[h];
-      const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-      const float d2 = (dx * dx + dy * dy) + dz * dz;
-      acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
-    }
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);  // every lane (., j) now holds WF[k = j]
     float o = 0.f;
@@ -292,8 +300,6 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
     a.out[static_cast<int64_t>(m) * a.ldo + lane] = v;
     st_s += static_cast<double>(v);
     st_ss += static_cast<double>(v) * static_cast<double>(v);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next query
-    __builtin_amdgcn_wave_barrier();
   }
   if (a.stats) {
     ex[wave][lane][0] = st_s;
@@ -326,7 +332,7 @@ constexpr int kQb32 = 16, kNw32 = 16, kIters32 = 2, kQb64 = 16, kNw64 = 8, kIter
 // these layers (profiles/r02_pmc_fetch_write.md); RDM_FUSED_KPCONV=0 selects the two-kernel form for A/B runs.
 extern "C" int rdm_kpconv_fused_enabled(void) {
   static const bool on = [] {
-    const char* v = getenv("RDM_FUSED_KPCONV");
+    const char* v = ::rdm::dev_knob("RDM_FUSED_KPCONV");
     return !(v != nullptr && v[0] == '0');
   }();
   return on ? 1 : 0;
@@ -375,8 +381,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
               "rdm_kpconv_fused: null pointer");
   RDM_REQUIRE(rdm_kpconv_fused_supported(c, c_out), "rdm_kpconv_fused: unsupported channel counts %lld -> %lld", (long long)c,
               (long long)c_out);
-  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0 && h <= kMaxH && ldo >= c_out, "rdm_kpconv_fused: bad sizes (h=%lld, max %d)",
-              (long long)h, kMaxH);
+  RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0 && ldo >= c_out, "rdm_kpconv_fused: bad sizes (h=%lld)", (long long)h);
   RDM_REQUIRE(c == 1 || (ldf % 4 == 0 && (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(w_packed) & 15) == 0),
               "rdm_kpconv_fused: features / packed weights must be 16-byte aligned with a row stride that is a multiple of 4");

@@ -373,7 +373,7 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     nblk = own_blk;
   }
   {
-    static const bool fin64 = getenv("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
+    static const bool fin64 = ::rdm::dev_knob("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
     const bool narrow = !fin64 && nblk >= 128 && c / groups <= 16 && 16 % (c / groups) == 0;
     RDM_DUP_LOOP("gnfin")
     if (narrow)
@@ -388,7 +388,7 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
   // 16-byte accesses whenever the layout allows; with the positive-row flag only where a row lies inside one wavefront AND
   // gn_apply_kernel's summation tree can be reproduced (up to 128 columns: at most two values per lane there)
-  static const bool narrow_rows = getenv("RDM_GN_APPLY_ROWS") != nullptr;  // developer knob (A/B): one wavefront per row below 256 columns
+  static const bool narrow_rows = ::rdm::dev_knob("RDM_GN_APPLY_ROWS") != nullptr;  // developer knob (A/B): one wavefront per row below 256 columns
   const int64_t c4 = c / 4;
   const bool flag_ok = c4 == 8 || c4 == 16 || c4 == 32;
   const bool wide = vec_ok && (narrow_rows ? (!positive && c >= 256) : (!positive || flag_ok));
@@ -437,7 +437,7 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
   RDM_REQUIRE(x && idx && y, "rdm_gather_max: null pointer");
   RDM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && h > 0, "rdm_gather_max: bad sizes");
   if (m == 0) return RDM_OK;
-  static const bool no_order = getenv("RDM_NO_POOL_ORDER") != nullptr;  // developer knob (A/B): row order
+  static const bool no_order = ::rdm::dev_knob("RDM_NO_POOL_ORDER") != nullptr;  // developer knob (A/B): row order
   if (no_order) order_records = nullptr;
   RDM_DUP_LOOP("pool")
   hipLaunchKernelGGL(gather_max_kernel, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)),

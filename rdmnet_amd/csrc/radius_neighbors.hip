@@ -717,10 +717,11 @@ int rdm::radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t
 int rdm::radius_redo_flush(void* queue, void* stream) {
   RnRedoBatch* b = static_cast<RnRedoBatch*>(queue);
   if (b->n == 0) return RDM_OK;
-  RDM_DUP_LOOP("rn")
-  hipLaunchKernelGGL(rn_query_multi_kernel, dim3(b->first_block[b->n]), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
-  // 64 workgroups (256 wavefronts) per search: two flag sweeps of 64 queries per wavefront cover a 32 k-point level
-  hipLaunchKernelGGL(rn_redo_multi_kernel, dim3(64, b->n), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
+  RDM_DUP_LOOP("rn") {  // (first pass + its large-buffer second pass: the pair is idempotent)
+    hipLaunchKernelGGL(rn_query_multi_kernel, dim3(b->first_block[b->n]), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
+    // 64 workgroups (256 wavefronts) per search: two flag sweeps of 64 queries per wavefront cover a 32 k-point level
+    hipLaunchKernelGGL(rn_redo_multi_kernel, dim3(64, b->n), dim3(64 * kWavesPerBlock), 0, static_cast<hipStream_t>(stream), *b);
+  }
   b->n = 0;
   b->first_block[0] = 0;
   return launch_status("rn_query_multi_kernel");

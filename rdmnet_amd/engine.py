@@ -26,7 +26,9 @@ class EngineResult(ctypes.Structure):
                 ('n_ref_nodes', ctypes.c_int64), ('n_src_nodes', ctypes.c_int64),
                 ('n_node_correspondences', ctypes.c_int64), ('level_sizes', ctypes.c_int64 * 5), ('level_ref_sizes', ctypes.c_int64 * 5),
                 ('ref_corr_points', ctypes.c_void_p), ('src_corr_points', ctypes.c_void_p),
-                ('corr_scores', ctypes.c_void_p), ('transform_dev', ctypes.c_void_p), ('arena_used', ctypes.c_size_t)]
+                ('corr_scores', ctypes.c_void_p), ('transform_dev', ctypes.c_void_p), ('arena_used', ctypes.c_size_t),
+                ('host_ref_corr_points', ctypes.c_void_p), ('host_src_corr_points', ctypes.c_void_p),
+                ('host_corr_scores', ctypes.c_void_p), ('n_host_correspondences', ctypes.c_int32)]
 
 
 class TensorView(ctypes.Structure):
@@ -44,12 +46,14 @@ class DataDict(ctypes.Structure):
                 ('subsampling', ctypes.c_void_p * 4), ('subsampling_width', ctypes.c_int64 * 4),
                 ('subsampling_ld', ctypes.c_int64 * 4), ('subsampling_count', ctypes.c_void_p * 4),
                 ('upsampling', ctypes.c_void_p * 4), ('upsampling_width', ctypes.c_int64 * 4),
-                ('upsampling_ld', ctypes.c_int64 * 4), ('upsampling_count', ctypes.c_void_p * 4)]
+                ('upsampling_ld', ctypes.c_int64 * 4), ('upsampling_count', ctypes.c_void_p * 4),
+                ('collate_status', ctypes.c_void_p), ('n_collate_status', ctypes.c_int64)]
 
 
 class KpconvProfile(ctypes.Structure):
     _fields_ = [('m', ctypes.c_int64), ('h', ctypes.c_int64), ('c_in', ctypes.c_int64), ('c_out', ctypes.c_int64),
-                ('pooled_channels', ctypes.c_int64), ('gather_ms', ctypes.c_float), ('total_ms', ctypes.c_float)]
+                ('pooled_channels', ctypes.c_int64), ('gather_ms', ctypes.c_float), ('total_ms', ctypes.c_float),
+                ('fused', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 _DTYPES = {0: torch.float32, 1: torch.int64, 2: torch.uint8, 3: torch.int32}
@@ -129,7 +133,7 @@ class Engine:
             gather = p.m * p.h * (8 + 12 + 4 * p.c_in)
             total = gather + 4 * p.m * p.c_out + (p.m * p.h * (8 + 4 * p.pooled_channels) if p.pooled_channels else 0)
             out.append({'m': p.m, 'h': p.h, 'cin': p.c_in, 'cout': p.c_out, 'bytes': total, 'gather_bytes': gather,
-                        'gather_ms': p.gather_ms, 'total_ms': p.total_ms, 'pooled': int(p.pooled_channels)})
+                        'gather_ms': p.gather_ms, 'total_ms': p.total_ms, 'pooled': int(p.pooled_channels), 'fused': int(p.fused)})
         return out
 
     def keep_taps(self, enable=True):
@@ -212,6 +216,10 @@ class Engine:
             n_ref = head[:5]
             if any(head[5:]):
                 raise RuntimeError('radius search: a search of the collate reported an internal error (status word set)')
+        cflags = data_dict.get('_flags')
+        if cflags is not None and cflags.is_cuda and cflags.dtype == torch.int32 and cflags.dim() == 2 and cflags.is_contiguous():
+            keep.append(cflags)  # checked by the native call at its first read-back (no synchronisation here)
+            d.collate_status, d.n_collate_status = cflags.data_ptr(), cflags.shape[0]
         widths = data_dict.get('_widths', {})
         feats = dev_t(data_dict['features'], torch.float32)
         if feats.dim() != 2 or feats.stride(1) != 1:
@@ -272,6 +280,18 @@ class Engine:
         typed = {0: buf.view(torch.float32), 1: buf.view(torch.int64), 2: buf, 3: buf.view(torch.int32)}
         return {names[i]: torch.as_strided(typed[v.dtype], (v.rows, v.cols), (v.ld, 1), offs[i] // _ESIZE[v.dtype])
                 for i, v in enumerate(arr_v)}
+
+    def host_corr(self):
+        """(ref_corr_points [n,3], src_corr_points [n,3], corr_scores [n]) of the last run as numpy copies of the engine's
+        pinned host buffer -- already on the host when run() / forward() return (no device copy, no synchronisation)."""
+        n = int(self.result.n_host_correspondences)
+
+        def view(ptr, count):
+            if count == 0:
+                return np.zeros((0,), np.float32)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_float)), shape=(count,)).copy()
+        return (view(self.result.host_ref_corr_points, 3 * n).reshape(n, 3), view(self.result.host_src_corr_points, 3 * n).reshape(n, 3),
+                view(self.result.host_corr_scores, n))
 
     def corr(self):
         """(ref_corr_points, src_corr_points, corr_scores) of the last run as fresh tensors."""

@@ -50,13 +50,16 @@ class RDMNet(torch.nn.Module):
             if parts[-1] == 'kernel_points':
                 node.register_buffer(parts[-1], value)
             else:
-                node.register_parameter(parts[-1], torch.nn.Parameter(value, requires_grad=False))
+                node.register_parameter(parts[-1], torch.nn.Parameter(value, requires_grad=True))  # as the reference's; DDP refuses a module without one
         self._w = None        # prepared device tensors of the per-op path
         self._np_state = None  # name -> numpy float32 (what the kernels' weight preparation reads)
         self.use_vote = bool(cfg.Vote.inference_use_vote and cfg.Vote.model_use_vote)
         self.attention_bf16 = bool(getattr(cfg.thdroformer, 'attention_bf16', False))
         self._tls = threading.local()  # .profile: list -> per-KPConv-layer HIP-event records (bench.py)
-        self._engines, self._engines_state, self._engines_lock = {}, None, threading.Lock()  # native engines by stream
+        # native engines by (device, stream), least recently used first; at most `max_engines` are kept (each owns an arena of
+        # >= 3 GiB of HBM): a caller that keeps creating streams recycles engines instead of accumulating them
+        self._engines, self._engines_state, self._engines_lock = OrderedDict(), None, threading.Lock()
+        self.max_engines = 8
         self.fast_path = True          # forward(data_dict) as one native call; False = the per-op mirror
         self.device = None
         if device is not None:
@@ -117,7 +120,7 @@ class RDMNet(torch.nn.Module):
                 b = torch.zeros((pad4(kdim), pad4(cout)), dtype=torch.float32)
                 b[:k * cin, :cout] = torch.from_numpy(S[name]).reshape(k * cin, cout)
                 W[name] = (b.to(dev), cin, cout)
-                if ops.kpconv_fused_enabled() and ops.kpconv_fused_supported(cin, cout):  # opt-in (RDM_FUSED_KPCONV=1)
+                if ops.kpconv_fused_enabled() and ops.kpconv_fused_supported(cin, cout):  # the one-kernel form of the fine levels
                     W[name + '.packed'] = torch.from_numpy(ops.kpconv_pack_weights(S[name])).to(dev)
             elif name.endswith('.weight') and S[name].ndim == 2:
                 lin(name[:-7])
@@ -134,9 +137,6 @@ class RDMNet(torch.nn.Module):
             W[p + '.qkv'] = _dev_linear(np.concatenate([wq, wk, wv], 0), np.concatenate([bq, bk, bv]), dev)[:2]
             W[p + '.q'] = _dev_linear(wq, bq, dev)[:2]
             W[p + '.kv'] = _dev_linear(np.concatenate([wk, wv], 0), np.concatenate([bk, bv]), dev)[:2]
-            if wq.shape == (128, 128):  # checkpoint layout ([out, in]) for rdm_attention_layer's projections
-                for key, ws in (('.qkv', [wq, wk, wv]), ('.q', [wq]), ('.kv', [wk, wv])):
-                    W[p + key + '.wt'] = torch.from_numpy(np.ascontiguousarray(np.concatenate(ws, 0), dtype=np.float32)).to(dev)
         self._w = W
         return W
 
@@ -274,10 +274,6 @@ class RDMNet(torch.nn.Module):
         W, heads = self._w, self.cfg.thdroformer.num_heads
         N = x.shape[0]
         n1 = N - n0
-        if self._fused_layers_ok(name, num_layers, heads, n0, n1):
-            return self._thdroformer_fused(name, pts4, x, n0, num_layers, out)
-        if self._tail_proj_ok(name, num_layers, n0, n1):
-            return self._thdroformer_tail_proj(name, pts4, x, n0, num_layers, out)
         emb = self._linear(name + '.embedding.proj', pts4)
         f = self._linear(name + '.in_proj', x)
         d = f.shape[1]
@@ -301,123 +297,6 @@ class RDMNet(torch.nn.Module):
             f = fnew
         self._linear(name + '.out_proj', f, out=out)
 
-    def _tail_proj_ok(self, name, num_layers, n0, n1):
-        """Opt-in (RDM_TAIL_PROJ=1; measured slower): the projections of a layer's new rows inside the tail's launch
-        (ops.attention_tail(projections=...)): width 128,
-        256-wide FFN, at most 1536 stacked rows (the sizes at which rdm_gemm runs the kernel whose arithmetic the tail
-        reproduces) -- the conditions of the native engine's thdroformer_tail_proj."""
-        W = self._w
-        if os.environ.get('RDM_TAIL_PROJ') != '1' or num_layers < 1 or n0 <= 0 or n1 <= 0 or n0 + n1 > 1536:
-            return False
-        op = W.get(name + '.out_proj')
-        if op is None or op[2] != 128 or (n0 + n1) * op[3] > 1536 * 512:
-            return False
-        for i in range(2 * num_layers):
-            p = f'{name}.transformer.layers.{i}'
-            shapes = [tuple(getattr(W.get(p + k + '.wt'), 'shape', ())) for k in ('.attention.linear', '.output.expand', '.output.squeeze')]
-            if shapes != [(128, 128), (256, 128), (128, 256)] or (p + '.qkv') not in W or W[p + '.qkv'][0].shape[0] != 128:
-                return False
-        return True
-
-    def _thdroformer_tail_proj(self, name, pts4, x, n0, num_layers, out):
-        """The per-op sequence of the native engine (engine.hip: thdroformer_tail_proj): 7 launches per (self, cross) layer pair."""
-        W, heads = self._w, self.cfg.thdroformer.num_heads
-        N, dev = x.shape[0], x.device
-        n1 = N - n0
-        emb = self._linear(name + '.embedding.proj', pts4)
-        f = self._linear(name + '.in_proj', x)
-        d = 128
-        L = lambda i: f'{name}.transformer.layers.{i}'
-        last = 2 * num_layers - 1
-        q2, kv = ops.feat_empty(N, d, dev), ops.feat_empty(N, 2 * d, dev)
-        qkv = ops.gemm(f, W[L(0) + '.qkv'][0], d, 3 * d, bias=W[L(0) + '.qkv'][1])
-
-        def tail(p, hid, xin, fout, projections):
-            lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
-            return ops.attention_tail(hid, xin, W[lo + '.wt'], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'],
-                                      W[l1 + '.wt'], W[l1][1], W[l2 + '.wt'], W[l2][1], W[p + '.output.norm.weight'],
-                                      W[p + '.output.norm.bias'], out=fout, projections=projections)
-
-        def proj(key, dst, n, lo, hi):
-            return (W[key][0], W[key][1], dst, n, lo, hi)
-
-        for i in range(2 * num_layers):
-            p = L(i)
-            fnew, hid = ops.feat_empty(N, d, dev), ops.feat_empty(N, d, dev)
-            if i % 2 == 0:
-                q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-                ops.rope(q, k, emb)
-                ops.attention_self_pair(q, k, v, n0, heads, out=hid, bf16=self.attention_bf16)
-                tail(p, hid, f, fnew, [proj(L(i + 1) + '.q', q2, d, 0, N), proj(L(i + 1) + '.kv', kv, 2 * d, n0, N)])
-            else:
-                qkv_next = ops.feat_empty(N, 3 * d, dev) if i != last else None
-
-                def next_inputs(row0, rows):
-                    if i == last:
-                        return (W[name + '.out_proj'][0], W[name + '.out_proj'][1], out[row0:], W[name + '.out_proj'][3], 0, rows)
-                    return proj(L(i + 1) + '.qkv', qkv_next[row0:], 3 * d, 0, rows)
-                ops.attention(q2[:n0], kv[n0:, :d], kv[n0:, d:], heads, out=hid[:n0], bf16=self.attention_bf16)
-                tail(p, hid[:n0], f[:n0], fnew[:n0], [proj(p + '.kv', kv, 2 * d, 0, n0), next_inputs(0, n0)])
-                ops.attention(q2[n0:], kv[:n0, :d], kv[:n0, d:], heads, out=hid[n0:], bf16=self.attention_bf16)
-                tail(p, hid[n0:], f[n0:], fnew[n0:], [next_inputs(n0, n1)])
-                qkv = qkv_next
-            f = fnew
-        return out
-
-    def _fused_layers_ok(self, name, num_layers, heads, n0, n1):
-        """rdm_attention_layer (opt-in, RDM_FUSED_LAYER=1, as in the native engine) covers the transformer width
-        128 = 4 heads x 32 with a 256-wide FFN."""
-        W = self._w
-        if os.environ.get('RDM_FUSED_LAYER') != '1' or heads != 4 or num_layers < 1 or n0 <= 0 or n1 <= 0:
-            return False
-        if tuple(getattr(W.get(name + '.out_proj.wt'), 'shape', ())) != (256, 128):
-            return False
-        for i in range(2 * num_layers):
-            p = f'{name}.transformer.layers.{i}'
-            shapes = [tuple(getattr(W.get(p + k + '.wt'), 'shape', ())) for k in ('.attention.linear', '.output.expand', '.output.squeeze')]
-            if shapes != [(128, 128), (256, 128), (128, 256)] or (p + '.qkv.wt') not in W:
-                return False
-        return True
-
-    def _thdroformer_fused(self, name, pts4, x, n0, num_layers, out):
-        """The same transformer with ONE launch per attention application (ops.attention_layer: attention + tail + the
-        projections the following layers need) -- the sequence of the native engine (engine.hip: thdroformer_fused)."""
-        W = self._w
-        N, dev = x.shape[0], x.device
-        n1 = N - n0
-        emb = self._linear(name + '.embedding.proj', pts4)
-        f = self._linear(name + '.in_proj', x)
-        qkv, q2, kv = ops.feat_empty(N, 384, dev), ops.feat_empty(N, 128, dev), ops.feat_empty(N, 256, dev)
-        L = lambda i: f'{name}.transformer.layers.{i}'
-        last = 2 * num_layers - 1
-
-        def proj(key, dst, rope_cols, seg_bits):
-            return (W[key + '.wt'], W[key][1], dst, rope_cols, seg_bits)
-
-        def next_inputs(i, seg_bits):  # the next self layer's q|k|v (with the rotary embedding), or the output projection
-            return proj(name + '.out_proj', out, 0, seg_bits) if i == last else proj(L(i + 1) + '.qkv', qkv, 256, seg_bits)
-
-        ops.attention_layer(out=f, segments=[(0, N, None, None)], projections=[proj(L(0) + '.qkv', qkv, 256, 1)], emb=emb,
-                            projections_only=True)
-        for i in range(2 * num_layers):
-            p = L(i)
-            lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
-            tail = (W[lo + '.wt'], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'], W[l1 + '.wt'], W[l1][1],
-                    W[l2 + '.wt'], W[l2][1], W[p + '.output.norm.weight'], W[p + '.output.norm.bias'])
-            fnew = ops.feat_empty(N, 128, dev)
-            common = dict(out=fnew, x=f, tail=tail, emb=emb, bf16=self.attention_bf16)
-            if i % 2 == 0:  # self: each cloud attends to itself; then the cross layer's q (all rows) and k|v (src rows)
-                ops.attention_layer(q=qkv, segments=[(0, n0, qkv[:n0, 128:256], qkv[:n0, 256:384]),
-                                                     (n0, n1, qkv[n0:, 128:256], qkv[n0:, 256:384])],
-                                    projections=[proj(L(i + 1) + '.q', q2, 0, 3), proj(L(i + 1) + '.kv', kv, 0, 2)], **common)
-            else:  # cross: ref <- src, then src <- the UPDATED ref (thdroformer.py:244-245)
-                ops.attention_layer(q=q2, segments=[(0, n0, kv[n0:, :128], kv[n0:, 128:256])],
-                                    projections=[proj(p + '.kv', kv, 0, 1), next_inputs(i, 1)], **common)
-                ops.attention_layer(q=q2, segments=[(n0, n1, kv[:n0, :128], kv[:n0, 128:256])],
-                                    projections=[next_inputs(i, 1)], **common)
-            f = fnew
-        return out
-
     @staticmethod
     def _pts4(pts):
         """[n,3] -> [n,4] zero padded (K of the positional Linear must be a multiple of 4)."""
@@ -429,7 +308,7 @@ class RDMNet(torch.nn.Module):
     def _engine(self):
         """The native engine of the CURRENT STREAM (an engine is not re-entrant and its work is ordered by the stream it
         runs on; bench.py drives one forward per host thread, each on its own stream), built from this module's state
-        dict on first use and kept for the life of the module."""
+        dict on first use and kept in an LRU cache of `max_engines` entries (>= 3 GiB of HBM each; release_engines() frees them)."""
         from . import engine as engine_mod
         if self.device is None:
             self.cuda()
@@ -437,6 +316,7 @@ class RDMNet(torch.nn.Module):
         with self._engines_lock:
             eng = self._engines.get(key)
             if eng is not None and self._engines_state is self._state:
+                self._engines.move_to_end(key)
                 return eng
             if self._engines_state is not self._state:  # parameters changed (load_state_dict / .to()): rebuild lazily
                 self._engines.clear()
@@ -446,7 +326,14 @@ class RDMNet(torch.nn.Module):
         eng.keep_taps(True)
         with self._engines_lock:
             self._engines[key] = eng
+            while len(self._engines) > max(int(self.max_engines), 1):
+                self._engines.popitem(last=False)  # the least recently used engine (its arena is freed with it)
         return eng
+
+    def release_engines(self):
+        """Drops every cached native engine (and its HBM arena); the next forward builds the calling stream's anew."""
+        with self._engines_lock:
+            self._engines.clear()
 
     def engine(self):
         """The calling thread's native engine (for rdmnet_amd.collate.registration_collate_fn_stack_mode(..., engine=...))."""

@@ -221,24 +221,16 @@ def layer_norm(x, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=Non
     return y
 
 
-def attention_tail(hidden, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, *, eps=1e-5, out=None, projections=()):
+def attention_tail(hidden, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, *, eps=1e-5, out=None):
     """The tail of an attention layer in one launch: y = LN(hidden @ wo.T + bo + x); out = LN(relu(y @ w1.T + b1) @ w2.T
-    + b2 + y).  Width 128, FFN 256; weights as nn.Linear stores them (wo [128,128], w1 [256,128], w2 [128,256]).
-    projections: up to two (b [128, pad4(n)], bias, dst [m, >= n] view, n, row_lo, row_hi) -- Linear layers of the new rows
-    [row_lo, row_hi) computed by the same launch with rdm_gemm's arithmetic (rdm_attention_tail_proj)."""
+    + b2 + y).  Width 128, FFN 256; weights as nn.Linear stores them (wo [128,128], w1 [256,128], w2 [128,256])."""
     L = _lib.lib()
     m = hidden.shape[0]
     y = out if out is not None else feat_empty(m, 128, hidden.device)
-    import ctypes
-    arr = (_lib.TailProjection * max(len(projections), 1))()
-    for i, (b, bias, dst, n, lo, hi) in enumerate(projections):
-        P = arr[i]
-        P.b, P.bias, P.dst, P.ncols, P.ldb, P.ldd, P.row_lo, P.row_hi = b.data_ptr(), _lib.ptr(bias), dst.data_ptr(), n, _ld(b), _ld(dst), lo, hi
-    _lib.check(L.rdm_attention_tail_proj(hidden.data_ptr(), _ld(hidden), x.data_ptr(), _ld(x), m, wo.shape[0], wo.data_ptr(), _ld(wo),
-                                         _lib.ptr(bo), gamma1.data_ptr(), beta1.data_ptr(), w1.data_ptr(), _ld(w1), _lib.ptr(b1),
-                                         w2.data_ptr(), _ld(w2), _lib.ptr(b2), gamma2.data_ptr(), beta2.data_ptr(), eps,
-                                         y.data_ptr(), _ld(y), ctypes.addressof(arr) if projections else None, len(projections),
-                                         _lib.stream_ptr()), 'rdm_attention_tail_proj')
+    _lib.check(L.rdm_attention_tail(hidden.data_ptr(), _ld(hidden), x.data_ptr(), _ld(x), m, wo.shape[0], wo.data_ptr(), _ld(wo),
+                                    _lib.ptr(bo), gamma1.data_ptr(), beta1.data_ptr(), w1.data_ptr(), _ld(w1), _lib.ptr(b1),
+                                    w2.data_ptr(), _ld(w2), _lib.ptr(b2), gamma2.data_ptr(), beta2.data_ptr(), eps,
+                                    y.data_ptr(), _ld(y), _lib.stream_ptr()), 'rdm_attention_tail')
     return y
 
 
@@ -286,44 +278,6 @@ def gather_rows(x, idx, out=None):
     _lib.check(L.rdm_gather_rows(x.data_ptr(), n, row_bytes // 4, x.stride(0) * x.element_size() // 4, idx.data_ptr(), m,
                                  out.data_ptr(), out.stride(0) * out.element_size() // 4, _lib.stream_ptr()),
                'rdm_gather_rows')
-    return out
-
-
-def attention_layer(*, out, q=None, x=None, segments=(), tail=None, projections=(), emb=None, bf16=False, heads=4,
-                    projections_only=False, eps=1e-5):
-    """One application of an attention layer as one launch (rdm_attention_layer): attention of the query-row segments,
-    the tail (output projection, LayerNorms, FFN) and up to two projections of the new rows for the layers that follow.
-
-    segments: [(row0, n_q, k, v)] -- query rows [row0, row0+n_q) of the stacked tensors attend to the rows of k / v (views);
-    tail: (wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2), weights in nn.Linear layout;
-    projections: [(w [ncols, 128], bias, dst [rows, ncols], rope_cols, segment_bits)];
-    projections_only: no attention / tail, the rows of `out` are projected (segments: [(row0, n_rows, None, None)])."""
-    L = _lib.lib()
-    a = _lib.AttentionLayerArgs()
-    a.out, a.ldo = out.data_ptr(), _ld(out)
-    a.heads, a.head_dim, a.bf16, a.eps = heads, 32, int(bf16), eps
-    a.projections_only = int(projections_only)
-    a.n_segments = len(segments)
-    for s, (row0, n_q, k, v) in enumerate(segments):
-        a.row0[s], a.n_q[s] = row0, n_q
-        if k is not None:
-            a.k[s], a.v[s], a.ldk[s], a.ldv[s], a.n_k[s] = k.data_ptr(), v.data_ptr(), _ld(k), _ld(v), k.shape[0]
-    if not projections_only:
-        a.q, a.ldq, a.x, a.ldx = q.data_ptr(), _ld(q), x.data_ptr(), _ld(x)
-        wo, bo, g1, be1, w1, b1, w2, b2, g2, be2 = tail
-        a.wo, a.bo, a.gamma1, a.beta1 = wo.data_ptr(), _lib.ptr(bo), g1.data_ptr(), be1.data_ptr()
-        a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), _lib.ptr(b1), w2.data_ptr(), _lib.ptr(b2)
-        a.gamma2, a.beta2 = g2.data_ptr(), be2.data_ptr()
-        a.ld_wo, a.ld_w1, a.ld_w2 = _ld(wo), _ld(w1), _ld(w2)
-    a.n_projections = len(projections)
-    for i, (w, bias, dst, rope_cols, seg_bits) in enumerate(projections):
-        P = a.proj[i]
-        P.w, P.bias, P.dst = w.data_ptr(), _lib.ptr(bias), dst.data_ptr()
-        P.ncols, P.ldw, P.ldd, P.rope_cols, P.segments = w.shape[0], _ld(w), _ld(dst), rope_cols, seg_bits
-    if emb is not None:
-        a.emb, a.lde = emb.data_ptr(), _ld(emb)
-    import ctypes
-    _lib.check(L.rdm_attention_layer(ctypes.addressof(a), _lib.stream_ptr()), 'rdm_attention_layer')
     return out
 
 

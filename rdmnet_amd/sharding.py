@@ -10,10 +10,11 @@ def pairs_for_rank(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def gather_records(records, world, dist=None):
+def gather_records(records, world, dist=None, force=False):
     """records: float32 [k, c] tensor of this rank (k may differ per rank).  Returns the list of all
-    ranks' records on every rank (one all_gather of a padded block + the per-rank counts)."""
-    if world == 1 or dist is None:
+    ranks' records on every rank (one all_gather of a padded block + the per-rank counts).
+    force=True sends a world of ONE through the collective too (bench.py --force-dist: the RCCL path on one GPU)."""
+    if dist is None or (world == 1 and not force):
         return [records]
     k = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
     counts = [torch.zeros_like(k) for _ in range(world)]
@@ -28,15 +29,15 @@ def gather_records(records, world, dist=None):
     return [b[:int(c)] for b, c in zip(blocks, counts)]
 
 
-def reduce_timing(elapsed_s, latencies_ms, world, dist=None, device='cpu'):
+def reduce_timing(elapsed_s, latencies_ms, world, dist=None, device='cpu', force=False):
     """The timed region of a multi-rank run ends when the slowest rank ends: -> (max over ranks of elapsed_s, the
     per-pair latencies of all ranks concatenated in rank order).  Ranks may hold different numbers of latencies."""
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not force):
         return float(elapsed_s), list(latencies_ms)
     tmax = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     lat = torch.tensor(list(latencies_ms), dtype=torch.float32, device=device).reshape(-1, 1)
-    return float(tmax.item()), torch.cat(gather_records(lat, world, dist)).reshape(-1).cpu().tolist()
+    return float(tmax.item()), torch.cat(gather_records(lat, world, dist, force)).reshape(-1).cpu().tolist()
 
 
 def summarize(all_records, rre_thresh=5.0, rte_thresh=2.0):

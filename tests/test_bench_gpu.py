@@ -42,3 +42,14 @@ def test_single_rank_line_has_the_contract_fields():
     assert r['n_gpus'] == 1 and r['vs_baseline'] is None and r['dtype'] == 'f32' and 'workload' in r['config']
     rf = r['roofline']
     assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+
+
+def test_single_rank_through_rccl():
+    """The RCCL path on the one GPU a test box has: world size 1, backend nccl; the barriers, the record all_gather and
+    the all_reduce(MAX) of the elapsed time go through the process group (the multi-GPU run's collectives,
+    geotransformer/engine/base_tester.py:70-76,123-128 in the reference)."""
+    r = run_bench('--gpus', '1', '--force-dist', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4',
+                  '--api-steps', '4', '--no-cpu-baseline', timeout=600)
+    assert r['collective']['backend'] == 'nccl' and r['collective']['forced_single_rank'] and r['collective']['library'].startswith('RCCL')
+    assert r['records'] == {'gathered': 8, 'distinct_steps': 8, 'distinct_pairs': 2}
+    assert r['n_gpus'] == 1 and r['value'] > 0 and r['host_to_host']['value'] > 0

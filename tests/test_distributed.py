@@ -49,6 +49,29 @@ def test_single_rank_is_identity():
     assert sharding.reduce_timing(0.5, [1.0, 2.0], 1) == (0.5, [1.0, 2.0])
 
 
+def _forced_single_worker(port, out_q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    rec = torch.arange(10, dtype=torch.float32).reshape(5, 2)
+    got = sharding.gather_records(rec, 1, dist, force=True)
+    out_q.put(([g.tolist() for g in got], got[0] is rec, sharding.reduce_timing(0.25, [3.0, 4.0], 1, dist, force=True)))
+    dist.destroy_process_group()
+
+
+def test_forced_single_rank_goes_through_the_collectives():
+    """bench.py --force-dist: a world of one still calls all_gather / all_reduce (on the GPU box: RCCL)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_worker, args=(29633, q))
+    p.start()
+    got, same_object, timing = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert got == [torch.arange(10, dtype=torch.float32).reshape(5, 2).tolist()] and not same_object  # a gathered copy
+    assert timing == (0.25, [3.0, 4.0])
+
+
 def test_bench_self_spawns_its_ranks(tmp_path):
     """`python bench.py --gpus N` without torch.distributed.run: the launcher half (bench.spawn_ranks) starts N copies
     of the script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and propagates a failing rank's exit code.  The
@@ -78,3 +101,28 @@ def test_bench_self_spawns_its_ranks(tmp_path):
     assert [e[0] for e in envs] == ['0', '1', '2'] and [e[1] for e in envs] == ['0', '1', '2']
     assert all(e[2] == '3' and e[3] == '3' and e[4] == '127.0.0.1' for e in envs) and len({e[5] for e in envs}) == 1
     assert subprocess.run([sys.executable, str(script), '2', 'fail'], timeout=30).returncode == 7
+
+
+def _ddp_wrap_worker(port, out_q):
+    from torch.nn.parallel import DistributedDataParallel
+    from rdmnet_amd import config, model
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    net = model.create_model(config.make_cfg())
+    ddp = DistributedDataParallel(net)  # what geotransformer/engine/base_tester.py:113 does with the reference's module
+    out_q.put((ddp.module is net, len(list(ddp.parameters())), len(net.state_dict()), len(ddp.state_dict())))
+    dist.destroy_process_group()
+
+
+def test_module_is_wrappable_by_distributed_data_parallel():
+    """DDP's constructor raises for a module without a parameter that requires a gradient; the module
+    registers its parameters as the reference's does (requires_grad=True; forward runs under no_grad)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_wrap_worker, args=(29641, q))
+    p.start()
+    same, n_par, n_keys, n_keys_ddp = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert same and n_keys == n_keys_ddp == 497 and n_par == 497 - 14  # 14 kernel_points buffers

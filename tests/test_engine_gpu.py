@@ -47,6 +47,10 @@ def test_engine_equals_per_op_path_bit_for_bit(ctx):
     assert torch.equal(rc, out['ref_corr_points']) and torch.equal(sc, out['src_corr_points']) and torch.equal(cs, out['corr_scores'])
     assert np.array_equal(eng.transform(), out['estimated_transform'].cpu().numpy())
     assert torch.equal(eng.tensor('estimated_transform'), out['estimated_transform'])
+    # the host half of the result (pinned buffer written by the run's last kernel) holds the same bits
+    hr, hs, hc = eng.host_corr()
+    assert res.n_host_correspondences == res.n_correspondences == hr.shape[0]
+    assert np.array_equal(hr, rc.cpu().numpy()) and np.array_equal(hs, sc.cpu().numpy()) and np.array_equal(hc, cs.cpu().numpy())
 
 
 def test_engine_matches_oracle_and_is_deterministic(ctx):
@@ -83,6 +87,8 @@ def test_full_size_pair_properties(ctx, golden_dir):
     assert res.level_sizes[0] == len(ref) + len(src) and all(res.level_sizes[i] > res.level_sizes[i + 1] for i in range(4))
     rc, sc, cs = eng.corr()
     assert rc.shape[0] == res.n_correspondences > 0 and bool((cs > 0).all()) and bool((cs <= 1.0 + 1e-6).all())
+    hr, hs, hc = eng.host_corr()
+    assert np.array_equal(hr, rc.cpu().numpy()) and np.array_equal(hs, sc.cpu().numpy()) and np.array_equal(hc, cs.cpu().numpy())
     pts_f = eng.tensor('points1')
     n_ref_f = int(res.level_sizes[1])  # both clouds stacked; correspondences must be rows of it
     fine = {tuple(p) for p in pts_f.cpu().numpy().round(6).tolist()}
@@ -137,6 +143,47 @@ def test_engine_deferred_large_buffer_pass_matches_per_op_searches(ctx):
     p0, l0 = data['points'][0], data['lengths'][0]
     full = ext.radius_neighbors(p0, p0, l0, l0, float(ctx['cfg'].backbone.init_radius))
     assert int((full < p0.shape[0]).sum(1).max()) > 256
+
+
+def test_neighbour_limits_beyond_128_slots(ctx, oracle_native):
+    """Neighbour limits are whatever calibrate_neighbors_stack_mode returns (geotransformer/utils/data.py:195-220); round 2
+    refused limits beyond the 128 slots the KPConv kernels stage in LDS (missing 5).  A dense cloud (hundreds
+    of points inside a search radius) with limits of 150-200: the engine equals the per-op mirror bit for bit, and both
+    follow the oracle run with the same limits (encoder taps 2e-5; the tables bit-exact)."""
+    import copy
+    from oracle import forward as ofw
+    from rdmnet_amd import engine, model
+    cfg = copy.deepcopy(ctx['cfg'])
+    cfg.neighbor_limits = [200, 180, 160, 150, 150]
+    rng = np.random.default_rng(9)
+    box = np.array([10.0, 10.0, 2.0])
+    a = (rng.uniform(-1, 1, (5000, 3)) * box).astype(np.float32)
+    b = (rng.uniform(-1, 1, (4500, 3)) * box).astype(np.float32)
+    odata = ofw.pyramid(np.concatenate([a, b]), np.array([len(a), len(b)], np.int64), cfg)
+    assert max(int((t < p.shape[0]).sum(1).max()) for t, p in zip(odata['neighbors'], odata['points'])) > 128
+    otaps = {}
+    ofw.forward(ofw.to_torch(ctx['state']), cfg, odata, otaps)
+    net = model.create_model(cfg).cuda()
+    net.load_state_dict(ctx['state'])
+    data = ctx['collate'].collate_pair(a, b, cfg, exact_shapes=True)
+    for key in ('neighbors', 'subsampling', 'upsampling'):
+        for x, y in zip(data[key], odata[key]):
+            assert torch.equal(x.cpu(), y), key
+    taps = {}
+    out = net(data, taps)
+    worst = 0.0
+    for k in taps:
+        if k.startswith('encoder.'):
+            d, r = (taps[k].cpu().double() - otaps[k].double()).abs().max().item(), otaps[k].double().abs().max().item()
+            worst = max(worst, d / r)
+    assert worst <= 2e-5, worst
+    eng = engine.Engine(cfg, ctx['state'])
+    eng.keep_taps(True)
+    eng.run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    for k in taps:
+        if k.startswith('encoder.'):
+            assert torch.equal(eng.tensor(k), taps[k]), k
+    assert np.array_equal(eng.transform(), out['estimated_transform'].cpu().numpy())
 
 
 def test_engine_handles_neighbourhoods_beyond_every_buffer(ctx, oracle_native):
@@ -237,7 +284,7 @@ def test_model_is_a_torch_module_with_the_reference_checkpoint_layout(ctx):
     assert list(sd.keys()) == list(weights.schema(cfg).keys()) and len(sd) == 497
     n_par, n_buf = sum(p.numel() for p in net.parameters()), sum(b.numel() for b in net.buffers())
     assert n_buf == 14 * 15 * 3 and n_par + n_buf == sum(int(np.prod(s)) for s in weights.schema(cfg).values())
-    assert not any(p.requires_grad for p in net.parameters())  # inference module
+    assert all(p.requires_grad for p in net.parameters())  # as the reference's module (DDP needs one; forward runs under no_grad)
     assert net.load_state_dict(ctx['state'], strict=True) is not None
     bad = dict(ctx['state'])
     bad.pop('optimal_transport.alpha')

@@ -145,6 +145,62 @@ def test_lgr_stage_teacher_forced(ctx):
     assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)  # degrees, metres (= 1e-3 cm)
 
 
+@pytest.mark.parametrize('full', [True, False])
+def test_lgr_with_more_correspondences_than_the_refinement_stages_in_lds(ctx, full):
+    """Trained weights give confident Sinkhorn outputs: up to 256 x (128 + 128) correspondences
+    (local_global_registration.py:145-202), where random weights give a few hundred.  Synthetic confident
+    `matching_scores` for 256 patches -> 16-33 k correspondences, beyond the 4 608 that lgr_refine_kernel stages in LDS
+    (its global-memory branch) -- teacher-forced against oracle.forward.lgr: correspondences bit-exact and in
+    torch.nonzero order, scores to 1e-6, the same hypothesis, pose within 1e-3 deg / 1e-3 cm of the float64 Procrustes of
+    the final inliers and 1e-3 deg / 1e-2 cm of the oracle's fp32 pose (tens of thousands of fp32 terms in its sums)."""
+    ops, cfg, ofw = ctx['ops'], ctx['cfg'], ctx['ofw']
+    fm = cfg.fine_matching
+    g = torch.Generator().manual_seed(11 + int(full))
+    B, K = 256, 128
+    ang = 0.3
+    R = torch.tensor([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    t = torch.tensor([4.0, -2.5, 0.3])
+    centres = (torch.rand(B, 1, 3, generator=g) - 0.5) * torch.tensor([60.0, 60.0, 4.0])
+    ref_knn = centres + (torch.rand(B, K, 3, generator=g) - 0.5) * 5.0
+    perm = torch.stack([torch.randperm(K, generator=g) for _ in range(B)])  # src slot of ref point i: perm[b, i]
+    src_true = (ref_knn - t) @ R  # R^T (ref - t) row-wise
+    src_knn = torch.zeros(B, K, 3)
+    src_knn.scatter_(1, perm[:, :, None].expand(-1, -1, 3), src_true + 0.03 * torch.randn(B, K, 3, generator=g))
+    n_valid = torch.full((B,), K) if full else torch.randint(2, K + 1, (B,), generator=g)
+    n_valid[3] = 2  # below correspondence_threshold: no hypothesis from this patch
+    ref_mask = torch.arange(K)[None] < n_valid[:, None]
+    src_mask = torch.zeros(B, K, dtype=torch.bool).scatter_(1, perm, ref_mask)
+    # every eighth patch is an outlier patch: its src points are somewhere else (other hypotheses, fewer inliers)
+    bad = torch.arange(B) % 8 == 5
+    src_knn[bad] += torch.tensor([7.0, 3.0, 0.0])
+    # log-scores: the true match dominates its row and column, everything else and the dustbins are small; a tenth of
+    # the rows prefer the dustbin (no correspondence from them); masked entries as the Sinkhorn leaves them
+    logit = torch.full((B, K + 1, K + 1), -12.0) + 0.5 * torch.randn(B, K + 1, K + 1, generator=g)
+    logit[:, :-1, :-1].scatter_(2, perm[:, :, None], -0.2 + 0.05 * torch.randn(B, K, 1, generator=g))
+    logit[:, :-1, -1] = torch.where(torch.rand(B, K, generator=g) < 0.1, torch.tensor(-0.05), torch.tensor(-4.0))
+    logit[:, -1, :-1] = -4.0
+    full_r = torch.cat([ref_mask, torch.ones(B, 1, dtype=torch.bool)], 1)
+    full_s = torch.cat([src_mask, torch.ones(B, 1, dtype=torch.bool)], 1)
+    logit = torch.where(full_r[:, :, None] & full_s[:, None, :], logit, torch.tensor(-1e12))
+    o_rc, o_sc, o_cs, o_T, info = ofw.lgr(ref_knn, src_knn, ref_mask, src_mask, logit, cfg)
+    C = o_cs.shape[0]
+    assert C > 2 * 4608 and len(info['chunks']) >= 200
+    rc, sc, cs, T, counts = ops.lgr(logit.cuda().contiguous(), ref_knn.cuda().contiguous(), src_knn.cuda().contiguous(),
+                                    ref_mask.cuda().to(torch.uint8).contiguous(), src_mask.cuda().to(torch.uint8).contiguous(),
+                                    fm.acceptance_radius, fm.correspondence_threshold, fm.num_refinement_steps)
+    assert int(counts[0]) == C and int(counts[1]) == len(info['chunks'])
+    assert torch.equal(rc[:C].cpu(), o_rc) and torch.equal(sc[:C].cpu(), o_sc)
+    assert rel_err(cs[:C], o_cs) <= 1e-6
+    assert int(counts[2]) == info['best']  # the FIRST argmax: most hypotheses tie exactly here (every clean patch explains every clean patch)
+    Tn = T.cpu().double().numpy()
+    res = np.linalg.norm(o_rc.double().numpy() - (o_sc.double().numpy() @ Tn[:3, :3].T + Tn[:3, 3]), axis=1)
+    T64, _ = ofw.procrustes_fp64(o_sc.double().numpy(), o_rc.double().numpy(), o_cs.double().numpy() * (res < fm.acceptance_radius))
+    rre, rte = ofw.rre_rte(Tn, T64)
+    assert rre <= 1e-3 and rte <= 1e-5, (rre, rte)
+    rre, rte = ofw.rre_rte(Tn, o_T.numpy())
+    assert rre <= 1e-3 and rte <= 1e-4, (rre, rte)
+
+
 def test_forward_end_to_end(ctx):
     net, ofw, oo, o = ctx['net'], ctx['ofw'], ctx['oout'], ctx['otaps']
     data = ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], ctx['cfg'])

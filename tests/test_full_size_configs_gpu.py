@@ -2,7 +2,8 @@
 round 1 compared floats with the oracle on a 5 k-point crop only.
 
   configs[1]  single pair, full pipeline, fp32:           every float tap, the discrete outputs and the pose
-  configs[3]  bf16 attention operands (fp32 softmax/SVD): taps within the bf16 tolerance of the oracle's bf16 restatement
+  configs[3]  bf16 attention operands (fp32 softmax/SVD): taps, NMS mask, superpoint pairs, correspondences and pose against
+                                                          the oracle's bf16 restatement
                                                           (parity unpinned against the reference: it has no such switch)
   configs[4]  Mulran-shaped low overlap, vote layer off:  collate bit-exact, float taps, pose against the float64 solution
                                                           of the same inliers (parity unpinned: the reference raises here)
@@ -88,8 +89,10 @@ def test_config1_full_size_pair_matches_oracle(oracle_native, golden_dir):
 
 def test_config3_bf16_attention_full_size(oracle_native, golden_dir):
     """configs[3]: bf16 operands in QK^T and PV (16x16x16 bf16 MFMA), fp32 softmax, accumulation and pose solve -- against
-    the oracle's restatement of the same rounding.  Tolerance: 1.5e-2 of the tensor maximum per attention output (bf16 has 8
-    mantissa bits; kernel and oracle round exp(s - running max) vs exp(s - final max)), compounding over 8 layers."""
+    the oracle's restatement of the same rounding (parity unpinned against the reference: it has no such switch).
+    Measured on both bench pairs (tools/dbg/config3_probe.py): transformer taps 1.2e-4 / 1.8e-4 of the tensor maximum (kernel
+    and oracle round exp(s - running max) vs exp(s - final max) to bf16), NMS mask equal, 256 / 256 superpoint pairs, 763 of
+    764 point correspondences, pose 5e-5 deg / 3e-5 m from the bf16 oracle's.  Asserted with a margin:"""
     from rdmnet_amd import config
     z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
     cfg = config.make_cfg()
@@ -98,11 +101,24 @@ def test_config3_bf16_attention_full_size(oracle_native, golden_dir):
     for k in taps:
         if k.startswith('encoder.'):
             assert rel(taps[k], otaps[k]) <= 2e-5, k  # the encoder does not depend on the switch
-    for k in ('t1_ref', 't1_src'):
-        assert rel(taps[k], otaps[k]) <= 5e-2, (k, rel(taps[k], otaps[k]))
-    assert rel(taps['decoder'], otaps['decoder']) <= 5e-2
+    for k in ('t1_ref', 't1_src', 't2_ref', 't2_src', 'vote_feats'):
+        assert rel(taps[k], otaps[k]) <= 2e-3, (k, rel(taps[k], otaps[k]))  # 8 layers of bf16-rounded attention
+    assert rel(taps['vote_xyz'], otaps['vote_xyz']) <= 2e-5 and rel(taps['decoder'], otaps['decoder']) <= 1e-4
+    # discrete outputs against the bf16 oracle
+    assert torch.equal(taps['nms_mask'].cpu().bool(), otaps['nms_mask'])
+    hp = set(zip(out['ref_node_corr_indices'].tolist(), out['src_node_corr_indices'].tolist()))
+    op = set(zip(oout['ref_node_corr_indices'].tolist(), oout['src_node_corr_indices'].tolist()))
+    assert len(hp & op) >= 0.9 * len(op), len(hp & op)
+
+    def rows(o):
+        return {tuple(r) for r in torch.cat([o['ref_corr_points'].cpu(), o['src_corr_points'].cpu()], 1).double().numpy().round(5).tolist()}
+    hc, oc = rows(out), rows(oout)
+    assert len(hc & oc) >= 0.9 * max(len(hc), len(oc)), (len(hc), len(oc), len(hc & oc))
+    # pose: fp32 solve on (nearly) the same correspondences -- 1e-3 deg / 1e-2 cm of the bf16 oracle's pose
     T = out['estimated_transform'].cpu().double().numpy()
-    assert np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-5  # fp32 pose solve: a proper rotation
+    assert np.isfinite(T).all() and abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-5
+    rre, rte = ofw.rre_rte(T, oout['estimated_transform'].numpy())
+    assert rre <= 1e-3 and rte <= 1e-4, (rre, rte)
 
 
 def test_config4_low_overlap_full_size(oracle_native):

@@ -50,13 +50,13 @@ def test_gemm_batched_patch_scores(ops):
     assert (out.cpu().double() - ref).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize('B,k,n_r,n_s', [(256, 128, 8000, 7500), (3, 128, 50, 40), (17, 64, 300, 300)])
-def test_patch_scores_gathers_inside_the_gemm(ops, B, k, n_r, n_s):
+@pytest.mark.parametrize('B,k,n_r,n_s,d', [(256, 128, 8000, 7500, 256), (3, 128, 50, 40, 256), (17, 64, 300, 300, 256),
+                                         (9, 128, 200, 150, 32), (5, 64, 90, 80, 44)])  # d < 48: the shallow-K dispatch
+def test_patch_scores_gathers_inside_the_gemm(ops, B, k, n_r, n_s, d):
     """rdm_patch_scores (model_infer.py:291-311: padded index_select of the patch features + einsum / sqrt(d)) against the
     separate launches (gather_rows + batched GEMM: same tile, same summation order -> same bits) and torch fp64 (1e-5 of the
     range).  Patches hold their real points first and shadow indices behind (point_to_node_partition), some none at all."""
     g = torch.Generator().manual_seed(B + k)
-    d = 256
     rf, sf = torch.randn(n_r, d, generator=g), torch.randn(n_s, d, generator=g)
 
     def indices(n):
@@ -137,6 +137,42 @@ def test_kpconv_gather_shadow_slots_anywhere(ops, c, h):
     assert torch.count_nonzero(wf_a[0, :15 * c]) == 0
 
 
+@pytest.mark.parametrize('c,h', [(1, 200), (32, 129), (64, 300), (256, 131)])
+def test_kpconv_rows_wider_than_the_lds_staging(ops, c, h):
+    """Neighbour limits beyond the 128 slots a wavefront stages in LDS run in chunks (the reference takes whatever
+    calibrate_neighbors_stack_mode returns, utils/data.py:195-220; round 2 refused them): gather and one-kernel KPConv
+    against the fp64 formula, 2e-5 of the range."""
+    g = torch.Generator().manual_seed(7 * c + h)
+    ns, m = 700, 150
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_pts = s_pts[torch.randint(0, ns, (m,), generator=g)] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g) if c > 1 else torch.ones(ns, 1)
+    idx = torch.randint(0, ns, (m, h), generator=g)
+    n_valid = torch.randint(0, h + 1, (m,), generator=g)
+    n_valid[0], n_valid[1] = h, 129
+    idx = torch.where(torch.arange(h)[None] < n_valid[:, None], idx, torch.full_like(idx, ns))
+    kp = torch.randn(15, 3, generator=g)
+    sigma = 1.7
+    sp = torch.cat([s_pts, torch.full((1, 3), 1e6)]).double()
+    sf = torch.cat([feats, torch.zeros(1, c)]).double()
+    rel = sp[idx] - q_pts.double()[:, None]
+    infl = torch.clamp(1 - ((rel[:, :, None] - kp.double()) ** 2).sum(-1).sqrt() / sigma, min=0)
+    ref = torch.einsum('mhk,mhc->mkc', infl, sf[idx]).reshape(m, 15 * c)
+    nn_ref = torch.cat([feats.sum(1) > 0, torch.zeros(1, dtype=torch.bool)])[idx].sum(1).clamp(min=1).float()
+    fd = padded(feats)
+    wf, nn = ops.kpconv_gather(q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), sigma)
+    assert torch.equal(nn[:m].cpu(), nn_ref)
+    assert (wf.cpu().double()[:, :15 * c] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    cout = 64 if c == 1 else c
+    if ops.kpconv_fused_supported(c, cout):
+        W = torch.randn(15, c, cout, generator=g) / np.sqrt(15 * c)
+        bias = torch.randn(cout, generator=g)
+        want = ref @ W.double().reshape(15 * c, cout) / nn_ref.double()[:, None] + bias.double()
+        packed = torch.from_numpy(ops.kpconv_pack_weights(W.numpy())).cuda()
+        out = ops.kpconv_fused(q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), sigma, packed, bias.cuda(), cout)
+        assert (out.cpu().double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_kpconv_gather_width_cap(ops):
     g = torch.Generator().manual_seed(3)
     ns, m, h, c = 200, 64, 20, 32
@@ -192,6 +228,7 @@ def test_pooling_ops_are_exact(ops):
 
 
 @pytest.mark.parametrize('ns,m,c1,c2,n,norm', [(300, 1000, 64, 36, 128, True), (563, 1310, 257, 1024, 1024, True),
+                                              (50, 1000, 32, 12, 64, True), (40, 300, 32, 4, 64, False),  # c1 + c2 < 48
                                               (1310, 3879, 1024, 512, 512, True), (900, 2500, 512, 256, 257, False)])
 def test_decoder_stage_matches_torch(ops, ns, m, c1, c2, n, norm):
     """Decoder stage (backbone.py:118-151: nearest_upsample + cat + UnaryBlock / Linear) against torch fp64, 2e-5 of the output
@@ -301,155 +338,6 @@ def test_attention_tail_fused_matches_torch(ops, m):
     z3 = ops.gemm(y3, c(w1.t().contiguous()), 128, 256, bias=c(b1), act=1)
     o3 = ops.linear_layer_norm(z3, c(w2), 256, 128, c(b2), c(g2), c(be2), residual=y3).cpu()
     assert (got - o3).abs().max() <= 3e-5 * want.abs().max()
-
-
-@pytest.mark.parametrize('m,lo,hi', [(431, 0, 431), (842, 431, 842), (17, 3, 9), (700, 0, 700)])
-def test_attention_tail_projections_have_the_bits_of_the_separate_gemm(ops, m, lo, hi):
-    """rdm_attention_tail_proj: the Linear layers of the new rows computed by the tail's own launch equal, bit for bit, the
-    rdm_gemm launches they replace (same MFMA tiles, K split and summation order), rows outside [row_lo, row_hi) stay
-    untouched, and the tail's own output does not change."""
-    rng = np.random.default_rng(m + lo)
-    t = lambda *s, scale=1.0: torch.from_numpy((rng.normal(size=s) * scale).astype(np.float32)).cuda()
-    hid, x = t(m, 128), t(m, 128)
-    tail = (t(128, 128, scale=.09), t(128), t(128).abs() + .5, t(128), t(256, 128, scale=.09), t(256), t(128, 256, scale=.06), t(128),
-            t(128).abs() + .5, t(128))
-    b_qkv, bias_qkv = t(128, 384, scale=.09), t(384)
-    b_kv, bias_kv = t(128, 256, scale=.09), t(256)
-    plain = ops.attention_tail(hid, x, *tail)
-    d0, d1 = torch.full((m, 384), 7.0, device='cuda'), torch.full((m, 256), 7.0, device='cuda')
-    out = ops.attention_tail(hid, x, *tail, projections=[(b_qkv, bias_qkv, d0, 384, 0, m), (b_kv, bias_kv, d1, 256, lo, hi)])
-    assert torch.equal(out, plain)
-    assert torch.equal(d0, ops.gemm(plain, b_qkv, 128, 384, bias=bias_qkv))
-    want1 = ops.gemm(plain, b_kv, 128, 256, bias=bias_kv)
-    assert torch.equal(d1[lo:hi], want1[lo:hi])
-    assert (d1[:lo] == 7.0).all() and (d1[hi:] == 7.0).all()
-
-
-@pytest.mark.parametrize('n0,n1', [(350, 301), (16, 1), (0, 40), (33, 0)])
-def test_attention_self_pair_equals_two_launches(ops, n0, n1):
-    """Both clouds' self-attention in one launch (thdroformer.py:225-236) gives the bits of the two separate launches."""
-    g = torch.Generator().manual_seed(n0 + 7 * n1)
-    q, k, v = (torch.randn(n0 + n1, 128, generator=g).cuda() for _ in range(3))
-    for bf16 in (False, True):
-        both = ops.attention_self_pair(q, k, v, n0, 4, bf16=bf16)
-        if n0:
-            assert torch.equal(both[:n0], ops.attention(q[:n0], k[:n0], v[:n0], 4, bf16=bf16))
-        if n1:
-            assert torch.equal(both[n0:], ops.attention(q[n0:], k[n0:], v[n0:], 4, bf16=bf16))
-
-
-@pytest.mark.parametrize('n0,n1,cross', [(350, 301, False), (17, 5, False), (431, 411, True), (16, 33, True)])
-def test_attention_layer_one_launch_matches_the_separate_launches_and_torch(ops, n0, n1, cross):
-    """rdm_attention_layer (attention + tail + the following layers' projections with the rotary embedding, one launch)
-    against (a) the launches it replaces (rdm_attention / rdm_attention_tail / rdm_gemm / rdm_rope): 2e-5 of the output range
-    -- the key split and the contraction order differ -- and (b) torch fp64 of the reference formulas
-    (thdroformer.py:56-85, 112-139, 142-173; output_layer.py:6-21): 5e-5 of the output range."""
-    rng = np.random.default_rng(n0 * 3 + n1)
-    t = lambda *s, scale=1.0: torch.from_numpy((rng.normal(size=s) * scale).astype(np.float32))
-    N = n0 + n1
-    q, x = t(N, 128), t(N, 128)
-    kv = t(N, 256)
-    emb = t(N, 64)
-    wo, w1, w2 = t(128, 128, scale=128 ** -0.5), t(256, 128, scale=128 ** -0.5), t(128, 256, scale=256 ** -0.5)
-    bo, b1, b2 = t(128), t(256), t(128)
-    g1, g2 = (torch.from_numpy(rng.uniform(0.5, 1.5, 128).astype(np.float32)) for _ in range(2))
-    be1, be2 = t(128), t(128)
-    wp, bp = t(384, 128, scale=128 ** -0.5), t(384)        # q|k|v of a following self layer (rotary embedding on q, k)
-    wq, bq = t(256, 128, scale=128 ** -0.5), t(256)        # a second projection of some rows only
-    c = lambda v: v.cuda().contiguous()
-    qd, xd, kvd, embd = c(q), c(x), c(kv), c(emb)
-    tail = tuple(c(v) for v in (wo, bo, g1, be1, w1, b1, w2, b2, g2, be2))
-    out, dst0, dst1 = (torch.full((N, w), 7.0, device='cuda') for w in (128, 384, 256))
-    if cross:   # one segment: rows [0, n0) attend to rows [n0, N)
-        segs = [(0, n0, kvd[n0:, :128], kvd[n0:, 128:])]
-        rows, keys = [slice(0, n0)], [slice(n0, N)]
-        bits1 = 1
-    else:       # two segments: each range attends to itself
-        segs = [(0, n0, kvd[:n0, :128], kvd[:n0, 128:]), (n0, n1, kvd[n0:, :128], kvd[n0:, 128:])]
-        rows, keys = [slice(0, n0), slice(n0, N)], [slice(0, n0), slice(n0, N)]
-        bits1 = 2
-    ops.attention_layer(out=out, q=qd, x=xd, segments=segs, tail=tail, emb=embd,
-                        projections=[(c(wp), c(bp), dst0, 256, 3), (c(wq), c(bq), dst1, 0, bits1)])
-    # (a) the separate launches
-    for r, kk in zip(rows, keys):
-        hid = ops.attention(qd[r], kvd[kk, :128], kvd[kk, 128:], 4)
-        o = ops.attention_tail(hid, xd[r], *tail)
-        scale = o.abs().max()
-        assert (out[r] - o).abs().max() <= 2e-5 * scale
-        p0 = ops.gemm(o, c(wp.t()), 128, 384, bias=c(bp))
-        ops.rope(p0[:, :128], p0[:, 128:256], embd[r])
-        assert (dst0[r] - p0).abs().max() <= 2e-5 * p0.abs().max()
-    sel = rows[-1] if not cross else rows[0]
-    p1 = ops.gemm(out[sel].contiguous(), c(wq.t()), 128, 256, bias=c(bq))
-    assert (dst1[sel] - p1).abs().max() <= 2e-5 * p1.abs().max()
-    if not cross:  # rows of the segment the second projection skips stay untouched, rows outside every segment too
-        assert (dst1[:n0] == 7.0).all()
-    else:
-        assert (out[n0:] == 7.0).all() and (dst0[n0:] == 7.0).all() and (dst1[n0:] == 7.0).all()
-    # (b) torch fp64
-    for r, kk in zip(rows, keys):
-        Q = q[r].double().reshape(-1, 4, 32).transpose(0, 1)
-        K = kv[kk, :128].double().reshape(-1, 4, 32).transpose(0, 1)
-        V = kv[kk, 128:].double().reshape(-1, 4, 32).transpose(0, 1)
-        hid = (torch.softmax(Q @ K.transpose(1, 2) / np.sqrt(32.0), -1) @ V).transpose(0, 1).reshape(-1, 128)
-        y = F.layer_norm(hid @ wo.double().t() + bo.double() + x[r].double(), (128,), g1.double(), be1.double(), 1e-5)
-        z = torch.relu(y @ w1.double().t() + b1.double())
-        want = F.layer_norm(z @ w2.double().t() + b2.double() + y, (128,), g2.double(), be2.double(), 1e-5)
-        assert (out[r].cpu().double() - want).abs().max() <= 5e-5 * want.abs().max()
-        p0 = want @ wp.double().t() + bp.double()
-        theta = 2 * np.pi * torch.sigmoid(emb[r].double())
-        cs, sn = torch.cos(theta), torch.sin(theta)
-        for base in (0, 128):
-            x0, x1 = p0[:, base:base + 128:2].clone(), p0[:, base + 1:base + 128:2].clone()
-            p0[:, base:base + 128:2] = x0 * cs - x1 * sn
-            p0[:, base + 1:base + 128:2] = x1 * cs + x0 * sn
-        assert (dst0[r].cpu().double() - p0).abs().max() <= 5e-5 * p0.abs().max()
-    # projections only: the rows of `out` through a projection
-    dst2 = torch.zeros((N, 384), device='cuda')
-    ops.attention_layer(out=out, segments=[(0, N, None, None)], projections=[(c(wp), c(bp), dst2, 256, 1)], emb=embd,
-                        projections_only=True)
-    if not cross:
-        assert torch.equal(dst2, dst0)
-    else:
-        assert torch.equal(dst2[:n0], dst0[:n0])
-
-
-def test_point_to_node_pair_equals_two_calls(ops):
-    """Both clouds' point-to-node grouping with one set of launches (point_to_node.py semantics) = two single calls."""
-    g = torch.Generator().manual_seed(11)
-    pa, pb = torch.randn(9000, 3, generator=g).cuda() * 20, torch.randn(7001, 3, generator=g).cuda() * 20
-    na, nb = pa[torch.randperm(9000, generator=g)[:330].cuda()].contiguous(), pb[torch.randperm(7001, generator=g)[:301].cuda()].contiguous()
-    st = torch.zeros(4, dtype=torch.int32, device='cuda')
-    both = ops.point_to_node_pair(pa, na, pb, nb, 128, st)
-    for got, (p, n) in zip(both, ((pa, na), (pb, nb))):
-        want = ops.point_to_node(p, n, 128, st)
-        for x, y in zip(got, want):
-            assert torch.equal(x, y)
-    assert int(st[0]) == 0
-
-
-@pytest.mark.parametrize('nr,nc', [(128, 128), (128, 40), (17, 128), (127, 128), (128, 1), (101, 100), (69, 68),
-                                   (31, 31), (32, 31), (8, 20), (1, 1), (63, 63), (64, 33), (3, 60)])
-def test_sinkhorn_full_and_partial_patches_match_oracle(ops, nr, nc):
-    """learnable_sinkhorn.py:13-66 on patches whose sides are FULL (128 valid points + dustbin = 129 lines, one more than the
-    128 lines the kernel's thread pairs own) and at the size-class boundaries; scattered masks.  Dustbin row and column
-    included: abs 2e-4 on log-scores of magnitude ~1e1-1e2, masked entries exactly fl(-1e12)."""
-    from oracle import forward as ofw
-    g = torch.Generator().manual_seed(1000 * nr + nc)
-    B = 3
-    scores = torch.randn(B, 128, 128, generator=g) * 4.0
-    rm, cm = torch.zeros(B, 128, dtype=torch.bool), torch.zeros(B, 128, dtype=torch.bool)
-    for b in range(B):
-        rm[b, torch.randperm(128, generator=g)[:nr]] = True
-        cm[b, torch.randperm(128, generator=g)[:nc]] = True
-    alpha = torch.tensor(1.0)
-    ref = ofw.sinkhorn(scores, rm, cm, alpha, 100)
-    out = ops.sinkhorn(scores.cuda(), rm.to(torch.uint8).cuda(), cm.to(torch.uint8).cuda(), alpha.reshape(1).cuda(), 100).cpu()
-    valid = ref > -1e11
-    assert torch.equal(out > -1e11, valid)
-    assert bool(valid[:, 128, :].any()) and bool(valid[:, :, 128].any())  # the dustbin lines are part of the check
-    assert (out[valid] - ref[valid]).abs().max().item() <= 2e-4
-    assert torch.equal(out[~valid], ref[~valid])
 
 
 @pytest.mark.parametrize('c,cout,h,m,ns', [(1, 64, 65, 1000, 1500), (32, 32, 65, 1000, 2000), (64, 64, 63, 700, 900), (32, 32, 3, 50, 60),

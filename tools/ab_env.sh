@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # interleaved A/B of one environment knob on the same box:  bash tools/ab_env.sh RDM_NO_VIRTUAL_CONCAT [rounds] [streams]
 K=$1; N=${2:-3}; S=${3:-4}
 run() {

@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 python -m pytest tests -q -m gpu -x 2>&1 | tail -3
 for v in multi single multi single; do
   if [ $v = single ]; then export RDM_GS_SINGLE=1; else unset RDM_GS_SINGLE; fi

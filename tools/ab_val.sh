@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # interleaved comparison of the values of one environment knob on the same box:  bash tools/ab_val.sh VAR "v1 v2 ..." [rounds] [streams]
 K=$1; VALS=$2; N=${3:-3}; S=${4:-4}
 run() {

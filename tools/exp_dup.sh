@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # Marginal cost of each kernel class with four pairs in flight: RDM_DUP=<class> launches every kernel of the class twice
 # (idempotent launches, same results), so  ms/pair(dup) - ms/pair(base)  is what the class costs per pair in the
 # throughput regime -- the number that says where a faster kernel would pay (sums of kernel durations do not: small

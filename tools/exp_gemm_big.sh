@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # larger GEMM tiles for the big un-split products with four pairs in flight (RDM_GEMM_BIG, gemm.hip)
 run() {
   python bench.py --streams 4 --steps 240 --warmup 16 --ramp-seconds 2 --no-cpu-baseline --host-steps 0 --api-steps 0 2>/dev/null | python -c "

@@ -2,6 +2,7 @@
 --kernel-trace).  `rowdiv` routes through the tiled kernels like the KPConv contraction does."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from rdmnet_amd import ops
 m, k, n = (int(x) for x in sys.argv[1:4])

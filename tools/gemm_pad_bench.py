@@ -1,6 +1,7 @@
 """Does the leading dimension of A matter (L2 channel aliasing)?  Times rdm_gemm with A row stride K vs K+pad."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from rdmnet_amd import ops
 shapes = [('kp3_2', 5289, 1920, 128), ('kp4_2', 1900, 3840, 256), ('kp5_1', 700, 3840, 256), ('kp5_2', 700, 7680, 512),

@@ -2,6 +2,7 @@
 graph-replayed timings as in gemm_sweep_graph.py.  Run once per setting and compare the sums."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from gemm_sweep_graph import shapes, timed
 

@@ -2,6 +2,7 @@
 the deep products of the path; graph-replayed (tools/gemm_sweep_graph.py)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from gemm_sweep_graph import shapes, timed
 deep = [s for s in shapes if s[0].startswith(('kp', 'dec')) or s[0] in ('u3c', 'u4b', 'u4c', 'u4d', 'u2c', 'u1e', 'u0c')]

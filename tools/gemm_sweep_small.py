@@ -2,6 +2,7 @@
 HIP events, 40 repetitions, operands resident."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from rdmnet_amd import ops
 shapes = [(32000, 64, 32), (32000, 32, 128), (32000, 64, 128), (32000, 128, 32), (10961, 128, 64), (10961, 64, 256),

@@ -1,6 +1,7 @@
 """Transformer-sized products: the 32x32 K-split kernel (RDM_GEMM_TUNE unset or '0,0') against the tiled kernels."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('RDM_LIB_PATH', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rdmnet_amd', 'librdmnet_hip_lab.so'))  # RDM_GEMM_TUNE lives in the lab build (make -C rdmnet_amd/csrc lab)
 import torch
 from rdmnet_amd import ops
 from gemm_sweep_graph import timed  # noqa

@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # HBM traffic (PMC) and per-layer times of the fused KPConv kernel (RDM_FUSED_KPCONV=1) beside the default gather + GEMM pair
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_r02; mkdir -p $O

@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 #!/bin/bash
 # gpurun -- 'bash tools/pmc_gemm.sh M K N'  : MFMA / wait / LDS counters of the tiled GEMM on one shape
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

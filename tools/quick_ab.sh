@@ -1,3 +1,4 @@
+source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in the lab build
 # quick throughput check: four pairs in flight and one (no CPU baseline, no host-to-host / API passes)
 for s in 4 1 4; do
   python bench.py --streams $s --steps ${STEPS:-320} --warmup 16 --ramp-seconds 2 --no-cpu-baseline --host-steps 0 --api-steps 0 2>/dev/null | python -c "
