@@ -137,6 +137,9 @@ int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int6
              int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c, int64_t m,
              int64_t n, int64_t k, int batches, const float* bias, const float* rowdiv, int act,
              void* ws, size_t ws_bytes, void* stream);
+/* The tile and split-K factor the dispatch model chose for the calling thread's last rdm_gemm / fused Linear call:
+ * out4_host = {tile rows, tile columns, k-tile depth, split-K factor} (diagnostic: profiles/r03_gemm_shapes.md).  */
+int rdm_gemm_last_plan(int* out4_host);
 
 /* ---- a4: KPConv neighbourhood aggregation ---------------------------------------------------
  * Replaces the gather half of KPConv.forward (geotransformer/modules/kpconv/kpconv.py:91-105,
@@ -155,12 +158,12 @@ int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, i
  * 64), 32 -> 32, 64 -> 64: out[m, c'] = (sum_k sum_c wf[m, k, c] W[k, c, c']) / nn[m] + bias[c'] with wf and nn as in
  * rdm_kpconv_gather; the [m, 15*c] intermediate stays in LDS.  w_packed: W [15, c_in, c_out] reordered by
  * rdm_kpconv_pack_weights (host arrays; rdm_kpconv_packed_floats floats).  gn_partial (optional): fp64 column sums /
- * sums of squares of the output per block of rdm_kpconv_fused_rows_per_block(c_in) rows, [blocks][2][c_out] -- the
+ * sums of squares of the output, one partial row per workgroup: [rdm_kpconv_fused_partial_rows(m, c_in)][2][c_out] -- the
  * input of the GroupNorm that follows every KPConv.  rdm_kpconv_fused_group_norm = that convolution +
  * act(GroupNorm(.)) (modules.py:141-145, 205-207), workspace rdm_kpconv_fused_workspace_bytes.                    */
 int rdm_kpconv_fused_enabled(void);   /* 1 iff RDM_FUSED_KPCONV is set: engine and per-op path then use the fused kernel */
 int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out);
-int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in);
+int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in);
 size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out);
 int rdm_kpconv_pack_weights(const float* w_host, int64_t c_in, int64_t c_out, float* packed_host);
 int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,

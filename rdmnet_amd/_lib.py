@@ -32,13 +32,14 @@ SIGNATURES = {
     'rdm_gemm_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_gemm': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_i64, c_i64, c_i64, c_i64,
                          c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_void]),
+    'rdm_gemm_last_plan': (c_int, [c_void]),
     'rdm_kpconv_gather': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
     'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
     'rdm_kpconv_fused_enabled': (c_int, []),
     'rdm_kpconv_fused_supported': (c_int, [c_i64, c_i64]),
-    'rdm_kpconv_fused_rows_per_block': (c_i64, [c_i64]),
+    'rdm_kpconv_fused_partial_rows': (c_i64, [c_i64, c_i64]),
     'rdm_kpconv_packed_floats': (c_size, [c_i64, c_i64]),
     'rdm_kpconv_pack_weights': (c_int, [c_void, c_i64, c_i64, c_void]),
     'rdm_kpconv_fused': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64, c_i64, c_void, c_void,

@@ -830,12 +830,15 @@ extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
 
 namespace {
 
+thread_local int g_last_plan[4] = {0, 0, 0, 0};  // tile rows, tile columns, k-tile depth, split-K factor of the last dispatch
+
 int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
   const long long m = g.M, n = g.N, k = g.K;
   const char* tune_env = ::rdm::dev_knob("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
   if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && !g.aidx && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
       m * n <= 1536 * 512 && !(tune_env && tune_env[0] != '0')) {
     if (stat_blocks) *stat_blocks = 0;
+    g_last_plan[0] = 32; g_last_plan[1] = 32; g_last_plan[2] = static_cast<int>(k / 4); g_last_plan[3] = 4;  // K over four wavefronts
     RDM_DUP_LOOP("gemmsmall")
     hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
     return launch_status("gemm_small_kernel");
@@ -937,6 +940,8 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   if (stat_blocks)
     *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm))
                            : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, stat_rows_per_block(n))) : 0);
+  g_last_plan[0] = bm; g_last_plan[1] = bn; g_last_plan[3] = g.splits;
+  g_last_plan[2] = tile == T128 ? 16 : ((tile == T64 ? (k >= 48 || g.aidx) : k >= 32) ? 32 : 16);
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   RDM_DUP_LOOP("gemm") {
@@ -1042,6 +1047,15 @@ int rdm::gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0,
   if (m0 > 0)
     if (int e = rdm_gemm(a0, lda0, 0, b0, ldb0, 0, 0, c0, ldc0, 0, m0, n0, k0, 1, bias0, nullptr, 0, ws, ws_bytes, stream)) return e;
   if (m1 > 0) return rdm_gemm(a1, lda1, 0, b1, ldb1, 0, 0, c1, ldc1, 0, m1, n1, k1, 1, bias1, nullptr, 0, ws, ws_bytes, stream);
+  return RDM_OK;
+}
+
+// What the dispatch model chose for the calling thread's last product: {tile rows, tile columns, k-tile depth, split-K factor}
+// ({32, 32, K/4, 4} = the transformer-width kernel whose four wavefronts split K).  For profiles/r03_gemm_shapes.md.
+extern "C" int rdm_gemm_last_plan(int* out4_host) {
+  using namespace rdm;
+  RDM_REQUIRE(out4_host, "rdm_gemm_last_plan: null pointer");
+  for (int i = 0; i < 4; ++i) out4_host[i] = g_last_plan[i];
   return RDM_OK;
 }
 

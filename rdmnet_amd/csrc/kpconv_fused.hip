@@ -16,9 +16,10 @@
 //   C = 64:  8 wavefronts x 2 queries, 4 column tiles x 2 K slices; 62 KB block + 16 KB staging -> 2 workgroups per CU
 //   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
 //   channel, 16 wavefronts x 4 queries per workgroup.
-// Measured (DESIGN.md §5b, profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
-// scan pair, the time does not (the LDS block caps a CU at 16-32 queries in flight in lock-step phases), so the engine
-// uses it only when RDM_FUSED_KPCONV=1.
+// Measured (DESIGN.md 5b / 5d, profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
+// scan pair at the same pairs/s; the engine's default for these layers since round 3.  The kernel's time is the sum of its
+// phases' L2 -> CU traffic (neighbour lines + W re-read per 16 queries: tools/kpconv_bench.py, tools/lab/kpconv_fused_pc.hip
+// for the producer / consumer variant that overlaps the phases and measured the same).
 #include <atomic>
 #include <cstdlib>
 
@@ -342,8 +343,13 @@ extern "C" int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out) {
   return (c_in == 1 && c_out == kC1Out) || (c_in == 32 && c_out == 32) || (c_in == 64 && c_out == 64);
 }
 
-extern "C" int64_t rdm_kpconv_fused_rows_per_block(int64_t c_in) {
-  return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64);
+namespace {
+int64_t rows_per_block(int64_t c_in) { return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64); }
+}  // namespace
+
+// Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries writes (one per workgroup).
+extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in) {
+  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in));
 }
 
 extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
@@ -392,7 +398,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned blocks = static_cast<unsigned>(ceil_div<int64_t>(m, rdm_kpconv_fused_rows_per_block(c)));
+  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows(m, c));
   if (c == 1) {
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     return launch_status("kpconv_fused_c1_kernel");
@@ -412,7 +418,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
 }
 
 extern "C" size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out) {
-  const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(m > 0 ? m : 1, rdm_kpconv_fused_rows_per_block(c_in)));
+  const size_t nblk = static_cast<size_t>(rdm_kpconv_fused_partial_rows(m > 0 ? m : 1, c_in));
   return rdm::align_up(nblk * 2 * c_out * sizeof(double)) + rdm_group_norm_workspace_bytes(m, c_out) + 256;
 }
 
@@ -429,7 +435,7 @@ extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, con
   RDM_REQUIRE(gamma && beta && conv_out && y, "rdm_kpconv_fused_group_norm: null pointer");
   if (m == 0) return RDM_OK;
   Arena ar(ws, ws_bytes);
-  const int nblk = static_cast<int>(ceil_div<int64_t>(m, rdm_kpconv_fused_rows_per_block(c)));
+  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, c));
   double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c_out);
   const size_t gn_ws = rdm_group_norm_workspace_bytes(m, c_out);
   char* nws = ar.take<char>(gn_ws);
