@@ -147,7 +147,7 @@ int rdm_gemm_last_plan(int* out4_host);
  * and nn[m] = max(1, #neighbours whose feature row sums to > 0) (as float).  Pad indices (>= n_s)
  * are the reference's shadow point/zero row.  s_positive[i] = (sum_c feats[i,c] > 0), see
  * rdm_row_positive / rdm_group_norm.  width (optional device int32) caps the row width like the
- * reference's `[:, :min(limit, max_count)]`.  c in {1, 32, 64, 128, 256, 512}; any h (rows wider than the 128 slots a wavefront stages in LDS run in chunks).
+ * reference's `[:, :min(limit, max_count)]`.  c = 1 or any multiple of 32; any h (rows wider than the 128 slots a wavefront stages in LDS run in chunks).
  * The second half of the convolution is rdm_gemm(wf, W[15*c, c'], rowdiv = nn, bias).          */
 int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
                       const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,

@@ -38,6 +38,7 @@ struct KpArgs {
   const int32_t* width;    // optional device int: effective row width (min(limit, max_count))
   const float4* order;     // optional processing order: query row = int bits of order[unit].w
   int units_per_block;     // work units (query x channel slice) per workgroup
+  int split;               // channel slices per query when the kernel's SPLIT parameter is 0 (generic channel counts)
   int xcd_remap;           // 1: workgroups re-mapped so that each XCD owns a contiguous range of the (cell-ordered) units
   float* wf;               // [M, ldw] (>= 15*C)
   float* nn;               // [M]
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   // so lines gathered for one query are still in this CU's L1 for its neighbours; workgroups are
   // re-mapped so that each XCD (own L2) gets a contiguous range of the level.  Small levels: one unit per
   // wavefront for parallelism.
-  const int total_units = a.M * SPLIT;
+  const int split = SPLIT > 0 ? SPLIT : a.split;  // (SPLIT = 0: any multiple of 16*VEC*U channels, slices counted at run time)
+  const int total_units = a.M * split;
   const int qpb = a.units_per_block;
   const int nblk = gridDim.x;
   int blk = blockIdx.x;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   for (int u0 = wave; u0 < qpb; u0 += kWaves) {
   const int unit = blk * qpb + u0;
   if (unit >= total_units) break;
-  const int slice = unit % SPLIT;
-  const int m = a.order ? __float_as_int(a.order[unit / SPLIT].w) : unit / SPLIT;
+  const int slice = unit % split;
+  const int m = a.order ? __float_as_int(a.order[unit / split].w) : unit / split;
   int H = a.H;
   if (a.width) H = min(H, *a.width);
   const int c_base = slice * (16 * VEC * U);  // first channel of this wavefront's slice
@@ -283,8 +285,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
               "rdm_kpconv_gather: null pointer");
   RDM_REQUIRE(m >= 0 && n_s > 0 && h > 0, "rdm_kpconv_gather: bad sizes (h=%lld)", (long long)h);
-  RDM_REQUIRE(c == 1 || (c % 32 == 0 && c <= 512), "rdm_kpconv_gather: unsupported channel count %lld",
-              (long long)c);
+  RDM_REQUIRE(c == 1 || c % 32 == 0, "rdm_kpconv_gather: unsupported channel count %lld (1 or a multiple of 32)", (long long)c);
   RDM_REQUIRE(ldw >= kKP * c && (c == 1 || (ldf % 4 == 0 && ldw % 4 == 0)),
               "rdm_kpconv_gather: ldw/ldf must be padded");
   if (m == 0) return RDM_OK;
@@ -294,7 +295,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   a.order = reinterpret_cast<const float4*>(order_records);
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
-  a.ldw = static_cast<int>(ldw); a.sigma = sigma;
+  a.ldw = static_cast<int>(ldw); a.sigma = sigma; a.split = 1;
   static const bool xcd_env = ::rdm::dev_knob("RDM_GATHER_XCD") != nullptr;  // developer knob (A/B)
   a.xcd_remap = (xcd_env && order_records) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -316,9 +317,10 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
     case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 4>), grid(2), block, 0, st, a); break;
     case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 4, 4>), grid(4), block, 0, st, a); break;
     case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 4, 2>), grid(4), block, 0, st, a); break;
-    default:
-      set_error("rdm_kpconv_gather: channel count %lld has no kernel instance", (long long)c);
-      return RDM_ERR_ARG;
+    default:  // any other multiple of 32 (the backbone's widths are 32 * 2^k; the reference takes any init_dim): 32-channel slices
+      a.split = static_cast<int>(c / 32);
+      hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 0, 4>), grid(a.split), block, 0, st, a);
+      break;
   }
   return launch_status("kpconv_gather_kernel");
 }

@@ -79,7 +79,8 @@ def test_patch_scores_gathers_inside_the_gemm(ops, B, k, n_r, n_s, d):
 
 
 @pytest.mark.parametrize('c,h,m,ns', [(1, 65, 500, 700), (32, 65, 400, 900), (64, 63, 300, 500), (128, 69, 200, 300),
-                                      (256, 70, 150, 200), (512, 81, 90, 100), (32, 3, 50, 60)])
+                                      (256, 70, 150, 200), (512, 81, 90, 100), (32, 3, 50, 60),
+                                      (96, 40, 120, 200), (160, 33, 70, 90), (1024, 20, 40, 60)])  # widths outside 32 * 2^k <= 512: the generic instance
 def test_kpconv_gather_matches_reference_formula(ops, c, h, m, ns):
     """kpconv.py:91-105,113-115 restated in fp64 on random clouds with pad slots."""
     g = torch.Generator().manual_seed(c + h)
@@ -171,6 +172,17 @@ def test_kpconv_rows_wider_than_the_lds_staging(ops, c, h):
         packed = torch.from_numpy(ops.kpconv_pack_weights(W.numpy())).cuda()
         out = ops.kpconv_fused(q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), sigma, packed, bias.cuda(), cout)
         assert (out.cpu().double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_kpconv_gather_refuses_channel_counts_it_has_no_layout_for(ops):
+    """Feature widths must be 1 or a multiple of 32 (16 lanes x 8-byte pieces of a row): anything else is a RuntimeError
+    with the reason, never a silent wrong answer (the reference's backbone widths are init_dim * 2^k, backbone.py:27-70)."""
+    g = torch.Generator().manual_seed(1)
+    s_pts, feats = torch.randn(50, 3, generator=g), torch.randn(50, 48, generator=g)
+    idx = torch.randint(0, 50, (20, 8), generator=g)
+    with pytest.raises(RuntimeError, match='unsupported channel count 48'):
+        ops.kpconv_gather(s_pts[:20].cuda(), s_pts.cuda(), padded(feats), ops.row_positive(padded(feats)), idx.cuda(),
+                          torch.randn(15, 3, generator=g).cuda(), 1.0)
 
 
 def test_kpconv_gather_width_cap(ops):
