@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rdmnet_amd import ops
-from layer_bench import timed
+from kpconv_bench import timed
 
 if __name__ == '__main__':
     torch.manual_seed(0)
