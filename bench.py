@@ -208,6 +208,8 @@ def main():
     ap.add_argument('--wait-us', type=int, default=-1,
                     help='how an engine waits at its size read-backs: 0 = hipStreamSynchronize (spins a core per pair in\n'
                          'flight), N > 0 = poll and sleep N us; -1 = choose from the CPU budget of this rank')
+    ap.add_argument('--stagger-ms', type=float, default=1.5,
+                    help='in-flight pair k starts k x this many ms after the first one (de-phases the pairs; 0 = all at once)')
     ap.add_argument('--ramp-seconds', type=float, default=5.0,
                     help='untimed pairs run for this long before the warm-up steps so that host and GPU clocks are at their\n'
                          'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
@@ -318,6 +320,7 @@ def main():
             eng = engine.Engine(cfg, state, device=dev)
             eng.enable_profile(False)
             eng.set_wait(wait_us)
+            eng.set_pairs_in_flight(args.streams)
             engines.append(eng)
 
     # Slots of every KPConv layer's neighbour table that hold a real neighbour (the rest is padding behind them), per
@@ -386,7 +389,16 @@ def main():
                     yield queue.popleft()  # atomic under the GIL
                 except IndexError:
                     return
-        threads = [threading.Thread(target=run_range, args=(draw(), streams[k], rec, lat_out, prof_lists[k],
+        # stream k draws its first step k x stagger into the region: after the fence the in-flight pairs would otherwise walk
+        # through the same stages in phase (four serial subsampling kernels, then four encoders contending), which costs a short
+        # region 6 % (measured with 20 steps: 432-437 -> 452-457 / 472-478 / 473-481 pairs/s at 0.5 / 1 / 1.5 ms); the sleeps are inside the timed region
+        stagger = float(os.environ.get('RDM_BENCH_STAGGER_MS', args.stagger_ms)) * 1e-3
+
+        def staggered(k):
+            if stagger > 0 and k > 0:
+                time.sleep(k * stagger)
+            yield from draw()
+        threads = [threading.Thread(target=run_range, args=(staggered(k), streams[k], rec, lat_out, prof_lists[k],
                                                             engines[k] if engines else None, events_every))
                    for k in range(len(streams))]
         for t in threads:
@@ -472,6 +484,7 @@ def main():
         if net is None:
             net = model.create_model(cfg).cuda(local_rank)
             net.load_state_dict(state)
+        net.pairs_in_flight = args.streams
 
         def make_data(i):
             r, s_ = dev_pairs[(rank + i * world) % len(dev_pairs)]

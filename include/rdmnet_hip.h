@@ -480,6 +480,10 @@ int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* data, rdm_engine_resu
  * which spins a host core per in-flight pair; sleep_us > 0 polls hipStreamQuery and sleeps that long in between (for
  * hosts whose CPU quota is smaller than ranks x pairs in flight). */
 int rdm_engine_set_wait(rdm_engine* e, int sleep_us);
+/* How many scan pairs the caller keeps in flight on this GPU (one engine and stream each; default 1).  A scheduling hint, results do
+ * not depend on it: from 3 the tiled GEMM leaves half of a CU's registers and LDS to the other pairs' kernels (two workgroups
+ * per CU instead of four: +3 % pairs/s at four in flight, -2 % with one pair alone).                            */
+int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n);
 int rdm_engine_enable_profile(rdm_engine* e, int enable);
 int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);

@@ -67,6 +67,7 @@ struct rdm_engine {
   std::map<std::string, rdm_tensor_view> taps;
   bool keep_taps = false;
   bool collate_only = false;  // rdm_engine_collate: stop after the pyramid and its searches
+  int pairs_in_flight = 1;    // rdm_engine_set_pairs_in_flight: how many pairs share the GPU (>= 3: GEMM residency capped)
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -726,6 +727,12 @@ extern "C" int rdm_engine_set_wait(rdm_engine* e, int sleep_us) {
   return RDM_OK;
 }
 
+extern "C" int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n) {
+  RDM_REQUIRE(e && n >= 1, "rdm_engine_set_pairs_in_flight: bad arguments");
+  e->pairs_in_flight = n;
+  return RDM_OK;
+}
+
 extern "C" int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap) {
   RDM_REQUIRE(e && out && cap >= 0, "rdm_engine_get_profile: bad arguments");
   const int n = std::min<int>(cap, static_cast<int>(e->prof.size()));
@@ -758,6 +765,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
 // re-run.  An arena size chosen by the caller (rdm_engine_config.arena_bytes) is never changed.
 static int engine_run_growing(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
                               const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
+  // with three or more pairs sharing the GPU the tiled GEMM keeps two workgroups per CU (gemm.hip: gemm_set_lds_pad)
+  struct PadGuard {
+    explicit PadGuard(unsigned b) { rdm::gemm_set_lds_pad(b); }
+    ~PadGuard() { rdm::gemm_set_lds_pad(0); }
+  } pad_guard(e->pairs_in_flight >= 3 ? 20480u : 0u);
   for (;;) {
     e->arena_exhausted = false;
     const int rc = engine_run_once(e, ref_points, n_ref, src_points, n_src, dd, res, stream);

@@ -799,26 +799,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, do
   }
 }
 
+thread_local unsigned g_lds_pad = 0;  // see rdm::gemm_set_lds_pad
+
 template <int BM, int BN, int WM, int WN, int BK, int PF = 1>
 void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   dim3 grid(ceil_div(g.N, BN), ceil_div(g.M, BM), batches * g.splits);
+  // unused dynamic LDS per workgroup = fewer GEMM workgroups per CU (rdm::gemm_set_lds_pad; lab build: RDM_GEMM_LDS_PAD=<bytes>)
+  static const int pad_env = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_LDS_PAD"); return v ? atoi(v) : -1; }();
+  const unsigned pad = pad_env >= 0 ? static_cast<unsigned>(pad_env) : g_lds_pad;
   if constexpr (BM == 64 && BN == 64 && BK == 32 && PF == 2) {
     if (g.aidx && g.bidx) {  // gathered rows on both sides (patch scores)
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>), grid, dim3(256), pad, st, g);
       return;
     }
     if (g.aidx) {  // virtual [upsample | skip] A operand
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>), grid, dim3(256), pad, st, g);
       return;
     }
   }
   if (trans_b)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF>), grid, dim3(256), pad, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF>), grid, dim3(256), 0, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF>), grid, dim3(256), pad, st, g);
 }
 
 }  // namespace
+
+// Residency of the tiled GEMM for the calling thread's launches: `bytes` of unused dynamic LDS per workgroup.  A 64 x 64 tile
+// holds 34 KB and 128 VGPRs x 4 wavefronts, so four of its workgroups fill a CU; when several scan pairs share the GPU, 20 KB
+// of padding (two workgroups per CU) leaves registers and LDS for the other pairs' kernels: +3 % pairs/s at four in flight,
+// -2 % with one.  The engine sets it from rdm_engine_set_pairs_in_flight; results do not depend on it.
+void rdm::gemm_set_lds_pad(unsigned bytes) { g_lds_pad = bytes; }
 
 extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {
   // split-K partials: at most 16 copies of the output, capped at 64 MB (the dispatch model never asks for more than

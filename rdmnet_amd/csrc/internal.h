@@ -15,6 +15,7 @@ int gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, fl
 
 // gemm_with_stats with A = [coarse[idx[:, 0]] | skip] formed inside the kernel (the decoder's upsample + concatenation,
 // backbone.py:118-151); returns 1 (nothing launched) when the shapes need the materialised concatenation instead.
+void gemm_set_lds_pad(unsigned bytes);
 int gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, int64_t n_coarse, const int64_t* idx, int64_t ldi,
                            const float* skip, int64_t ld2, int64_t c2, const float* b, int64_t ldb, float* c, int64_t ldc,
                            int64_t m, int64_t n, const float* bias, int act, void* ws, size_t ws_bytes, double* gn_partial,

@@ -121,6 +121,10 @@ class Engine:
         """0: spin in hipStreamSynchronize at the size read-backs; > 0: poll and sleep (frees the host core)."""
         _lib.check(self.L.rdm_engine_set_wait(self._h, int(sleep_us)), 'rdm_engine_set_wait')
 
+    def set_pairs_in_flight(self, n):
+        """Scheduling hint: how many pairs (engines / streams) share this GPU; from 3 the GEMM tiles keep two workgroups per CU."""
+        _lib.check(self.L.rdm_engine_set_pairs_in_flight(self._h, int(n)), 'rdm_engine_set_pairs_in_flight')
+
     def enable_profile(self, enable=True):
         _lib.check(self.L.rdm_engine_enable_profile(self._h, int(enable)), 'rdm_engine_enable_profile')
 

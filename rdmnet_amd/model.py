@@ -60,6 +60,7 @@ class RDMNet(torch.nn.Module):
         # >= 3 GiB of HBM): a caller that keeps creating streams recycles engines instead of accumulating them
         self._engines, self._engines_state, self._engines_lock = OrderedDict(), None, threading.Lock()
         self.max_engines = 8
+        self.pairs_in_flight = 1       # scheduling hint handed to the native engines (Engine.set_pairs_in_flight): set it before the first forward
         self.fast_path = True          # forward(data_dict) as one native call; False = the per-op mirror
         self.device = None
         if device is not None:
@@ -324,6 +325,7 @@ class RDMNet(torch.nn.Module):
         with torch.cuda.device(self.device):
             eng = engine_mod.Engine(self.cfg, self._state, device=self.device)
         eng.keep_taps(True)
+        eng.set_pairs_in_flight(self.pairs_in_flight)
         with self._engines_lock:
             self._engines[key] = eng
             while len(self._engines) > max(int(self.max_engines), 1):
