@@ -399,9 +399,10 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows(m, c));
+  RDM_DUP_LOOP("fused") {
   if (c == 1) {
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
-    return launch_status("kpconv_fused_c1_kernel");
+    continue;
   }
   // (the C = 64 instance needs > 64 KB of dynamic LDS: the attribute is set once per device)
   static std::atomic<uint64_t> attr32{0}, attr64{0};
@@ -414,6 +415,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
     hipLaunchKernelGGL((kpconv_fused_kernel<32, kQb32, kNw32, kIters32>), dim3(blocks), dim3(64 * kNw32), lds32, st, a);
   else
     hipLaunchKernelGGL((kpconv_fused_kernel<64, kQb64, kNw64, kIters64>), dim3(blocks), dim3(64 * kNw64), lds64, st, a);
+  }
   return launch_status("kpconv_fused_kernel");
 }
 
