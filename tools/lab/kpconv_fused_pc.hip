@@ -5,8 +5,8 @@
 // kernel that ships (graph-replayed, tools/kpconv_bench.py, us): 32->32 at 32 k queries 65.0 vs 61.3, 32->32 strided 28.4 vs
 // 31.0, 64->64 at 11 k 44.6 vs 48.5, 64->64 strided 19.7 vs 18.5-20.5 -- a wash.  The phase stamps say why: under the
 // gather's load every memory round trip takes 2.5-5 us, and the W operand (61 / 245 KB re-read from L2 per 16 queries) costs
-// the consumers 13 us per block; both forms move the same L2 -> CU bytes (neighbour lines + W) at the ~9-10 TB/s the chip's
-// CUs draw from L2 together, so overlapping the phases buys nothing.  (A first version with read-modify-write LDS counters
+// the consumers 13 us per block; a later variant with W register-resident measured the same again, so neither the
+// phase structure nor W is what bounds these layers.  (A first version with read-modify-write LDS counters
 // dead-locked; single-writer counters with release stores / acquire loads are what works.)
 // a4 -- KPConv.forward as ONE kernel for the fine levels (C_in = 1, 32, 64): neighbourhood aggregation AND the
 // kernel-weight contraction, without the [M, 15*C] intermediate in HBM.
