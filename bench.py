@@ -446,6 +446,8 @@ def main():
                 ctx.__enter__()
             try:
                 eng.enable_profile(False)
+                if indices and args.stagger_ms > 0:  # (the same staggered starts as the timed region: indices[0] = the stream's number)
+                    time.sleep(indices[0] % len(streams) * args.stagger_ms * 1e-3)
                 for i in indices:
                     pr, ps = pinned[(rank + i * world) % len(pinned)]
                     res = eng.run(pr.to(dev, non_blocking=True), ps.to(dev, non_blocking=True))
@@ -501,6 +503,8 @@ def main():
             if ctx is not None:
                 ctx.__enter__()
             try:
+                if indices and args.stagger_ms > 0:
+                    time.sleep(indices[0] % len(streams) * args.stagger_ms * 1e-3)
                 for i in indices:
                     out = net(make_data(i))
                     out['estimated_transform'].cpu()
