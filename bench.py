@@ -317,7 +317,7 @@ def main():
     engines = []
     if args.path == 'engine':
         for _ in range(args.streams):
-            eng = engine.Engine(cfg, state, device=dev)
+            eng = engine.Engine(cfg, state, device=dev, share_with=engines[0] if engines else None)  # one copy of the weights
             eng.enable_profile(False)
             eng.set_wait(wait_us)
             eng.set_pairs_in_flight(args.streams)

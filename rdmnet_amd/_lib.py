@@ -110,6 +110,7 @@ SIGNATURES = {
     'rdm_engine_destroy': (None, [c_void]),
     'rdm_engine_set_param': (c_int, [c_void, ctypes.c_char_p, c_void, c_void, c_int]),
     'rdm_engine_finalize': (c_int, [c_void]),
+    'rdm_engine_share_params': (c_int, [c_void, c_void]),
     'rdm_engine_run': (c_int, [c_void, c_void, c_i64, c_void, c_i64, c_void, c_void]),
     'rdm_engine_collate': (c_int, [c_void, c_void, c_i64, c_void, c_i64, c_void, c_void]),
     'rdm_engine_forward': (c_int, [c_void, c_void, c_void, c_void]),

@@ -711,6 +711,21 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
   return RDM_OK;
 }
 
+// The prepared parameters of `src` (device copies of the weights in the kernels' layouts, ~250 MB) serve `e` too: engines of
+// one process that keep several pairs in flight hold ONE copy instead of one each.  `src` must be finalized, live on the same
+// device and outlive `e`; e's own parameters (if any) are released.
+extern "C" int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src) {
+  RDM_REQUIRE(e && src && e != src, "rdm_engine_share_params: bad arguments");
+  RDM_REQUIRE(src->finalized, "rdm_engine_share_params: the source engine is not finalized");
+  for (void* p : e->owned) (void)hipFree(p);
+  e->owned.clear();
+  e->host.clear();
+  e->lin = src->lin;
+  e->vec = src->vec;
+  e->finalized = true;
+  return RDM_OK;
+}
+
 extern "C" int rdm_engine_enable_profile(rdm_engine* e, int enable) {
   RDM_REQUIRE(e, "rdm_engine_enable_profile: null engine");
   e->profile = enable != 0;

@@ -85,7 +85,9 @@ def make_config(cfg, arena_bytes=0):
 class Engine:
     """Owns a native engine bound to the current device.  Not thread-safe: one engine per in-flight pair."""
 
-    def __init__(self, cfg, state, device=None, arena_bytes=0):
+    def __init__(self, cfg, state, device=None, arena_bytes=0, share_with=None):
+        """share_with: another Engine of the same device and weights whose prepared device parameters this one uses (one copy
+        of the weights for all engines in flight; `state` is ignored then)."""
         if not torch.cuda.is_available():
             raise RuntimeError('rdmnet_amd.engine needs a GPU (no CPU fallback)')
         self.L = _lib.lib()
@@ -95,7 +97,11 @@ class Engine:
         with torch.cuda.device(self.device):
             c = make_config(cfg, arena_bytes)
             _lib.check(self.L.rdm_engine_create(ctypes.byref(c), ctypes.byref(self._h)), 'rdm_engine_create')
-            for name, shape in weights.schema(cfg).items():
+            self._shares = share_with  # (keeps the owner of the parameters alive)
+            if share_with is not None:
+                assert share_with.device == self.device
+                _lib.check(self.L.rdm_engine_share_params(self._h, share_with._h), 'rdm_engine_share_params')
+            for name, shape in ({} if share_with is not None else weights.schema(cfg)).items():
                 v = state[name]
                 v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
                 if tuple(v.shape) != tuple(shape):
@@ -104,7 +110,8 @@ class Engine:
                 shp = (ctypes.c_int64 * max(len(shape), 1))(*shape)
                 _lib.check(self.L.rdm_engine_set_param(self._h, name.encode(), v.ctypes.data, ctypes.addressof(shp),
                                                        len(shape)), 'rdm_engine_set_param')
-            _lib.check(self.L.rdm_engine_finalize(self._h), 'rdm_engine_finalize')
+            if share_with is None:
+                _lib.check(self.L.rdm_engine_finalize(self._h), 'rdm_engine_finalize')
         self.result = EngineResult()
         self._export_cache = {}
 

@@ -323,7 +323,9 @@ class RDMNet(torch.nn.Module):
                 self._engines.clear()
                 self._engines_state = self._state
         with torch.cuda.device(self.device):
-            eng = engine_mod.Engine(self.cfg, self._state, device=self.device)
+            with self._engines_lock:
+                owner = next((x for (d, _), x in self._engines.items() if d == self.device.index), None)
+            eng = engine_mod.Engine(self.cfg, self._state, device=self.device, share_with=owner)
         eng.keep_taps(True)
         eng.set_pairs_in_flight(self.pairs_in_flight)
         with self._engines_lock:

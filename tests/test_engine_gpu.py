@@ -71,6 +71,21 @@ def test_engine_matches_oracle_and_is_deterministic(ctx):
     assert np.array_equal(eng.transform(), T1) and r2.n_correspondences == n1  # run-to-run bit-reproducible
 
 
+def test_engines_share_one_copy_of_the_weights(ctx):
+    """rdm_engine_share_params: a second engine on the first one's prepared device parameters (what bench.py's in-flight
+    engines and a module's per-stream engines do) gives the same bits, also after the first engine ran something else."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    n1 = eng.run(rp, sp).n_correspondences  # (the result structure is the engine's: read it before the next run)
+    T1, c1 = eng.transform(), [x.copy() for x in eng.host_corr()]
+    twin = engine.Engine(cfg, None, share_with=eng)
+    eng.run(sp, rp)  # (the owner moves on)
+    r2 = twin.run(rp, sp)
+    assert r2.n_correspondences == n1 and np.array_equal(twin.transform(), T1)
+    assert all(np.array_equal(a, b) for a, b in zip(twin.host_corr(), c1))
+
+
 def test_full_size_pair_properties(ctx, golden_dir):
     """BASELINE-size workload (2 x 16k points): the engine equals the per-op mirror bit for bit, the pose
     is a proper rigid transform, correspondences are points of the fine level, neighbour tables are
