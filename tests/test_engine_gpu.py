@@ -86,6 +86,22 @@ def test_engines_share_one_copy_of_the_weights(ctx):
     assert all(np.array_equal(a, b) for a, b in zip(twin.host_corr(), c1))
 
 
+def test_pairs_in_flight_hint_changes_no_bit(ctx):
+    """rdm_engine_set_pairs_in_flight(n >= 3) caps the tiled GEMM at two workgroups per CU (a scheduling hint for several pairs
+    sharing the GPU): results are the same bits as without it."""
+    eng = ctx['eng']
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    eng.run(rp, sp)
+    T1, c1, feats = eng.transform(), [x.copy() for x in eng.host_corr()], eng.tensor('decoder').clone()
+    eng.set_pairs_in_flight(4)
+    try:
+        eng.run(rp, sp)
+        assert np.array_equal(eng.transform(), T1) and all(np.array_equal(a, b) for a, b in zip(eng.host_corr(), c1))
+        assert torch.equal(eng.tensor('decoder'), feats)
+    finally:
+        eng.set_pairs_in_flight(1)
+
+
 def test_full_size_pair_properties(ctx, golden_dir):
     """BASELINE-size workload (2 x 16k points): the engine equals the per-op mirror bit for bit, the pose
     is a proper rigid transform, correspondences are points of the fine level, neighbour tables are
