@@ -956,11 +956,14 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   RDM_DUP_LOOP("gemm") {
+#ifdef RDM_DEV_KNOBS  // the experimental tiles exist in the lab build only (RDM_GEMM_TUNE=4..7, RDM_GEMM_BIG)
   if (exp_tile == 4) launch<128, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 5) launch<64, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 6) launch<128, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 7) launch<256, 64, 4, 1, 32, 2>(g, batches, trans_b, st);
-  else switch (tile) {
+  else
+#endif
+  switch (tile) {
     case T128: launch<128, 128, 2, 2, 16>(g, batches, trans_b, st); break;  // 32-deep measured slower (LDS halves residency)
     case T64:
       // 32-deep k-tiles: 34 KB of LDS per block -> 4 blocks per CU (64-deep: 2); measured +2 % with 4 pairs in flight
