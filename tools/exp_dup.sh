@@ -13,7 +13,7 @@ for l in sys.stdin:
 }
 for s in 4 1; do
   unset RDM_DUP; run $s
-  for c in gemm gemmsmall gather gnapply gnfin pool attn tail sinkhorn rn gs; do
+  for c in gemm gemmsmall fused gather gnapply gnfin pool attn tail sinkhorn rn gs splitk; do
     export RDM_DUP=$c; run $s
   done
   unset RDM_DUP; run $s
