@@ -438,7 +438,8 @@ void rdm_engine_destroy(rdm_engine* e);
 int rdm_engine_set_param(rdm_engine* e, const char* name, const float* data_host, const int64_t* shape_host, int ndim);
 int rdm_engine_finalize(rdm_engine* e);
 /* Instead of set_param + finalize: `e` uses the prepared device parameters of `src` (finalized, same device, must outlive e) -- one
- * copy of the weights for all the engines a process keeps in flight.                                                  */
+ * copy of the weights for all the engines a process keeps in flight.  Destroy the sharers before `src`; rdm_engine_finalize of an
+ * engine whose parameters others use fails.                                                                             */
 int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src);
 /* ref/src points: device f32 [n,3].  Synchronises `stream` (4 small read-backs of data-dependent sizes). */
 int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -68,6 +69,8 @@ struct rdm_engine {
   bool keep_taps = false;
   bool collate_only = false;  // rdm_engine_collate: stop after the pyramid and its searches
   int pairs_in_flight = 1;    // rdm_engine_set_pairs_in_flight: how many pairs share the GPU (>= 3: GEMM residency capped)
+  rdm_engine* params_from = nullptr;        // rdm_engine_share_params: whose device parameters this engine uses
+  mutable std::atomic<int> n_sharers{0};    // engines using THIS engine's parameters (they must go first)
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -587,6 +590,7 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
 
 extern "C" void rdm_engine_destroy(rdm_engine* e) {
   if (!e) return;
+  if (e->params_from) e->params_from->n_sharers.fetch_sub(1);
   for (void* p : e->owned) (void)hipFree(p);
   for (auto& ev : e->events) (void)hipEventDestroy(ev);
   if (e->arena) (void)hipFree(e->arena);
@@ -657,6 +661,12 @@ bool ends_with(const std::string& s, const char* suf) {
 
 extern "C" int rdm_engine_finalize(rdm_engine* e) {
   RDM_REQUIRE(e, "rdm_engine_finalize: null engine");
+  RDM_REQUIRE(e->n_sharers.load() == 0, "rdm_engine_finalize: %d other engine(s) use this engine's parameters (rdm_engine_share_params)",
+              e->n_sharers.load());
+  if (e->params_from) {  // back to parameters of its own
+    e->params_from->n_sharers.fetch_sub(1);
+    e->params_from = nullptr;
+  }
   for (void* p : e->owned) (void)hipFree(p);
   e->owned.clear();
   e->lin.clear();
@@ -717,6 +727,10 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
 extern "C" int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src) {
   RDM_REQUIRE(e && src && e != src, "rdm_engine_share_params: bad arguments");
   RDM_REQUIRE(src->finalized, "rdm_engine_share_params: the source engine is not finalized");
+  RDM_REQUIRE(e->n_sharers.load() == 0, "rdm_engine_share_params: other engines use this engine's parameters");
+  if (e->params_from) e->params_from->n_sharers.fetch_sub(1);
+  e->params_from = const_cast<rdm_engine*>(src->params_from ? src->params_from : src);  // (the owner of the buffers)
+  e->params_from->n_sharers.fetch_add(1);
   for (void* p : e->owned) (void)hipFree(p);
   e->owned.clear();
   e->host.clear();
