@@ -361,6 +361,7 @@ def main():
                 if rec is not None:
                     rre, rte = pose_error(T, pairs[pid][2])
                     rec[slot] = torch.tensor([pid, rre, rte, n_corr, rank + i * world])
+                if rec is not None or lat_out is iso_lat:
                     lat_out.append((time.perf_counter() - ts) * 1e3)
         except BaseException as exc:  # surfaced by run_all (a worker thread must not fail silently)
             errors.append(exc)
@@ -371,6 +372,7 @@ def main():
                 ctx.__exit__(None, None, None)
 
     errors = []
+    iso_lat = []  # per-pair latencies of the one-pair-in-flight pass after the timed region
 
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
         if len(streams) == 1:
@@ -613,7 +615,9 @@ def main():
     # same kernels' durations when they own the GPU (reported beside, never instead of, the timed-region figure).
     iso_prof = []
     if engines:
-        run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, [], iso_prof, engines[0], 1)
+        engines[0].set_pairs_in_flight(1)  # (this pass IS one pair in flight: no GEMM residency cap)
+        run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, iso_lat, iso_prof, engines[0], 1)
+        engines[0].set_pairs_in_flight(args.streams)
         fence()
         if errors:
             raise errors[0]
@@ -687,6 +691,9 @@ def main():
                        'host_cpus_per_rank': budget, 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
+            'one_pair_in_flight': ({'p50_ms_per_pair': float(np.median(iso_lat)), 'pairs': len(iso_lat),
+                                    'note': 'latency with the GPU to one pair: 8 pairs on one stream after the timed region, per-layer HIP events on'}
+                                   if iso_lat else None),
             'mean_ms_per_pair_by_quarter': [float(np.mean(q)) for q in np.array_split(np.asarray(lat), 4)] if len(lat) >= 4 else None,
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},
             'records': {'gathered': int(sum(g.shape[0] for g in gathered)),
