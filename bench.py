@@ -2,7 +2,8 @@
 """Benchmark of the RDMNet dense-matching inference path on MI355X.
 
 A step = one scan pair through the WHOLE path: GPU collate (4 grid subsamplings + 13 radius
-searches) + RDMNet.forward (KPConv encoder/decoder, 3DRoFormer x2, vote, NMS, grouping, coarse
+searches; 12 in the one-call engine, which does not build the up-sampling table of level 0 that
+nothing reads -- the drop-in API pass builds all 13) + RDMNet.forward (KPConv encoder/decoder, 3DRoFormer x2, vote, NMS, grouping, coarse
 matching, Sinkhorn, LGR) -> 4x4 pose on the device.  Inputs (synthetic KITTI-shaped pairs,
 ~16 k points per scan) are resident in HBM before the timed region; weights are the seeded
 synthetic state dict (the reference ships no trained weights).  Metric: scan pairs per second,

@@ -989,10 +989,14 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     RDM_DUP_LOOP("rnbuild")
   ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
   }
+  // The forward consumes column 0 of upsampling[1..3] only (nearest_upsample, functional.py:6-22) and upsampling[0] not at all
+  // (backbone.py:118-151 stops at the second level): a plain run skips that search (32 000 queries, a quarter of all) and keeps one
+  // column of the others; the collate API and runs that keep their stage tensors build the reference's full tables.
+  const bool full_up = e->keep_taps || e->collate_only;
   for (int i = 0; i < 5; ++i) {
     ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i]));
     if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i]));
-    if (i > 0) ENG_CHECK(search(lv[i - 1], grids[i], radius, c.neighbor_limits[i], up[i - 1]));
+    if (i > 0 && (full_up || i > 1)) ENG_CHECK(search(lv[i - 1], grids[i], radius, full_up ? c.neighbor_limits[i] : 1, up[i - 1]));
     radius *= 2.f;
   }
   ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));
