@@ -139,6 +139,42 @@ def test_full_size_pair_properties(ctx, golden_dir):
     assert np.array_equal(eng.transform(), T) and res2.n_correspondences == rc.shape[0]
 
 
+@pytest.mark.parametrize('seed', range(10))
+def test_plain_engine_run_equals_per_op_mirror_on_random_scenes(ctx, seed):
+    """Randomised end-to-end equality: a PLAIN rdm_engine_run (no stage tensors kept: the production form, which skips the
+    up-sampling search nothing reads, shares another engine's parameters and hands its result over in pinned host memory)
+    against the per-op Python mirror on the full collate -- lidar-like scenes of 2-25 k points per scan (a plane, boxes and
+    clutter, the second scan moved and cropped), one in four with the GEMM residency hint.  Pose, correspondences and their
+    scores must be the same bits."""
+    from rdmnet_amd import engine
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(2000, 25000))
+    extent = float(rng.uniform(15.0, 70.0))
+
+    def scene(k):
+        ground = np.c_[rng.uniform(-extent, extent, (k // 2, 2)), rng.normal(-1.7, 0.03, k // 2)]
+        centres = rng.uniform(-extent, extent, (12, 2))
+        walls = np.concatenate([np.c_[c + rng.uniform(-3, 3, (k // 30, 2)) * [1.0, 0.05], rng.uniform(-1.7, 4.0, k // 30)] for c in centres])
+        clutter = np.c_[rng.uniform(-extent, extent, (k - k // 2 - 12 * (k // 30), 2)), rng.uniform(-1.7, 2.0, k - k // 2 - 12 * (k // 30))]
+        return np.concatenate([ground, walls, clutter]).astype(np.float32)
+    ref = scene(n)
+    ang = rng.uniform(-0.3, 0.3)
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], np.float32)
+    src = (ref[rng.random(n) < rng.uniform(0.6, 1.0)] - np.array([rng.uniform(2, 12), rng.uniform(-2, 2), 0], np.float32)) @ R
+    src = (src + rng.normal(0, 0.02, src.shape)).astype(np.float32)
+    cfg, net = ctx['cfg'], ctx['net']
+    plain = engine.Engine(cfg, None, share_with=ctx['eng'])
+    if seed % 4 == 3:
+        plain.set_pairs_in_flight(4)
+    res = plain.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
+    T, (hr, hs, hc) = plain.transform(), plain.host_corr()
+    out = net(ctx['collate'].collate_pair(ref, src, cfg), {})
+    assert np.array_equal(T, out['estimated_transform'].cpu().numpy())
+    assert res.n_correspondences == out['corr_scores'].shape[0]
+    assert np.array_equal(hr, out['ref_corr_points'].cpu().numpy()) and np.array_equal(hs, out['src_corr_points'].cpu().numpy())
+    assert np.array_equal(hc, out['corr_scores'].cpu().numpy())
+
+
 @pytest.mark.parametrize('n,scale', [(500, 20.0), (50, 5.0), (5, 1.0), (1, 1.0), (4000, 200.0)])
 def test_engine_handles_degenerate_clouds(ctx, n, scale):
     """Tiny, single-point and extremely sparse clouds (every point its own voxel at all levels) run through the whole
