@@ -20,7 +20,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')  # several pairs in flight per GPU: one hardware queue per stream
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')  # (rdmnet_amd/__init__.py sets the same default: one hardware queue per in-flight pair)
 
 import numpy as np
 import torch
@@ -37,23 +37,7 @@ def make_pairs(n_pairs, cache_dir):
     fixture (tests/golden/synthetic_pairs.npz, the generator's exact output) to skip ~10 s of host
     ray casting per pair; further ids are generated and cached under gpurun_out/."""
     from rdmnet_amd import synthetic
-    os.makedirs(cache_dir, exist_ok=True)
-    pairs = []
-    stored = os.path.join(ROOT, 'tests', 'golden', 'synthetic_pairs.npz')
-    fixture = np.load(stored) if os.path.exists(stored) else None
-    for pid in range(n_pairs):
-        if fixture is not None and f'ref{pid}' in fixture.files:
-            pairs.append((fixture[f'ref{pid}'], fixture[f'src{pid}'], fixture[f'T{pid}']))
-            continue
-        f = os.path.join(cache_dir, f'pair_{pid}.npz')
-        if os.path.exists(f):
-            z = np.load(f)
-            pairs.append((z['ref'], z['src'], z['T']))
-        else:
-            ref, src, T = synthetic.make_pair(pid)
-            np.savez(f, ref=ref, src=src, T=T)
-            pairs.append((ref, src, T))
-    return pairs
+    return synthetic.cached_pairs(n_pairs, cache_dir, os.path.join(ROOT, 'tests', 'golden', 'synthetic_pairs.npz'))
 
 
 def _cpu_baseline_worker(cache_dir, n_pairs, threads, budget_s):
@@ -134,24 +118,6 @@ def pose_error(T_est, T_gt):
     return float(np.degrees(ang)), float(np.linalg.norm(T_gt[:3, 3] - T_est[:3, 3]))
 
 
-def cpu_budget():
-    """Host CPUs this process may use: affinity mask capped by the cgroup quota (cpu.max / cfs_quota_us)."""
-    n = float(len(os.sched_getaffinity(0)))
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            n = min(n, float(quota) / float(period))
-    except (OSError, ValueError):
-        try:
-            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
-            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                n = min(n, q / per)
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: one child process per GPU (the reference's own multi-GPU entry
     self-spawns too, experiments/test_batchoffline.py:255-264 with rank setup engine/base_tester.py:36-40,70-76).  Each
@@ -214,6 +180,8 @@ def main():
     ap.add_argument('--ramp-seconds', type=float, default=5.0,
                     help='untimed pairs run for this long before the warm-up steps so that host and GPU clocks are at their\n'
                          'steady state (a fresh box is 15-20 %% slower for its first seconds); 0 = none')
+    ap.add_argument('--full-steps', type=int, default=96,
+                    help='pairs of the all-13-tables pass of the engine path after the timed region (0 = skip)')
     ap.add_argument('--host-steps', type=int, default=96,
                     help='pairs of the host-to-host pass that follows the timed region (0 = skip)')
     ap.add_argument('--api-collate', choices=['native', 'python'], default='native',
@@ -223,6 +191,8 @@ def main():
     ap.add_argument('--real-slots', choices=['on', 'off'], default='on',
                     help='on: count the real (non-padding) neighbour slots of every distinct pair before the run (8 untimed\n'
                          'collates) for the real-slot variant of the roofline; off: profile runs that should contain bench pairs only')
+    ap.add_argument('--pin', choices=['on', 'off'], default='on',
+                    help='with several ranks on one host: pin rank r to the r-th contiguous slice of the CPUs this job may use')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
     args = ap.parse_args()
 
@@ -233,6 +203,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
+    # one contiguous slice of the host's CPUs per rank (self-spawned ranks and torch.distributed.run launches alike): with
+    # spinning waits a rank keeps `--streams` host threads busy, which should not migrate over the sockets of a NUMA host
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    from rdmnet_amd import pipeline
+    pinned_cpus = pipeline.pin_rank(local_rank, local_world) if args.pin == 'on' else None
     if os.environ.get('RDM_BENCH_SHARE_DEVICE') == '1':
         local_rank = 0  # test hook: all ranks on one GPU
     torch.cuda.set_device(local_rank)
@@ -286,11 +261,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    import threading
     # (RDM_BENCH_HIGH_PRIORITY_STREAMS=k, developer experiment: the first k streams are created with high priority)
     n_high = int(os.environ.get('RDM_BENCH_HIGH_PRIORITY_STREAMS', '0'))
-    streams = ([torch.cuda.Stream(device=dev, priority=-1 if k < n_high else 0) for k in range(args.streams)]
-               if args.streams > 1 else [None])
+    custom_streams = None
+    if n_high > 0 and args.streams > 1:
+        custom_streams = [torch.cuda.Stream(device=dev, priority=-1 if k < n_high else 0) for k in range(args.streams)]
     # (RDM_BENCH_CU_MASK=interleave|blocks, developer experiment: every stream gets its own 1/streams of the CUs through
     # hipExtStreamCreateWithCUMask -- spatial partitioning instead of contention for the same CUs)
     cu_mode = os.environ.get('RDM_BENCH_CU_MASK')
@@ -298,7 +273,7 @@ def main():
         import ctypes
         hip = ctypes.CDLL('libamdhip64.so')
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        streams = []
+        custom_streams = []
         for k in range(args.streams):
             bits = [0] * ((n_cu + 31) // 32)
             for cu in range(n_cu):
@@ -309,25 +284,23 @@ def main():
             h = ctypes.c_void_p()
             rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(bits), arr)
             assert rc == 0, rc
-            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+            custom_streams.append(torch.cuda.ExternalStream(h.value, device=dev))
 
-    # spinning waits need a core per pair in flight on every rank; poll + sleep when the budget is smaller
-    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    budget = cpu_budget() / max(local_world, 1)
-    wait_us = args.wait_us if args.wait_us >= 0 else (0 if budget >= 2 * args.streams else 50)
-    engines = []
-    if args.path == 'engine':
-        for _ in range(args.streams):
-            eng = engine.Engine(cfg, state, device=dev, share_with=engines[0] if engines else None)  # one copy of the weights
-            eng.enable_profile(False)
-            eng.set_wait(wait_us)
-            eng.set_pairs_in_flight(args.streams)
-            engines.append(eng)
+    # The scheduler is the PRODUCT's (rdmnet_amd.pipeline.PairPipeline, the one `python -m rdmnet_amd.infer` runs on): N engines
+    # sharing one copy of the weights, N host threads / HIP streams drawing steps from one queue, staggered starts, the
+    # pairs-in-flight hint, and spin-or-poll waits chosen from this rank's CPU budget.
+    budget = pipeline.cpu_budget() / max(local_world, 1)
+    pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
+                                 stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams)
+    wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
+    worker_of = {id(e): k for k, e in enumerate(engines)}
+    for eng in engines:
+        eng.enable_profile(False)
 
     # Slots of every KPConv layer's neighbour table that hold a real neighbour (the rest is padding behind them), per
     # distinct pair: the `real_slots` variant of the roofline.  Untimed; layer order = Encoder.forward (backbone.py:72-107).
     real_slots = {}
-    if engines and args.real_slots == 'on':
+    if args.real_slots == 'on':
         for pid, (r_, s_) in enumerate(dev_pairs):
             dd = engines[0].collate(r_, s_)
             nb = [int((dd['neighbors'][l] < dd['points'][l].shape[0]).sum()) for l in range(5)]
@@ -335,81 +308,40 @@ def main():
             real_slots[pid] = [nb[0], nb[0], sub[0], nb[1], nb[1], sub[1], nb[2], nb[2], sub[2], nb[3], nb[3], sub[3], nb[4], nb[4]]
         del dd
 
-    def run_range(indices, stream, rec, lat_out, prof_out, eng, events_every=None):
-        events_every = args.layer_events_every if events_every is None else events_every
-        ctx = torch.cuda.stream(stream) if stream is not None else None
-        if ctx is not None:
-            ctx.__enter__()
-        try:
-            if net is not None:
-                net.set_thread_profile(prof_out)
-            for slot, i in indices:
-                ts = time.perf_counter()
-                pid = (rank + i * world) % len(dev_pairs)
-                if eng is not None:
-                    sampled = prof_out is not None and events_every > 0 and (slot // max(len(streams), 1)) % events_every == 0
-                    eng.enable_profile(sampled)
-                    res = eng.run(*dev_pairs[pid])  # returns with pose AND correspondences in host memory
-                    T, n_corr = eng.transform(), res.n_correspondences
-                    rc_h, sc_h, cs_h = eng.host_corr()  # "... to estimated_transform + correspondences on the host"
-                    assert rc_h.shape[0] == n_corr
-                    if sampled:
-                        for li, layer_rec in enumerate(eng.kpconv_profile()):
-                            layer_rec['pid'], layer_rec['layer'] = pid, li
-                            prof_out.append(layer_rec)
-                else:
-                    T, n_corr = step(i)
-                if rec is not None:
-                    rre, rte = pose_error(T, pairs[pid][2])
-                    rec[slot] = torch.tensor([pid, rre, rte, n_corr, rank + i * world])
-                if rec is not None or lat_out is iso_lat:
-                    lat_out.append((time.perf_counter() - ts) * 1e3)
-        except BaseException as exc:  # surfaced by run_all (a worker thread must not fail silently)
-            errors.append(exc)
-        finally:
-            if net is not None:
-                net.set_thread_profile(None)
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
-
-    errors = []
     iso_lat = []  # per-pair latencies of the one-pair-in-flight pass after the timed region
 
+    def one_step(eng, slot, first, rec, lat_out, prof_out, events_every, n_workers):
+        """One step of the hot path on the worker thread / stream the pipeline hands it to."""
+        i = first + slot
+        ts = time.perf_counter()
+        pid = (rank + i * world) % len(dev_pairs)
+        if net is None or args.path == 'engine':
+            sampled = prof_out is not None and events_every > 0 and (slot // max(n_workers, 1)) % events_every == 0
+            eng.enable_profile(sampled)
+            res = eng.run(*dev_pairs[pid])  # returns with pose AND correspondences in host memory
+            T, n_corr = eng.transform(), res.n_correspondences
+            rc_h, sc_h, cs_h = eng.host_corr()  # SURVEY 8d: "... to estimated_transform + correspondences on the host"
+            assert rc_h.shape[0] == n_corr
+            if sampled:
+                for li, layer_rec in enumerate(eng.kpconv_profile()):
+                    layer_rec['pid'], layer_rec['layer'] = pid, li
+                    prof_out.append(layer_rec)
+        else:
+            net.set_thread_profile(prof_out)
+            try:
+                T, n_corr = step(i)
+            finally:
+                net.set_thread_profile(None)
+        if rec is not None:
+            rre, rte = pose_error(T, pairs[pid][2])
+            rec[slot] = torch.tensor([pid, rre, rte, n_corr, rank + i * world])
+        if rec is not None or lat_out is iso_lat:
+            lat_out.append((time.perf_counter() - ts) * 1e3)
+
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
-        if len(streams) == 1:
-            run_range([(slot, first + slot) for slot in range(count)], streams[0], rec, lat_out, prof_lists[0],
-                      engines[0] if engines else None, events_every)
-            if errors:
-                raise errors[0]
-            return
-        # the in-flight pairs draw their steps from one queue (a stream that falls behind -- its pairs met the fat kernels
-        # of three others -- takes fewer), so that all streams drain together at the end of a K-step region
-        queue = collections.deque((slot, first + slot) for slot in range(count))
-
-        def draw():
-            while True:
-                try:
-                    yield queue.popleft()  # atomic under the GIL
-                except IndexError:
-                    return
-        # stream k draws its first step k x stagger into the region: after the fence the in-flight pairs would otherwise walk
-        # through the same stages in phase (four serial subsampling kernels, then four encoders contending), which costs a short
-        # region 6 % (measured with 20 steps: 432-437 -> 452-457 / 472-478 / 473-481 pairs/s at 0.5 / 1 / 1.5 ms); the sleeps are inside the timed region
-        stagger = float(os.environ.get('RDM_BENCH_STAGGER_MS', args.stagger_ms)) * 1e-3
-
-        def staggered(k):
-            if stagger > 0 and k > 0:
-                time.sleep(k * stagger)
-            yield from draw()
-        threads = [threading.Thread(target=run_range, args=(staggered(k), streams[k], rec, lat_out, prof_lists[k],
-                                                            engines[k] if engines else None, events_every))
-                   for k in range(len(streams))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        events_every = args.layer_events_every if events_every is None else events_every
+        pipe.map(range(count), lambda eng, slot: one_step(eng, slot, first, rec, lat_out, prof_lists[worker_of[id(eng)]],
+                                                          events_every, len(streams)))
 
     # Clock ramp (untimed, before the W warm-up steps): the first GPU process on a freshly started box runs 15-20 % slower
     # for its first seconds -- idle host cores and GPU power states take that long to reach their steady clocks (measured:
@@ -436,48 +368,50 @@ def main():
         json.dump(lat, open(os.environ['RDM_BENCH_DUMP_LAT'], 'w'))
     elapsed, lat = sharding.reduce_timing(elapsed, lat, world, dist, comm_dev, force)  # max over ranks; all ranks' latencies
 
+    def timed_pass(n_steps, fn):
+        """A second, shorter region after the timed one, same pairs in flight, fenced like it: -> pairs/s (whole job)."""
+        fence()
+        tp0 = time.perf_counter()
+        pipe.map(range(n_steps), fn)
+        fence()
+        t_pass, _ = sharding.reduce_timing(time.perf_counter() - tp0, [], world, dist, comm_dev, force)
+        return n_steps * world / t_pass
+
+    # ---- the same engine path building ALL 13 search tables (a plain rdm_engine_run skips the up-sampling search of level 0,
+    # which nothing reads, and keeps one column of the other three: `value` times 12 searches; DESIGN.md 5d).  Side key,
+    # never `value`: with the stage tensors kept the engine builds the reference's full tables.
+    full_tables = None
+    if args.path == 'engine' and args.full_steps > 0:
+        def full_step(eng, i):
+            eng.enable_profile(False)
+            res = eng.run(*dev_pairs[(rank + i * world) % len(dev_pairs)])
+            assert eng.host_corr()[0].shape[0] == res.n_correspondences
+        for eng in engines:
+            eng.keep_taps(True)
+        try:
+            pipe.map(range(4 * len(streams)), full_step)
+            full_tables = {'value': timed_pass(args.full_steps, full_step), 'unit': 'pairs/s', 'steps': args.full_steps,
+                           'note': 'rdm_engine_run with every stage tensor kept: all 13 radius searches at the reference\'s '
+                                   'table widths (the 32 k-query up-sampling search of level 0 included), same pairs in flight'}
+        finally:
+            for eng in engines:
+                eng.keep_taps(False)
+
     # ---- host-to-host rate (SURVEY §8d's definition of a pair: two clouds in HOST memory -> transform + correspondences
     # in HOST memory).  Never `value`: a second, shorter region after the timed one.  Each in-flight pair copies its scans
     # from pinned host memory on its own stream, runs the engine, and copies the correspondences back.
     host_to_host = None
-    if engines and args.host_steps > 0:
+    if args.path == 'engine' and args.host_steps > 0:
         pinned = [(torch.from_numpy(r).pin_memory(), torch.from_numpy(s_).pin_memory()) for r, s_, _ in pairs]
 
-        def h2h_range(indices, stream, eng):
-            ctx = torch.cuda.stream(stream) if stream is not None else None
-            if ctx is not None:
-                ctx.__enter__()
-            try:
-                eng.enable_profile(False)
-                if indices and args.stagger_ms > 0:  # (the same staggered starts as the timed region: indices[0] = the stream's number)
-                    time.sleep(indices[0] % len(streams) * args.stagger_ms * 1e-3)
-                for i in indices:
-                    pr, ps = pinned[(rank + i * world) % len(pinned)]
-                    res = eng.run(pr.to(dev, non_blocking=True), ps.to(dev, non_blocking=True))
-                    rc, sc, cs = eng.host_corr()  # written to pinned host memory by the run's last kernel; the pose too
-                    assert rc.shape[0] == res.n_correspondences and cs.shape[0] == res.n_correspondences
-            except BaseException as exc:
-                errors.append(exc)
-            finally:
-                if ctx is not None:
-                    ctx.__exit__(None, None, None)
+        def h2h_step(eng, i):
+            eng.enable_profile(False)
+            pr, ps = pinned[(rank + i * world) % len(pinned)]
+            res = eng.run(pr.to(dev, non_blocking=True), ps.to(dev, non_blocking=True))
+            rc, sc, cs = eng.host_corr()  # written to pinned host memory by the run's last kernel; the pose too
+            assert rc.shape[0] == res.n_correspondences and cs.shape[0] == res.n_correspondences
 
-        jobs = [list(range(k, args.host_steps, len(streams))) for k in range(len(streams))]
-        fence()
-        th0 = time.perf_counter()
-        if len(streams) == 1:
-            h2h_range(jobs[0], streams[0], engines[0])
-        else:
-            threads = [threading.Thread(target=h2h_range, args=(jobs[k], streams[k], engines[k])) for k in range(len(streams))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        fence()
-        h_elapsed, _ = sharding.reduce_timing(time.perf_counter() - th0, [], world, dist, comm_dev, force)
-        if errors:
-            raise errors[0]
-        host_to_host = {'value': args.host_steps * world / h_elapsed, 'unit': 'pairs/s', 'steps': args.host_steps,
+        host_to_host = {'value': timed_pass(args.host_steps, h2h_step), 'unit': 'pairs/s', 'steps': args.host_steps,
                         'note': 'pinned host scans -> H2D -> engine -> D2H of correspondences (points + scores) and pose; '
                                 'measured after the timed region, same pairs in flight'}
 
@@ -501,36 +435,12 @@ def main():
             data['testing'] = True
             return data
 
-        def api_range(indices, stream):
-            ctx = torch.cuda.stream(stream) if stream is not None else None
-            if ctx is not None:
-                ctx.__enter__()
-            try:
-                if indices and args.stagger_ms > 0:
-                    time.sleep(indices[0] % len(streams) * args.stagger_ms * 1e-3)
-                for i in indices:
-                    out = net(make_data(i))
-                    out['estimated_transform'].cpu()
-            except BaseException as exc:
-                errors.append(exc)
-            finally:
-                if ctx is not None:
-                    ctx.__exit__(None, None, None)
+        def api_step(eng, i):  # (the module keeps its own engine per stream; `eng` of the pipeline idles in this pass)
+            out = net(make_data(i))
+            out['estimated_transform'].cpu()
 
-        for warm in (True, False):
-            n_api = len(streams) * 6 if warm else args.api_steps
-            jobs = [list(range(k, n_api, len(streams))) for k in range(len(streams))]
-            fence()
-            ta0 = time.perf_counter()
-            threads = [threading.Thread(target=api_range, args=(jobs[k], streams[k])) for k in range(len(streams))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            fence()
-            a_elapsed, _ = sharding.reduce_timing(time.perf_counter() - ta0, [], world, dist, comm_dev, force)
-            if errors:
-                raise errors[0]
+        pipe.map(range(len(streams) * 6), api_step)  # warm-up: the module builds its per-stream engines here
+        api_rate = timed_pass(args.api_steps, api_step)
         # forward only, one pair in flight: model(data_dict) (output_dict assembled) against the bare native call
         fwd_model, fwd_native = [], []
         eng_f = net._engine()
@@ -546,7 +456,7 @@ def main():
             t3 = time.perf_counter()
             fwd_model.append((t2 - t1) * 1e3)
             fwd_native.append((t3 - t2) * 1e3)
-        api = {'value': args.api_steps * world / a_elapsed, 'unit': 'pairs/s', 'steps': args.api_steps,
+        api = {'value': api_rate, 'unit': 'pairs/s', 'steps': args.api_steps,
                'forward_only_ms': {'model(data_dict)': float(np.median(fwd_model)), 'rdm_engine_forward': float(np.median(fwd_native))},
                'collate': args.api_collate,
                'note': 'rdmnet_amd.collate.registration_collate_fn_stack_mode (engine=model.engine(): one native call) + '
@@ -615,13 +525,12 @@ def main():
     # shares the CUs with other pairs' kernels.  A short single-stream pass after the timed region gives the
     # same kernels' durations when they own the GPU (reported beside, never instead of, the timed-region figure).
     iso_prof = []
-    if engines:
+    if args.path == 'engine':
         engines[0].set_pairs_in_flight(1)  # (this pass IS one pair in flight: no GEMM residency cap)
-        run_range([(k, args.warmup + k) for k in range(min(8, args.steps))], None, None, iso_lat, iso_prof, engines[0], 1)
+        for k in range(min(8, args.steps)):  # on the calling thread's current stream
+            one_step(engines[0], k, args.warmup, None, iso_lat, iso_prof, 1, 1)
         engines[0].set_pairs_in_flight(args.streams)
         fence()
-        if errors:
-            raise errors[0]
     for rec in iso_prof:
         if 'pid' in rec and real_slots.get(rec['pid']):
             rec['real_bytes'] = real_slots[rec['pid']][rec['layer']] * (8 + 12 + 4 * rec['cin'])
@@ -655,6 +564,10 @@ def main():
     # stop at a row's last real neighbour).  `achieved`/`frac` are the TIMED REGION's (several pairs share the GPU),
     # `one_pair_in_flight` the same kernels with the GPU to themselves; `traffic` (PMC) covers the same kernels.
     roofline = {'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', **roofline_of(forms),
+                'definition': 'HEADLINE (fixed since r03): padded-slot bytes M*H*(8 + 12 + 4*C_in) of the 14 KPConv neighbourhood '
+                              'launches of a pair / their summed durations (HIP events on the launch stream) in the timed region; side keys: '
+                              'real_slots (slots holding a neighbour only), by_form (one-kernel vs gather-only layers), one_pair_in_flight '
+                              '(same kernels, GPU to themselves), whole_layer (round-comparable layer figure)',
                 'traffic': traffic, 'traffic_scope': traffic_note,
                 'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_fused_kernel<32|64> (6) and '
                           'kpconv_gather_kernel<*> (8)',
@@ -663,7 +576,10 @@ def main():
                 'one_pair_in_flight': ({**roofline_of(iforms), 'note': 'same kernels, 8 pairs on one stream after the timed region'}
                                        if iso_prof else None),
                 # the whole KPConv layer (+ weight GEMM / GroupNorm passes + shortcut pool) against the same HBM peak, as round 1 reported it
-                'kpconv_layer': {'kernels': 'neighbourhood kernel + gemm_kernel (weights, two-kernel layers) + GroupNorm passes (one-kernel layers) + gather_max (strided layers)',
+                'whole_layer': {'definition': 'SURVEY 8d bytes of the WHOLE KPConv layer (gather + 4 M C_out output + the strided blocks\' pool) / the '
+                                               'time from the layer\'s first launch to its last (events 0 -> 2): the same quantity in every round, '
+                                               'whichever kernels the layer is made of (r01 0.34-0.36, r02 0.38, r03 0.39 of the HBM peak, one pair in flight)',
+                                 'kernels': 'neighbourhood kernel + gemm_kernel (weights, two-kernel layers) + GroupNorm passes (one-kernel layers) + gather_max (strided layers)',
                                  'bytes_per_launch': tot['b_total'] / n_layers,
                                  'timed_region': {'achieved': tot['b_total'] / tot['t_total'] / 1e9 if tot['t_total'] > 0 else 0.0,
                                                   'frac': tot['b_total'] / tot['t_total'] / 1e9 / HBM_PEAK_GBS if tot['t_total'] > 0 else 0.0,
@@ -687,9 +603,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
-                                   'fp32, seeded random-init weights', 'points_per_pair': n_points,
+                                   'fp32, seeded random-init weights', 'searches_per_pair': 12 if args.path == 'engine' else 13,
+                       'scheduler': 'rdmnet_amd.pipeline.PairPipeline', 'points_per_pair': n_points,
                        'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
-                       'host_cpus_per_rank': budget, 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
+                       'host_cpus_per_rank': budget, 'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None, 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'one_pair_in_flight': ({'p50_ms_per_pair': float(np.median(iso_lat)), 'pairs': len(iso_lat),
@@ -704,6 +621,7 @@ def main():
                             'library': ('RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version())) if args.dist_backend == 'nccl' else 'gloo',
                             'ops': 'barrier x2 per region, all_gather (counts + records), all_reduce(MAX) of the elapsed time'}
                            if dist is not None else None),
+            'full_tables': full_tables,
             'host_to_host': host_to_host,
             'drop_in_api': api,
             'roofline': roofline,

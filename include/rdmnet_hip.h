@@ -24,9 +24,14 @@
 extern "C" {
 #endif
 
-#define RDM_ABI_VERSION 1
+#define RDM_ABI_VERSION 2   /* 2: rdm_engine_result / rdm_data_dict / rdm_kpconv_profile grew, three entry points left (round 3);
+                               parameter sets are reference counted (round 4) */
 
 int rdm_abi_version(void);
+/* sizeof of the structs that cross this boundary, so that a binding can verify its own layout against the library it
+ * loaded: which = 0 rdm_engine_config, 1 rdm_engine_result, 2 rdm_tensor_view, 3 rdm_kpconv_profile, 4 rdm_data_dict;
+ * anything else returns 0.                                                                                        */
+size_t rdm_abi_struct_size(int which);
 const char* rdm_last_error(void);
 
 /* libstdc++ std::unordered_map growth schedule used by rdm_grid_subsample to reproduce the
@@ -437,9 +442,10 @@ int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out);
 void rdm_engine_destroy(rdm_engine* e);
 int rdm_engine_set_param(rdm_engine* e, const char* name, const float* data_host, const int64_t* shape_host, int ndim);
 int rdm_engine_finalize(rdm_engine* e);
-/* Instead of set_param + finalize: `e` uses the prepared device parameters of `src` (finalized, same device, must outlive e) -- one
- * copy of the weights for all the engines a process keeps in flight.  Destroy the sharers before `src`; rdm_engine_finalize of an
- * engine whose parameters others use fails.                                                                             */
+/* Instead of set_param + finalize: `e` uses the prepared device parameters of `src` (finalized, SAME device, same model-shape
+ * fields of the configuration -- else RDM_ERR_ARG) -- one copy of the weights for all the engines a process keeps in flight.
+ * The parameter set is reference counted: the engines may be destroyed in any order (the device memory goes with the last
+ * user), and rdm_engine_finalize of `src` afterwards gives `src` a fresh set while its sharers keep the one they have.   */
 int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src);
 /* ref/src points: device f32 [n,3].  Synchronises `stream` (4 small read-backs of data-dependent sizes). */
 int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,

@@ -4,4 +4,11 @@ Host-side mirror of the reference's operator API on top of the C-ABI library
 `librdmnet_hip.so` (sources in rdmnet_amd/csrc, interface in include/rdmnet_hip.h).
 PyTorch is used for device memory and streams only.
 """
-__version__ = '0.1.0'
+import os as _os
+
+# Several pairs in flight per GPU (rdmnet_amd.pipeline): one hardware queue per HIP stream.  The runtime reads this when the
+# process makes its first HIP call, so it is set at import unless the caller chose a value (DESIGN.md 5b: four worker streams
+# + the default stream on the runtime's default of four queues run at 345 instead of 460 pairs/s).
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+__version__ = '0.2.0'

@@ -12,9 +12,12 @@ c_int = ctypes.c_int
 c_f32 = ctypes.c_float
 c_size = ctypes.c_size_t
 
+ABI_VERSION = 2  # = RDM_ABI_VERSION of include/rdmnet_hip.h this binding was written against
+
 # name -> (restype, argtypes); mirrors include/rdmnet_hip.h one to one
 SIGNATURES = {
     'rdm_abi_version': (c_int, []),
+    'rdm_abi_struct_size': (c_size, [c_int]),
     'rdm_last_error': (ctypes.c_char_p, []),
     'rdm_rehash_schedule': (c_int, [c_i64, c_void, c_void, c_int]),
     'rdm_grid_subsample_workspace_bytes': (c_size, [c_i64, c_int]),
@@ -148,8 +151,23 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        got = handle.rdm_abi_version()
+        if got != ABI_VERSION:  # a stale .so with other struct layouts would corrupt memory silently
+            raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding expects {ABI_VERSION}: rebuild it '
+                               '(`make -C rdmnet_amd/csrc`)')
+        _check_struct_sizes(handle)
         _lib = handle
     return _lib
+
+
+def _check_struct_sizes(handle):
+    """The ctypes mirrors of the structs that cross the C-ABI must have the library's sizes (the C side memsets and fills
+    them through the pointers it is given)."""
+    from . import engine as E  # (the mirrors live next to their user)
+    for which, cls in enumerate((E.EngineConfig, E.EngineResult, E.TensorView, E.KpconvProfile, E.DataDict)):
+        want, have = handle.rdm_abi_struct_size(which), ctypes.sizeof(cls)
+        if want != have:
+            raise RuntimeError(f'{LIB_PATH}: sizeof({cls.__name__}) is {want} in the library, {have} in rdmnet_amd/engine.py')
 
 
 def check(code, what):

@@ -19,4 +19,14 @@ const char* last_error() { return g_error; }
 }  // namespace rdm
 
 extern "C" int rdm_abi_version(void) { return RDM_ABI_VERSION; }
+extern "C" size_t rdm_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(rdm_engine_config);
+    case 1: return sizeof(rdm_engine_result);
+    case 2: return sizeof(rdm_tensor_view);
+    case 3: return sizeof(rdm_kpconv_profile);
+    case 4: return sizeof(rdm_data_dict);
+    default: return 0;
+  }
+}
 extern "C" const char* rdm_last_error(void) { return rdm::last_error(); }

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -49,14 +50,29 @@ struct Linear {  // B operand [K_pad, N_pad] + bias
 
 inline int64_t pad4(int64_t n) { return (n + 3) / 4 * 4; }
 
+// The prepared device parameters (weights in the kernels' layouts, ~250 MB).  Engines hold them through a shared_ptr:
+// rdm_engine_share_params hands the SAME set to another engine, and the device memory is released when the last engine
+// that uses it is destroyed or re-finalized -- in whatever order the caller destroys them.
+struct ParamSet {
+  std::map<std::string, Linear> lin;
+  std::map<std::string, float*> vec;
+  std::vector<void*> owned;  // device allocations
+  int device = -1;
+  ParamSet() = default;
+  ParamSet(const ParamSet&) = delete;
+  ParamSet& operator=(const ParamSet&) = delete;
+  ~ParamSet() {
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
 }  // namespace
 
 struct rdm_engine {
   rdm_engine_config cfg;
+  int device = -1;            // the device that was current at rdm_engine_create
   std::map<std::string, HostParam> host;
-  std::map<std::string, Linear> lin;
-  std::map<std::string, float*> vec;
-  std::vector<void*> owned;   // device allocations of parameters
+  std::shared_ptr<ParamSet> params = std::make_shared<ParamSet>();
   char* arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
   bool arena_exhausted = false, arena_fixed = false;  // fixed: the caller chose arena_bytes, never regrown
@@ -69,8 +85,6 @@ struct rdm_engine {
   bool keep_taps = false;
   bool collate_only = false;  // rdm_engine_collate: stop after the pyramid and its searches
   int pairs_in_flight = 1;    // rdm_engine_set_pairs_in_flight: how many pairs share the GPU (>= 3: GEMM residency capped)
-  rdm_engine* params_from = nullptr;        // rdm_engine_share_params: whose device parameters this engine uses
-  mutable std::atomic<int> n_sharers{0};    // engines using THIS engine's parameters (they must go first)
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -126,8 +140,8 @@ void tap(Run& r, const char* name, const Mat& m) { tap(r, name, m.p, m.rows, m.c
 
 int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, bool alloc_out = true) {
   rdm_engine* e = r.e;
-  auto it = e->lin.find(name);
-  if (it == e->lin.end()) {
+  auto it = e->params->lin.find(name);
+  if (it == e->params->lin.end()) {
     set_error("rdm_engine: missing parameter %s", name.c_str());
     return RDM_ERR_ARG;
   }
@@ -143,9 +157,9 @@ int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, b
 // two independent Linear layers as one launch when both are transformer-sized (gemm_pair)
 int linear_pair(Run& r, const std::string& name0, const Mat& x0, Mat& y0, const std::string& name1, const Mat& x1, Mat& y1) {
   rdm_engine* e = r.e;
-  auto i0 = e->lin.find(name0), i1 = e->lin.find(name1);
-  if (i0 == e->lin.end() || i1 == e->lin.end()) {
-    set_error("rdm_engine: missing parameter %s", (i0 == e->lin.end() ? name0 : name1).c_str());
+  auto i0 = e->params->lin.find(name0), i1 = e->params->lin.find(name1);
+  if (i0 == e->params->lin.end() || i1 == e->params->lin.end()) {
+    set_error("rdm_engine: missing parameter %s", (i0 == e->params->lin.end() ? name0 : name1).c_str());
     return RDM_ERR_ARG;
   }
   const Linear &L0 = i0->second, &L1 = i1->second;
@@ -157,8 +171,8 @@ int linear_pair(Run& r, const std::string& name0, const Mat& x0, Mat& y0, const 
 }
 
 float* vecp(Run& r, const std::string& name) {
-  auto it = r.e->vec.find(name);
-  return it == r.e->vec.end() ? nullptr : it->second;
+  auto it = r.e->params->vec.find(name);
+  return it == r.e->params->vec.end() ? nullptr : it->second;
 }
 
 int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
@@ -178,8 +192,8 @@ int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, c
 // Linear + GroupNorm (+ residual, activation): statistics come out of the GEMM epilogue
 int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
   rdm_engine* e = r.e;
-  auto it = e->lin.find(name + ".mlp");
-  if (it == e->lin.end()) {
+  auto it = e->params->lin.find(name + ".mlp");
+  if (it == e->params->lin.end()) {
     set_error("rdm_engine: missing parameter %s.mlp", name.c_str());
     return RDM_ERR_ARG;
   }
@@ -204,8 +218,8 @@ int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const 
 int decoder_stage(Run& r, const std::string& lin_name, const std::string* norm_name, const Mat& coarse, const int64_t* up_idx,
                   int64_t up_ld, const Mat& skip, int64_t m, Mat& y) {
   rdm_engine* e = r.e;
-  auto it = e->lin.find(lin_name);
-  if (it == e->lin.end()) {
+  auto it = e->params->lin.find(lin_name);
+  if (it == e->params->lin.end()) {
     set_error("rdm_engine: missing parameter %s", lin_name.c_str());
     return RDM_ERR_ARG;
   }
@@ -267,8 +281,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
            const Table& t, float sigma, const std::string& norm_name, Mat& y, const float* order,
            const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
   rdm_engine* e = r.e;
-  auto it = e->lin.find(name + ".weights");
-  if (it == e->lin.end()) {
+  auto it = e->params->lin.find(name + ".weights");
+  if (it == e->params->lin.end()) {
     set_error("rdm_engine: missing parameter %s.weights", name.c_str());
     return RDM_ERR_ARG;
   }
@@ -371,8 +385,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
 // LayerNorm(Linear(x) + residual): one fused launch at the transformer width (rdm_linear_layer_norm), else two
 int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat& x, const Mat& res, Mat& y, bool alloc_out) {
   rdm_engine* e = r.e;
-  auto it = e->lin.find(lin);
-  if (it == e->lin.end()) {
+  auto it = e->params->lin.find(lin);
+  if (it == e->params->lin.end()) {
     set_error("rdm_engine: missing parameter %s", lin.c_str());
     return RDM_ERR_ARG;
   }
@@ -392,8 +406,8 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
 
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
   rdm_engine* e = r.e;
-  auto lo = e->lin.find(p + ".attention.linear"), l1 = e->lin.find(p + ".output.expand"), l2 = e->lin.find(p + ".output.squeeze");
-  if (lo != e->lin.end() && l1 != e->lin.end() && l2 != e->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&
+  auto lo = e->params->lin.find(p + ".attention.linear"), l1 = e->params->lin.find(p + ".output.expand"), l2 = e->params->lin.find(p + ".output.squeeze");
+  if (lo != e->params->lin.end() && l1 != e->params->lin.end() && l2 != e->params->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&
       lo->second.out == 128 && lo->second.kpad == 128 && l1->second.out == 256 && l1->second.kpad == 128 &&
       l2->second.out == 128 && l2->second.kpad == 256) {
     const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
@@ -562,8 +576,12 @@ int d2h(Run& r, const void* dev, size_t bytes, void* host_dst) {
 extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out) {
   RDM_REQUIRE(cfg && out, "rdm_engine_create: null pointer");
   RDM_REQUIRE(cfg->num_stages == 5 && cfg->kernel_size == 15, "rdm_engine_create: only 5 stages / 15 kernel points");
+  int device = -1;
+  RDM_HIP_CHECK(hipGetDevice(&device));
   rdm_engine* e = new rdm_engine();
   e->cfg = *cfg;
+  e->device = device;
+  e->params->device = device;
   e->arena_cap = cfg->arena_bytes ? cfg->arena_bytes : (size_t(3) << 30);
   e->arena_fixed = cfg->arena_bytes != 0;
   hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
@@ -590,8 +608,7 @@ extern "C" int rdm_engine_create(const rdm_engine_config* cfg, rdm_engine** out)
 
 extern "C" void rdm_engine_destroy(rdm_engine* e) {
   if (!e) return;
-  if (e->params_from) e->params_from->n_sharers.fetch_sub(1);
-  for (void* p : e->owned) (void)hipFree(p);
+  e->params.reset();  // (the device parameters go with the LAST engine that uses them)
   for (auto& ev : e->events) (void)hipEventDestroy(ev);
   if (e->arena) (void)hipFree(e->arena);
   if (e->pinned) (void)hipHostFree(e->pinned);
@@ -618,7 +635,7 @@ int upload(rdm_engine* e, const std::vector<float>& h, float** dev) {
   void* p = nullptr;
   RDM_HIP_CHECK(hipMalloc(&p, (h.size() + 4) * sizeof(float)));
   RDM_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-  e->owned.push_back(p);
+  e->params->owned.push_back(p);
   *dev = static_cast<float*>(p);
   return RDM_OK;
 }
@@ -650,7 +667,7 @@ int make_linear(rdm_engine* e, const std::string& key, const std::vector<const H
     }
     ENG_CHECK(upload(e, wt, &L.wt));
   }
-  e->lin[key] = L;
+  e->params->lin[key] = L;
   return RDM_OK;
 }
 bool ends_with(const std::string& s, const char* suf) {
@@ -661,16 +678,9 @@ bool ends_with(const std::string& s, const char* suf) {
 
 extern "C" int rdm_engine_finalize(rdm_engine* e) {
   RDM_REQUIRE(e, "rdm_engine_finalize: null engine");
-  RDM_REQUIRE(e->n_sharers.load() == 0, "rdm_engine_finalize: %d other engine(s) use this engine's parameters (rdm_engine_share_params)",
-              e->n_sharers.load());
-  if (e->params_from) {  // back to parameters of its own
-    e->params_from->n_sharers.fetch_sub(1);
-    e->params_from = nullptr;
-  }
-  for (void* p : e->owned) (void)hipFree(p);
-  e->owned.clear();
-  e->lin.clear();
-  e->vec.clear();
+  // a fresh set: engines that share the previous one (rdm_engine_share_params) keep it alive and unchanged
+  e->params = std::make_shared<ParamSet>();
+  e->params->device = e->device;
   for (auto& kv : e->host) {
     const std::string& name = kv.first;
     const HostParam& p = kv.second;
@@ -690,7 +700,7 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
         ENG_CHECK(rdm_kpconv_pack_weights(p.data.data(), cin, cout, pk.data()));
         ENG_CHECK(upload(e, pk, &L.packed));
       }
-      e->lin[name] = L;
+      e->params->lin[name] = L;
     } else if (ends_with(name, ".weight") && p.shape.size() == 2) {
       const std::string base = name.substr(0, name.size() - 7);
       auto bi = e->host.find(base + ".bias");
@@ -709,13 +719,13 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
                  e->host.at(name.substr(0, name.size() - 5) + ".weight").shape.size() == 2)) {
       float* d = nullptr;
       ENG_CHECK(upload(e, p.data, &d));
-      e->vec[name] = d;
+      e->params->vec[name] = d;
     }
   }
   {
     float* d = nullptr;
     ENG_CHECK(upload(e, std::vector<float>(static_cast<size_t>(e->cfg.points_in_patch), std::sqrt(static_cast<float>(e->cfg.out_dim))), &d));
-    e->vec["__sqrt_out_dim"] = d;
+    e->params->vec["__sqrt_out_dim"] = d;
   }
   e->finalized = true;
   return RDM_OK;
@@ -727,15 +737,18 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
 extern "C" int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src) {
   RDM_REQUIRE(e && src && e != src, "rdm_engine_share_params: bad arguments");
   RDM_REQUIRE(src->finalized, "rdm_engine_share_params: the source engine is not finalized");
-  RDM_REQUIRE(e->n_sharers.load() == 0, "rdm_engine_share_params: other engines use this engine's parameters");
-  if (e->params_from) e->params_from->n_sharers.fetch_sub(1);
-  e->params_from = const_cast<rdm_engine*>(src->params_from ? src->params_from : src);  // (the owner of the buffers)
-  e->params_from->n_sharers.fetch_add(1);
-  for (void* p : e->owned) (void)hipFree(p);
-  e->owned.clear();
+  RDM_REQUIRE(e->device == src->device && src->params->device == src->device,
+              "rdm_engine_share_params: the engines live on different devices (%d vs %d)", e->device, src->device);
+  // the prepared layouts depend on the model-shape fields of the configuration (packed KPConv / Linear shapes, the
+  // points_in_patch entries of the einsum divisor): they must agree
+  const rdm_engine_config &a = e->cfg, &b = src->cfg;
+  RDM_REQUIRE(a.num_stages == b.num_stages && a.kernel_size == b.kernel_size && a.group_norm == b.group_norm &&
+                  a.out_dim == b.out_dim && a.num_heads == b.num_heads && a.num_layers == b.num_layers &&
+                  a.num_layers2 == b.num_layers2 && a.vote_mlp_layers == b.vote_mlp_layers &&
+                  a.points_in_patch == b.points_in_patch,
+              "rdm_engine_share_params: the engines were created with different model shapes");
   e->host.clear();
-  e->lin = src->lin;
-  e->vec = src->vec;
+  e->params = src->params;  // (its previous set is released here unless other engines use it)
   e->finalized = true;
   return RDM_OK;
 }
@@ -1067,7 +1080,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
         Mat h = x;
         uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
         ENG_ALLOC(h_pos);
-        if (e->lin.count(name + ".unary1.mlp")) {
+        if (e->params->lin.count(name + ".unary1.mlp")) {
           ENG_CHECK(unary(r, name + ".unary1", x, h, 2, nullptr, h_pos));
         } else {
           ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
@@ -1076,7 +1089,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
         Mat sc = x;
         ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, order,
                          strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
-        if (e->lin.count(name + ".unary_shortcut.mlp")) {
+        if (e->params->lin.count(name + ".unary_shortcut.mlp")) {
           Mat s2;
           ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));
           sc = s2;

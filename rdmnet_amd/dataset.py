@@ -118,6 +118,22 @@ class ArrayPairDataset:
         return d
 
 
+class CyclingPairDataset:
+    """`length` items that cycle through the pairs of `base` (an ArrayPairDataset of a few distinct synthetic pairs):
+    a long pair stream for throughput runs without a dataset on disk.  Frame ids follow the position in the stream."""
+
+    def __init__(self, base, length):
+        self.base, self.length = base, int(length)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        d = dict(self.base[i % len(self.base)])
+        d['ref_frame'], d['src_frame'] = 2 * i, 2 * i + 1
+        return d
+
+
 def neighbor_histograms(item, num_stages, voxel_size, search_radius, hist_n, hists=None, device=None):
     """Adds the neighbourhood-size histograms of one pair to `hists` (int32 [num_stages, hist_n] on the
     device).  Level i: counts of the self search with radius r*2^i over the stacked [ref; src] level."""

@@ -86,8 +86,10 @@ class Engine:
     """Owns a native engine bound to the current device.  Not thread-safe: one engine per in-flight pair."""
 
     def __init__(self, cfg, state, device=None, arena_bytes=0, share_with=None):
-        """share_with: another Engine of the same device and weights whose prepared device parameters this one uses (one copy
-        of the weights for all engines in flight; `state` is ignored then)."""
+        """share_with: another Engine of the same device and configuration whose prepared device parameters this one uses
+        (one copy of the weights for all engines in flight; `state` is ignored then).  The parameter set is reference
+        counted in the library: no Python reference to `share_with` is kept, so dropping that engine frees its arena
+        while this one keeps working."""
         if not torch.cuda.is_available():
             raise RuntimeError('rdmnet_amd.engine needs a GPU (no CPU fallback)')
         self.L = _lib.lib()
@@ -97,9 +99,7 @@ class Engine:
         with torch.cuda.device(self.device):
             c = make_config(cfg, arena_bytes)
             _lib.check(self.L.rdm_engine_create(ctypes.byref(c), ctypes.byref(self._h)), 'rdm_engine_create')
-            self._shares = share_with  # (keeps the owner of the parameters alive)
             if share_with is not None:
-                assert share_with.device == self.device
                 _lib.check(self.L.rdm_engine_share_params(self._h, share_with._h), 'rdm_engine_share_params')
             for name, shape in ({} if share_with is not None else weights.schema(cfg)).items():
                 v = state[name]

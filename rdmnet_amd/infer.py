@@ -3,6 +3,7 @@ registration report, on the native engine.
 
     python -m rdmnet_amd.infer --infer-root /path/to/assets/pc --out out/           # the two bundled pairs
     python -m rdmnet_amd.infer --dataset-root /data/kitti --subset test --out out/ --weights rdmnet.pth.tar
+    python -m rdmnet_amd.infer --synthetic 512 --no-npz                              # throughput on synthetic KITTI-shaped pairs
     python -m torch.distributed.run --nproc-per-node 8 -m rdmnet_amd.infer ...       # pairs sharded over ranks
 
 Per pair it writes what the reference writes: one line in `<seq>_pose` and one `<seq>_<src>_<ref>.npz`
@@ -19,7 +20,7 @@ import numpy as np
 import torch
 
 from . import config, dataset as ds_mod, evaluation, ops, sharding, weights
-from .engine import Engine
+from .pipeline import DEFAULT_PAIRS_IN_FLIGHT, PairPipeline, pin_rank
 
 
 def load_state(path, cfg, seed=0):
@@ -31,22 +32,26 @@ def load_state(path, cfg, seed=0):
 
 
 class Tester:
-    """One engine on the current device; `run(stager)` processes this rank's pairs."""
+    """`run(stager)` processes this rank's pairs with `pairs_in_flight` of them on the GPU at a time
+    (rdmnet_amd.pipeline.PairPipeline: what replaces the one-pair-at-a-time loop of engine/single_tester.py:86-134);
+    records, pose lines and the report come out in dataset order whatever the completion order."""
 
-    def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True, write_poses=True):
+    def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True, write_poses=True,
+                 pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None):
         self.cfg, self.output_dir, self.save_npz, self.ransac = cfg, output_dir, save_npz, ransac
         self.write_poses = write_poses  # False under several ranks: rank 0 writes all poses, in pair order, at the end
-        self.engine = Engine(cfg, state)
-        if save_npz and output_dir:
-            self.engine.keep_taps(True)
+        self.pipeline = PairPipeline(cfg, state, pairs_in_flight=pairs_in_flight, wait_us=wait_us,
+                                     keep_taps=bool(save_npz and output_dir))
+        self.engine = self.pipeline.engines[0]  # (the serial entry point `step` runs on this one)
         if output_dir:
             os.makedirs(output_dir, exist_ok=True)
         self.summary = evaluation.Summary()
         self.records = []
 
-    def output_dict(self, n_ref):
-        """The tensors infer.py:84-101 stores, from the engine's taps of the last run."""
-        e, r = self.engine, self.engine.result
+    @staticmethod
+    def output_dict(e, n_ref):
+        """The tensors infer.py:84-101 stores, from engine e's taps of its last run."""
+        r = e.result
         lv0, lv1 = e.tensor('points0'), e.tensor('points1')
         nodes, feats = e.tensor('nodes'), e.tensor('feats_c')
         m_r, n_ref_f = int(r.n_ref_nodes), int(r.level_ref_sizes[1])
@@ -61,34 +66,46 @@ class Tester:
                'estimated_transform': torch.from_numpy(e.transform())}
         return out
 
-    def step(self, item, ref_dev, src_dev):
+    def _work(self, eng, job):
+        """One pair on a worker thread / stream of the pipeline: run it and take everything the harness needs out of the
+        engine (the next pair reuses its arena).  The .npz of a pair is an independent file: written here."""
+        item, ref_dev, src_dev = job
         t0 = time.perf_counter()
-        res = self.engine.run(ref_dev.contiguous(), src_dev.contiguous())  # returns with the pose on the host
+        res = eng.run(ref_dev.contiguous(), src_dev.contiguous())  # returns with pose AND correspondences on the host
         ms = (time.perf_counter() - t0) * 1e3
-        T = self.engine.transform()
+        T = eng.transform()
         rec = {'seq_id': item['seq_id'], 'ref_frame': item['ref_frame'], 'src_frame': item['src_frame'],
                'n_corr': int(res.n_correspondences), 'ms': ms, 'transform': T}
-        if self.output_dir:
-            if self.write_poses:
-                evaluation.append_pose(self.output_dir, item, T)
-            if self.save_npz:
-                od = self.output_dict(item['ref_points'].shape[0])
-                T_ransac = None
-                if self.ransac:  # infer.py:75-82: distance 0.3, ransac_n 4, 50 000 iterations, on the GPU
-                    T_ransac = ops.ransac_correspondences(od['src_corr_points'].contiguous(), od['ref_corr_points'].contiguous(),
-                                                          0.3, 4, 50000)[0].cpu().numpy().astype(np.float64)
-                evaluation.save_pair_npz(self.output_dir, item, od, estimated_transform_ransac=T_ransac)
         if 'transform' in item:
-            rc, sc, cs = self.engine.corr()
-            rec.update(self.summary.update((item['seq_id'], item['src_frame'], item['ref_frame']),
-                                           np.asarray(item['transform'], np.float64), T, rc.cpu().numpy(),
-                                           sc.cpu().numpy(), cs.cpu().numpy()))
+            rec['_gt'] = np.asarray(item['transform'], np.float64)
+            rec['_corr'] = eng.host_corr()
+        if self.output_dir and self.save_npz:
+            od = self.output_dict(eng, item['ref_points'].shape[0])
+            T_ransac = None
+            if self.ransac:  # infer.py:75-82: distance 0.3, ransac_n 4, 50 000 iterations, on the GPU
+                T_ransac = ops.ransac_correspondences(od['src_corr_points'].contiguous(), od['ref_corr_points'].contiguous(),
+                                                      0.3, 4, 50000)[0].cpu().numpy().astype(np.float64)
+            evaluation.save_pair_npz(self.output_dir, item, od, estimated_transform_ransac=T_ransac)
+        return rec
+
+    def _commit(self, rec):
+        """In dataset order, on the calling thread: pose line, registration meters, record list."""
+        if self.output_dir and self.write_poses:
+            evaluation.append_pose(self.output_dir, rec, rec['transform'])
+        gt = rec.pop('_gt', None)
+        if gt is not None:
+            rc, sc, cs = rec.pop('_corr')
+            rec.update(self.summary.update((rec['seq_id'], rec['src_frame'], rec['ref_frame']), gt, rec['transform'], rc, sc, cs))
         self.records.append(rec)
         return rec
 
+    def step(self, item, ref_dev, src_dev):
+        """One pair, serially, on the calling thread's current stream."""
+        return self._commit(self._work(self.engine, (item, ref_dev, src_dev)))
+
     def run(self, stager, log=None):
-        for item, ref_dev, src_dev in stager:
-            rec = self.step(item, ref_dev, src_dev)
+        for rec in self.pipeline.imap(stager, self._work):
+            self._commit(rec)
             if log:
                 log('seq_id: {}, id0: {}, id1: {}, nCorr: {}'.format(rec['seq_id'], rec['ref_frame'], rec['src_frame'],
                                                                       rec['n_corr']))
@@ -106,10 +123,20 @@ def main(argv=None):
     ap.add_argument('--no-npz', action='store_true')
     ap.add_argument('--neighbor-limits', type=int, nargs=5, default=None, help='skip the calibration')
     ap.add_argument('--bf16-attention', action='store_true')
+    ap.add_argument('--synthetic', type=int, default=0, metavar='N',
+                    help='no dataset: N pairs cycling through the bench workload\'s seeded synthetic KITTI-shaped pairs '
+                         '(rdmnet_amd.synthetic; --synthetic-distinct of them, cached under --synthetic-cache)')
+    ap.add_argument('--synthetic-distinct', type=int, default=8)
+    ap.add_argument('--synthetic-cache', default=os.path.join('gpurun_out', 'bench_pairs'))
+    ap.add_argument('--pairs-in-flight', type=int, default=DEFAULT_PAIRS_IN_FLIGHT,
+                    help='pairs on the GPU at a time (engines / host threads / HIP streams; rdmnet_amd.pipeline)')
+    ap.add_argument('--no-ransac', action='store_true', help='skip the RANSAC estimate stored beside the LGR pose in the .npz')
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+    local_rank, local_world = int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    pin_rank(local_rank, local_world)  # one contiguous slice of the host's CPUs per rank
+    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -119,14 +146,20 @@ def main(argv=None):
         cfg.Vote.inference_use_vote = False
     cfg.thdroformer.attention_bf16 = bool(args.bf16_attention)
     b = cfg.backbone
-    if args.infer_root:
+    if args.synthetic > 0:
+        from . import synthetic
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'synthetic_pairs.npz')
+        base = ds_mod.ArrayPairDataset(synthetic.cached_pairs(args.synthetic_distinct, args.synthetic_cache, fixture))
+        data = ds_mod.CyclingPairDataset(base, args.synthetic)
+        calib = base
+    elif args.infer_root:
         data = ds_mod.OdometryKittiPairDataset('.', 'infer', infer_root=args.infer_root)
         calib = data
     elif args.dataset_root:
         data = ds_mod.OdometryKittiPairDataset(args.dataset_root, args.subset)
         calib = data
     else:
-        ap.error('give --infer-root or --dataset-root')
+        ap.error('give --infer-root, --dataset-root or --synthetic N')
     t0 = time.time()
     if args.neighbor_limits:
         cfg.neighbor_limits = list(args.neighbor_limits)
@@ -136,10 +169,15 @@ def main(argv=None):
     if rank == 0:
         print(f'Data loader created: {time.time() - t0:.3f}s collapsed.')
         print(f'Calibrate neighbors: {cfg.neighbor_limits}.')
-    tester = Tester(cfg, load_state(args.weights, cfg), args.out, save_npz=not args.no_npz, write_poses=world == 1)
+    tester = Tester(cfg, load_state(args.weights, cfg), args.out, save_npz=not args.no_npz, ransac=not args.no_ransac,
+                    write_poses=world == 1, pairs_in_flight=args.pairs_in_flight)
     mine = sharding.pairs_for_rank(len(data), rank, world)
-    stager = ds_mod.PairStager(data, mine)
-    records = tester.run(stager, log=print if rank == 0 else None)
+    # scans are read and staged (pinned host -> HBM on a side stream) two pairs ahead of every in-flight pair
+    stager = ds_mod.PairStager(data, mine, depth=2 * args.pairs_in_flight, workers=max(2, args.pairs_in_flight))
+    t_run = time.perf_counter()
+    records = tester.run(stager, log=print if rank == 0 and len(mine) <= 64 else None)
+    torch.cuda.synchronize()
+    t_run = time.perf_counter() - t_run
     # one gather of fixed-size records: ids, counts, time, errors, the pose (12 floats) and the pair's dataset index
     rec = torch.tensor([[r['seq_id'], r['ref_frame'], r['src_frame'], r['n_corr'], r['ms'], r.get('r_RRE', float('nan')),
                          r.get('r_RTE', float('nan')), *np.asarray(r['transform'], np.float64).reshape(-1)[:12], idx]
@@ -151,7 +189,9 @@ def main(argv=None):
             for row in allrec:
                 evaluation.append_pose(args.out, {'seq_id': int(row[0]), 'ref_frame': int(row[1]), 'src_frame': int(row[2])},
                                        row[7:19].astype(np.float32))
-        print(f'pairs: {allrec.shape[0]}, mean ms/pair: {allrec[:, 4].mean() if len(allrec) else 0:.2f}')
+        print(f'pairs: {allrec.shape[0]}, mean ms/pair: {allrec[:, 4].mean() if len(allrec) else 0:.2f}, '
+              f'{allrec.shape[0] / max(t_run, 1e-9):.1f} pairs/s (rank 0 wall time {t_run:.2f} s: host scans -> staging -> '
+              f'{args.pairs_in_flight} pairs in flight -> poses and correspondences on the host)')
         if len(allrec) and np.isfinite(allrec[:, 5]).any():
             ok = (allrec[:, 5] < tester.summary.rre_threshold) & (allrec[:, 6] < tester.summary.rte_threshold)
             print('  Registration (all ranks), RR: {:.4f}, RRE: {:.3f}, RTE: {:.3f}'.format(

@@ -309,7 +309,9 @@ class RDMNet(torch.nn.Module):
     def _engine(self):
         """The native engine of the CURRENT STREAM (an engine is not re-entrant and its work is ordered by the stream it
         runs on; bench.py drives one forward per host thread, each on its own stream), built from this module's state
-        dict on first use and kept in an LRU cache of `max_engines` entries (>= 3 GiB of HBM each; release_engines() frees them)."""
+        dict on first use and kept in an LRU cache of `max_engines` entries (>= 3 GiB of HBM each; release_engines() frees them;
+        an evicted engine's arena is freed at once -- the shared weights are reference counted by the library and stay
+        as long as any engine uses them)."""
         from . import engine as engine_mod
         if self.device is None:
             self.cuda()

@@ -1,0 +1,234 @@
+"""Several scan pairs in flight on one GPU: the product's scheduler.
+
+The reference's test loop (geotransformer/engine/single_tester.py:86-134) pushes one pair at a time through the
+model and synchronises after each; most kernels of one pair are far too small to fill 256 CUs, so a GPU driven
+like that idles (240 pairs/s with one pair in flight against 500+ with four).  `PairPipeline` is
+what replaces that loop here -- used by `rdmnet_amd.infer.Tester`, by `bench.py`'s timed region and by anything
+else that has a stream of pairs:
+
+  * N native engines (`rdm_engine`, one per in-flight pair) that share ONE copy of the prepared weights
+    (`rdm_engine_share_params`, reference counted by the library),
+  * N host threads, each with its own HIP stream, drawing their next job from ONE shared queue (a stream that
+    falls behind takes fewer; all drain together at the end of the input),
+  * staggered starts: worker k draws its first job k x `stagger_ms` after worker 0, so the in-flight pairs do
+    not walk through the same stages in phase (four serial subsampling kernels, then four encoders contending),
+  * `rdm_engine_set_pairs_in_flight(N)` (GEMM residency hint from three pairs up),
+  * waits at the engines' size read-backs by spinning (`hipStreamSynchronize`) when the process owns two host
+    cores per in-flight pair, by polling with 50 us sleeps otherwise (`cpu_budget`),
+  * one hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware
+    queues, and four worker streams + the default stream on four queues serialise two streams (345 instead of
+    460 pairs/s); `rdmnet_amd/__init__.py` sets GPU_MAX_HW_QUEUES=8 unless the caller chose a value -- it must
+    be in the environment before the first HIP call of the process.
+
+Results come back in INPUT order whatever the completion order, and every engine is deterministic, so N pairs in
+flight give the bits of a serial run (tests/test_pipeline_gpu.py).
+"""
+import os
+import threading
+import time
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe with another one
+DEFAULT_STAGGER_MS = 1.5
+
+
+def cpu_budget():
+    """Host CPUs this process may use: affinity mask capped by the cgroup quota (cpu.max / cfs_quota_us)."""
+    n = float(len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, float(quota) / float(period))
+    except (OSError, ValueError):
+        try:
+            q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, q / per)
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def pin_rank(local_rank, local_world):
+    """One process per GPU on a shared host: rank r keeps the r-th contiguous slice of the CPUs this process may run on
+    (its engines' worker threads and the runtime's helper threads then stay on one NUMA neighbourhood instead of
+    migrating over all sockets; with spinning waits that is 4 busy threads per rank).  No-op for a single rank, when
+    there are fewer CPUs than ranks, or where the platform has no affinity call.  Returns the CPU list it set (or None).
+    The same slice is what `torch.distributed.run` launches get: call this at the top of the rank's main()."""
+    if local_world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // local_world
+    if per < 1:
+        return None
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
+def choose_wait_us(pairs_in_flight, local_world=1):
+    """0 = spin at the read-backs (needs ~2 host cores per in-flight pair of this rank), else poll with 50 us sleeps."""
+    return 0 if cpu_budget() / max(local_world, 1) >= 2 * pairs_in_flight else 50
+
+
+class PairResult:
+    """What a pair leaves on the host: pose, correspondences (numpy copies of the engine's pinned buffer) and counters."""
+    __slots__ = ('transform', 'ref_corr_points', 'src_corr_points', 'corr_scores', 'n_correspondences', 'n_ref_nodes',
+                 'n_src_nodes', 'n_node_correspondences', 'level_sizes', 'ms')
+
+    def __init__(self, eng, res, ms):
+        self.transform = eng.transform()
+        self.ref_corr_points, self.src_corr_points, self.corr_scores = eng.host_corr()
+        self.n_correspondences = int(res.n_correspondences)
+        self.n_ref_nodes, self.n_src_nodes = int(res.n_ref_nodes), int(res.n_src_nodes)
+        self.n_node_correspondences = int(res.n_node_correspondences)
+        self.level_sizes = [int(x) for x in res.level_sizes]
+        self.ms = ms
+
+
+class PairPipeline:
+    """`pairs_in_flight` engines / host threads / HIP streams on one device; see the module docstring.
+
+    map(jobs, fn) / imap(jobs, fn): fn(engine, job) runs on a worker thread inside `torch.cuda.stream(<its stream>)`
+    and must take what it needs from the engine before returning (the next job reuses the engine's arena).  Jobs are
+    drawn lazily from the iterable under a lock, IN the worker's stream context -- a `dataset.PairStager` works as the
+    job source (its hand-off event is waited for by the drawing worker's stream)."""
+
+    def __init__(self, cfg, state, device=None, pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None,
+                 stagger_ms=DEFAULT_STAGGER_MS, keep_taps=False, local_world=None, engines=None, streams=None):
+        self._gpu = torch.cuda.is_available()
+        if not self._gpu and engines is None:
+            raise RuntimeError('rdmnet_amd.pipeline needs a GPU (no CPU fallback)')
+        # (without a GPU only the scheduler itself can run, on engines the caller injected: tests/test_pipeline.py)
+        self.device = (torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)) if self._gpu else None
+        self.n = max(1, int(pairs_in_flight))
+        self.stagger_s = max(0.0, float(stagger_ms)) * 1e-3
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1')) if local_world is None else local_world
+        self.wait_us = choose_wait_us(self.n, local_world) if wait_us is None or wait_us < 0 else int(wait_us)
+        if streams is not None:
+            self.streams = list(streams)
+        else:  # a single pair in flight runs on the caller's current stream
+            self.streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.n)]
+                            if self.n > 1 and self._gpu else [None] * self.n)
+        self.engines = list(engines) if engines is not None else []
+        if len(self.engines) < self.n:
+            with torch.cuda.device(self.device):
+                while len(self.engines) < self.n:
+                    self.engines.append(Engine(cfg, state, device=self.device,
+                                               share_with=self.engines[0] if self.engines else None))
+        for eng in self.engines:
+            eng.set_wait(self.wait_us)
+            eng.set_pairs_in_flight(self.n)
+            eng.keep_taps(keep_taps)
+        self.cfg = cfg
+
+    # ------------------------------------------------------------------ generic scheduler
+    def imap(self, jobs, fn, stagger=True, window=None):
+        """Yields fn(engine, job) for every job, in job order.  `window` bounds how far completion may run ahead of
+        the consumer (default 4 x pairs_in_flight results held)."""
+        n = self.n
+        window = max(n, 4 * n if window is None else int(window))
+        it = enumerate(iter(jobs))
+        draw_lock = threading.Lock()
+        cv = threading.Condition()
+        done = {}
+        state = {'next_out': 0, 'drawn': 0, 'exhausted': False, 'error': None, 'stop': False, 'alive': n}
+
+        def draw():
+            with draw_lock:
+                if state['exhausted'] or state['stop']:
+                    return None
+                try:
+                    slot, job = next(it)
+                except StopIteration:
+                    state['exhausted'] = True
+                    return None
+                state['drawn'] = slot + 1
+                return slot, job
+
+        def worker(k):
+            stream = self.streams[k]
+            import contextlib
+            try:
+                with (torch.cuda.device(self.device) if self._gpu else contextlib.nullcontext()):
+                    ctx = torch.cuda.stream(stream) if stream is not None else None
+                    if ctx is not None:
+                        ctx.__enter__()
+                    try:
+                        if stagger and k > 0 and self.stagger_s > 0:
+                            time.sleep(k * self.stagger_s)
+                        while True:
+                            with cv:  # do not run further ahead of the consumer than `window` results
+                                while state['drawn'] - state['next_out'] >= window and not state['stop']:
+                                    cv.wait(timeout=0.05)
+                            got = draw()
+                            if got is None:
+                                return
+                            slot, job = got
+                            out = fn(self.engines[k], job)
+                            with cv:
+                                done[slot] = out
+                                cv.notify_all()
+                    finally:
+                        if ctx is not None:
+                            ctx.__exit__(None, None, None)
+            except BaseException as exc:  # surfaced by the consumer (a worker thread must not fail silently)
+                with cv:
+                    if state['error'] is None:
+                        state['error'] = exc
+                    state['stop'] = True
+            finally:
+                with cv:
+                    state['alive'] -= 1
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(n)]
+        for t in threads:
+            t.start()
+        try:
+            while True:
+                with cv:
+                    while True:
+                        if state['error'] is not None:
+                            raise state['error']
+                        if state['next_out'] in done:
+                            break
+                        if state['alive'] == 0:  # every worker has left: nothing more will arrive
+                            return
+                        cv.wait(timeout=0.05)
+                    out = done.pop(state['next_out'])
+                    state['next_out'] += 1
+                    cv.notify_all()
+                yield out
+        finally:
+            with cv:
+                state['stop'] = True
+                cv.notify_all()
+            for t in threads:
+                t.join()
+
+    def map(self, jobs, fn, stagger=True):
+        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30))
+
+    # ------------------------------------------------------------------ the common case
+    def run_pairs(self, pairs, stagger=True):
+        """pairs: iterable of (ref_points, src_points) float32 CUDA tensors [n,3] on this device (or of
+        (item, ref, src) triples as a PairStager yields them).  Returns the PairResults in input order."""
+        def one(eng, job):
+            ref, src = job[-2], job[-1]
+            t0 = time.perf_counter()
+            res = eng.run(ref.contiguous(), src.contiguous())
+            return PairResult(eng, res, (time.perf_counter() - t0) * 1e3)
+        return self.map(pairs, one, stagger=stagger)
+
+    def close(self):
+        """Drops the engines (their arenas; the shared weights go with the last one)."""
+        self.engines = []

@@ -131,3 +131,26 @@ def make_low_overlap_pair(pair_id, target_points=16000, tolerance=500, fov_loss_
     ref = ref[np.random.default_rng(1).permutation(ref.shape[0])]
     src = src[np.random.default_rng(2).permutation(src.shape[0])]
     return ref, src, T
+
+
+def cached_pairs(n_pairs, cache_dir, fixture=None):
+    """The bench workload's pairs 0 .. n-1 (make_pair): from `fixture` (an .npz with ref<i> / src<i> / T<i>, e.g.
+    tests/golden/synthetic_pairs.npz: the generator's exact output for the first pairs) where present, else from
+    `cache_dir`, else generated (~10 s of host ray casting each) and cached there.  -> [(ref, src, T)]."""
+    import os
+    os.makedirs(cache_dir, exist_ok=True)
+    fx = np.load(fixture) if fixture and os.path.exists(fixture) else None
+    pairs = []
+    for pid in range(n_pairs):
+        if fx is not None and f'ref{pid}' in fx.files:
+            pairs.append((fx[f'ref{pid}'], fx[f'src{pid}'], fx[f'T{pid}']))
+            continue
+        f = os.path.join(cache_dir, f'pair_{pid}.npz')
+        if os.path.exists(f):
+            z = np.load(f)
+            pairs.append((z['ref'], z['src'], z['T']))
+        else:
+            ref, src, T = make_pair(pid)
+            np.savez(f, ref=ref, src=src, T=T)
+            pairs.append((ref, src, T))
+    return pairs

@@ -26,7 +26,7 @@ def run_bench(*args, env_extra=None, timeout=900):
 
 def test_two_ranks_self_spawned_on_one_device():
     r = run_bench('--gpus', '2', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--streams', '2', '--pairs', '4',
-                  '--host-steps', '4', '--api-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
+                  '--host-steps', '4', '--full-steps', '4', '--api-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
     assert r['n_gpus'] == 2 and r['steps'] == 8 and r['scaling'] == 'weak' and r['unit'] == 'pairs/s'
     assert r['records'] == {'gathered': 16, 'distinct_steps': 16, 'distinct_pairs': 4}
     assert r['registration']['pairs'] == 16
@@ -35,13 +35,17 @@ def test_two_ranks_self_spawned_on_one_device():
 
 
 def test_single_rank_line_has_the_contract_fields():
-    r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--api-steps', '8', '--no-cpu-baseline')
+    r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--full-steps', '4', '--api-steps', '8', '--no-cpu-baseline')
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in r, key
     assert r['n_gpus'] == 1 and r['vs_baseline'] is None and r['dtype'] == 'f32' and 'workload' in r['config']
     rf = r['roofline']
     assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    # round-stable side keys of the roofline, the all-13-tables figure beside `value`, and the product scheduler
+    assert 'definition' in rf and rf['whole_layer']['one_pair_in_flight']['frac'] > 0 and rf['by_form'] and rf['real_slots']['fill'] <= 1
+    assert r['full_tables']['value'] > 0 and r['config']['searches_per_pair'] == 12
+    assert r['config']['scheduler'] == 'rdmnet_amd.pipeline.PairPipeline'
 
 
 def test_single_rank_through_rccl():
@@ -49,7 +53,7 @@ def test_single_rank_through_rccl():
     the all_reduce(MAX) of the elapsed time go through the process group (the multi-GPU run's collectives,
     geotransformer/engine/base_tester.py:70-76,123-128 in the reference)."""
     r = run_bench('--gpus', '1', '--force-dist', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4',
-                  '--api-steps', '4', '--no-cpu-baseline', timeout=600)
+                  '--full-steps', '0', '--api-steps', '4', '--no-cpu-baseline', timeout=600)
     assert r['collective']['backend'] == 'nccl' and r['collective']['forced_single_rank'] and r['collective']['library'].startswith('RCCL')
     assert r['records'] == {'gathered': 8, 'distinct_steps': 8, 'distinct_pairs': 2}
     assert r['n_gpus'] == 1 and r['value'] > 0 and r['host_to_host']['value'] > 0

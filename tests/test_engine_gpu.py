@@ -86,6 +86,35 @@ def test_engines_share_one_copy_of_the_weights(ctx):
     assert all(np.array_equal(a, b) for a, b in zip(twin.host_corr(), c1))
 
 
+def test_shared_parameters_outlive_their_first_owner(ctx):
+    """the prepared parameters are reference counted in the library.  The engine that uploaded them may be
+    destroyed first (an LRU eviction does exactly that): its sharers keep working on the same bits, a sharer of a sharer
+    too, and a configuration with another model shape is refused."""
+    import copy
+    import gc
+    from rdmnet_amd import engine
+    cfg = ctx['cfg']
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    owner = engine.Engine(cfg, ctx['state'])
+    n1 = owner.run(rp, sp).n_correspondences
+    T1 = owner.transform()
+    twin = engine.Engine(cfg, None, share_with=owner)
+    grand = engine.Engine(cfg, None, share_with=twin)
+    other = copy.deepcopy(cfg)
+    other.model.num_points_in_patch = 64
+    with pytest.raises(RuntimeError, match='different model shapes'):
+        engine.Engine(other, None, share_with=owner)
+    free0 = torch.cuda.mem_get_info()[0]
+    del owner  # rdm_engine_destroy(owner): its 3 GiB arena goes, the parameters stay with twin / grand
+    gc.collect()
+    assert torch.cuda.mem_get_info()[0] - free0 >= (2 << 30)
+    for e in (twin, grand):
+        assert e.run(rp, sp).n_correspondences == n1 and np.array_equal(e.transform(), T1)
+    del twin
+    gc.collect()
+    assert grand.run(rp, sp).n_correspondences == n1 and np.array_equal(grand.transform(), T1)
+
+
 def test_pairs_in_flight_hint_changes_no_bit(ctx):
     """rdm_engine_set_pairs_in_flight(n >= 3) caps the tiled GEMM at two workgroups per CU (a scheduling hint for several pairs
     sharing the GPU): results are the same bits as without it."""

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f'{n} declared in include/rdmnet_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in rdmnet_amd/_lib.py'
-    assert L.rdm_abi_version() == 1
+    assert L.rdm_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_rehash_schedule_matches_a_real_unordered_map(oracle_native):

@@ -1,0 +1,83 @@
+"""GPU: several pairs in flight (rdmnet_amd.pipeline.PairPipeline, what `python -m rdmnet_amd.infer` and bench.py run on)
+give the bits of a serial run, in dataset order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup(golden_dir):
+    from rdmnet_amd import config, weights
+    cfg = config.make_cfg()
+    state = weights.synthetic_state_dict(cfg, seed=0)
+    scans = np.load(os.path.join(golden_dir, 'scans.npz'))
+    a, b, c = scans['s000000'], scans['s000004'], scans['s000007']
+
+    def crop(p, r):
+        return np.ascontiguousarray(p[np.linalg.norm(p[:, :2], axis=1) < r])
+    # five distinct pairs of different sizes (their stages take different times, so completion order differs from input order)
+    distinct = [(crop(a, 10.0), crop(b, 10.0)), (crop(a, 16.0), crop(b, 16.0)), (crop(a, 12.0), crop(c, 12.0)),
+                (crop(b, 9.0), crop(a, 9.0)), (crop(a, 20.0), crop(b, 20.0))]
+    return cfg, state, distinct
+
+
+def test_pairs_in_flight_equal_the_serial_run_bit_for_bit_in_dataset_order(setup):
+    from rdmnet_amd import pipeline
+    cfg, state, distinct = setup
+    order = [0, 1, 2, 3, 4, 4, 0, 3, 1, 2, 0, 0, 4, 2, 3, 1, 1, 4]
+    dev = [(torch.from_numpy(r).cuda(), torch.from_numpy(s).cuda()) for r, s in distinct]
+    serial = pipeline.PairPipeline(cfg, state, pairs_in_flight=1)
+    want = serial.run_pairs([dev[i] for i in order])
+    flight = pipeline.PairPipeline(cfg, None, pairs_in_flight=4, engines=[serial.engines[0]])  # (shares the weights)
+    assert len(flight.engines) == 4 and len({id(s) for s in flight.streams}) == 4
+    for _ in range(2):
+        got = flight.run_pairs([dev[i] for i in order])
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.transform, w.transform)
+            assert g.n_correspondences == w.n_correspondences and g.level_sizes == w.level_sizes
+            assert np.array_equal(g.ref_corr_points, w.ref_corr_points) and np.array_equal(g.src_corr_points, w.src_corr_points)
+            assert np.array_equal(g.corr_scores, w.corr_scores)
+    # pairs of one size gave one result (the engines are deterministic and independent)
+    for i in set(order):
+        rows = [g for g, k in zip(got, order) if k == i]
+        assert all(np.array_equal(rows[0].transform, r.transform) for r in rows[1:])
+
+
+def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):
+    """`Tester.run` (python -m rdmnet_amd.infer) with four pairs in flight: records, pose lines (dataset order) and the
+    per-pair .npz files equal the one-pair-at-a-time run's."""
+    from rdmnet_amd import dataset, infer
+    cfg, state, distinct = setup
+    pairs = [distinct[i] + (np.eye(4),) for i in (0, 1, 2, 3, 4, 1, 0, 2)]
+    outs = {}
+    for n in (1, 4):
+        d = tmp_path / f'flight{n}'
+        t = infer.Tester(cfg, state, str(d), ransac=False, pairs_in_flight=n)
+        recs = t.run(dataset.PairStager(dataset.ArrayPairDataset(pairs), depth=2 * n))
+        outs[n] = (recs, open(d / '00_pose').read(), t.summary.lines())
+        assert [r['ref_frame'] for r in recs] == [2 * i for i in range(len(pairs))]
+    (r1, pose1, rep1), (r4, pose4, rep4) = outs[1], outs[4]
+    assert pose1 == pose4 and rep1 == rep4
+    for a, b in zip(r1, r4):
+        assert np.array_equal(a['transform'], b['transform']) and a['n_corr'] == b['n_corr']
+        za = np.load(tmp_path / 'flight1' / f"0_{a['src_frame']}_{a['ref_frame']}.npz")
+        zb = np.load(tmp_path / 'flight4' / f"0_{a['src_frame']}_{a['ref_frame']}.npz")
+        assert set(za.files) == set(zb.files)
+        for k in za.files:
+            assert np.array_equal(za[k], zb[k]), k
+
+
+def test_an_engine_error_inside_the_pipeline_reaches_the_caller(setup):
+    from rdmnet_amd import pipeline
+    cfg, state, distinct = setup
+    p = pipeline.PairPipeline(cfg, state, pairs_in_flight=2)
+    good = (torch.from_numpy(distinct[0][0]).cuda(), torch.from_numpy(distinct[0][1]).cuda())
+    bad = (good[0], torch.zeros((0, 3), device='cuda'))  # an empty cloud: rdm_engine_run refuses it
+    with pytest.raises(RuntimeError, match='rdm_engine_run'):
+        p.run_pairs([good, good, bad, good])
+    assert len(p.run_pairs([good, good])) == 2  # the pipeline is usable afterwards

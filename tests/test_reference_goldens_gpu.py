@@ -183,7 +183,8 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
     # on every case the HIP pose IS one of the two poses the reference itself returned (8- or 1-thread run)
     e1 = rre_rte(T, g['self/transform_1_thread'])
     rep['pose']['vs_reference_1_thread_pose'] = {'rre_deg': e1[0], 'rte_m': e1[1]}
-    assert min((rre_own, rte_own), e1) <= (1e-3, bound_t) and min(rte_own, e1[1]) <= bound_t
+    # (component-wise: RRE AND RTE of the SAME candidate pose -- ADVICE r3: a tuple comparison would ignore RTE)
+    assert (rre_own <= 1e-3 and rte_own <= bound_t) or (e1[0] <= 1e-3 and e1[1] <= bound_t), ((rre_own, rte_own), e1)
     if margin >= 3:
         assert pick == own and len(errs) == 1
     # the pose is the reference's local-to-global registration OF THIS RUN'S OWN matching scores: the restated LGR
@@ -195,7 +196,7 @@ def test_hip_forward_matches_reference_goldens(setup, golden_dir, tag):
         ofw, cfg, out['ref_node_corr_knn_points'].cpu(), out['src_node_corr_knn_points'].cpu(),
         out['ref_node_corr_knn_masks'].cpu().bool(), out['src_node_corr_knn_masks'].cpu().bool(), out['matching_scores'].cpu())
     assert torch.equal(orc, out['ref_corr_points'].cpu()) and torch.equal(osc, out['src_corr_points'].cpu())
-    e2 = min(rre_rte(T, A) for _, A in alts)
+    e2 = min((rre_rte(T, A) for _, A in alts), key=lambda e: max(e[0] / 1e-3, e[1] / bound_t))  # both components of one pose
     rep['pose']['vs_reference_lgr_on_own_scores'] = {'rre_deg': e2[0], 'rte_m': e2[1], 'inlier_margin': own_margin,
                                                       'n_near_tie_hypotheses': len(alts)}
     assert e2[0] <= 1e-3 and e2[1] <= bound_t, (e2, own_margin)
