@@ -180,8 +180,11 @@ def calibrate_neighbors_stack_mode(dataset, collate_fn=None, num_stages=5, voxel
 
 class PairStager:
     """Iterates a dataset as (item, ref_dev, src_dev): scans are read by `workers` background threads,
-    packed into pinned host buffers and copied to HBM on a side stream; `depth` pairs are in flight.
-    The consumer's current stream waits on the copy's event, so no host synchronisation is needed.
+    packed into pinned host buffers and copied to HBM on a side stream; `depth` pairs are staged ahead.
+    The consumer's current stream waits on the copy's event, so no host synchronisation is needed; with several
+    consumer threads (rdmnet_amd.pipeline: one per in-flight pair, drawing under a lock) each draw makes the DRAWING
+    thread's stream wait.  The pinned buffers are a fixed ring of `depth + workers` allocations that are re-used (an
+    allocation or release of pinned memory synchronises the device: per pair it capped the harness at ~60 pairs/s).
     `indices` selects this rank's pairs (see sharding.pairs_for_rank)."""
 
     def __init__(self, dataset, indices=None, device=None, depth=2, workers=2):
@@ -199,25 +202,41 @@ class PairStager:
             todo.put((slot, i))
         ready = {}
         cv = threading.Condition()
-        budget = threading.Semaphore(self.depth + self.workers)  # bounds pinned memory in flight
+        pool = queue.Queue()  # [pinned tensor or None, event of the last copy out of it or None]
+        for _ in range(self.depth + self.workers):
+            pool.put([None, None])
         errors = []
+        stop = threading.Event()
 
         def work():
-            while True:
+            while not stop.is_set():
+                # the buffer first, then the slot: whoever holds a buffer takes the LOWEST unclaimed slot, so the slot the
+                # consumer waits for can never starve behind later slots that took every buffer
+                try:
+                    buf = pool.get(timeout=0.1)  # (bounds the pinned memory in flight)
+                except queue.Empty:
+                    continue
                 try:
                     slot, i = todo.get_nowait()
                 except queue.Empty:
+                    pool.put(buf)
                     return
-                budget.acquire()
                 try:
                     item = self.dataset[i]
                     ref, src = item['ref_points'], item['src_points']
-                    host = torch.empty((ref.shape[0] + src.shape[0], 3), dtype=torch.float32).pin_memory()
+                    rows = ref.shape[0] + src.shape[0]
+                    if buf[1] is not None:
+                        buf[1].synchronize()  # the previous copy out of this buffer has finished
+                        buf[1] = None
+                    if buf[0] is None or buf[0].shape[0] < rows:  # first use, or a larger pair than any before
+                        buf[0] = torch.empty((max(rows, 1) * 5 // 4, 3), dtype=torch.float32).pin_memory()
+                    host = buf[0][:rows]
                     host[:ref.shape[0]] = torch.from_numpy(np.ascontiguousarray(ref, np.float32))
                     host[ref.shape[0]:] = torch.from_numpy(np.ascontiguousarray(src, np.float32))
-                    out = (item, host)
+                    out = (item, host, buf)
                 except Exception as e:  # surfaced in the consumer
                     errors.append(e)
+                    pool.put(buf)
                     out = None
                 with cv:
                     ready[slot] = out
@@ -238,29 +257,32 @@ class PairStager:
                 got = ready.pop(slot)
             if got is None:
                 raise errors[0]
-            item, host = got
+            item, host, buf = got
             with torch.cuda.stream(copy_stream):
                 dev = host.to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
-            return item, host, dev, ev
+            buf[1] = ev
+            pool.put(buf)  # (its next user waits for `ev` before it overwrites the buffer)
+            return item, dev, ev
 
-        n = len(self.indices)
-        nxt = 0
-        while nxt < min(self.depth, n):
-            staged.append(stage(nxt))
-            nxt += 1
-        for _ in range(n):
-            item, host, dev, ev = staged.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            n_ref = item['ref_points'].shape[0]
-            yield item, dev[:n_ref], dev[n_ref:]
-            del host
-            budget.release()
-            if nxt < n:
+        try:
+            n = len(self.indices)
+            nxt = 0
+            while nxt < min(self.depth, n):
                 staged.append(stage(nxt))
                 nxt += 1
+            for _ in range(n):
+                item, dev, ev = staged.pop(0)
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                dev.record_stream(torch.cuda.current_stream(self.device))
+                n_ref = item['ref_points'].shape[0]
+                yield item, dev[:n_ref], dev[n_ref:]
+                if nxt < n:
+                    staged.append(stage(nxt))
+                    nxt += 1
+        finally:
+            stop.set()
 
 
 def infer_data_loader(cfg, dataset='kitti', infer_root='./assets/pc', rank=0, world=1):
