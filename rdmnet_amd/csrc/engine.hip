@@ -304,11 +304,11 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
     // (rdm_kpconv_fused_group_norm's two halves, so that the layer events bracket the convolution kernel alone)
-    const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, cin));
+    const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, cin, t.width));
     double* gn_partial = static_cast<double*>(r.ws);
     const size_t stat_bytes = align_up(static_cast<size_t>(nblk) * 2 * W.out * sizeof(double));
     ENG_CHECK(rdm_kpconv_fused(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
-                               vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, r.st));
+                               vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, order, r.st));
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
     ENG_CHECK(group_norm_finish(gn_partial, nblk, conv.p, q.n, W.out, conv.ld, r.groups, gam, bet, 1e-5f, nullptr, 0, 2, y.p, y.ld,
                                 nullptr, static_cast<char*>(r.ws) + stat_bytes, r.ws_bytes - stat_bytes, r.st));
@@ -917,6 +917,27 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
                                       t.flags + 1, redo_flags, redo_queue.data(), r.st);
   };
+  // the five level grids with one set of launches (radius r_i = 2^i r_0): they serve the searches of the collate and, through
+  // their cell-sorted records, the spatial query order of the KPConv kernels and the shortcut pools
+  auto build_level_grids = [&]() -> int {
+    const float* gp[5];
+    int64_t gn[5];
+    const int64_t* gl[5];
+    float gr[5];
+    void* gw[5];
+    size_t gb[5];
+    float rad = c.init_radius;
+    for (int i = 0; i < 5; ++i, rad *= 2.f) {
+      grids[i].n_s = lv[i].n;
+      grids[i].bytes = rdm_radius_grid_workspace_bytes(lv[i].n);
+      grids[i].ws = e->alloc<char>(grids[i].bytes);
+      ENG_ALLOC(grids[i].ws);
+      gp[i] = lv[i].pts; gn[i] = lv[i].n; gl[i] = lv[i].lengths; gr[i] = rad; gw[i] = grids[i].ws; gb[i] = grids[i].bytes;
+    }
+    RDM_DUP_LOOP("rnbuild")
+    ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
+    return RDM_OK;
+  };
   if (dd) {
     // ------------------------------------------------------------ the caller's data_dict (model_infer.py:113-131)
     for (int i = 0; i < 5; ++i) {
@@ -938,6 +959,9 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       up[i].rows = lv[i].n; up[i].width = dd->upsampling_width[i]; up[i].ld = dd->upsampling_ld[i];
       up[i].flags = const_cast<int32_t*>(dd->upsampling_count[i]);
     }
+    // the caller collated (no grids of ours): build them for the spatial query order of the encoder's kernels -- the same
+    // grids the per-op mirror builds (rdmnet_amd/model.py: run_encoder), so both give the same GroupNorm partials
+    ENG_CHECK(build_level_grids());
     if (dd->collate_status && dd->n_collate_status > 0) {  // the collate's status words join the engine's own (checked below)
       hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(64), 0, r.st, dd->collate_status, static_cast<int>(dd->n_collate_status),
                          flags + 2 * call + 1);
@@ -984,24 +1008,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   res->level_ref_sizes[0] = n_ref;
 
   float radius = c.init_radius;
-  {  // the five level grids with one set of launches (radius r_i = 2^i r_0)
-    const float* gp[5];
-    int64_t gn[5];
-    const int64_t* gl[5];
-    float gr[5];
-    void* gw[5];
-    size_t gb[5];
-    float rad = radius;
-    for (int i = 0; i < 5; ++i, rad *= 2.f) {
-      grids[i].n_s = lv[i].n;
-      grids[i].bytes = rdm_radius_grid_workspace_bytes(lv[i].n);
-      grids[i].ws = e->alloc<char>(grids[i].bytes);
-      ENG_ALLOC(grids[i].ws);
-      gp[i] = lv[i].pts; gn[i] = lv[i].n; gl[i] = lv[i].lengths; gr[i] = rad; gw[i] = grids[i].ws; gb[i] = grids[i].bytes;
-    }
-    RDM_DUP_LOOP("rnbuild")
-  ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
-  }
+  ENG_CHECK(build_level_grids());
   // The forward consumes column 0 of upsampling[1..3] only (nearest_upsample, functional.py:6-22) and upsampling[0] not at all
   // (backbone.py:118-151 stops at the second level): a plain run skips that search (32 000 queries, a quarter of all) and keeps one
   // column of the others; the collate API and runs that keep their stage tensors build the reference's full tables.
@@ -1071,7 +1078,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
       // visit the queries in the cell order of their level's search grid: neighbouring queries share most
       // neighbours, so gathered lines are re-used from L1 (results do not depend on the order)
-      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];  // (no grids when the caller collated: row order then)
+      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];
       const float* order = qg.ws ? rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s) : nullptr;
       Mat y;
       if (b == 0) {

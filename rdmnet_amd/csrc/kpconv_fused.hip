@@ -36,6 +36,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kKP = 15;
 constexpr int kMaxH = 128;
 
+// Influence of kernel point k on a neighbour at relative position rel (kpconv.py:96-99), d = rel - kp_k:
+// max(0, 1 - |d| / sigma) with the hardware square root and a reciprocal multiply.  The fused multiply-adds are written out
+// (and contraction is off inside) so that every kernel of this file rounds alike whatever surrounds the call: the form is the
+// one the compiler had chosen for the round-2 / round-3 kernels -- fma(dy, dy, dx dx) + dz dz, then fma(-1/sigma, sqrt, 1).
+__device__ __forceinline__ float kp_influence(float dx, float dy, float dz, float inv_sigma) {
+#pragma clang fp contract(off)
+  const float xx = dx * dx, zz = dz * dz;
+  const float d2 = __builtin_fmaf(dy, dy, xx) + zz;
+  return fmaxf(0.f, __builtin_fmaf(-inv_sigma, __builtin_amdgcn_sqrtf(d2), 1.f));
+}
+
 struct FusedArgs {
   const float* q_points;       // [M,3]
   const float* s_points;       // [Ns,3]
@@ -52,6 +63,19 @@ struct FusedArgs {
   int ldf, ldi, ldo;
   float sigma;
 };
+
+// The same for two neighbours at once on the packed-fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two IEEE operations per
+// lane and instruction, same roundings as the scalar form -- the aggregation of the LDS-tile kernel is bound by VALU issue).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 kp_influence2(f32x2 dx, f32x2 dy, f32x2 dz, float inv_sigma) {
+#pragma clang fp contract(off)
+  const f32x2 xx = dx * dx, zz = dz * dz;
+  const f32x2 d2 = __builtin_elementwise_fma(dy, dy, xx) + zz;
+  const f32x2 sq = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+  const f32x2 ninv = {-inv_sigma, -inv_sigma}, one = {1.f, 1.f};
+  const f32x2 w = __builtin_elementwise_fma(ninv, sq, one);
+  return f32x2{fmaxf(0.f, w.x), fmaxf(0.f, w.y)};
+}
 
 // ---- C_in in {32, 64}
 template <int C, int QB, int NW, int ITERS>
@@ -130,9 +154,7 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
             if (h < Hq) {
               const float4 v = nb[h];
               id = __float_as_int(v.w);
-              const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-              const float d2 = (dx * dx + dy * dy) + dz * dz;
-              w[p] = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma);
+              w[p] = kp_influence(v.x - kx, v.y - ky, v.z - kz, inv_sigma);
               if (j >= kKP || id < 0) w[p] = 0.f;
             }
             const float* row = a.s_feats + static_cast<int64_t>(id < 0 ? 0 : id) * a.ldf + VEC * j;
@@ -234,6 +256,419 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
       a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + c] = ss;
     }
   }
+}
+
+// ---- C_in in {32, 64}, neighbour rows of at most 128 slots: the support rows of a block of queries staged ONCE in LDS
+//
+// The lock-step kernel above fetches the feature row, the point and the positive flag of every (query, neighbour) pair
+// from L2 -- three 128-B lines per pair, M x H_real of them -- although neighbouring queries share most of their
+// neighbours (a query has ~37 real neighbours at the fine levels; 16 queries of one grid cell have 100-200 distinct ones).
+// Here a workgroup takes 16 queries that are consecutive in the CELL ORDER of their level's search grid (`order`: the
+// cell-sorted {x, y, z, row} records of rdm_radius_grid_records; null = row order), and
+//   1. every wavefront reads its queries' index rows (coalesced) and enters the ids into an LDS hash set (atomicCAS,
+//      1024 entries, 16 probes),
+//   2. the occupied entries are numbered by ballots + a prefix over the wavefronts (slot < CAP; the rest stay "global"),
+//   3. the distinct rows -- feature row, point, positive flag -- are fetched ONCE by all threads together (one round trip
+//      with every load in flight, 16-B accesses, a row = 8 / 16 consecutive lanes) into the LDS tile,
+//   4. the aggregation of kpconv_fused_kernel runs with its B operand (feature rows) and the points read from LDS through
+//      the id -> slot map; neighbour order h, influence arithmetic and MFMA sequence are unchanged, so the block
+//      WF[16, 15 C] holds the same bits; ids that found no slot (hash probes exhausted, more than CAP distinct rows in the
+//      block) are fetched from global memory as before,
+//   5. the tile is overwritten by the parked block and the contraction with W, normalisation, bias and GroupNorm partials
+//      follow as above (same K split over the wavefronts as kpconv_fused_kernel<C>: the output is bit-identical to it).
+//   C = 32: 16 wavefronts x 1 query, tile of 384 rows (48 KB) -> 66 KB, two workgroups per CU
+//   C = 64:  8 wavefronts x 2 queries, tile of 240 rows (60 KB, the parked block needs 60.3 KB) -> 75 KB, two per CU
+#ifdef RDM_TILE_TIMING
+// tools/tile_lab.py: s_memtime stamps (100 MHz) of wavefront 0 at the phase boundaries of every workgroup
+__device__ long long* rdm_tile_clk;  // [blocks][8]
+#define TILE_T0() long long tl_t = __builtin_amdgcn_s_memtime(); int tl_k = 0; const long long tl_rt0 = wall_clock64()
+#define TILE_PHASE() do { const long long now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[blockIdx.x * 8 + tl_k] = now - tl_t; tl_t = now; ++tl_k; } while (0)
+// per-wavefront stamps inside the aggregation phase: [blocks][16 waves][4] = sum prologue, trips, (trips count), -
+__device__ long long* rdm_tile_wclk;
+#define TILE_W(slot, val) do { if ((threadIdx.x & 63) == 0 && rdm_tile_wclk) rdm_tile_wclk[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = (val); } while (0)
+#define TILE_NOW() __builtin_amdgcn_s_memtime()
+#ifdef RDM_TILE_TRIP_STAMPS  // serialising stamps inside a trip (diagnosis only: they change the schedule)
+#define TRIP_DECL() long long ts_a = 0, ts_b = 0, ts_c = 0, ts_d = 0, ts_t = 0
+#define TRIP_BEGIN() ts_t = TILE_NOW()
+#define TRIP_LDS(acc_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long n_ = TILE_NOW(); acc_ += n_ - ts_t; ts_t = n_; } while (0)
+#define TRIP_REG(acc_, v_) do { asm volatile("" ::"v"(v_)); asm volatile("s_nop 0" ::: "memory"); const long long n_ = TILE_NOW(); acc_ += n_ - ts_t; ts_t = n_; } while (0)
+#define TRIP_END() do { TILE_W(4, ts_a); TILE_W(5, ts_b); TILE_W(6, ts_c); TILE_W(7, ts_d); } while (0)
+#endif
+#else
+#define TILE_T0() do { } while (0)
+#define TILE_PHASE() do { } while (0)
+#define TILE_W(slot, val) do { } while (0)
+#define TILE_NOW() 0ll
+#endif
+#ifndef RDM_TILE_TRIP_STAMPS
+#define TRIP_DECL() do { } while (0)
+#define TRIP_BEGIN() do { } while (0)
+#define TRIP_LDS(acc_) do { } while (0)
+#define TRIP_REG(acc_, v_) do { } while (0)
+#define TRIP_END() do { } while (0)
+#endif
+constexpr int kTileQB = 16;       // queries per workgroup
+constexpr int kTileHash = 1024;   // entries of the id -> slot hash
+constexpr int kTileProbes = 16;
+
+template <int C> struct TileCfg;
+template <> struct TileCfg<32> { static constexpr int NW = 16, CAP = 384; };
+template <> struct TileCfg<64> { static constexpr int NW = 8, CAP = 240; };
+
+template <int C>
+struct TileLds {
+  static constexpr int CAP = TileCfg<C>::CAP;
+  static constexpr int LDW = kKP * C + 4;
+  // floats: the tile [CAP + 1][C] (row CAP = the shadow slot: zero features), then the parked block
+  static constexpr int R0 = kTileQB * LDW > (CAP + 1) * C ? kTileQB * LDW : (CAP + 1) * C;
+  static constexpr size_t off_pts = static_cast<size_t>(R0) * 4;                 // float4 [CAP + 1]: x, y, z, positive flag
+  static constexpr size_t off_hkey = off_pts + static_cast<size_t>(CAP + 1) * 16;  // int [kTileHash]
+  static constexpr size_t off_hval = off_hkey + kTileHash * 4;                   // short [kTileHash]
+  static constexpr size_t off_sid = off_hval + kTileHash * 2;                    // int [CAP]: slot -> support row
+  static constexpr size_t off_code = off_sid + static_cast<size_t>(CAP) * 4;     // short [kTileQB][kMaxH]
+  static constexpr size_t off_misc = off_code + kTileQB * kMaxH * 2;             // nn_s [16], mrow [16], wtot [16]
+  static constexpr size_t bytes = off_misc + 256;
+};
+
+// (two workgroups per CU: 64 * NW threads x 2 = 8 / 4 wavefronts per SIMD, i.e. at most 64 / 128 registers)
+template <int C>
+__global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order) {
+  using L = TileLds<C>;
+  constexpr int NW = TileCfg<C>::NW, CAP = TileCfg<C>::CAP, NTH = 64 * NW, QB = kTileQB, QPW = QB / NW;
+  constexpr int VEC = C / 16, NT = C / 16, TILES = NT, KS = NW / TILES, K16 = kKP * C / 16, LDW = L::LDW, PF = 4;
+  constexpr int LPR = C / 4;                               // 16-B lanes per feature row
+  constexpr int ROW_PASSES = (CAP * LPR + NTH - 1) / NTH;  // tile-load trips of the whole workgroup
+  static_assert(TILES * KS == NW && QPW * NW == QB && static_cast<size_t>(KS - 1) * TILES * 1024 <= L::off_misc - L::off_pts &&
+                    CAP <= NTH && kTileHash % NTH == 0 && CAP < 32768,
+                "wavefront roles / reduction area / one point per thread / 16-bit slot codes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* R0 = reinterpret_cast<float*>(smem_raw);
+  float4* pts = reinterpret_cast<float4*>(smem_raw + L::off_pts);
+  int* hkey = reinterpret_cast<int*>(smem_raw + L::off_hkey);
+  short* hval = reinterpret_cast<short*>(smem_raw + L::off_hval);
+  int* sid = reinterpret_cast<int*>(smem_raw + L::off_sid);
+  short* code = reinterpret_cast<short*>(smem_raw + L::off_code);
+  float* nn_s = reinterpret_cast<float*>(smem_raw + L::off_misc);
+  int* mrow = reinterpret_cast<int*>(smem_raw + L::off_misc + 64);
+  int* wtot = reinterpret_cast<int*>(smem_raw + L::off_misc + 128);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
+  const int q0 = blockIdx.x * QB;
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);  // (<= kMaxH: checked by the host)
+  const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
+  const float inv_sigma = 1.0f / a.sigma;
+
+  TILE_T0();
+  // ---------------------------------------------------------------- 0 / 1: index rows (in flight while the hash is emptied)
+  int qm[QPW], qHq[QPW], qid[QPW][2], qpos[QPW][2];
+  float qx[QPW], qy[QPW], qz[QPW];
+  int64_t raw[QPW][2];
+#pragma unroll
+  for (int qq = 0; qq < QPW; ++qq) {
+    const int ql = wave * QPW + qq, u = q0 + ql;
+    int m = -1;
+    qx[qq] = qy[qq] = qz[qq] = 0.f;
+    if (u < a.M) {
+      if (order) {
+        const float4 rec = order[u];
+        m = __float_as_int(rec.w);
+        qx[qq] = rec.x; qy[qq] = rec.y; qz[qq] = rec.z;  // (the record carries the point's own bits)
+      } else {
+        m = u;
+        qx[qq] = a.q_points[3 * m]; qy[qq] = a.q_points[3 * m + 1]; qz[qq] = a.q_points[3 * m + 2];
+      }
+    }
+    qm[qq] = m;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int h = lane + 64 * k;
+      raw[qq][k] = (m >= 0 && h < H) ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+    }
+    if (lane == 0) mrow[ql] = m;
+  }
+  for (int t = tid; t < kTileHash; t += NTH) hkey[t] = -1;
+  __syncthreads();
+  TILE_PHASE();  // 0: index rows issued, hash emptied
+  // distinct support rows: ids into the hash set
+#pragma unroll
+  for (int qq = 0; qq < QPW; ++qq) {
+    int Hq = 0;  // slots up to the last real neighbour
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t id64 = raw[qq][k];
+      const bool real = id64 >= 0 && id64 < a.Ns;
+      const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
+      if (rm) Hq = 64 * k + 64 - __builtin_clzll(rm);
+      const int id = real ? static_cast<int>(id64) : -1;
+      int pos = -1;
+      if (real) {
+        unsigned p = (static_cast<unsigned>(id) * 2654435761u) >> 22;  // 10 bits
+        for (int t = 0; t < kTileProbes; ++t) {
+          const int old = atomicCAS(&hkey[p], -1, id);
+          if (old == -1 || old == id) {
+            pos = static_cast<int>(p);
+            break;
+          }
+          p = (p + 1) & (kTileHash - 1);
+        }
+      }
+      qid[qq][k] = id;
+      qpos[qq][k] = pos;
+    }
+    qHq[qq] = Hq;
+  }
+  __syncthreads();
+  TILE_PHASE();  // 1: hash inserts
+
+  // ---------------------------------------------------------------- 2: slots of the occupied entries (entry order)
+  int n_slots = 0;
+  for (int t0 = 0; t0 < kTileHash; t0 += NTH) {
+    const int key = hkey[t0 + tid];
+    const bool occ = key != -1;
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(occ);
+    const int pre = __builtin_popcountll(bm & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __builtin_popcountll(bm);
+    __syncthreads();
+    int wbase = n_slots, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int c = wtot[w];
+      if (w < wave) wbase += c;
+      tot += c;
+    }
+    if (occ) {
+      const int sl = wbase + pre;
+      if (sl < CAP) {
+        hval[t0 + tid] = static_cast<short>(sl);
+        sid[sl] = key;
+      } else {
+        hval[t0 + tid] = -1;
+      }
+    }
+    n_slots += tot;
+    __syncthreads();
+  }
+  n_slots = min(n_slots, CAP);
+  TILE_PHASE();  // 2: slot numbering
+
+  // ---------------------------------------------------------------- 3: the tile, one round trip; slot codes of every (query, h)
+  {
+    float4 row[ROW_PASSES];
+    const int c4 = 4 * (tid % LPR), r_first = tid / LPR;
+    const int r_last = n_slots > 0 ? n_slots - 1 : 0;
+#pragma unroll
+    for (int ps = 0; ps < ROW_PASSES; ++ps) {  // (every load is issued -- rows beyond the tile re-read its last one -- then stored)
+      const int rr = min(r_first + ps * (NTH / LPR), r_last);
+      row[ps] = n_slots > 0 ? *reinterpret_cast<const float4*>(a.s_feats + static_cast<int64_t>(sid[rr]) * a.ldf + c4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < n_slots) {
+      const int id = sid[tid];
+      pt = make_float4(a.s_points[3 * id], a.s_points[3 * id + 1], a.s_points[3 * id + 2], static_cast<float>(a.s_pos[id]));
+    }
+    // codes: slot (0 .. CAP - 1); CAP = the shadow slot (a point at 1e6 with a zero feature row: kpconv.py:91-93, its
+    // influence and its features are exact zeros) for the padding behind a row's neighbours; -2 = a real neighbour without a
+    // slot (fetched from global memory below)
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int sl = qpos[qq][k] >= 0 ? static_cast<int>(hval[qpos[qq][k]]) : -1;
+        const int cd = qid[qq][k] < 0 ? CAP : (sl >= 0 ? sl : -2);
+        code[(wave * QPW + qq) * kMaxH + lane + 64 * k] = static_cast<short>(cd);
+        qpos[qq][k] = cd;  // (from here on: the code)
+      }
+    if (tid < C / 4) *reinterpret_cast<float4*>(R0 + CAP * C + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) pts[CAP] = make_float4(1.0e6f, 1.0e6f, 1.0e6f, 0.f);
+#pragma unroll
+    for (int ps = 0; ps < ROW_PASSES; ++ps) {
+      const int rr = r_first + ps * (NTH / LPR);
+      if (rr < n_slots) *reinterpret_cast<float4*>(R0 + rr * C + c4) = row[ps];
+    }
+    if (tid < n_slots) pts[tid] = pt;
+  }
+  __syncthreads();
+  TILE_PHASE();  // 3: tile load
+
+  // ---------------------------------------------------------------- 4: aggregation (kpconv_fused_kernel's, operands from LDS)
+  // A trip = 16 neighbours (four per lane group g): slot codes, then points and feature rows, all from LDS with no branch
+  // and no select -- padding slots carry the shadow slot's code, whose influence and features are exact zeros, and lane
+  // j = 15 (no kernel point) fills accumulator row 15, which is never parked.  A query that has a neighbour without a slot
+  // (wavefront-uniform test, rare) takes the second loop, which patches those neighbours in from global memory.
+  f32x4 acc[QPW][VEC];
+  int positives[QPW];
+#pragma unroll
+  for (int qq = 0; qq < QPW; ++qq) {
+#pragma unroll
+    for (int t = 0; t < VEC; ++t) acc[qq][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ql = wave * QPW + qq, m = qm[qq];
+    const long long tw0 = TILE_NOW();
+    const bool slow = __builtin_amdgcn_ballot_w64(qpos[qq][0] < 0 || qpos[qq][1] < 0) != 0ull;  // (wavefront-uniform)
+    int pc = static_cast<int>(pts[max(qpos[qq][0], 0)].w) * (qpos[qq][0] >= 0) + static_cast<int>(pts[max(qpos[qq][1], 0)].w) * (qpos[qq][1] >= 0);
+    if (slow) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (qpos[qq][k] < 0) pc += a.s_pos[qid[qq][k]];
+    }
+    positives[qq] = wave_sum_i(pc);
+    const int Hq = qHq[qq];
+    const short* crow = code + ql * kMaxH + g;
+    const long long tw1 = TILE_NOW();
+    if (qq == 0) { TILE_W(0, tw1 - tw0); TILE_W(2, (long long)Hq); TILE_W(3, (long long)slow); }
+    TRIP_DECL();
+    if (!slow) {
+      for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {  // (h0 + 15 <= 127: the code row has 128 entries)
+        TRIP_BEGIN();
+        int c[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) c[p] = crow[h0 + 4 * p];
+        TRIP_LDS(ts_a);
+        float4 P[PF];
+        float f[PF][VEC];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          P[p] = pts[c[p]];
+          const float* row = R0 + c[p] * C + VEC * j;
+          if constexpr (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(row);
+            f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
+          } else {
+            const float2 t = *reinterpret_cast<const float2*>(row);
+            f[p][0] = t.x; f[p][1] = t.y;
+          }
+        }
+        TRIP_LDS(ts_b);
+        float w[PF];
+#pragma unroll
+        for (int p = 0; p < PF; p += 2) {  // two neighbours per packed instruction
+          const f32x2 q2x = {qx[qq], qx[qq]}, q2y = {qy[qq], qy[qq]}, q2z = {qz[qq], qz[qq]};
+          const f32x2 k2x = {kx, kx}, k2y = {ky, ky}, k2z = {kz, kz};
+          const f32x2 wx = kp_influence2((f32x2{P[p].x, P[p + 1].x} - q2x) - k2x, (f32x2{P[p].y, P[p + 1].y} - q2y) - k2y,
+                                         (f32x2{P[p].z, P[p + 1].z} - q2z) - k2z, inv_sigma);
+          w[p] = wx.x;
+          w[p + 1] = wx.y;
+        }
+        TRIP_REG(ts_c, w[PF - 1]);
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[qq][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][e], acc[qq][e], 0, 0, 0);
+        TRIP_REG(ts_d, acc[qq][VEC - 1][0]);
+      }
+      if (qq == 0) TRIP_END();
+    } else {
+      for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {
+        float w[PF];
+        float f[PF][VEC];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+          const int h = h0 + 4 * p + g;
+          const int c = crow[h0 + 4 * p];
+          if (c >= 0) {
+            const float4 P = pts[c];
+            w[p] = kp_influence((P.x - qx[qq]) - kx, (P.y - qy[qq]) - ky, (P.z - qz[qq]) - kz, inv_sigma);
+            const float* row = R0 + c * C + VEC * j;
+            if constexpr (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(row);
+              f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
+            } else {
+              const float2 t = *reinterpret_cast<const float2*>(row);
+              f[p][0] = t.x; f[p][1] = t.y;
+            }
+          } else {  // no slot: this neighbour's row comes from global memory
+            const int id = static_cast<int>(a.idx[static_cast<int64_t>(m) * a.ldi + h]);
+            w[p] = kp_influence((a.s_points[3 * id] - qx[qq]) - kx, (a.s_points[3 * id + 1] - qy[qq]) - ky,
+                                (a.s_points[3 * id + 2] - qz[qq]) - kz, inv_sigma);
+            const float* row = a.s_feats + static_cast<int64_t>(id) * a.ldf + VEC * j;
+            if constexpr (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(row);
+              f[p][0] = t.x; f[p][1] = t.y; f[p][2] = t.z; f[p][3] = t.w;
+            } else {
+              const float2 t = *reinterpret_cast<const float2*>(row);
+              f[p][0] = t.x; f[p][1] = t.y;
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[qq][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[p], f[p][e], acc[qq][e], 0, 0, 0);
+      }
+    }
+#ifdef RDM_TILE_TIMING
+    if (qq == 0) { const float probe = acc[0][0][0]; asm volatile("" ::"v"(probe)); TILE_W(1, TILE_NOW() - tw1); }
+#endif
+  }
+  __syncthreads();  // every wavefront is done with the tile: the parked block takes its place
+  TILE_PHASE();  // 4: aggregation
+
+#pragma unroll
+  for (int qq = 0; qq < QPW; ++qq) {
+    const int ql = wave * QPW + qq;
+    float* dst = R0 + ql * LDW + VEC * j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * g + r;
+      if (k >= kKP) continue;
+      if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + k * C) = make_float4(acc[qq][0][r], acc[qq][1][r], acc[qq][2][r], acc[qq][3][r]);
+      else *reinterpret_cast<float2*>(dst + k * C) = make_float2(acc[qq][0][r], acc[qq][1][r]);
+    }
+    if (lane == 0) nn_s[ql] = static_cast<float>(positives[qq] > 1 ? positives[qq] : 1);
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- 5: out[16, C'] = WF[16, 15 C] W[15 C, C'] (as above, one row tile)
+  const int ct = wave % TILES, kh = wave / TILES;
+  const float bias_v = a.bias[16 * ct + j];
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* arow = R0 + j * LDW + 4 * g;
+    const float4* wp = reinterpret_cast<const float4*>(a.w) + static_cast<int64_t>(ct) * 64 + lane;
+    const int s_begin = kh * K16 / KS, s_end = (kh + 1) * K16 / KS;
+#pragma unroll 4
+    for (int s = s_begin; s < s_end; ++s) {
+      const float4 bv = wp[static_cast<int64_t>(s) * NT * 64];
+      const float4 av = *reinterpret_cast<const float4*>(arow + 16 * s);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, o1, 0, 0, 0);
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, o1, 0, 0, 0);
+    }
+  }
+  f32x4 o = o0 + o1;
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + L::off_pts);  // [(KS - 1) * TILES][64]: the staging areas are idle now
+  if (kh > 0) red[((kh - 1) * TILES + ct) * 64 + lane] = o;
+  __syncthreads();
+  TILE_PHASE();  // 5: park + contraction
+  double st_s = 0.0, st_ss = 0.0;
+  if (kh == 0) {
+#pragma unroll
+    for (int k = 1; k < KS; ++k) o = o + red[((k - 1) * TILES + ct) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ql = 4 * g + r, m = mrow[ql];
+      if (m >= 0) {
+        float v = o[r] / nn_s[ql];
+        v += bias_v;
+        a.out[static_cast<int64_t>(m) * a.ldo + 16 * ct + j] = v;
+        st_s += static_cast<double>(v);
+        st_ss += static_cast<double>(v) * static_cast<double>(v);
+      }
+    }
+  }
+  if (a.stats) {  // column sums of this workgroup's rows: lane groups g in a fixed order
+    st_s = (st_s + __shfl_xor(st_s, 16, 64)) + (__shfl_xor(st_s, 32, 64) + __shfl_xor(st_s, 48, 64));
+    st_ss = (st_ss + __shfl_xor(st_ss, 16, 64)) + (__shfl_xor(st_ss, 32, 64) + __shfl_xor(st_ss, 48, 64));
+    if (kh == 0 && g == 0) {
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + 16 * ct + j] = st_s;
+      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + 16 * ct + j] = st_ss;
+    }
+  }
+  TILE_PHASE();  // 6: epilogue
+#ifdef RDM_TILE_TIMING
+  if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[blockIdx.x * 8 + 7] = n_slots + ((wall_clock64() - tl_rt0) << 16);  // (100 MHz clock)
+#endif
 }
 
 // ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
@@ -344,12 +779,29 @@ extern "C" int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out) {
 }
 
 namespace {
-int64_t rows_per_block(int64_t c_in) { return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64); }
+// The LDS-tile kernel serves c_in = 32 / 64 with neighbour rows of at most 128 slots (every KITTI limit); wider rows and
+// RDM_KPCONV_TILE=0 (lab build, A/B runs) take the lock-step kernel.
+// form: 0 = the library's choice, 1 = the lock-step kernel, 2 = the LDS-tile kernel where it applies
+bool use_tile(int64_t c_in, int64_t h, int form = 0) {
+  static const bool on = [] {
+    const char* v = ::rdm::dev_knob("RDM_KPCONV_TILE");
+    return !(v != nullptr && v[0] == '0');
+  }();
+  return (form == 0 ? on : form == 2) && (c_in == 32 || c_in == 64) && h <= kMaxH;
+}
+int64_t rows_per_block(int64_t c_in, int64_t h, int form = 0) {
+  if (use_tile(c_in, h, form)) return kTileQB;
+  return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64);
+}
 }  // namespace
 
-// Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries writes (one per workgroup).
-extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in) {
-  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in));
+// Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries and neighbour rows of h slots writes
+// (one per workgroup).
+extern "C" int64_t rdm_kpconv_fused_partial_rows_form(int64_t m, int64_t c_in, int64_t h, int form) {
+  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in, h, form));
+}
+extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in, int64_t h) {
+  return rdm_kpconv_fused_partial_rows_form(m, c_in, h, 0);
 }
 
 extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
@@ -381,8 +833,18 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
                                 int64_t c, int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h,
                                 int64_t ldi, const int32_t* width, const float* kernel_points, float sigma,
                                 const float* w_packed, const float* bias, int64_t c_out, float* out, int64_t ldo,
-                                double* gn_partial, void* stream) {
+                                double* gn_partial, const float* order_records, void* stream) {
+  return rdm_kpconv_fused_form(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
+                               w_packed, bias, c_out, out, ldo, gn_partial, order_records, 0, stream);
+}
+
+extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,
+                                     int64_t c, int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h,
+                                     int64_t ldi, const int32_t* width, const float* kernel_points, float sigma,
+                                     const float* w_packed, const float* bias, int64_t c_out, float* out, int64_t ldo,
+                                     double* gn_partial, const float* order_records, int form, void* stream) {
   using namespace rdm;
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_kpconv_fused_form: form must be 0, 1 or 2");
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && w_packed && bias && out,
               "rdm_kpconv_fused: null pointer");
   RDM_REQUIRE(rdm_kpconv_fused_supported(c, c_out), "rdm_kpconv_fused: unsupported channel counts %lld -> %lld", (long long)c,
@@ -398,10 +860,25 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows(m, c));
+  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows_form(m, c, h, form));
   RDM_DUP_LOOP("fused") {
   if (c == 1) {
+    // (measured and dropped in round 4: the queries in cell order -- 28.2 against 26.8 us at the first level -- and the index rows
+    // and gathers of a wavefront's four queries requested together -- 30.4 us: the kernel is bound by its ~250 VALU
+    // instructions per query, not by its round trips)
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    continue;
+  }
+  if (use_tile(c, h, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
+    static std::atomic<uint64_t> tattr32{0}, tattr64{0};
+    const float4* order = reinterpret_cast<const float4*>(order_records);
+    if (c == 32) {
+      RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<32>), static_cast<int>(TileLds<32>::bytes), tattr32));
+      hipLaunchKernelGGL((kpconv_tile_kernel<32>), dim3(blocks), dim3(64 * TileCfg<32>::NW), TileLds<32>::bytes, st, a, order);
+    } else {
+      RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<64>), static_cast<int>(TileLds<64>::bytes), tattr64));
+      hipLaunchKernelGGL((kpconv_tile_kernel<64>), dim3(blocks), dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, st, a, order);
+    }
     continue;
   }
   // (the C = 64 instance needs > 64 KB of dynamic LDS: the attribute is set once per device)
@@ -420,7 +897,7 @@ extern "C" int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s
 }
 
 extern "C" size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out) {
-  const size_t nblk = static_cast<size_t>(rdm_kpconv_fused_partial_rows(m > 0 ? m : 1, c_in));
+  const size_t nblk = static_cast<size_t>(rdm_kpconv_fused_partial_rows(m > 0 ? m : 1, c_in, 1));  // (the finer of the two block sizes)
   return rdm::align_up(nblk * 2 * c_out * sizeof(double)) + rdm_group_norm_workspace_bytes(m, c_out) + 256;
 }
 
@@ -432,12 +909,12 @@ extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, con
                                            const float* kernel_points, float sigma, const float* w_packed, const float* bias,
                                            int64_t c_out, int groups, const float* gamma, const float* beta, float eps, int act,
                                            float* conv_out, int64_t ld_conv, float* y, int64_t ldy, void* ws, size_t ws_bytes,
-                                           void* stream) {
+                                           const float* order_records, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(gamma && beta && conv_out && y, "rdm_kpconv_fused_group_norm: null pointer");
   if (m == 0) return RDM_OK;
   Arena ar(ws, ws_bytes);
-  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, c));
+  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, c, h));
   double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c_out);
   const size_t gn_ws = rdm_group_norm_workspace_bytes(m, c_out);
   char* nws = ar.take<char>(gn_ws);
@@ -446,8 +923,19 @@ extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, con
     return RDM_ERR_WORKSPACE;
   }
   if (int e = rdm_kpconv_fused(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
-                               w_packed, bias, c_out, conv_out, ld_conv, partial, stream))
+                               w_packed, bias, c_out, conv_out, ld_conv, partial, order_records, stream))
     return e;
   return group_norm_finish(partial, nblk, conv_out, m, c_out, ld_conv, groups, gamma, beta, eps, nullptr, 0, act, y, ldy, nullptr,
                            nws, gn_ws, stream);
 }
+
+#ifdef RDM_TILE_TIMING
+extern "C" int rdm_dbg_tile_timing(long long* buffer) {
+  RDM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rdm_tile_clk), &buffer, sizeof(buffer)));
+  return rdm::RDM_OK;
+}
+extern "C" int rdm_dbg_tile_wave_timing(long long* buffer) {
+  RDM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rdm_tile_wclk), &buffer, sizeof(buffer)));
+  return rdm::RDM_OK;
+}
+#endif

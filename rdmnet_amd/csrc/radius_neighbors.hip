@@ -4,8 +4,11 @@
 // (per-cloud kd-tree, `sorted = true`), nanoflann.hpp:435-441 (metric), :249-250 (strict `<`).
 // The result set of a radius query does not depend on the search structure, so the kd-tree is
 // replaced by a uniform grid (cell edge >= radius) built on the fly:
-//   bbox -> per-cell counts (atomics) -> cell segments (atomic bump allocation, no scan)
-//   -> scatter {x,y,z,index} -> one wavefront per query scans its 27 cells with coalesced float4
+//   bbox -> per-cell counts (atomics; integer sums, so the counts do not depend on their order) -> cell segments in
+//   CELL ORDER (prefix over 4096-cell chunks, whose sums the count kernel accumulates) -> member lists -> records
+//   {x,y,z,index} placed by the rank of their index inside the cell: the sorted array is a function of the points
+//   alone, run to run (round 4: it also orders the queries of the KPConv tile kernel, whose GroupNorm partials follow
+//   its workgroups) -> one wavefront per query scans its 27 cells with coalesced float4
 //   loads, keeps hits with wave ballots, sorts (d2, index) keys bitonically in LDS.
 // Float semantics (must not be contracted): d = q - s per axis, d2 = ((dx*dx)+(dy*dy))+(dz*dz),
 // accept iff d2 < radius*radius (all fp32).  Ties in d2 are ordered by index (canonical order; the
@@ -23,13 +26,16 @@ using namespace rdm;
 constexpr int kMaxCells = 1 << 20;   // cells over all clouds of one call
 constexpr int kMaxBatch = 64;
 constexpr int kWavesPerBlock = 4;
+constexpr int kChunkShift = 12;      // cells per chunk of the segment prefix (4096)
+constexpr int kChunks = kMaxCells >> kChunkShift;  // 256
 
 struct GridMeta {
   float org[3];
   float inv_cell;
   int dim[3];
   int cells_per_cloud;
-  int total;  // bump allocator for cell segments
+  int total;
+  int chunk_sum[kChunks];  // points per chunk of 4096 consecutive cells
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -47,6 +53,7 @@ struct RnBuildItem {
   int* cell_start;
   int* pt_cell;
   int* pt_slot;
+  int* cell_list;  // point indices grouped by cell (arrival order inside a cell)
   float4* sorted;
 };
 struct RnBuildBatch {
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(1024) void rn_bbox_kernel(RnBuildBatch bb) {
     meta->cells_per_cloud = dim[0] * dim[1] * dim[2];
     meta->total = 0;
   }
+  if (threadIdx.x < kChunks) meta->chunk_sum[threadIdx.x] = 0;
 }
 
 __device__ __forceinline__ void cell_of(const GridMeta& g, float x, float y, float z, int& cx,
@@ -159,30 +167,73 @@ __global__ void rn_count_kernel(RnBuildBatch bb) {
   const int c = b * g.cells_per_cloud + (cz * g.dim[1] + cy) * g.dim[0] + cx;
   it.pt_cell[i] = c;
   it.pt_slot[i] = atomicAdd(&it.cell_count[c], 1);
+  atomicAdd(&it.meta->chunk_sum[c >> kChunkShift], 1);
 }
 
-__global__ void rn_alloc_kernel(RnBuildBatch bb) {
+// cell_start = exclusive prefix of cell_count in cell order: block b owns the 4096 cells of chunk b (16 per thread); its
+// base is the sum of the chunks before it
+__global__ __launch_bounds__(256) void rn_alloc_kernel(RnBuildBatch bb) {
   const RnBuildItem& it = bb.item[blockIdx.y];
   const int ncell = it.meta->cells_per_cloud * bb.batch;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += gridDim.x * blockDim.x) {
-    const int n = it.cell_count[c];
-    it.cell_start[c] = n > 0 ? atomicAdd(&it.meta->total, n) : 0;
+  if ((static_cast<int>(blockIdx.x) << kChunkShift) >= ncell) return;  // (uniform over the workgroup)
+  __shared__ int part[256];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x;
+  const int c0 = (static_cast<int>(blockIdx.x) << kChunkShift) + 16 * tid;
+  int cnt[16], mine = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    cnt[k] = c0 + k < ncell ? it.cell_count[c0 + k] : 0;
+    mine += cnt[k];
+  }
+  part[tid] = mine;
+  int before = tid < static_cast<int>(blockIdx.x) ? it.meta->chunk_sum[tid] : 0;  // (kChunks == blockDim.x)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = before;
+  __syncthreads();
+  const int base = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  for (int o = 1; o < 256; o <<= 1) {  // inclusive prefix of the per-thread sums
+    const int add = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  int run = base + part[tid] - mine;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (c0 + k < ncell) it.cell_start[c0 + k] = run;
+    run += cnt[k];
   }
 }
 
+// member lists: the indices of a cell's points, in arrival order
 __global__ void rn_scatter_kernel(RnBuildBatch bb) {
   const RnBuildItem& it = bb.item[blockIdx.y];
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= it.ns) return;
   const int c = it.pt_cell[i];
   if (c < 0) return;
+  it.cell_list[it.cell_start[c] + it.pt_slot[i]] = static_cast<int>(i);
+}
+
+// records in (cell, index) order: a point's place inside its cell is the number of members with a smaller index
+__global__ void rn_rank_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= it.ns) return;
+  const int c = it.pt_cell[i];
+  if (c < 0) return;
+  const int start = it.cell_start[c], n = it.cell_count[c];
+  int rank = 0;
+  for (int k = 0; k < n; ++k) rank += it.cell_list[start + k] < static_cast<int>(i) ? 1 : 0;
   const float* s = it.s;
   float4 v;
   v.x = s[3 * i];
   v.y = s[3 * i + 1];
   v.z = s[3 * i + 2];
   v.w = __int_as_float(static_cast<int>(i));
-  it.sorted[it.cell_start[c] + it.pt_slot[i]] = v;
+  it.sorted[start + rank] = v;
 }
 
 // broadcast of lane `i` (wave-uniform) through scalar registers
@@ -610,6 +661,7 @@ struct GridViews {
   int* cell_start;
   int* pt_cell;
   int* pt_slot;
+  int* cell_list;
   float4* sorted;
 };
 bool carve_grid(rdm::Arena& ar, int64_t n_s, GridViews* g) {
@@ -619,6 +671,7 @@ bool carve_grid(rdm::Arena& ar, int64_t n_s, GridViews* g) {
   g->cell_start = ar.take<int>(kMaxCells);
   g->pt_cell = ar.take<int>(ns);
   g->pt_slot = ar.take<int>(ns);
+  g->cell_list = ar.take<int>(ns);
   g->sorted = ar.take<float4>(ns);
   return ar.ok;
 }
@@ -647,7 +700,7 @@ int rdm::radius_grid_build_multi(int n, const float* const* s_points, const int6
       set_error("rdm_radius_grid_build: workspace too small (%zu < %zu bytes)", grid_ws_bytes[k], ar.off);
       return RDM_ERR_WORKSPACE;
     }
-    bb.item[k] = RnBuildItem{s_points[k], n_s[k], s_lengths[k], radius[k], g.meta, g.cell_count, g.cell_start, g.pt_cell, g.pt_slot, g.sorted};
+    bb.item[k] = RnBuildItem{s_points[k], n_s[k], s_lengths[k], radius[k], g.meta, g.cell_count, g.cell_start, g.pt_cell, g.pt_slot, g.cell_list, g.sorted};
     max_ns = std::max(max_ns, n_s[k]);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -656,8 +709,9 @@ int rdm::radius_grid_build_multi(int n, const float* const* s_points, const int6
   if (max_ns > 0) {
     const int blocks = static_cast<int>(ceil_div<int64_t>(max_ns, 256));
     hipLaunchKernelGGL(rn_count_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
-    hipLaunchKernelGGL(rn_alloc_kernel, dim3(256, n), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(rn_alloc_kernel, dim3(kChunks, n), dim3(256), 0, st, bb);
     hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(rn_rank_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
   }
   return launch_status("radius grid build");
 }

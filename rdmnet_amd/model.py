@@ -150,7 +150,7 @@ class RDMNet(torch.nn.Module):
         return ops.group_norm(x, self._w[name + '.norm.weight'], self._w[name + '.norm.bias'],
                               self.cfg.backbone.group_norm, act=act, residual=residual, want_positive=want_positive)
 
-    def _kpconv(self, name, norm, x, x_pos, q, s, idx, sigma, width=None, pool_src=None):
+    def _kpconv(self, name, norm, x, x_pos, q, s, idx, sigma, width=None, pool_src=None, order=None):
         """KPConv + its GroupNorm + LeakyReLU (gather kernel, then the weight GEMM whose epilogue emits the
         GroupNorm statistics).  `norm` = parameter prefix of the GroupNorm that follows the convolution."""
         b, cin, cout = self._w[name + '.weights']
@@ -162,7 +162,8 @@ class RDMNet(torch.nn.Module):
         if packed is not None:
             y = ops.kpconv_fused_group_norm(q, s, x, x_pos, idx, self._w[name + '.kernel_points'], sigma, packed,
                                             self._w[name + '.bias'], cout, self._w[norm + '.norm.weight'],
-                                            self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, width=width, act=ACT_LEAKY)
+                                            self._w[norm + '.norm.bias'], self.cfg.backbone.group_norm, width=width, act=ACT_LEAKY,
+                                            order=order)
             if prof is not None:
                 e1.record()
         else:
@@ -189,19 +190,19 @@ class RDMNet(torch.nn.Module):
                                      self._w[name + '.norm.norm.bias'], self.cfg.backbone.group_norm, act=act,
                                      residual=residual, want_positive=want_positive)
 
-    def _conv_block(self, name, x, x_pos, q, s, idx, sigma, width):
-        return self._kpconv(name + '.KPConv', name + '.norm', x, x_pos, q, s, idx, sigma, width)
+    def _conv_block(self, name, x, x_pos, q, s, idx, sigma, width, order=None):
+        return self._kpconv(name + '.KPConv', name + '.norm', x, x_pos, q, s, idx, sigma, width, order=order)
 
-    def _residual_block(self, name, x, x_pos, q, s, idx, sigma, strided, width):
+    def _residual_block(self, name, x, x_pos, q, s, idx, sigma, strided, width, order=None):
         W = self._w
         if (name + '.unary1.mlp') in W:
             y, y_pos = self._unary(name + '.unary1', x, want_positive=True)
         else:
             y, y_pos = x, (x_pos if x_pos is not None else ops.row_positive(x))
         if strided:
-            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width, pool_src=x)
+            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width, pool_src=x, order=order)
         else:
-            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width), x
+            y, sc = self._kpconv(name + '.KPConv', name + '.norm_conv', y, y_pos, q, s, idx, sigma, width, order=order), x
         if (name + '.unary_shortcut.mlp') in W:
             sc = self._unary(name + '.unary_shortcut', sc, act=ACT_NONE)
         # leaky_relu(unary2(y) + shortcut): the add and the activation ride on unary2's GroupNorm apply
@@ -214,15 +215,25 @@ class RDMNet(torch.nn.Module):
         widths = data.get('_widths', {})
         x_pos = ops.row_positive(x)
         feats = []
+        # the query order of the one-kernel KPConv layers: the cell-sorted records of each level's search grid (radius r_0 2^l),
+        # exactly what the native engine builds -- the records are a function of the points alone, so both paths group the
+        # same rows into the same workgroups and produce the same GroupNorm partials
+        orders = {}
+
+        def order_of(level):
+            if level not in orders:
+                orders[level] = ops.radius_grid_records(P[level], data['lengths'][level], cfg.backbone.init_radius * 2 ** level)
+            return orders[level]
         for name, kind, _, _, lvl, strided in weights.encoder_blocks(cfg):
             out_lvl = lvl + 1 if strided else lvl
             idx = data['subsampling'][lvl] if strided else data['neighbors'][lvl]
             width = widths.get(('subsampling' if strided else 'neighbors', lvl))
             sigma = weights.kpconv_sigma(cfg, lvl)
             if kind == 'conv':
-                x = self._conv_block('encoder.' + name, x, x_pos, P[out_lvl], P[lvl], idx, sigma, width)
+                x = self._conv_block('encoder.' + name, x, x_pos, P[out_lvl], P[lvl], idx, sigma, width, order=order_of(out_lvl))
             else:
-                x = self._residual_block('encoder.' + name, x, x_pos, P[out_lvl], P[lvl], idx, sigma, strided, width)
+                x = self._residual_block('encoder.' + name, x, x_pos, P[out_lvl], P[lvl], idx, sigma, strided, width,
+                                         order=order_of(out_lvl) if out_lvl <= 2 else None)
             x_pos = None
             if taps is not None:
                 taps['encoder.' + name] = x

@@ -133,7 +133,7 @@ def kpconv_pack_weights(w):
 
 
 def kpconv_fused(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, w_packed, bias, c_out, width=None,
-                 want_partials=False):
+                 want_partials=False, order=None, form=0):
     """The whole KPConv.forward (kpconv.py:79-122) in one kernel (c_in = 1, 32, 64) -> out [m, c_out]
     (, fp64 GroupNorm partials [blocks, 2, c_out])."""
     L = _lib.lib()
@@ -141,17 +141,18 @@ def kpconv_fused(q_points, s_points, s_feats, s_positive, idx, kernel_points, si
     out = feat_empty(m, c_out, q_points.device)
     part = None
     if want_partials:
-        nblk = max(int(L.rdm_kpconv_fused_partial_rows(m, c)), 1)
+        nblk = max(int(L.rdm_kpconv_fused_partial_rows_form(m, c, idx.shape[1], form)), 1)
         part = torch.empty((nblk, 2, c_out), dtype=torch.float64, device=q_points.device)
-    _lib.check(L.rdm_kpconv_fused(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(), c,
+    _lib.check(L.rdm_kpconv_fused_form(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(), c,
                                   _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0), _lib.ptr(width),
                                   kernel_points.data_ptr(), float(sigma), w_packed.data_ptr(), bias.data_ptr(), c_out,
-                                  out.data_ptr(), _ld(out), _lib.ptr(part), _lib.stream_ptr()), 'rdm_kpconv_fused')
+                                       out.data_ptr(), _ld(out), _lib.ptr(part), _lib.ptr(order), int(form), _lib.stream_ptr()),
+               'rdm_kpconv_fused')
     return (out, part) if want_partials else out
 
 
 def kpconv_fused_group_norm(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, w_packed, bias, c_out, gamma,
-                            beta, groups, *, width=None, act=ACT_LEAKY, eps=1e-5):
+                            beta, groups, *, width=None, act=ACT_LEAKY, eps=1e-5, order=None):
     """act(GroupNorm(KPConv(...))) -- the fused convolution followed by the normalisation every backbone block applies."""
     L = _lib.lib()
     m, c = q_points.shape[0], s_feats.shape[1]
@@ -162,7 +163,7 @@ def kpconv_fused_group_norm(q_points, s_points, s_feats, s_positive, idx, kernel
                                              _lib.ptr(width), kernel_points.data_ptr(), float(sigma), w_packed.data_ptr(),
                                              bias.data_ptr(), c_out, groups, gamma.data_ptr(), beta.data_ptr(), eps, act,
                                              conv.data_ptr(), _ld(conv), y.data_ptr(), _ld(y), ws.data_ptr(), ws.numel(),
-                                             _lib.stream_ptr()), 'rdm_kpconv_fused_group_norm')
+                                             _lib.ptr(order), _lib.stream_ptr()), 'rdm_kpconv_fused_group_norm')
     return y
 
 
@@ -346,6 +347,22 @@ def radius_search_device(q, s, q_lengths, s_lengths, radius, width, flags):
                                       float(radius), width, out.data_ptr(), 0, flags.data_ptr(), flags[1:].data_ptr(),
                                       ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_radius_neighbors')
     return out[:nq]
+
+
+def radius_grid_records(points, lengths, radius):
+    """The cell-sorted records {x, y, z, row (int bits)} of the search grid of `points` (stacked clouds, `lengths` int64 on
+    the device) for `radius`: float32 [n, 4], in (cloud, cell, row) order -- a function of the points alone.  Used as the
+    spatial query order of the KPConv kernels (rdm_kpconv_fused / rdm_kpconv_gather_ordered)."""
+    L = _lib.lib()
+    n = points.shape[0]
+    nbytes = L.rdm_radius_grid_workspace_bytes(n)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)  # (its own allocation: the records are a view of it)
+    lengths = lengths.to(device=points.device, dtype=torch.int64).contiguous()
+    _lib.check(L.rdm_radius_grid_build(points.data_ptr(), n, lengths.data_ptr(), lengths.shape[0], float(radius), ws.data_ptr(),
+                                       nbytes, _lib.stream_ptr()), 'rdm_radius_grid_build')
+    rec = L.rdm_radius_grid_records(ws.data_ptr(), nbytes, n)
+    off = rec - ws.data_ptr()
+    return ws[off:off + 16 * max(n, 1)].view(torch.float32).reshape(-1, 4)[:n]
 
 
 def grid_subsample_device(points, lengths, voxel, form=0):

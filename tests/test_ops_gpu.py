@@ -399,3 +399,52 @@ def test_kpconv_fused_matches_reference_formula(ops, c, cout, h, m, ns):
         a = ops.kpconv_fused(*args, width=cap)
         b2 = ops.kpconv_fused(*args[:4], idx[:, :h - 3].contiguous().cuda(), *args[5:])
         assert torch.equal(a, b2)
+
+
+@pytest.mark.parametrize('c,h,m,ns,spread', [(32, 65, 1000, 4000, 0.3), (64, 63, 777, 3000, 0.3), (32, 128, 333, 900, 3.0),
+                                             (64, 100, 300, 5000, 3.0), (32, 17, 16, 40, 1.0), (64, 9, 5, 9, 1.0)])
+def test_kpconv_lds_tile_kernel_has_the_bits_of_the_lock_step_kernel(ops, c, h, m, ns, spread):
+    """Round 4, 'LDS-staged neighbour tiles': form 2 of rdm_kpconv_fused_form stages the union of the support rows of 16
+    queries once in LDS and aggregates from there.  Neighbour order, influence arithmetic, MFMA sequence and the K split of the
+    contraction are the lock-step kernel's (form 1), so the convolution output is the same BITS -- with the queries in row
+    order, in a spatial order (shuffled order records, as rdm_radius_grid_records would give), with unions far beyond the tile's
+    capacity (neighbours drawn from the whole cloud: most rows fall back to global fetches), shadow slots, a width cap and a
+    last block that is not full; the GroupNorm partials are the column sums of the output, one row per 16 queries."""
+    g = torch.Generator().manual_seed(1000 * c + h + m)
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_sel = torch.randint(0, ns, (m,), generator=g)
+    q_pts = s_pts[q_sel] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g)
+    feats[torch.rand(ns, generator=g) < 0.2] *= -1  # (some rows with a negative sum: the positive flags matter)
+    # neighbours: the h nearest support points of a jittered copy of the query (small spread: neighbouring queries share them;
+    # large spread: nearly disjoint unions), padded behind a random count
+    d = torch.cdist(q_pts + spread * torch.randn(m, 3, generator=g), s_pts)
+    idx = d.argsort(1)[:, :h].contiguous()
+    n_valid = torch.randint(0, h + 1, (m,), generator=g)
+    n_valid[0] = h
+    idx = torch.where(torch.arange(h)[None] < n_valid[:, None], idx, torch.full_like(idx, ns))
+    kp = torch.randn(15, 3, generator=g)
+    W = torch.randn(15, c, c, generator=g) / np.sqrt(15 * c)
+    bias = torch.randn(c, generator=g)
+    packed = torch.from_numpy(ops.kpconv_pack_weights(W.numpy())).cuda()
+    fd = padded(feats)
+    args = (q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), 1.7, packed, bias.cuda(), c)
+    lock = ops.kpconv_fused(*args, form=1)
+    tile, part = ops.kpconv_fused(*args, form=2, want_partials=True)
+    assert torch.equal(tile, lock)
+    assert part.shape[0] == (m + 15) // 16
+    got = tile.cpu().double()
+    assert (part[:, 0].sum(0).cpu() - got.sum(0)).abs().max().item() <= 1e-9 * max(1.0, got.abs().sum(0).max().item())
+    assert (part[:, 1].sum(0).cpu() - (got * got).sum(0)).abs().max().item() <= 1e-9 * max(1.0, (got * got).sum(0).max().item())
+    # cell-ordered records {x, y, z, row}: here sorted along x (any permutation must give the same output)
+    perm = torch.argsort(q_pts[:, 0])
+    rec = torch.cat([q_pts[perm], perm.to(torch.int32).view(torch.float32)[:, None]], 1).contiguous().cuda()
+    ordered, part_o = ops.kpconv_fused(*args, form=2, want_partials=True, order=rec)
+    assert torch.equal(ordered, lock)
+    rows16 = got[perm[:16]] if m >= 16 else got[perm]
+    assert (part_o[0, 0].cpu() - rows16.sum(0)).abs().max().item() <= 1e-9 * max(1.0, rows16.abs().sum(0).max().item())
+    # the default form is the tile kernel for these shapes
+    assert torch.equal(ops.kpconv_fused(*args, order=rec), lock)
+    if h > 4:
+        cap = torch.tensor([h - 3], dtype=torch.int32).cuda()
+        assert torch.equal(ops.kpconv_fused(*args, width=cap, form=2, order=rec), ops.kpconv_fused(*args, width=cap, form=1))

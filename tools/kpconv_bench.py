@@ -56,8 +56,14 @@ if __name__ == '__main__':
         rows = []
         if ops.kpconv_fused_supported(cin, cout):
             packed = torch.from_numpy(ops.kpconv_pack_weights(W)).cuda()
-            t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True))
-            rows.append(('fused (gather + contraction)', t))
+            t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=1))
+            rows.append(('one kernel, lock-step (r03)', t))
+            rec = ops.radius_grid_records(q, dd['lengths'][ql], cfg.backbone.init_radius * 2 ** ql)
+            if cin > 1:
+                t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=2))
+                rows.append(('one kernel, LDS tile, row order', t))
+                t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=2, order=rec))
+                rows.append(('one kernel, LDS tile, cell order', t))
         t = timed(lambda: ops.kpconv_gather(q, s, feats, pos, idx, kp, sigma))
         rows.append(('gather alone', t))
         for name, t in rows:
