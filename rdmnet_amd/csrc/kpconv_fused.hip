@@ -276,8 +276,14 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
 //      block) are fetched from global memory as before,
 //   5. the tile is overwritten by the parked block and the contraction with W, normalisation, bias and GroupNorm partials
 //      follow as above (same K split over the wavefronts as kpconv_fused_kernel<C>: the output is bit-identical to it).
-//   C = 32: 16 wavefronts x 1 query, tile of 384 rows (48 KB) -> 66 KB, two workgroups per CU
-//   C = 64:  8 wavefronts x 2 queries, tile of 240 rows (60 KB, the parked block needs 60.3 KB) -> 75 KB, two per CU
+//   C = 32: 8 wavefronts x 2 queries, tile of 240 rows (30 KB, under the 30.3 KB of the parked block) -> 46 KB, THREE workgroups
+//           per CU (two of 16 wavefronts measured 65.6 against 59.4 us at the first level: the third workgroup's compute
+//           phases fill more of the other two's latency phases)
+//   C = 64: 8 wavefronts x 2 queries, tile of 240 rows (60 KB, the parked block needs 60.3 KB) -> 75 KB, two per CU
+// What bounds it (tools/tile_lab.py): inside the aggregation the CU's four matrix pipes are ~80 % busy (fp32 MFMA
+// at 64 flop / clk / SIMD) -- points and rows now come from LDS, L2 -> CU traffic of the layer drops by the re-use factor --
+// while index rows, hash inserts, tile load and epilogue (half of a workgroup's residency) are serial latencies that two or
+// three resident workgroups only partly overlap; the layer lands within 15 % of the lock-step kernel either way.
 #ifdef RDM_TILE_TIMING
 // tools/tile_lab.py: s_memtime stamps (100 MHz) of wavefront 0 at the phase boundaries of every workgroup
 __device__ long long* rdm_tile_clk;  // [blocks][8]
@@ -312,7 +318,11 @@ constexpr int kTileHash = 1024;   // entries of the id -> slot hash
 constexpr int kTileProbes = 16;
 
 template <int C> struct TileCfg;
-template <> struct TileCfg<32> { static constexpr int NW = 16, CAP = 384; };
+#ifndef RDM_TILE32_NW  // (lab builds: -DRDM_TILE32_NW=16 -DRDM_TILE32_CAP=384 = two workgroups of 16 wavefronts per CU, 65.6 against 59.4 us at the first level)
+#define RDM_TILE32_NW 8
+#define RDM_TILE32_CAP 240
+#endif
+template <> struct TileCfg<32> { static constexpr int NW = RDM_TILE32_NW, CAP = RDM_TILE32_CAP; };
 template <> struct TileCfg<64> { static constexpr int NW = 8, CAP = 240; };
 
 template <int C>
@@ -321,24 +331,27 @@ struct TileLds {
   static constexpr int LDW = kKP * C + 4;
   // floats: the tile [CAP + 1][C] (row CAP = the shadow slot: zero features), then the parked block
   static constexpr int R0 = kTileQB * LDW > (CAP + 1) * C ? kTileQB * LDW : (CAP + 1) * C;
-  static constexpr size_t off_pts = static_cast<size_t>(R0) * 4;                 // float4 [CAP + 1]: x, y, z, positive flag
+  static constexpr size_t off_pts = static_cast<size_t>(R0) * 4;                 // float4 [CAP + 1]: x, y, z, 1 (0: shadow slot)
   static constexpr size_t off_hkey = off_pts + static_cast<size_t>(CAP + 1) * 16;  // int [kTileHash]
   static constexpr size_t off_hval = off_hkey + kTileHash * 4;                   // short [kTileHash]
   static constexpr size_t off_sid = off_hval + kTileHash * 2;                    // int [CAP]: slot -> support row
   static constexpr size_t off_code = off_sid + static_cast<size_t>(CAP) * 4;     // short [kTileQB][kMaxH]
-  static constexpr size_t off_misc = off_code + kTileQB * kMaxH * 2;             // nn_s [16], mrow [16], wtot [16]
+  static constexpr size_t off_ppos = off_code + kTileQB * kMaxH * 2;             // uint8 [CAP + 1 (+ pad)]: positive flags
+  static constexpr size_t off_misc = off_ppos + ((static_cast<size_t>(CAP) + 1 + 15) / 16) * 16;  // nn_s [16], mrow [16], count
   static constexpr size_t bytes = off_misc + 256;
 };
 
-// (two workgroups per CU: 64 * NW threads x 2 = 8 / 4 wavefronts per SIMD, i.e. at most 64 / 128 registers)
+// (two workgroups of 16 / three of 8 wavefronts per CU at C = 32, two of 8 at C = 64: 8 / 6 / 4 wavefronts per SIMD)
 template <int C>
-__global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order) {
+__global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order) {
   using L = TileLds<C>;
   constexpr int NW = TileCfg<C>::NW, CAP = TileCfg<C>::CAP, NTH = 64 * NW, QB = kTileQB, QPW = QB / NW;
-  constexpr int VEC = C / 16, NT = C / 16, TILES = NT, KS = NW / TILES, K16 = kKP * C / 16, LDW = L::LDW, PF = 4;
+  constexpr int VEC = C / 16, NT = C / 16, TILES = NT, K16 = kKP * C / 16, LDW = L::LDW, PF = 4;
+  constexpr int KS = C == 32 ? 8 : 2;      // K slices of the contraction: kpconv_fused_kernel<C>'s (the same partial sums, added in the same order)
+  constexpr int SPW = KS * TILES / NW;     // slices a wavefront contracts one after the other
   constexpr int LPR = C / 4;                               // 16-B lanes per feature row
   constexpr int ROW_PASSES = (CAP * LPR + NTH - 1) / NTH;  // tile-load trips of the whole workgroup
-  static_assert(TILES * KS == NW && QPW * NW == QB && static_cast<size_t>(KS - 1) * TILES * 1024 <= L::off_misc - L::off_pts &&
+  static_assert(TILES * KS == NW * SPW && SPW >= 1 && QPW * NW == QB && static_cast<size_t>(KS - 1) * TILES * 1024 <= L::off_misc - L::off_pts &&
                     CAP <= NTH && kTileHash % NTH == 0 && CAP < 32768,
                 "wavefront roles / reduction area / one point per thread / 16-bit slot codes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -350,7 +363,8 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
   short* code = reinterpret_cast<short*>(smem_raw + L::off_code);
   float* nn_s = reinterpret_cast<float*>(smem_raw + L::off_misc);
   int* mrow = reinterpret_cast<int*>(smem_raw + L::off_misc + 64);
-  int* wtot = reinterpret_cast<int*>(smem_raw + L::off_misc + 128);
+  int* n_keys = reinterpret_cast<int*>(smem_raw + L::off_misc + 128);
+  unsigned char* ppos = smem_raw + L::off_ppos;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
   const int q0 = blockIdx.x * QB;
   int H = a.H;
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
     if (lane == 0) mrow[ql] = m;
   }
   for (int t = tid; t < kTileHash; t += NTH) hkey[t] = -1;
+  if (tid == 0) *n_keys = 0;
   __syncthreads();
   TILE_PHASE();  // 0: index rows issued, hash emptied
   // distinct support rows: ids into the hash set
@@ -405,6 +420,11 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
         unsigned p = (static_cast<unsigned>(id) * 2654435761u) >> 22;  // 10 bits
         for (int t = 0; t < kTileProbes; ++t) {
           const int old = atomicCAS(&hkey[p], -1, id);
+          if (old == -1) {  // this lane entered the id: it also numbers it (arrival order; the output does not depend on it)
+            const int sl = atomicAdd(n_keys, 1);
+            hval[p] = static_cast<short>(sl < CAP ? sl : -1);
+            if (sl < CAP) sid[sl] = id;
+          }
           if (old == -1 || old == id) {
             pos = static_cast<int>(p);
             break;
@@ -418,38 +438,10 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
     qHq[qq] = Hq;
   }
   __syncthreads();
-  TILE_PHASE();  // 1: hash inserts
+  TILE_PHASE();  // 1: hash inserts + slot numbers
 
-  // ---------------------------------------------------------------- 2: slots of the occupied entries (entry order)
-  int n_slots = 0;
-  for (int t0 = 0; t0 < kTileHash; t0 += NTH) {
-    const int key = hkey[t0 + tid];
-    const bool occ = key != -1;
-    const unsigned long long bm = __builtin_amdgcn_ballot_w64(occ);
-    const int pre = __builtin_popcountll(bm & ((1ull << lane) - 1ull));
-    if (lane == 0) wtot[wave] = __builtin_popcountll(bm);
-    __syncthreads();
-    int wbase = n_slots, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int c = wtot[w];
-      if (w < wave) wbase += c;
-      tot += c;
-    }
-    if (occ) {
-      const int sl = wbase + pre;
-      if (sl < CAP) {
-        hval[t0 + tid] = static_cast<short>(sl);
-        sid[sl] = key;
-      } else {
-        hval[t0 + tid] = -1;
-      }
-    }
-    n_slots += tot;
-    __syncthreads();
-  }
-  n_slots = min(n_slots, CAP);
-  TILE_PHASE();  // 2: slot numbering
+  const int n_slots = min(*n_keys, CAP);
+  TILE_PHASE();  // 2: (slot numbering: folded into the inserts)
 
   // ---------------------------------------------------------------- 3: the tile, one round trip; slot codes of every (query, h)
   {
@@ -465,7 +457,8 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
     float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < n_slots) {
       const int id = sid[tid];
-      pt = make_float4(a.s_points[3 * id], a.s_points[3 * id + 1], a.s_points[3 * id + 2], static_cast<float>(a.s_pos[id]));
+      pt = make_float4(a.s_points[3 * id], a.s_points[3 * id + 1], a.s_points[3 * id + 2], 1.f);
+      ppos[tid] = a.s_pos[id];
     }
     // codes: slot (0 .. CAP - 1); CAP = the shadow slot (a point at 1e6 with a zero feature row: kpconv.py:91-93, its
     // influence and its features are exact zeros) for the padding behind a row's neighbours; -2 = a real neighbour without a
@@ -476,11 +469,16 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
       for (int k = 0; k < 2; ++k) {
         const int sl = qpos[qq][k] >= 0 ? static_cast<int>(hval[qpos[qq][k]]) : -1;
         const int cd = qid[qq][k] < 0 ? CAP : (sl >= 0 ? sl : -2);
-        code[(wave * QPW + qq) * kMaxH + lane + 64 * k] = static_cast<short>(cd);
+        // layout [query][trip = h / 16][g = h % 4][p = (h % 16) / 4]: lane group g reads the four codes of a trip as one 8-byte word
+        const int h = lane + 64 * k;
+        code[(wave * QPW + qq) * kMaxH + (h & ~15) + 4 * (h & 3) + ((h & 15) >> 2)] = static_cast<short>(cd);
         qpos[qq][k] = cd;  // (from here on: the code)
       }
     if (tid < C / 4) *reinterpret_cast<float4*>(R0 + CAP * C + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid == 0) pts[CAP] = make_float4(1.0e6f, 1.0e6f, 1.0e6f, 0.f);
+    if (tid == 0) {
+      pts[CAP] = make_float4(1.0e6f, 1.0e6f, 1.0e6f, 0.f);
+      ppos[CAP] = 0;
+    }
 #pragma unroll
     for (int ps = 0; ps < ROW_PASSES; ++ps) {
       const int rr = r_first + ps * (NTH / LPR);
@@ -498,6 +496,13 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
   // (wavefront-uniform test, rare) takes the second loop, which patches those neighbours in from global memory.
   f32x4 acc[QPW][VEC];
   int positives[QPW];
+#ifdef RDM_TILE_DEPHASE
+  // the wavefronts leave the barrier together and would hit LDS, then the VALU, then the matrix pipe in lock-step, trip after
+  // trip; staggered starts let one group's LDS reads run beside another's MFMAs
+  if ((wave & 3) == 1) __builtin_amdgcn_s_sleep(RDM_TILE_DEPHASE);
+  if ((wave & 3) == 2) __builtin_amdgcn_s_sleep(2 * RDM_TILE_DEPHASE);
+  if ((wave & 3) == 3) __builtin_amdgcn_s_sleep(3 * RDM_TILE_DEPHASE);
+#endif
 #pragma unroll
   for (int qq = 0; qq < QPW; ++qq) {
 #pragma unroll
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
     const int ql = wave * QPW + qq, m = qm[qq];
     const long long tw0 = TILE_NOW();
     const bool slow = __builtin_amdgcn_ballot_w64(qpos[qq][0] < 0 || qpos[qq][1] < 0) != 0ull;  // (wavefront-uniform)
-    int pc = static_cast<int>(pts[max(qpos[qq][0], 0)].w) * (qpos[qq][0] >= 0) + static_cast<int>(pts[max(qpos[qq][1], 0)].w) * (qpos[qq][1] >= 0);
+    int pc = static_cast<int>(ppos[max(qpos[qq][0], 0)]) * (qpos[qq][0] >= 0) + static_cast<int>(ppos[max(qpos[qq][1], 0)]) * (qpos[qq][1] >= 0);
     if (slow) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
     }
     positives[qq] = wave_sum_i(pc);
     const int Hq = qHq[qq];
-    const short* crow = code + ql * kMaxH + g;
+    const short* crow = code + ql * kMaxH + 4 * g;  // [trip][g][p]
     const long long tw1 = TILE_NOW();
     if (qq == 0) { TILE_W(0, tw1 - tw0); TILE_W(2, (long long)Hq); TILE_W(3, (long long)slow); }
     TRIP_DECL();
@@ -521,8 +526,10 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
       for (int h0 = 0; h0 < Hq; h0 += 4 * PF) {  // (h0 + 15 <= 127: the code row has 128 entries)
         TRIP_BEGIN();
         int c[PF];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) c[p] = crow[h0 + 4 * p];
+        {
+          const short4 cw = *reinterpret_cast<const short4*>(crow + h0);
+          c[0] = cw.x; c[1] = cw.y; c[2] = cw.z; c[3] = cw.w;
+        }
         TRIP_LDS(ts_a);
         float4 P[PF];
         float f[PF][VEC];
@@ -546,8 +553,10 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
           const f32x2 k2x = {kx, kx}, k2y = {ky, ky}, k2z = {kz, kz};
           const f32x2 wx = kp_influence2((f32x2{P[p].x, P[p + 1].x} - q2x) - k2x, (f32x2{P[p].y, P[p + 1].y} - q2y) - k2y,
                                          (f32x2{P[p].z, P[p + 1].z} - q2z) - k2z, inv_sigma);
-          w[p] = wx.x;
-          w[p + 1] = wx.y;
+          // (x 1 for a row of the tile, x 0 for the shadow slot, whose influence is 0 anyway: the factor makes the 4th component
+          // of the point live, so that the read stays one 16-byte LDS access instead of a 12-byte one at half the rate)
+          w[p] = wx.x * P[p].w;
+          w[p + 1] = wx.y * P[p + 1].w;
         }
         TRIP_REG(ts_c, w[PF - 1]);
 #pragma unroll
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
           const int h = h0 + 4 * p + g;
-          const int c = crow[h0 + 4 * p];
+          const int c = crow[h0 + p];
           if (c >= 0) {
             const float4 P = pts[c];
             w[p] = kp_influence((P.x - qx[qq]) - kx, (P.y - qy[qq]) - ky, (P.z - qz[qq]) - kz, inv_sigma);
@@ -619,10 +628,14 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
   __syncthreads();
 
   // ---------------------------------------------------------------- 5: out[16, C'] = WF[16, 15 C] W[15 C, C'] (as above, one row tile)
-  const int ct = wave % TILES, kh = wave / TILES;
+  const int ct = wave % TILES, khg = wave / TILES;
   const float bias_v = a.bias[16 * ct + j];
-  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-  {
+  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + L::off_pts);  // [(KS - 1) * TILES][64]: the staging areas are idle now
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sub = 0; sub < SPW; ++sub) {
+    const int kh = khg * SPW + sub;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
     const float* arow = R0 + j * LDW + 4 * g;
     const float4* wp = reinterpret_cast<const float4*>(a.w) + static_cast<int64_t>(ct) * 64 + lane;
     const int s_begin = kh * K16 / KS, s_end = (kh + 1) * K16 / KS;
@@ -635,14 +648,14 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
       o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, o1, 0, 0, 0);
     }
+    const f32x4 os = o0 + o1;
+    if (kh == 0) o = os;
+    else red[((kh - 1) * TILES + ct) * 64 + lane] = os;
   }
-  f32x4 o = o0 + o1;
-  f32x4* red = reinterpret_cast<f32x4*>(smem_raw + L::off_pts);  // [(KS - 1) * TILES][64]: the staging areas are idle now
-  if (kh > 0) red[((kh - 1) * TILES + ct) * 64 + lane] = o;
   __syncthreads();
   TILE_PHASE();  // 5: park + contraction
   double st_s = 0.0, st_ss = 0.0;
-  if (kh == 0) {
+  if (khg == 0) {
 #pragma unroll
     for (int k = 1; k < KS; ++k) o = o + red[((k - 1) * TILES + ct) * 64 + lane];
 #pragma unroll
@@ -660,7 +673,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, 2 * TileCfg<C>::NW / 4) void k
   if (a.stats) {  // column sums of this workgroup's rows: lane groups g in a fixed order
     st_s = (st_s + __shfl_xor(st_s, 16, 64)) + (__shfl_xor(st_s, 32, 64) + __shfl_xor(st_s, 48, 64));
     st_ss = (st_ss + __shfl_xor(st_ss, 16, 64)) + (__shfl_xor(st_ss, 32, 64) + __shfl_xor(st_ss, 48, 64));
-    if (kh == 0 && g == 0) {
+    if (khg == 0 && g == 0) {
       a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + 16 * ct + j] = st_s;
       a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + 16 * ct + j] = st_ss;
     }
@@ -781,27 +794,33 @@ extern "C" int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out) {
 namespace {
 // The LDS-tile kernel serves c_in = 32 / 64 with neighbour rows of at most 128 slots (every KITTI limit); wider rows and
 // RDM_KPCONV_TILE=0 (lab build, A/B runs) take the lock-step kernel.
-// form: 0 = the library's choice, 1 = the lock-step kernel, 2 = the LDS-tile kernel where it applies
-bool use_tile(int64_t c_in, int64_t h, int form = 0) {
+// form: 0 = the library's choice, 1 = the lock-step kernel, 2 = the LDS-tile kernel where it applies.  The choice (measured per
+// shape on MI355X, tools/kpconv_bench.py): c_in = 32 always (59.4 / 28.6 us against 60.7 / 30.7 at the first level and its
+// strided block); c_in = 64 when queries and support are the same level (44 against 51 us) -- a strided block's 16 queries (of
+// the coarser level) reach 145 ... 240+ distinct rows, beyond the 240 the tile holds beside the parked block, and the rows
+// that overflow are fetched the old way on top of the tile's fixed costs (23.7 against 18.3 us).
+bool use_tile(int64_t c_in, int64_t h, int64_t m, int64_t n_s, int form = 0) {
   static const bool on = [] {
     const char* v = ::rdm::dev_knob("RDM_KPCONV_TILE");
     return !(v != nullptr && v[0] == '0');
   }();
-  return (form == 0 ? on : form == 2) && (c_in == 32 || c_in == 64) && h <= kMaxH;
+  if (!((c_in == 32 || c_in == 64) && h <= kMaxH)) return false;
+  if (form != 0) return form == 2;
+  return on && (c_in == 32 || 2 * m > n_s);
 }
-int64_t rows_per_block(int64_t c_in, int64_t h, int form = 0) {
-  if (use_tile(c_in, h, form)) return kTileQB;
+int64_t rows_per_block(int64_t c_in, int64_t h, int64_t m, int64_t n_s, int form = 0) {
+  if (use_tile(c_in, h, m, n_s, form)) return kTileQB;
   return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64);
 }
 }  // namespace
 
 // Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries and neighbour rows of h slots writes
 // (one per workgroup).
-extern "C" int64_t rdm_kpconv_fused_partial_rows_form(int64_t m, int64_t c_in, int64_t h, int form) {
-  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in, h, form));
+extern "C" int64_t rdm_kpconv_fused_partial_rows_form(int64_t m, int64_t n_s, int64_t c_in, int64_t h, int form) {
+  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in, h, m, n_s, form));
 }
-extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in, int64_t h) {
-  return rdm_kpconv_fused_partial_rows_form(m, c_in, h, 0);
+extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t n_s, int64_t c_in, int64_t h) {
+  return rdm_kpconv_fused_partial_rows_form(m, n_s, c_in, h, 0);
 }
 
 extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
@@ -860,7 +879,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows_form(m, c, h, form));
+  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows_form(m, n_s, c, h, form));
   RDM_DUP_LOOP("fused") {
   if (c == 1) {
     // (measured and dropped in round 4: the queries in cell order -- 28.2 against 26.8 us at the first level -- and the index rows
@@ -869,7 +888,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     continue;
   }
-  if (use_tile(c, h, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
+  if (use_tile(c, h, m, n_s, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
     static std::atomic<uint64_t> tattr32{0}, tattr64{0};
     const float4* order = reinterpret_cast<const float4*>(order_records);
     if (c == 32) {
@@ -897,7 +916,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
 }
 
 extern "C" size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out) {
-  const size_t nblk = static_cast<size_t>(rdm_kpconv_fused_partial_rows(m > 0 ? m : 1, c_in, 1));  // (the finer of the two block sizes)
+  const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(m > 0 ? m : 1, kTileQB));  // (the finest block size of the forms)
   return rdm::align_up(nblk * 2 * c_out * sizeof(double)) + rdm_group_norm_workspace_bytes(m, c_out) + 256;
 }
 
@@ -914,7 +933,7 @@ extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, con
   RDM_REQUIRE(gamma && beta && conv_out && y, "rdm_kpconv_fused_group_norm: null pointer");
   if (m == 0) return RDM_OK;
   Arena ar(ws, ws_bytes);
-  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, c, h));
+  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, n_s, c, h));
   double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c_out);
   const size_t gn_ws = rdm_group_norm_workspace_bytes(m, c_out);
   char* nws = ar.take<char>(gn_ws);

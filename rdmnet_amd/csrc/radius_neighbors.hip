@@ -5,7 +5,7 @@
 // The result set of a radius query does not depend on the search structure, so the kd-tree is
 // replaced by a uniform grid (cell edge >= radius) built on the fly:
 //   bbox -> per-cell counts (atomics; integer sums, so the counts do not depend on their order) -> cell segments in
-//   CELL ORDER (prefix over 4096-cell chunks, whose sums the count kernel accumulates) -> member lists -> records
+//   CELL ORDER (prefix over 4096-cell chunks) -> member lists -> records
 //   {x,y,z,index} placed by the rank of their index inside the cell: the sorted array is a function of the points
 //   alone, run to run (round 4: it also orders the queries of the KPConv tile kernel, whose GroupNorm partials follow
 //   its workgroups) -> one wavefront per query scans its 27 cells with coalesced float4
@@ -167,7 +167,23 @@ __global__ void rn_count_kernel(RnBuildBatch bb) {
   const int c = b * g.cells_per_cloud + (cz * g.dim[1] + cy) * g.dim[0] + cx;
   it.pt_cell[i] = c;
   it.pt_slot[i] = atomicAdd(&it.cell_count[c], 1);
-  atomicAdd(&it.meta->chunk_sum[c >> kChunkShift], 1);
+}
+
+// points per chunk of 4096 consecutive cells (block b = chunk b).  A plain reduction: accumulating these in the count kernel
+// would be tens of thousands of atomics on a handful of addresses (neighbouring cells share a chunk).
+__global__ __launch_bounds__(256) void rn_chunk_kernel(RnBuildBatch bb) {
+  const RnBuildItem& it = bb.item[blockIdx.y];
+  const int ncell = it.meta->cells_per_cloud * bb.batch;
+  const int c0 = (static_cast<int>(blockIdx.x) << kChunkShift);
+  if (c0 >= ncell) return;  // (uniform over the workgroup)
+  __shared__ int wsum[4];
+  int mine = 0;
+  for (int k = threadIdx.x; k < (1 << kChunkShift); k += 256) mine += c0 + k < ncell ? it.cell_count[c0 + k] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) it.meta->chunk_sum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // cell_start = exclusive prefix of cell_count in cell order: block b owns the 4096 cells of chunk b (16 per thread); its
@@ -709,6 +725,7 @@ int rdm::radius_grid_build_multi(int n, const float* const* s_points, const int6
   if (max_ns > 0) {
     const int blocks = static_cast<int>(ceil_div<int64_t>(max_ns, 256));
     hipLaunchKernelGGL(rn_count_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(rn_chunk_kernel, dim3(kChunks, n), dim3(256), 0, st, bb);
     hipLaunchKernelGGL(rn_alloc_kernel, dim3(kChunks, n), dim3(256), 0, st, bb);
     hipLaunchKernelGGL(rn_scatter_kernel, dim3(blocks, n), dim3(256), 0, st, bb);
     hipLaunchKernelGGL(rn_rank_kernel, dim3(blocks, n), dim3(256), 0, st, bb);

@@ -95,7 +95,10 @@ def compute_registration_error(gt_transform, est_transform):
 
 
 def get_nearest_neighbor(q_points, s_points):
-    return cKDTree(s_points).query(q_points, k=1, workers=-1)[0]
+    """registration.py: cKDTree(...).query(k=1, n_jobs=-1).  Same distances; one thread below 50 000 queries -- `workers=-1`
+    starts a thread per host CPU, which for the few hundred correspondences of a pair cost 80 ms on a 16-CPU-quota container
+    (the harness measured 46 pairs/s with it, every worker thread throttled)."""
+    return cKDTree(s_points).query(q_points, k=1, workers=-1 if len(q_points) >= 50000 else 1)[0]
 
 
 def compute_correspondence_residual(ref_corr_points, src_corr_points, transform):
@@ -160,26 +163,37 @@ class Summary:
         v = self.meters.get(name, [])
         return float(np.std(v)) if v else 0.0
 
-    def update(self, ids, gt_transform, est_transform, ref_corr_points=None, src_corr_points=None, corr_scores=None,
-               nodes=None):
-        """ids = (seq_id, src_frame, ref_frame).  nodes = (ref_nodes, src_nodes, ref_idx, src_idx,
-        gt_node_corr_indices) enables the coarse-matching meters.  Returns the per-pair dict."""
-        out = {}
+    def measure(self, gt_transform, est_transform, ref_corr_points=None, src_corr_points=None, corr_scores=None, nodes=None):
+        """The per-pair numbers of `update` as a pure function (no state touched): safe on the worker threads of a
+        rdmnet_amd.pipeline.PairPipeline, where the kd-tree of the overlap and the matrix products of several pairs then run
+        side by side; `commit` adds them to the meters in dataset order."""
+        m = {}
         if nodes is not None:
-            c = evaluate_sparse_correspondences(*nodes)['precision']
+            m['precision'] = evaluate_sparse_correspondences(*nodes)['precision']
+        if ref_corr_points is not None and len(ref_corr_points):
+            f = evaluate_correspondences(ref_corr_points, src_corr_points, gt_transform, self.acceptance_radius)
+            f['n'] = len(ref_corr_points) if corr_scores is None else corr_scores.shape[0]
+            m['fine'] = f
+        m['registration'] = compute_registration_error(np.asarray(gt_transform, np.float64), np.asarray(est_transform, np.float64))
+        return m
+
+    def commit(self, ids, m):
+        """Adds one pair's `measure` result to the meters.  Returns the per-pair dict of `update`."""
+        out = {}
+        if 'precision' in m:
+            c = m['precision']
             out['c_PIR'] = c
             self._update('precision', c)
             for tag, ok in (('PMR>0', c > 0), ('PMR>=0.1', c >= 0.1), ('PMR>=0.3', c >= 0.3), ('PMR>=0.5', c >= 0.5)):
                 self._update(tag, float(ok))
-        if ref_corr_points is not None and len(ref_corr_points):
-            f = evaluate_correspondences(ref_corr_points, src_corr_points, gt_transform, self.acceptance_radius)
+        if 'fine' in m:
+            f = m['fine']
             for k in ('inlier_ratio', 'inlier_ratio_0.3', 'inlier_ratio_0.1', 'overlap'):
                 self._update(k, f[k])
             self._update('fine_recall', float(f['inlier_ratio'] >= self.inlier_ratio_threshold))
-            self._update('num_corr', len(ref_corr_points) if corr_scores is None else corr_scores.shape[0])
+            self._update('num_corr', f['n'])
             out.update(f_IR=f['inlier_ratio'], f_OV=f['overlap'], f_RS=f['residual'], f_NU=f['num_corr'])
-        rre, rte, rx, ry, rz = compute_registration_error(np.asarray(gt_transform, np.float64),
-                                                          np.asarray(est_transform, np.float64))
+        rre, rte, rx, ry, rz = m['registration']
         accepted = bool(rre < self.rre_threshold and rte < self.rte_threshold)
         if accepted:
             for k, v in (('rre', rre), ('rte', rte), ('x', rx), ('y', ry), ('z', rz)):
@@ -189,6 +203,12 @@ class Summary:
         self._update('recall', float(accepted))
         out.update(r_RRE=rre, r_RTE=rte, accepted=accepted)
         return out
+
+    def update(self, ids, gt_transform, est_transform, ref_corr_points=None, src_corr_points=None, corr_scores=None,
+               nodes=None):
+        """ids = (seq_id, src_frame, ref_frame).  nodes = (ref_nodes, src_nodes, ref_idx, src_idx,
+        gt_node_corr_indices) enables the coarse-matching meters.  Returns the per-pair dict."""
+        return self.commit(ids, self.measure(gt_transform, est_transform, ref_corr_points, src_corr_points, corr_scores, nodes))
 
     def lines(self):
         m = self.mean

@@ -76,9 +76,9 @@ class Tester:
         T = eng.transform()
         rec = {'seq_id': item['seq_id'], 'ref_frame': item['ref_frame'], 'src_frame': item['src_frame'],
                'n_corr': int(res.n_correspondences), 'ms': ms, 'transform': T}
-        if 'transform' in item:
-            rec['_gt'] = np.asarray(item['transform'], np.float64)
-            rec['_corr'] = eng.host_corr()
+        if 'transform' in item:  # the pair's registration / correspondence numbers, computed here (in parallel with other pairs)
+            rc, sc, cs = eng.host_corr()
+            rec['_metrics'] = self.summary.measure(np.asarray(item['transform'], np.float64), T, rc, sc, cs)
         if self.output_dir and self.save_npz:
             od = self.output_dict(eng, item['ref_points'].shape[0])
             T_ransac = None
@@ -92,10 +92,9 @@ class Tester:
         """In dataset order, on the calling thread: pose line, registration meters, record list."""
         if self.output_dir and self.write_poses:
             evaluation.append_pose(self.output_dir, rec, rec['transform'])
-        gt = rec.pop('_gt', None)
-        if gt is not None:
-            rc, sc, cs = rec.pop('_corr')
-            rec.update(self.summary.update((rec['seq_id'], rec['src_frame'], rec['ref_frame']), gt, rec['transform'], rc, sc, cs))
+        m = rec.pop('_metrics', None)
+        if m is not None:
+            rec.update(self.summary.commit((rec['seq_id'], rec['src_frame'], rec['ref_frame']), m))
         self.records.append(rec)
         return rec
 
@@ -192,6 +191,10 @@ def main(argv=None):
         print(f'pairs: {allrec.shape[0]}, mean ms/pair: {allrec[:, 4].mean() if len(allrec) else 0:.2f}, '
               f'{allrec.shape[0] / max(t_run, 1e-9):.1f} pairs/s (rank 0 wall time {t_run:.2f} s: host scans -> staging -> '
               f'{args.pairs_in_flight} pairs in flight -> poses and correspondences on the host)')
+        st = tester.pipeline.last_stats
+        if st and st['jobs']:
+            print('  worker time per pair (ms): drawing + staging the next pair {:.2f}, engine + outputs {:.2f}, waiting for the '
+                  'in-order consumer {:.2f}'.format(*(1e3 * st[k] / st['jobs'] for k in ('draw_s', 'work_s', 'window_s'))))
         if len(allrec) and np.isfinite(allrec[:, 5]).any():
             ok = (allrec[:, 5] < tester.summary.rre_threshold) & (allrec[:, 6] < tester.summary.rte_threshold)
             print('  Registration (all ranks), RR: {:.4f}, RRE: {:.3f}, RTE: {:.3f}'.format(

@@ -129,6 +129,7 @@ class PairPipeline:
             eng.set_pairs_in_flight(self.n)
             eng.keep_taps(keep_taps)
         self.cfg = cfg
+        self.last_stats = None
 
     # ------------------------------------------------------------------ generic scheduler
     def imap(self, jobs, fn, stagger=True, window=None):
@@ -141,6 +142,10 @@ class PairPipeline:
         cv = threading.Condition()
         done = {}
         state = {'next_out': 0, 'drawn': 0, 'exhausted': False, 'error': None, 'stop': False, 'alive': n}
+        # where the workers' time went (seconds, summed over workers): waiting for / drawing the next job (the job source's
+        # cost: reading and staging a pair), running fn, waiting for the consumer's window -- `last_stats` after the run
+        stats = self.last_stats = {'draw_s': 0.0, 'work_s': 0.0, 'window_s': 0.0, 'jobs': 0, 'wall_s': 0.0, 'workers': n}
+        t_begin = time.perf_counter()
 
         def draw():
             with draw_lock:
@@ -166,16 +171,24 @@ class PairPipeline:
                         if stagger and k > 0 and self.stagger_s > 0:
                             time.sleep(k * self.stagger_s)
                         while True:
+                            t0 = time.perf_counter()
                             with cv:  # do not run further ahead of the consumer than `window` results
                                 while state['drawn'] - state['next_out'] >= window and not state['stop']:
                                     cv.wait(timeout=0.05)
+                            t1 = time.perf_counter()
                             got = draw()
+                            t2 = time.perf_counter()
                             if got is None:
                                 return
                             slot, job = got
                             out = fn(self.engines[k], job)
+                            t3 = time.perf_counter()
                             with cv:
                                 done[slot] = out
+                                stats['window_s'] += t1 - t0
+                                stats['draw_s'] += t2 - t1
+                                stats['work_s'] += t3 - t2
+                                stats['jobs'] += 1
                                 cv.notify_all()
                     finally:
                         if ctx is not None:
@@ -214,6 +227,7 @@ class PairPipeline:
                 cv.notify_all()
             for t in threads:
                 t.join()
+            stats['wall_s'] = time.perf_counter() - t_begin
 
     def map(self, jobs, fn, stagger=True):
         return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30))
