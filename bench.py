@@ -464,7 +464,7 @@ def main():
                        '8 pairs, one in flight'}
 
     # ---- roofline of the KPConv layers from HIP events recorded on the launch stream
-    # Layer forms (rdm_kpconv_profile.fused): c_in = 1 / 32 / 64 run as ONE kernel (kpconv_fused*: neighbourhood gather + weight
+    # Layer forms (rdm_kpconv_profile.fused): c_in = 1 / 32 / 64 run as ONE kernel (kpconv_fused* / kpconv_tile*: neighbourhood gather + weight
     # contraction, no [M, 15 C] tensor in HBM; 6 launches per pair), c_in >= 128 as kpconv_gather_kernel + gemm_kernel (8).
     # `gather_ms` of a record is the neighbourhood kernel alone in both forms.
     def kp_totals(prof):
@@ -552,7 +552,7 @@ def main():
 
     n_layers = max(len(prof), 1)
     traffic, traffic_note = None, None
-    for tag in ('r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
+    for tag in ('r04', 'r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
         pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_kpconv_gather.json')
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
@@ -569,8 +569,8 @@ def main():
                               'real_slots (slots holding a neighbour only), by_form (one-kernel vs gather-only layers), one_pair_in_flight '
                               '(same kernels, GPU to themselves), whole_layer (round-comparable layer figure)',
                 'traffic': traffic, 'traffic_scope': traffic_note,
-                'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_fused_kernel<32|64> (6) and '
-                          'kpconv_gather_kernel<*> (8)',
+                'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / '
+                          'kpconv_fused_kernel<64> (6: gather + weight contraction in one launch) and kpconv_gather_kernel<*> (8)',
                 'region': f'timed region, {len(streams)} pair(s) in flight',
                 'pairs_with_layer_events': len(prof) // 14,
                 'one_pair_in_flight': ({**roofline_of(iforms), 'note': 'same kernels, 8 pairs on one stream after the timed region'}

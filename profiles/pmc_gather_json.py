@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""HBM traffic per KPConv neighbourhood-kernel dispatch (kpconv_gather* and kpconv_fused*) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> json."""
+"""HBM traffic per KPConv neighbourhood-kernel dispatch (kpconv_gather*, kpconv_fused* and kpconv_tile*) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> json."""
 import json
 import sqlite3
 import sys
@@ -7,7 +7,7 @@ import sys
 
 def total(db, counter):
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%kpconv_gather%' or name like '%kpconv_fused%')",
+    rows = cur.execute("select count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%kpconv_gather%' or name like '%kpconv_fused%' or name like '%kpconv_tile%')",
                        (counter,)).fetchall()
     return rows[0]
 
@@ -17,7 +17,7 @@ def main(fetch_db, write_db, source):
     nw, w = total(write_db, 'WRITE_SIZE')
     fetch_kb, write_kb = f / nf, w / nw
     out = {'source': source,
-           'kernel': 'kpconv_fused_c1_kernel + kpconv_fused_kernel<32|64> + kpconv_gather_kernel<*> (14 dispatches per pair)',
+           'kernel': 'kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / kpconv_fused_kernel<64> + kpconv_gather_kernel<*> (14 dispatches per pair)',
            'dispatches': nf, 'fetch_kb_per_dispatch_raw': fetch_kb, 'write_kb_per_dispatch_raw': write_kb,
            'correction': 'MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -> reads '
                          'doubled; WRITE_SIZE uncalibrated, taken as is',
