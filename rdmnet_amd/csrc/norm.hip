@@ -223,42 +223,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, i
 // then visited in cell order and workgroups re-mapped so that each XCD (workgroup b runs on XCD b % 8, own 4 MB L2) owns a
 // contiguous range of them -- a slab of space, whose support rows (one eighth of the tensor plus a halo) stay in that L2;
 // in row order (hash-map order, spatially random) every XCD streams the whole tensor from the fabric.
+// LPR = lanes per feature row (a lane holds 4 channels): rows of 64 / 128 channels take 16 / 32 lanes, so a wavefront serves
+// four / two queries at once (round 4: with one query per wavefront three quarters of the lanes idled on the 64-channel pool of
+// the first strided block, and a wavefront walked its 65 slots in nine dependent trips of eight rows: 47 us); 256 channels and
+// more: one query per wavefront and 256-channel chunk (blockIdx.y).  Sixteen slots per trip, and a shadow slot costs no load:
+// it contributes the zero row, i.e. max(., 0) once at the end.
+// SPLIT (coarse levels: a few hundred queries of 256+ channels leave most CUs idle, and a wavefront's five dependent trips set
+// the kernel's time): the four wavefronts of a workgroup share ONE (query, 256-channel chunk), each takes every fourth
+// group of slots, and the four partial maxima meet in LDS (max is exact: the result does not depend on the split).
+template <int LPR, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
                                                          const int64_t* idx, int m_total, int h, int ldi,
                                                          const int32_t* width, float* y, int ldy, const float4* order) {
+  constexpr int QPW = 64 / LPR, U = SPLIT ? 8 : 16;
+  static_assert(!SPLIT || LPR == 64, "the slot split is for one query per wavefront");
+  __shared__ float4 part[SPLIT ? 3 * 64 : 1];
   int blk = blockIdx.x;
   if (order && gridDim.x >= 16) {  // bijective: XCD x takes logical workgroups [start_x, start_x + count_x)
     const int nblk = gridDim.x, q = nblk / 8, rr = nblk % 8, xcd = blk % 8, within = blk / 8;
     blk = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + within;
   }
-  const int unit = blk * 4 + (threadIdx.x >> 6);
-  if (unit >= m_total) return;
-  const int m = order ? __float_as_int(order[unit].w) : unit;
-  const int lane = threadIdx.x & 63;
-  const int c0 = blockIdx.y * 256 + lane * 4;
-  if (c0 >= c) return;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR, wave = threadIdx.x >> 6;
+  const int unit = SPLIT ? blk : (blk * 4 + wave) * QPW + sub;
+  const bool active = unit < m_total;
+  const int m = active ? (order ? __float_as_int(order[unit].w) : unit) : 0;
+  const int c0 = blockIdx.y * 256 + l * 4;
   int H = h;
   if (width) H = min(H, *width);
+  if (!active || c0 >= c) H = 0;  // (idle lanes run the loop without loads; the trip count below is wavefront-uniform)
   float4 best = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+  bool shadow = false;
   const int64_t* row_idx = idx + static_cast<int64_t>(m) * ldi;
-  for (int k0 = 0; k0 < H; k0 += 8) {  // eight neighbour rows in flight (index -> row is a dependent load pair)
-    int64_t id[8];
+  const int Hmax = width ? min(h, *width) : h;
+  for (int k0 = SPLIT ? wave * U : 0; k0 < Hmax; k0 += SPLIT ? 4 * U : U) {  // U neighbour rows in flight (index -> row is a dependent load pair)
+    int id[U];  // support row, or -1
 #pragma unroll
-    for (int u = 0; u < 8; ++u) id[u] = k0 + u < H ? row_idx[k0 + u] : -1;
-    float4 v[8];
+    for (int u = 0; u < U; ++u) {
+      const int64_t raw = k0 + u < H ? row_idx[k0 + u] : -1;
+      const bool real = raw >= 0 && raw < ns;
+      shadow = shadow || (k0 + u < H && !real);
+      id[u] = real ? static_cast<int>(raw) : -1;
+    }
+    float4 v[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      v[u] = (id[u] >= 0 && id[u] < ns) ? *reinterpret_cast<const float4*>(x + id[u] * ldx + c0)
-                                        : (k0 + u < H ? make_float4(0.f, 0.f, 0.f, 0.f) : best);
+    for (int u = 0; u < U; ++u) {
+      const float4 t = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(max(id[u], 0)) * ldx + (c0 < c ? c0 : 0));
+      v[u] = make_float4(id[u] >= 0 ? t.x : best.x, id[u] >= 0 ? t.y : best.y, id[u] >= 0 ? t.z : best.z, id[u] >= 0 ? t.w : best.w);
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       best.x = fmaxf(best.x, v[u].x);
       best.y = fmaxf(best.y, v[u].y);
       best.z = fmaxf(best.z, v[u].z);
       best.w = fmaxf(best.w, v[u].w);
     }
   }
-  *reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy + c0) = best;
+  if constexpr (SPLIT) {
+    if (wave > 0) part[(wave - 1) * 64 + lane] = make_float4(shadow ? fmaxf(best.x, 0.f) : best.x, shadow ? fmaxf(best.y, 0.f) : best.y,
+                                                            shadow ? fmaxf(best.z, 0.f) : best.z, shadow ? fmaxf(best.w, 0.f) : best.w);
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const float4 t = part[w * 64 + lane];
+      best.x = fmaxf(best.x, t.x); best.y = fmaxf(best.y, t.y); best.z = fmaxf(best.z, t.z); best.w = fmaxf(best.w, t.w);
+    }
+  }
+  if (shadow) {  // a shadow neighbour is the zero row (functional.py:54-67)
+    best.x = fmaxf(best.x, 0.f);
+    best.y = fmaxf(best.y, 0.f);
+    best.z = fmaxf(best.z, 0.f);
+    best.w = fmaxf(best.w, 0.f);
+  }
+  if (active && c0 < c) *reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy + c0) = best;
 }
 
 // y[m, 0:c1] = coarse[idx[m,0]] (pad -> 0), y[m, c1:c1+c2] = skip[m], y[m, c1+c2:ldy] = 0
@@ -439,12 +476,22 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
   if (m == 0) return RDM_OK;
   static const bool no_order = ::rdm::dev_knob("RDM_NO_POOL_ORDER") != nullptr;  // developer knob (A/B): row order
   if (no_order) order_records = nullptr;
-  RDM_DUP_LOOP("pool")
-  hipLaunchKernelGGL(gather_max_kernel, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)),
-                     dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n_s),
-                     static_cast<int>(c), static_cast<int>(ldx), idx, static_cast<int>(m),
-                     static_cast<int>(h), static_cast<int>(ldi), width, y, static_cast<int>(ldy),
-                     reinterpret_cast<const float4*>(order_records));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float4* ord = reinterpret_cast<const float4*>(order_records);
+  const int ns = static_cast<int>(n_s), ci = static_cast<int>(c), lx = static_cast<int>(ldx), mi = static_cast<int>(m), hi = static_cast<int>(h),
+            li = static_cast<int>(ldi), ly = static_cast<int>(ldy);
+  RDM_DUP_LOOP("pool") {
+    if (c <= 64)  // four queries per wavefront
+      hipLaunchKernelGGL(gather_max_kernel<16>, dim3(ceil_div<int64_t>(m, 16), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord);
+    else if (c <= 128)
+      hipLaunchKernelGGL(gather_max_kernel<32>, dim3(ceil_div<int64_t>(m, 8), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord);
+    else if (m * ceil_div<int64_t>(c, 256) <= 4096)  // coarse levels: a workgroup per (query, chunk), slots split over its wavefronts
+      hipLaunchKernelGGL((gather_max_kernel<64, true>), dim3(static_cast<unsigned>(m), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx,
+                         idx, mi, hi, li, width, y, ly, ord);
+    else
+      hipLaunchKernelGGL(gather_max_kernel<64>, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx, idx, mi,
+                         hi, li, width, y, ly, ord);
+  }
   return launch_status("gather_max_kernel");
 }
 
