@@ -1176,7 +1176,15 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     nodes_all.pts = shifted; nodes_all.n = Nc; nodes_all.lengths = lv[4].lengths; nodes_all.n_ref = nc_ref;
     Table nms_t;
     Grid nms_grid;
-    ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
+    if (Nc <= 4096) {  // a few hundred superpoints: one cell per cloud (brute force) in one launch instead of the grid's seven
+      nms_grid.n_s = Nc;
+      nms_grid.bytes = rdm_radius_grid_workspace_bytes(Nc);
+      nms_grid.ws = e->alloc<char>(nms_grid.bytes);
+      ENG_ALLOC(nms_grid.ws);
+      ENG_CHECK(radius_grid_build_trivial(shifted, Nc, lv[4].lengths, 2, nms_grid.ws, nms_grid.bytes, r.st));
+    } else {
+      ENG_CHECK(build_grid(nodes_all, c.nms_radius, nms_grid));
+    }
     ENG_CHECK(search(nodes_all, nms_grid, c.nms_radius, c.neighbor_limits[4], nms_t));
     ENG_CHECK(radius_redo_flush(redo_queue.data(), r.st));  // (searches are recorded and run at the flush)
     uint8_t* keep = e->alloc<uint8_t>(Nc > 0 ? Nc : 1);

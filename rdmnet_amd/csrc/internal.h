@@ -54,6 +54,11 @@ int gather_rows_multi(int n, const void* const* x, const int64_t* n_src, const i
 int radius_grid_build_multi(int n, const float* const* s_points, const int64_t* n_s, const int64_t* const* s_lengths, int batch,
                             const float* radius, void* const* grid_ws, const size_t* grid_ws_bytes, void* stream);
 
+// A search "grid" of one cell per cloud (brute force: every query tests every point of its cloud) in ONE launch, for support sets
+// of a few hundred points; same workspace layout and queries as rdm_radius_grid_build (any radius).
+int radius_grid_build_trivial(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch, void* grid_ws,
+                              size_t grid_ws_bytes, void* stream);
+
 // rdm_compact_indices for the rows [0, n_ref) and [n_ref, n) with one launch (order + 0 / order + n_ref, counts[0 / 1]);
 // optionally mirrors `mirror_words` int32 status words (which must contain `counts`) into mapped host memory.
 int compact_indices_pair(const uint8_t* keep, int64_t n_ref, int64_t n, int32_t* order, int32_t* counts,

@@ -733,6 +733,46 @@ int rdm::radius_grid_build_multi(int n, const float* const* s_points, const int6
   return launch_status("radius grid build");
 }
 
+namespace {
+// "Grid" of ONE cell per cloud: the queries then test every point of their cloud (brute force), which for a few hundred
+// points -- the NMS search over the shifted superpoints, vote.py:24-31 -- is cheaper than the seven launches of a real grid.
+__global__ void rn_trivial_grid_kernel(const float* s, int64_t ns, const int64_t* lengths, int batch, GridMeta* meta, int* cell_count,
+                                       int* cell_start, float4* sorted) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i == 0) {
+    for (int d = 0; d < 3; ++d) {
+      meta->org[d] = 0.f;
+      meta->dim[d] = 1;
+    }
+    meta->inv_cell = 0.f;  // cell_of -> (0, 0, 0) for every point; any radius passes the "grid built for this radius" test
+    meta->cells_per_cloud = 1;
+    meta->total = 0;
+    int64_t acc = 0;
+    for (int b = 0; b < batch; ++b) {
+      cell_start[b] = static_cast<int>(acc);
+      cell_count[b] = static_cast<int>(lengths[b]);
+      acc += lengths[b];
+    }
+  }
+  if (i < ns) sorted[i] = make_float4(s[3 * i], s[3 * i + 1], s[3 * i + 2], __int_as_float(static_cast<int>(i)));
+}
+}  // namespace
+
+int rdm::radius_grid_build_trivial(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch, void* grid_ws,
+                                   size_t grid_ws_bytes, void* stream) {
+  RDM_REQUIRE(s_points && s_lengths && grid_ws && n_s > 0 && n_s < (1ll << 31) && batch > 0 && batch <= kMaxBatch,
+              "radius_grid_build_trivial: bad arguments");
+  Arena ar(grid_ws, grid_ws_bytes);
+  GridViews g;
+  if (!carve_grid(ar, n_s, &g)) {
+    set_error("radius_grid_build_trivial: workspace too small (%zu < %zu bytes)", grid_ws_bytes, ar.off);
+    return RDM_ERR_WORKSPACE;
+  }
+  hipLaunchKernelGGL(rn_trivial_grid_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(n_s, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), s_points, n_s, s_lengths, batch, g.meta, g.cell_count, g.cell_start, g.sorted);
+  return launch_status("rn_trivial_grid_kernel");
+}
+
 extern "C" int rdm_radius_grid_build(const float* s_points, int64_t n_s, const int64_t* s_lengths, int batch,
                                      float radius, void* grid_ws, size_t grid_ws_bytes, void* stream) {
   RDM_REQUIRE(s_lengths && grid_ws, "rdm_radius_grid_build: null pointer");
