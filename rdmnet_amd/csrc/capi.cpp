@@ -8,7 +8,10 @@
 namespace rdm {
 namespace {
 thread_local char g_error[512] = "";
+thread_local bool g_index32 = false;
 }
+bool index32() { return g_index32; }
+void set_index32(bool on) { g_index32 = on; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -22,6 +22,19 @@ enum : int {
 
 void set_error(const char* fmt, ...);
 
+// Width of the neighbour-index tables the NEXT calls of this thread read or write: false = int64 (the C-ABI's and the
+// reference's layout), true = int32 (rdm_engine_run keeps the tables it builds and consumes itself in 32 bits: half the bytes
+// written by the searches and read by every KPConv layer and shortcut pool; the int64 layout stays at the rdm_engine_forward /
+// rdm_engine_collate boundary).  Thread-local, set only by the engine around its own calls (Index32Scope); every public entry
+// point called from outside sees int64.
+bool index32();
+void set_index32(bool on);
+struct Index32Scope {
+  bool before;
+  explicit Index32Scope(bool on) : before(index32()) { set_index32(on); }
+  ~Index32Scope() { set_index32(before); }
+};
+
 #define RDM_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
@@ -120,6 +133,15 @@ inline hipError_t set_max_dynamic_lds(const void* kernel, int bytes, std::atomic
 }
 
 constexpr int kWave = 64;
+
+// element `off` of a neighbour-index table held as int64 (i32 = 0) or int32 (i32 = 1)
+__device__ __forceinline__ long long ld_index(const int64_t* p, long long off, int i32) {
+  return i32 ? static_cast<long long>(reinterpret_cast<const int32_t*>(p)[off]) : static_cast<long long>(p[off]);
+}
+__device__ __forceinline__ void st_index(int64_t* p, long long off, long long v, int i32) {
+  if (i32) reinterpret_cast<int32_t*>(p)[off] = static_cast<int32_t>(v);
+  else p[off] = v;
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -270,7 +270,8 @@ struct Level {
   int64_t n_ref = 0;
 };
 struct Table {
-  int64_t* idx = nullptr;
+  int64_t* idx = nullptr;     // int32 elements when i32 (tables the engine builds AND consumes itself in a plain run)
+  bool i32 = false;
   int64_t rows = 0, width = 0;
   int64_t ld = 0;            // row stride; 0 = width (tables built by the engine's own collate)
   int32_t* flags = nullptr;  // device [2]: max_count, status (optional: null = every column is valid)
@@ -288,6 +289,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   }
   const Linear& W = it->second;
   const int64_t cin = x.cols, kdim = cin == 1 ? 16 : 15 * cin;
+  Index32Scope index_scope(t.i32);  // the convolution kernels and the shortcut pool read `t` in its own element width
   if (W.packed && rdm_kpconv_fused_enabled()) {
     // fine levels (c_in = 1, 32, 64): the whole convolution is one kernel, the [M, 15 C] block never leaves the CU
     float* gam = vecp(r, norm_name + ".norm.weight");
@@ -907,10 +909,12 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(g.ws);
     return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
   };
-  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t) -> int {
+  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t, bool i32 = false) -> int {
     t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
-    t.idx = e->alloc<int64_t>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit);
+    t.i32 = i32;
+    t.idx = reinterpret_cast<int64_t*>(e->alloc<char>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit * (i32 ? 4 : 8)));
     ENG_ALLOC(t.idx);
+    Index32Scope index_scope(i32);  // (the query's arguments are fixed here, also when it runs at the flush)
     // the large-buffer second pass of all 14 searches is one launch after the loop (radius_redo_flush)
     unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
     ENG_ALLOC(redo_flags);
@@ -1013,9 +1017,13 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // (backbone.py:118-151 stops at the second level): a plain run skips that search (32 000 queries, a quarter of all) and keeps one
   // column of the others; the collate API and runs that keep their stage tensors build the reference's full tables.
   const bool full_up = e->keep_taps || e->collate_only;
+  // ... and keeps the neighbour / subsampling tables, which only its own KPConv layers and shortcut pools read, in 32 bits
+  // (33 MB less written and 65 MB less read per pair; the int64 layout of the reference stays wherever a table leaves the
+  // engine: stage tensors, rdm_engine_collate, rdm_engine_forward's data_dict)
+  const bool i32 = !full_up;
   for (int i = 0; i < 5; ++i) {
-    ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i]));
-    if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i]));
+    ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i], i32));
+    if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i], i32));
     if (i > 0 && (full_up || i > 1)) ENG_CHECK(search(lv[i - 1], grids[i], radius, full_up ? c.neighbor_limits[i] : 1, up[i - 1]));
     radius *= 2.f;
   }

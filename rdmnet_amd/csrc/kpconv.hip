@@ -33,7 +33,8 @@ struct KpArgs {
   const float* s_points;   // [Ns,3]
   const float* s_feats;    // [Ns, ldf]
   const unsigned char* s_pos;  // [Ns] 1 iff sum_c feats > 0
-  const int64_t* idx;      // [M, ldi]
+  const int64_t* idx;      // [M, ldi] (int32 elements when i32)
+  int i32;
   const float* kp;         // [15,3]
   const int32_t* width;    // optional device int: effective row width (min(limit, max_count))
   const float4* order;     // optional processing order: query row = int bits of order[unit].w
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   int Hq = 0;  // slots up to the last real neighbour: shadow neighbours contribute exact zeros, and the searches pad at the end
   for (int hb = 0; hb < Hc; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
     const int h = hb + lane;
-    const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+    const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
     const bool real = id >= 0 && id < a.Ns;
     const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
     if (rm) Hq = hb + 64 - __builtin_clzll(rm);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
     int Hq = 0;  // slots up to the last real neighbour (the rest are shadow neighbours: zero feature)
     for (int hb = 0; hb < Hc; hb += 64) {  // (wavefront-uniform trip count: Hq must be the same in every lane)
       const int h = hb + lane;
-      const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+      const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
       if (rm) Hq = hb + 64 - __builtin_clzll(rm);
@@ -291,7 +292,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   if (m == 0) return RDM_OK;
   KpArgs a;
   a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive;
-  a.idx = idx; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
+  a.idx = idx; a.i32 = index32() ? 1 : 0; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
   a.order = reinterpret_cast<const float4*>(order_records);
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);

@@ -52,7 +52,8 @@ struct FusedArgs {
   const float* s_points;       // [Ns,3]
   const float* s_feats;        // [Ns, ldf]
   const unsigned char* s_pos;  // [Ns]
-  const int64_t* idx;          // [M, ldi]
+  const int64_t* idx;          // [M, ldi] (int32 elements when i32)
+  int i32;
   const float* kp;             // [15,3]
   const int32_t* width;        // optional device int: effective row width
   const float* w;              // packed weights (see rdm_kpconv_pack_weights)
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
         int Hq = 0;  // slots up to the last real neighbour (kpconv.hip: shadow slots contribute exact zeros)
         for (int hb = 0; hb < Hc; hb += 64) {
           const int h = hb + lane;
-          const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+          const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
           const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
           if (rm) Hq = hb + 64 - __builtin_clzll(rm);
           float4 v;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int h = lane + 64 * k;
-      raw[qq][k] = (m >= 0 && h < H) ? a.idx[static_cast<int64_t>(m) * a.ldi + h] : -1;
+      raw[qq][k] = (m >= 0 && h < H) ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + h, a.i32) : -1;
     }
     if (lane == 0) mrow[ql] = m;
   }
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
               f[p][0] = t.x; f[p][1] = t.y;
             }
           } else {  // no slot: this neighbour's row comes from global memory
-            const int id = static_cast<int>(a.idx[static_cast<int64_t>(m) * a.ldi + h]);
+            const int id = static_cast<int>(ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + h, a.i32));
             w[p] = kp_influence((a.s_points[3 * id] - qx[qq]) - kx, (a.s_points[3 * id + 1] - qy[qq]) - ky,
                                 (a.s_points[3 * id + 2] - qz[qq]) - kz, inv_sigma);
             const float* row = a.s_feats + static_cast<int64_t>(id) * a.ldf + VEC * j;
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
       int Hq = 0;  // slots up to the last real neighbour
       for (int hb = 0; hb < Hc; hb += 64) {
         const int h = hb + lane;
-        const int64_t id = h < Hc ? a.idx[static_cast<int64_t>(m) * a.ldi + hc + h] : -1;
+        const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
         const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
         if (rm) Hq = hb + 64 - __builtin_clzll(rm);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -874,7 +875,8 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
               "rdm_kpconv_fused: features / packed weights must be 16-byte aligned with a row stride that is a multiple of 4");
   if (m == 0) return RDM_OK;
   FusedArgs a;
-  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.kp = kernel_points;
+  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.i32 = index32() ? 1 : 0;
+  a.kp = kernel_points;
   a.width = width; a.w = w_packed; a.bias = bias; a.out = out; a.stats = gn_partial;
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;

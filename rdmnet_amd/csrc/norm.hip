@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, i
 template <int LPR, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
                                                          const int64_t* idx, int m_total, int h, int ldi,
-                                                         const int32_t* width, float* y, int ldy, const float4* order) {
+                                                         const int32_t* width, float* y, int ldy, const float4* order, int i32) {
   constexpr int QPW = 64 / LPR, U = SPLIT ? 8 : 16;
   static_assert(!SPLIT || LPR == 64, "the slot split is for one query per wavefront");
   __shared__ float4 part[SPLIT ? 3 * 64 : 1];
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns,
   if (!active || c0 >= c) H = 0;  // (idle lanes run the loop without loads; the trip count below is wavefront-uniform)
   float4 best = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
   bool shadow = false;
-  const int64_t* row_idx = idx + static_cast<int64_t>(m) * ldi;
+  const long long row_idx = static_cast<long long>(m) * ldi;  // element offset (int64 or int32 elements)
   const int Hmax = width ? min(h, *width) : h;
   for (int k0 = SPLIT ? wave * U : 0; k0 < Hmax; k0 += SPLIT ? 4 * U : U) {  // U neighbour rows in flight (index -> row is a dependent load pair)
     int id[U];  // support row, or -1
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t raw = k0 + u < H ? row_idx[k0 + u] : -1;
+      const int64_t raw = k0 + u < H ? ld_index(idx, row_idx + k0 + u, i32) : -1;
       const bool real = raw >= 0 && raw < ns;
       shadow = shadow || (k0 + u < H && !real);
       id[u] = real ? static_cast<int>(raw) : -1;
@@ -478,19 +478,20 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
   if (no_order) order_records = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float4* ord = reinterpret_cast<const float4*>(order_records);
+  const int i32 = index32() ? 1 : 0;
   const int ns = static_cast<int>(n_s), ci = static_cast<int>(c), lx = static_cast<int>(ldx), mi = static_cast<int>(m), hi = static_cast<int>(h),
             li = static_cast<int>(ldi), ly = static_cast<int>(ldy);
   RDM_DUP_LOOP("pool") {
     if (c <= 64)  // four queries per wavefront
-      hipLaunchKernelGGL(gather_max_kernel<16>, dim3(ceil_div<int64_t>(m, 16), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord);
+      hipLaunchKernelGGL(gather_max_kernel<16>, dim3(ceil_div<int64_t>(m, 16), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
     else if (c <= 128)
-      hipLaunchKernelGGL(gather_max_kernel<32>, dim3(ceil_div<int64_t>(m, 8), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord);
+      hipLaunchKernelGGL(gather_max_kernel<32>, dim3(ceil_div<int64_t>(m, 8), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
     else if (m * ceil_div<int64_t>(c, 256) <= 4096)  // coarse levels: a workgroup per (query, chunk), slots split over its wavefronts
       hipLaunchKernelGGL((gather_max_kernel<64, true>), dim3(static_cast<unsigned>(m), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx,
-                         idx, mi, hi, li, width, y, ly, ord);
+                         idx, mi, hi, li, width, y, ly, ord, i32);
     else
       hipLaunchKernelGGL(gather_max_kernel<64>, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx, idx, mi,
-                         hi, li, width, y, ly, ord);
+                         hi, li, width, y, ly, ord, i32);
   }
   return launch_status("gather_max_kernel");
 }

@@ -281,6 +281,7 @@ struct RnQueryArgs {
   const float4* sorted;
   int width;
   int64_t* out_idx;
+  int out32;  // rows of out_idx are int32 (the engine's internal tables) instead of int64
   int32_t* out_counts;
   int32_t* out_max;
   int32_t* status;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void rn_dense_row(const RnQueryArgs& a, int64_t qi, i
                                              const int* seg_start_w, const int* seg_pref_w, int total, int count, float qx,
                                              float qy, float qz, float r2) {
   const int out_n = count < a.width ? count : a.width;
-  int64_t* row = a.out_idx + qi * static_cast<int64_t>(a.width);
+  const long long row = qi * static_cast<long long>(a.width);  // element offset of the row (int64 or int32 elements: st_index)
   unsigned long long lower = 0;  // keys <= lower are already written (valid once emitted > 0)
   int emitted = 0;
   while (emitted < out_n) {
@@ -442,13 +443,13 @@ __device__ __forceinline__ void rn_dense_row(const RnQueryArgs& a, int64_t qi, i
     n = cnt < 1024 ? cnt : 1024;  // (= below + in_bin)
     rn_sort_keys(K, n, lane);
     const int m = n < out_n - emitted ? n : out_n - emitted;
-    for (int c = lane; c < m; c += 64) row[emitted + c] = static_cast<int64_t>(K[c] & 0xffffffffull);
+    for (int c = lane; c < m; c += 64) st_index(a.out_idx, row + emitted + c, static_cast<long long>(K[c] & 0xffffffffull), a.out32);
     lower = K[m - 1];
     emitted += m;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // K is rewritten by the next round
     __builtin_amdgcn_wave_barrier();
   }
-  for (int c = out_n + lane; c < a.width; c += 64) row[c] = a.ns;
+  for (int c = out_n + lane; c < a.width; c += 64) st_index(a.out_idx, row + c, a.ns, a.out32);
 }
 
 template <int CAP>
@@ -596,18 +597,17 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
     }
     RN_PHASE(3);
     // every lane knows the final column of its keys: write the row directly (pads behind the n-th column)
-    int64_t* row = out_idx + qi * static_cast<int64_t>(width);
-    if (lane < n && r0 < width) row[r0] = static_cast<int64_t>(k0 & 0xffffffffull);
-    if (64 + lane < n && r1 < width) row[r1] = static_cast<int64_t>(k1 & 0xffffffffull);
-    for (int c = n + lane; c < width; c += 64) row[c] = ns;
+    const long long row = qi * static_cast<long long>(width);
+    if (lane < n && r0 < width) st_index(out_idx, row + r0, static_cast<long long>(k0 & 0xffffffffull), a.out32);
+    if (64 + lane < n && r1 < width) st_index(out_idx, row + r1, static_cast<long long>(k1 & 0xffffffffull), a.out32);
+    for (int c = n + lane; c < width; c += 64) st_index(out_idx, row + c, ns, a.out32);
     RN_PHASE(4);
     return;
   }
   rn_sort_keys(K, n, lane);
   // offset of this cloud's supports is already folded in (indices are global rows)
-  int64_t* row = out_idx + qi * static_cast<int64_t>(width);
-  for (int c = lane; c < width; c += 64)
-    row[c] = c < n ? static_cast<int64_t>(K[c] & 0xffffffffull) : ns;
+  const long long row = qi * static_cast<long long>(width);
+  for (int c = lane; c < width; c += 64) st_index(out_idx, row + c, c < n ? static_cast<long long>(K[c] & 0xffffffffull) : ns, a.out32);
 }
 
 // First pass (CAP = 256, one wavefront per query, every query) and the stand-alone second pass (CAP = 1024, only the
@@ -797,6 +797,7 @@ int grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_
   RnQueryArgs a;
   a.q = q_points; a.nq = n_q; a.ns = n_s; a.q_lengths = q_lengths; a.batch = batch; a.radius = radius; a.meta = g.meta;
   a.cell_count = g.cell_count; a.cell_start = g.cell_start; a.sorted = g.sorted; a.width = width; a.out_idx = out_idx;
+  a.out32 = index32() ? 1 : 0;
   a.out_counts = out_counts; a.out_max = out_max; a.status = status; a.redo = redo;
   const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
   // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
