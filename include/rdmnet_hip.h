@@ -163,18 +163,18 @@ int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, i
  * 64), 32 -> 32, 64 -> 64: out[m, c'] = (sum_k sum_c wf[m, k, c] W[k, c, c']) / nn[m] + bias[c'] with wf and nn as in
  * rdm_kpconv_gather; the [m, 15*c] intermediate stays in LDS.  w_packed: W [15, c_in, c_out] reordered by
  * rdm_kpconv_pack_weights (host arrays; rdm_kpconv_packed_floats floats).  gn_partial (optional): fp64 column sums /
- * sums of squares of the output, one partial row per workgroup: [rdm_kpconv_fused_partial_rows(m, n_s, c_in, h)][2][c_out] -- the
+ * sums of squares of the output, one partial row per workgroup: [rdm_kpconv_fused_partial_rows(m, c_in)][2][c_out] -- the
  * input of the GroupNorm that follows every KPConv.  rdm_kpconv_fused_group_norm = that convolution +
  * act(GroupNorm(.)) (modules.py:141-145, 205-207), workspace rdm_kpconv_fused_workspace_bytes.
  * order_records (optional, round 4): m x float4 {x, y, z, query row} in the cell order of the query level's search grid
  * (rdm_radius_grid_records).  For h <= 128 and c_in = 32, or c_in = 64 with queries and support on the same level (2 m > n_s),
  * a workgroup then takes 16 queries that are neighbours in space, stages the union of their support rows (feature row,
  * point, positive flag) ONCE in LDS and aggregates from there ("LDS-staged neighbour tiles"); null = the queries in row order
- * (same kernel, less re-use).  The convolution
+ * (spatially random for a level of the pyramid: nothing to share, the lock-step kernel runs).  The convolution
  * output does not depend on the order; the GroupNorm partials group the rows by workgroup, i.e. by that order.      */
 int rdm_kpconv_fused_enabled(void);   /* 1 iff RDM_FUSED_KPCONV is set: engine and per-op path then use the fused kernel */
 int rdm_kpconv_fused_supported(int64_t c_in, int64_t c_out);
-int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t n_s, int64_t c_in, int64_t h);
+int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in);
 size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out);
 int rdm_kpconv_pack_weights(const float* w_host, int64_t c_in, int64_t c_out, float* packed_host);
 int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,
@@ -184,8 +184,8 @@ int rdm_kpconv_fused(const float* q_points, int64_t m, const float* s_points, in
                      const float* order_records, void* stream);
 /* The same with the kernel chosen by the caller (tests and A/B runs): form 0 = the library's choice (rdm_kpconv_fused), 1 = the
  * lock-step kernel (every (query, neighbour) row fetched from L2), 2 = the LDS-tile kernel where it applies (c_in = 32 / 64,
- * h <= 128).  Both give the same convolution output bit for bit; the GroupNorm partial rows follow the form's workgroups. */
-int64_t rdm_kpconv_fused_partial_rows_form(int64_t m, int64_t n_s, int64_t c_in, int64_t h, int form);
+ * h <= 128).  Both give the same convolution output bit for bit and one partial row per 16 queries (form 2 groups the
+ * queries of a row by `order_records`).                                                                              */
 int rdm_kpconv_fused_form(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats,
                           int64_t c, int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi,
                           const int32_t* width, const float* kernel_points, float sigma, const float* w_packed,

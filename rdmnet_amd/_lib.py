@@ -42,12 +42,11 @@ SIGNATURES = {
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
     'rdm_kpconv_fused_enabled': (c_int, []),
     'rdm_kpconv_fused_supported': (c_int, [c_i64, c_i64]),
-    'rdm_kpconv_fused_partial_rows': (c_i64, [c_i64, c_i64, c_i64, c_i64]),
+    'rdm_kpconv_fused_partial_rows': (c_i64, [c_i64, c_i64]),
     'rdm_kpconv_packed_floats': (c_size, [c_i64, c_i64]),
     'rdm_kpconv_pack_weights': (c_int, [c_void, c_i64, c_i64, c_void]),
     'rdm_kpconv_fused': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64, c_i64, c_void, c_void,
                                  c_f32, c_void, c_void, c_i64, c_void, c_i64, c_void, c_void, c_void]),
-    'rdm_kpconv_fused_partial_rows_form': (c_i64, [c_i64, c_i64, c_i64, c_i64, c_int]),
     'rdm_kpconv_fused_form': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64, c_i64, c_void, c_void,
                                       c_f32, c_void, c_void, c_i64, c_void, c_i64, c_void, c_void, c_int, c_void]),
     'rdm_kpconv_fused_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),

@@ -306,7 +306,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
     // (rdm_kpconv_fused_group_norm's two halves, so that the layer events bracket the convolution kernel alone)
-    const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, s.n, cin, t.width));
+    const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, cin));
     double* gn_partial = static_cast<double*>(r.ws);
     const size_t stat_bytes = align_up(static_cast<size_t>(nblk) * 2 * W.out * sizeof(double));
     ENG_CHECK(rdm_kpconv_fused(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,

@@ -417,20 +417,30 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
       if (rm) Hq = 64 * k + 64 - __builtin_clzll(rm);
       const int id = real ? static_cast<int>(id64) : -1;
       int pos = -1;
+      bool entered = false;
       if (real) {
         unsigned p = (static_cast<unsigned>(id) * 2654435761u) >> 22;  // 10 bits
         for (int t = 0; t < kTileProbes; ++t) {
           const int old = atomicCAS(&hkey[p], -1, id);
-          if (old == -1) {  // this lane entered the id: it also numbers it (arrival order; the output does not depend on it)
-            const int sl = atomicAdd(n_keys, 1);
-            hval[p] = static_cast<short>(sl < CAP ? sl : -1);
-            if (sl < CAP) sid[sl] = id;
-          }
+          if (old == -1) entered = true;  // this lane entered the id: it also numbers it below
           if (old == -1 || old == id) {
             pos = static_cast<int>(p);
             break;
           }
           p = (p + 1) & (kTileHash - 1);
+        }
+      }
+      // slot numbers of the ids this wavefront entered: one counter update per wavefront (arrival order; the output does
+      // not depend on the numbering)
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(entered);
+      if (em) {
+        int base = 0;
+        if (lane == __builtin_ctzll(em)) base = atomicAdd(n_keys, __builtin_popcountll(em));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(em));
+        if (entered) {
+          const int sl = base + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+          hval[pos] = static_cast<short>(sl < CAP ? sl : -1);
+          if (sl < CAP) sid[sl] = id;
         }
       }
       qid[qq][k] = id;
@@ -773,7 +783,7 @@ constexpr size_t fused_lds_bytes() { return sizeof(float) * (static_cast<size_t>
 
 // C = 32: 16 wavefronts x 1 query, 31 KB block + 32 KB staging = 63 KB -> two workgroups (32 wavefronts) per CU, the
 // occupancy of the stand-alone gather; C = 64: the 62 KB block leaves room for 8 wavefronts x 2 queries (78 KB, two per CU)
-constexpr int kQb32 = 16, kNw32 = 16, kIters32 = 2, kQb64 = 16, kNw64 = 8, kIters64 = 1;
+constexpr int kQb32 = 16, kNw32 = 16, kIters32 = 1, kQb64 = 16, kNw64 = 8, kIters64 = 1;  // (16 rows per workgroup in every form: one partial-row count)
 
 }  // namespace
 
@@ -799,29 +809,27 @@ namespace {
 // shape on MI355X, tools/kpconv_bench.py): c_in = 32 always (59.4 / 28.6 us against 60.7 / 30.7 at the first level and its
 // strided block); c_in = 64 when queries and support are the same level (44 against 51 us) -- a strided block's 16 queries (of
 // the coarser level) reach 145 ... 240+ distinct rows, beyond the 240 the tile holds beside the parked block, and the rows
-// that overflow are fetched the old way on top of the tile's fixed costs (23.7 against 18.3 us).
-bool use_tile(int64_t c_in, int64_t h, int64_t m, int64_t n_s, int form = 0) {
+// that overflow are fetched the old way on top of the tile's fixed costs (23.7 against 18.3 us).  Without order records (queries
+// in row order = the hash-map order of the subsampling: spatially random) there is nothing to share: the lock-step kernel.
+bool use_tile(int64_t c_in, int64_t h, int64_t m, int64_t n_s, bool has_order, int form = 0) {
   static const bool on = [] {
     const char* v = ::rdm::dev_knob("RDM_KPCONV_TILE");
     return !(v != nullptr && v[0] == '0');
   }();
   if (!((c_in == 32 || c_in == 64) && h <= kMaxH)) return false;
   if (form != 0) return form == 2;
-  return on && (c_in == 32 || 2 * m > n_s);
+  return on && has_order && (c_in == 32 || 2 * m > n_s);
 }
-int64_t rows_per_block(int64_t c_in, int64_t h, int64_t m, int64_t n_s, int form = 0) {
-  if (use_tile(c_in, h, m, n_s, form)) return kTileQB;
-  return c_in == 1 ? kC1Waves * kC1Qpw : (c_in == 32 ? kQb32 * kIters32 : kQb64 * kIters64);
+int64_t rows_per_block(int64_t c_in) {  // (the same in every form: the caller sizes the partial array before the form is chosen)
+  static_assert(kTileQB == kQb32 * kIters32 && kTileQB == kQb64 * kIters64, "one partial-row count for both forms");
+  return c_in == 1 ? kC1Waves * kC1Qpw : kTileQB;
 }
 }  // namespace
 
 // Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries and neighbour rows of h slots writes
 // (one per workgroup).
-extern "C" int64_t rdm_kpconv_fused_partial_rows_form(int64_t m, int64_t n_s, int64_t c_in, int64_t h, int form) {
-  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in, h, m, n_s, form));
-}
-extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t n_s, int64_t c_in, int64_t h) {
-  return rdm_kpconv_fused_partial_rows_form(m, n_s, c_in, h, 0);
+extern "C" int64_t rdm_kpconv_fused_partial_rows(int64_t m, int64_t c_in) {
+  return m <= 0 ? 0 : rdm::ceil_div<int64_t>(m, rows_per_block(c_in));
 }
 
 extern "C" size_t rdm_kpconv_packed_floats(int64_t c_in, int64_t c_out) {
@@ -881,7 +889,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldo); a.sigma = sigma;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows_form(m, n_s, c, h, form));
+  const unsigned blocks = static_cast<unsigned>(rdm_kpconv_fused_partial_rows(m, c));
   RDM_DUP_LOOP("fused") {
   if (c == 1) {
     // (measured and dropped in round 4: the queries in cell order -- 28.2 against 26.8 us at the first level -- and the index rows
@@ -890,7 +898,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
     hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     continue;
   }
-  if (use_tile(c, h, m, n_s, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
+  if (use_tile(c, h, m, n_s, order_records != nullptr, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
     static std::atomic<uint64_t> tattr32{0}, tattr64{0};
     const float4* order = reinterpret_cast<const float4*>(order_records);
     if (c == 32) {
@@ -918,7 +926,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
 }
 
 extern "C" size_t rdm_kpconv_fused_workspace_bytes(int64_t m, int64_t c_in, int64_t c_out) {
-  const size_t nblk = static_cast<size_t>(rdm::ceil_div<int64_t>(m > 0 ? m : 1, kTileQB));  // (the finest block size of the forms)
+  const size_t nblk = static_cast<size_t>(rdm_kpconv_fused_partial_rows(m > 0 ? m : 1, c_in));
   return rdm::align_up(nblk * 2 * c_out * sizeof(double)) + rdm_group_norm_workspace_bytes(m, c_out) + 256;
 }
 
@@ -935,7 +943,7 @@ extern "C" int rdm_kpconv_fused_group_norm(const float* q_points, int64_t m, con
   RDM_REQUIRE(gamma && beta && conv_out && y, "rdm_kpconv_fused_group_norm: null pointer");
   if (m == 0) return RDM_OK;
   Arena ar(ws, ws_bytes);
-  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, n_s, c, h));
+  const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(m, c));
   double* partial = ar.take<double>(static_cast<size_t>(nblk) * 2 * c_out);
   const size_t gn_ws = rdm_group_norm_workspace_bytes(m, c_out);
   char* nws = ar.take<char>(gn_ws);

@@ -141,7 +141,7 @@ def kpconv_fused(q_points, s_points, s_feats, s_positive, idx, kernel_points, si
     out = feat_empty(m, c_out, q_points.device)
     part = None
     if want_partials:
-        nblk = max(int(L.rdm_kpconv_fused_partial_rows_form(m, s_points.shape[0], c, idx.shape[1], form)), 1)
+        nblk = max(int(L.rdm_kpconv_fused_partial_rows(m, c)), 1)
         part = torch.empty((nblk, 2, c_out), dtype=torch.float64, device=q_points.device)
     _lib.check(L.rdm_kpconv_fused_form(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(), c,
                                   _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0), _lib.ptr(width),
