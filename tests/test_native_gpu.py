@@ -191,3 +191,40 @@ def test_multi_launch_subsampling_equals_single_workgroup_form_and_oracle(scans,
         for p, l in outs:
             assert np.array_equal(l, rl), (lens, voxel)
             assert np.array_equal(p, rp), (lens, voxel)
+
+
+def test_grid_records_are_a_function_of_the_points_alone():
+    """Round 4: the cell-sorted records of a search grid (rdm_radius_grid_records) also order the queries of the KPConv tile
+    kernel, whose GroupNorm partials follow its workgroups -- so the order must not depend on how the build's atomics raced:
+    cell segments lie in cell order (prefix over cells) and the points of a cell in the order of their rows.  Two builds give the
+    same bytes; the records are a permutation of the rows, grouped by cloud, with ascending rows inside every run of one cell."""
+    from rdmnet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n0, n1 = 9000, 7000
+    pts = torch.cat([torch.randn(n0, 3, generator=g) * torch.tensor([20.0, 20.0, 1.0]),
+                     torch.randn(n1, 3, generator=g) * torch.tensor([15.0, 25.0, 1.0]) + 3.0]).cuda()
+    pts[100:400] = pts[100]  # a crowded cell (300 coincident points)
+    lengths = torch.tensor([n0, n1], dtype=torch.int64).cuda()
+    radius = 1.5
+    a = ops.radius_grid_records(pts, lengths, radius).clone()
+    for _ in range(3):
+        torch.cuda.synchronize()
+        assert torch.equal(ops.radius_grid_records(pts, lengths, radius), a)
+    rows = a[:, 3].contiguous().view(torch.int32).cpu().numpy()
+    assert sorted(rows.tolist()) == list(range(n0 + n1))
+    assert torch.equal(a[:, :3].cpu(), pts.cpu()[rows])
+    assert rows[:n0].max() < n0 and rows[n0:].min() >= n0  # cloud by cloud
+    # the order is (cloud, cell, row): cells recomputed here with the kernel's fp32 arithmetic (rn_bbox_kernel / cell_of: one
+    # bounding box for both clouds, cell edge 1.001 r, x fastest)
+    p32 = pts.cpu().numpy()
+    lo, hi = p32.min(0), p32.max(0)
+    cell = np.float32(radius) * np.float32(1.001) * np.float32(1.0)
+    dim = (np.floor((hi - lo).astype(np.float64) / np.float64(cell)) + 1).astype(np.int64)
+    inv = np.float32(1.0) / cell
+    xyz = a[:, :3].cpu().numpy()
+    c3 = np.clip(np.floor((xyz - lo) * inv).astype(np.int64), 0, dim - 1)
+    lin = (c3[:, 2] * dim[1] + c3[:, 1]) * dim[0] + c3[:, 0]
+    cloud = (rows >= n0).astype(np.int64)
+    key = np.stack([cloud, lin, rows.astype(np.int64)], 1)
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+    assert np.array_equal(order, np.arange(len(rows))), 'records are not in (cloud, cell, row) order'
