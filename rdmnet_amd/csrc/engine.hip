@@ -1016,6 +1016,9 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // The forward consumes column 0 of upsampling[1..3] only (nearest_upsample, functional.py:6-22) and upsampling[0] not at all
   // (backbone.py:118-151 stops at the second level): a plain run skips that search (32 000 queries, a quarter of all) and keeps one
   // column of the others; the collate API and runs that keep their stage tensors build the reference's full tables.
+  // (in a plain run up[0] stays the default-constructed Table -- null pointer, zero rows, never read -- and the status
+  // rows `flags` are numbered in CALL order, i.e. without the skipped search: self0 sub0 self1 sub1 self2 sub2 up1 ... ; the
+  // layout Engine.collate documents (rows 4 / 7 / 10 / 12 = the up-sampling tables) holds for runs that build all 13 tables.)
   const bool full_up = e->keep_taps || e->collate_only;
   // ... and keeps the neighbour / subsampling tables, which only its own KPConv layers and shortcut pools read, in 32 bits
   // (33 MB less written and 65 MB less read per pair; the int64 layout of the reference stays wherever a table leaves the

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void rn_alloc_kernel(RnBuildBatch bb) {
     mine += cnt[k];
   }
   part[tid] = mine;
-  int before = tid < static_cast<int>(blockIdx.x) ? it.meta->chunk_sum[tid] : 0;  // (kChunks == blockDim.x)
+  static_assert(kChunks == 256, "one thread per chunk sum below");
+  int before = tid < static_cast<int>(blockIdx.x) ? it.meta->chunk_sum[tid] : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
   if ((tid & 63) == 0) wsum[tid >> 6] = before;
