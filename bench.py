@@ -309,6 +309,7 @@ def main():
         del dd
 
     iso_lat = []  # per-pair latencies of the one-pair-in-flight pass after the timed region
+    iso_serial = []  # the same with the engine's latency mode off
 
     def one_step(eng, slot, first, rec, lat_out, prof_out, events_every, n_workers):
         """One step of the hot path on the worker thread / stream the pipeline hands it to."""
@@ -335,7 +336,7 @@ def main():
         if rec is not None:
             rre, rte = pose_error(T, pairs[pid][2])
             rec[slot] = torch.tensor([pid, rre, rte, n_corr, rank + i * world])
-        if rec is not None or lat_out is iso_lat:
+        if rec is not None or lat_out is iso_lat or lat_out is iso_serial:
             lat_out.append((time.perf_counter() - ts) * 1e3)
 
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
@@ -524,11 +525,23 @@ def main():
     # With several pairs in flight the event-bracketed durations above include the time a KPConv kernel
     # shares the CUs with other pairs' kernels.  A short single-stream pass after the timed region gives the
     # same kernels' durations when they own the GPU (reported beside, never instead of, the timed-region figure).
+    # Two passes: the roofline pass (HIP events around every KPConv layer of every pair, latency mode off so that the kernels
+    # really have the GPU to themselves) and the latency pass (no events -- 42 event records cost a pair 0.2-0.3 ms -- and the
+    # engine as a user with one pair in flight gets it: latency mode on, rdm_engine_set_overlap).
     iso_prof = []
     if args.path == 'engine':
-        engines[0].set_pairs_in_flight(1)  # (this pass IS one pair in flight: no GEMM residency cap)
-        for k in range(min(8, args.steps)):  # on the calling thread's current stream
-            one_step(engines[0], k, args.warmup, None, iso_lat, iso_prof, 1, 1)
+        engines[0].set_pairs_in_flight(1)  # (these passes ARE one pair in flight: no GEMM residency cap)
+        with torch.cuda.stream(streams[0] if streams[0] is not None else torch.cuda.Stream()):  # (never the null stream)
+            engines[0].set_overlap(0)
+            for k in range(min(8, args.steps)):
+                one_step(engines[0], k, args.warmup, None, [], iso_prof, 1, 1)
+            for k in range(min(16, args.steps)):  # serial, no events: the figure comparable with earlier rounds' (minus their events)
+                one_step(engines[0], k, args.warmup, None, iso_serial, None, 0, 1)
+            engines[0].set_overlap(1)
+            for k in range(min(4, args.steps)):  # (the first latency-mode run picks the side stream)
+                one_step(engines[0], k, args.warmup, None, [], None, 0, 1)
+            for k in range(min(24, args.steps)):
+                one_step(engines[0], k, args.warmup, None, iso_lat, None, 0, 1)
         engines[0].set_pairs_in_flight(args.streams)
         fence()
     for rec in iso_prof:
@@ -610,7 +623,10 @@ def main():
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'one_pair_in_flight': ({'p50_ms_per_pair': float(np.median(iso_lat)), 'pairs': len(iso_lat),
-                                    'note': 'latency with the GPU to one pair: 8 pairs on one stream after the timed region, per-layer HIP events on'}
+                                    'serial_p50_ms_per_pair': float(np.median(iso_serial)) if iso_serial else None,
+                                    'note': 'latency with the GPU to one pair: 24 pairs on one stream after the timed region, no HIP events, '
+                                            'the engine in its latency mode (rdm_engine_set_overlap, the default with one pair in flight); '
+                                            'serial_p50 = the same with that mode off (16 pairs)'}
                                    if iso_lat else None),
             'mean_ms_per_pair_by_quarter': [float(np.mean(q)) for q in np.array_split(np.asarray(lat), 4)] if len(lat) >= 4 else None,
             'registration': {**sharding.summarize(gathered), 'note': 'random-init weights: accuracy is not meaningful'},

@@ -510,6 +510,16 @@ int rdm_engine_set_wait(rdm_engine* e, int sleep_us);
  * not depend on it: from 3 the tiled GEMM leaves half of a CU's registers and LDS to the other pairs' kernels (two workgroups
  * per CU instead of four: +3 % pairs/s at four in flight, -2 % with one pair alone).                            */
 int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n);
+/* Latency mode.  With one pair in flight most of the GPU idles while chains of one-workgroup kernels run, so the engine runs the
+ * wide, independent parts of a pair -- the first level's grid, neighbour search and encoder blocks beside the subsampling of the
+ * deeper levels; the decoder beside the second transformer / grouping / coarse-matching chain -- on a side stream of its own
+ * (created on first use) and joins them by host waits next to read-backs the run performs anyway.  Same kernels on the same
+ * operands: results are bit-identical in every mode.  mode: 0 = never, 1 = when pairs_in_flight == 1 (default), 2 = always.
+ * Not used when `stream` is the null stream; the first half only when `stream` is idle at the call.  The side stream must lie on
+ * another hardware pipe than `stream` (two queues of one pipe are served in turns); the engine finds that out with a pair of 60 us
+ * spin kernels the first time it sees a caller stream (a few hundred microseconds, once) and stays serial where no such stream exists.
+ * The reference has no counterpart (its loop is synchronous: geotransformer/engine/single_tester.py:86-134).                    */
+int rdm_engine_set_overlap(rdm_engine* e, int mode);
 int rdm_engine_enable_profile(rdm_engine* e, int enable);
 int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);

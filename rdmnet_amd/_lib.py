@@ -121,6 +121,7 @@ SIGNATURES = {
     'rdm_engine_forward': (c_int, [c_void, c_void, c_void, c_void]),
     'rdm_engine_set_wait': (c_int, [c_void, c_int]),
     'rdm_engine_set_pairs_in_flight': (c_int, [c_void, c_int]),
+    'rdm_engine_set_overlap': (c_int, [c_void, c_int]),
     'rdm_engine_enable_profile': (c_int, [c_void, c_int]),
     'rdm_engine_get_profile': (c_int, [c_void, c_void, c_int]),
     'rdm_engine_keep_taps': (c_int, [c_void, c_int]),

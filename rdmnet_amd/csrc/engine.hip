@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -85,6 +86,12 @@ struct rdm_engine {
   bool keep_taps = false;
   bool collate_only = false;  // rdm_engine_collate: stop after the pyramid and its searches
   int pairs_in_flight = 1;    // rdm_engine_set_pairs_in_flight: how many pairs share the GPU (>= 3: GEMM residency capped)
+  // Latency mode (rdm_engine_set_overlap): with ONE pair in flight most of the GPU idles while a chain of one-workgroup kernels
+  // runs, so the engine runs the wide, independent parts of a pair (the first level's search + blocks, the decoder) on a side
+  // stream of its own and joins them where their results are needed.  Same kernels, same operands: same bits.
+  int overlap_mode = 1;       // 0: never, 1: when pairs_in_flight == 1, 2: always
+  hipStream_t side = nullptr;
+  std::map<hipStream_t, bool> side_ok;  // caller stream -> the side stream runs beside it (see ensure_side)
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -548,22 +555,87 @@ int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
 
 // Wait for the engine's stream at a size read-back.  The runtime's synchronize busy-waits: with several pairs in
 // flight per GPU and 8 ranks per node that is 32 spinning cores; hosts with a small CPU quota poll instead.
-int wait_stream(Run& r) {
-  if (r.e->wait_sleep_us <= 0) {
-    RDM_HIP_CHECK(hipStreamSynchronize(r.st));
+int wait_on(rdm_engine* e, hipStream_t st) {
+  if (e->wait_sleep_us <= 0) {
+    RDM_HIP_CHECK(hipStreamSynchronize(st));
     return RDM_OK;
   }
   for (;;) {
-    const hipError_t q = hipStreamQuery(r.st);
+    const hipError_t q = hipStreamQuery(st);
     if (q == hipSuccess) return RDM_OK;
     if (q != hipErrorNotReady) {
       set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
       return RDM_ERR_HIP;
     }
-    timespec ts{0, static_cast<long>(r.e->wait_sleep_us) * 1000};
+    timespec ts{0, static_cast<long>(e->wait_sleep_us) * 1000};
     nanosleep(&ts, nullptr);
   }
 }
+int wait_stream(Run& r) { return wait_on(r.e, r.st); }
+
+// The engine's side stream (latency mode).  Measured and dropped (tools/overlap_probe.py): a CU mask that keeps the side stream's
+// wide launches off every n-th CU, and a second masked stream for the chains beside it -- the one-workgroup kernels slow down
+// by a third whenever the rest of the GPU is busy, whichever CUs they run on.
+// The side stream has to sit on another hardware pipe than the caller's stream: the runtime hands its hardware queues to the chip's
+// four compute pipes in creation order, and two queues of one pipe are served in turns -- their kernels never run side by side
+// (a process with four worker streams puts the sixth queue on the pipe of the second: measured, tools/overlap_probe.py).  There
+// is no query for that, so the engine tries it: two 60 us spin kernels, one per stream, take 60 us together or 120.
+__global__ void spin_kernel(long long ticks) {  // 100 MHz wall clock
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+  }
+}
+bool runs_beside(hipStream_t a, hipStream_t b) {
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 6000ll);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 6000ll);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return best < 100.0;  // (60 us + launch and wake-up when concurrent, 120+ when serialised)
+}
+// -> whether latency mode can be used with `st` as the caller's stream (decided once per caller stream and engine)
+int ensure_side(rdm_engine* e, hipStream_t st, bool* usable) {
+  auto known = e->side_ok.find(st);
+  if (known != e->side_ok.end()) {
+    *usable = known->second;
+    return RDM_OK;
+  }
+  if (e->side_ok.size() >= 64) e->side_ok.clear();  // (a caller that keeps creating streams)
+  if (e->side && runs_beside(st, e->side)) {
+    *usable = e->side_ok[st] = true;
+    return RDM_OK;
+  }
+  bool have_user = false;  // is the present side stream already serving another caller stream?
+  for (const auto& kv : e->side_ok) have_user |= kv.second;
+  if (have_user) {
+    *usable = e->side_ok[st] = false;
+    return RDM_OK;
+  }
+  std::vector<hipStream_t> rejected;
+  if (e->side) rejected.push_back(e->side);
+  e->side = nullptr;
+  for (int attempt = 0; attempt < 6 && !e->side; ++attempt) {
+    hipStream_t cand = nullptr;
+    RDM_HIP_CHECK(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+    if (runs_beside(st, cand)) e->side = cand;
+    else rejected.push_back(cand);
+  }
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);  // (only now: a destroyed stream's queue would be handed out again)
+  *usable = e->side_ok[st] = e->side != nullptr;
+  return RDM_OK;
+}
+// A run that returns early (an error between fork and join) must not leave side-stream work behind: the next run reuses the arena.
+struct SideGuard {
+  rdm_engine* e;
+  int pending = 0;
+  ~SideGuard() {
+    if (pending > 0 && e->side) (void)hipStreamSynchronize(e->side);
+  }
+};
 
 int d2h(Run& r, const void* dev, size_t bytes, void* host_dst) {
   // a kernel stores straight into the mapped pinned buffer (no runtime copy operation on the stream)
@@ -612,6 +684,10 @@ extern "C" void rdm_engine_destroy(rdm_engine* e) {
   if (!e) return;
   e->params.reset();  // (the device parameters go with the LAST engine that uses them)
   for (auto& ev : e->events) (void)hipEventDestroy(ev);
+  if (e->side) {
+    (void)hipStreamSynchronize(e->side);
+    (void)hipStreamDestroy(e->side);
+  }
   if (e->arena) (void)hipFree(e->arena);
   if (e->pinned) (void)hipHostFree(e->pinned);
   delete e;
@@ -777,6 +853,12 @@ extern "C" int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n) {
   return RDM_OK;
 }
 
+extern "C" int rdm_engine_set_overlap(rdm_engine* e, int mode) {
+  RDM_REQUIRE(e && mode >= 0 && mode <= 2, "rdm_engine_set_overlap: bad arguments");
+  e->overlap_mode = mode;
+  return RDM_OK;
+}
+
 extern "C" int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap) {
   RDM_REQUIRE(e && out && cap >= 0, "rdm_engine_get_profile: bad arguments");
   const int n = std::min<int>(cap, static_cast<int>(e->prof.size()));
@@ -885,6 +967,10 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   Run r;
   r.e = e; r.st = static_cast<hipStream_t>(stream); r.groups = c.group_norm;
   const int64_t n0 = n_ref + n_src;
+  // latency mode (see rdm_engine::overlap_mode); never on the legacy null stream, which every other blocking stream serialises with
+  bool overlap = !e->collate_only && r.st != nullptr && (e->overlap_mode == 2 || (e->overlap_mode == 1 && e->pairs_in_flight == 1));
+  if (overlap) ENG_CHECK(ensure_side(e, r.st, &overlap));
+  SideGuard side_guard{e};
   // kernel scratch: the largest consumers are the grid-subsample tables and split-K partials
   r.ws_bytes = std::max<size_t>(rdm_grid_subsample_workspace_bytes(n0, 2),
                                 std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(96) << 20));
@@ -896,7 +982,19 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   Table nb[5], sub[4], up[4];
   int32_t* flags = e->alloc<int32_t>(64);
   ENG_ALLOC(flags);
-  fill_words<int32_t>(flags, 64, 0, r.st);
+  // Latency mode, first half: the caller's stream runs the subsampling of levels 1-4 (a chain of one- and two-workgroup kernels,
+  // ~0.4 ms) while the side stream builds the first level's grid, searches its neighbours and runs the encoder's first two
+  // blocks (wide launches that need nothing but level 0).  No device-side dependency: taken only when the caller's stream is
+  // idle at the call (the inputs are then complete), and joined by a host wait next to the read-back of the level sizes.
+  const bool overlap_l0 = overlap && !dd && hipStreamQuery(r.st) == hipSuccess;
+  Run rs = r;  // the side stream's launches of the first level
+  if (overlap_l0) {
+    rs.st = e->side;
+    rs.ws_bytes = std::max<size_t>(size_t(96) << 20, rdm_linear_group_norm_workspace_bytes(n0, 128));
+    rs.ws = e->alloc<char>(rs.ws_bytes);
+    ENG_ALLOC(rs.ws);
+  }
+  fill_words<int32_t>(flags, 64, 0, overlap_l0 ? rs.st : r.st);  // (the first searches write their status rows on that stream)
   int call = 0;
   struct Grid { void* ws; size_t bytes; int64_t n_s; };
   Grid grids[5] = {};
@@ -909,7 +1007,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(g.ws);
     return rdm_radius_grid_build(s.pts, s.n, s.lengths, 2, rad, g.ws, g.bytes, r.st);
   };
-  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t, bool i32 = false) -> int {
+  auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t, bool i32 = false, void* queue = nullptr,
+                    hipStream_t qst = nullptr) -> int {
     t.rows = q.n; t.width = limit; t.flags = flags + 2 * call++;
     t.i32 = i32;
     t.idx = reinterpret_cast<int64_t*>(e->alloc<char>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit * (i32 ? 4 : 8)));
@@ -919,11 +1018,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
     ENG_ALLOC(redo_flags);
     return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
-                                      t.flags + 1, redo_flags, redo_queue.data(), r.st);
+                                      t.flags + 1, redo_flags, queue ? queue : redo_queue.data(), qst ? qst : r.st);
   };
   // the five level grids with one set of launches (radius r_i = 2^i r_0): they serve the searches of the collate and, through
   // their cell-sorted records, the spatial query order of the KPConv kernels and the shortcut pools
-  auto build_level_grids = [&]() -> int {
+  auto build_level_grids = [&](int first = 0, int last = 5, hipStream_t gst = nullptr) -> int {  // levels [first, last)
     const float* gp[5];
     int64_t gn[5];
     const int64_t* gl[5];
@@ -931,15 +1030,82 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     void* gw[5];
     size_t gb[5];
     float rad = c.init_radius;
-    for (int i = 0; i < 5; ++i, rad *= 2.f) {
+    int k = 0;
+    for (int i = 0; i < last; ++i, rad *= 2.f) {
+      if (i < first) continue;
       grids[i].n_s = lv[i].n;
       grids[i].bytes = rdm_radius_grid_workspace_bytes(lv[i].n);
       grids[i].ws = e->alloc<char>(grids[i].bytes);
       ENG_ALLOC(grids[i].ws);
-      gp[i] = lv[i].pts; gn[i] = lv[i].n; gl[i] = lv[i].lengths; gr[i] = rad; gw[i] = grids[i].ws; gb[i] = grids[i].bytes;
+      gp[k] = lv[i].pts; gn[k] = lv[i].n; gl[k] = lv[i].lengths; gr[k] = rad; gw[k] = grids[i].ws; gb[k] = grids[i].bytes;
+      ++k;
     }
     RDM_DUP_LOOP("rnbuild")
-    ENG_CHECK(radius_grid_build_multi(5, gp, gn, gl, 2, gr, gw, gb, r.st));
+    ENG_CHECK(radius_grid_build_multi(k, gp, gn, gl, 2, gr, gw, gb, gst ? gst : r.st));
+    return RDM_OK;
+  };
+  // ---------------------------------------------------------------- encoder (backbone.py:72-107), as two callables: the
+  // latency mode runs the input and the first two blocks on the side stream while the deeper levels are still being subsampled
+  Mat x;
+  uint8_t* x_pos = nullptr;
+  Mat feats[5];
+  int fi = 0;
+  auto encoder_input = [&](Run& rr) -> int {
+    if (dd) {  // data_dict['features'] (model_infer.py:113), [N0, 1]
+      x.p = const_cast<float*>(dd->features); x.rows = n0; x.cols = 1; x.ld = dd->features_ld;
+    } else {
+      x = e->mat(n0, 1);
+      ENG_ALLOC(x.p);
+    }
+    x_pos = e->alloc<uint8_t>(n0);
+    ENG_ALLOC(x_pos);
+    if (dd) ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, rr.st));
+    else ENG_CHECK(launch1d("unit_features", unit_features_kernel, n0, rr.st, x.p, n0, x.ld, x_pos));
+    return RDM_OK;
+  };
+  auto encoder_blocks = [&](Run& rr, int b0, int b1) -> int {
+    const char* names[14] = {"encoder1_1", "encoder1_2", "encoder2_1", "encoder2_2", "encoder2_3", "encoder3_1", "encoder3_2",
+                             "encoder3_3", "encoder4_1", "encoder4_2", "encoder4_3", "encoder5_1", "encoder5_2", "encoder5_3"};
+    const int level[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
+    const bool strided[14] = {false, false, true, false, false, true, false, false, true, false, false, true, false, false};
+    for (int b = b0; b < b1; ++b) {
+      const std::string name = std::string("encoder.") + names[b];
+      const int lvl = level[b];
+      const Level& s = lv[lvl];
+      const Level& q = strided[b] ? lv[lvl + 1] : lv[lvl];
+      const Table& t = strided[b] ? sub[lvl] : nb[lvl];
+      const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
+      // visit the queries in the cell order of their level's search grid: neighbouring queries share most
+      // neighbours, so gathered lines are re-used from L1 (results do not depend on the order)
+      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];
+      const float* order = qg.ws ? rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s) : nullptr;
+      Mat y;
+      if (b == 0) {
+        ENG_CHECK(kpconv(rr, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y, order));
+      } else {
+        Mat h = x;
+        uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
+        ENG_ALLOC(h_pos);
+        if (e->params->lin.count(name + ".unary1.mlp")) {
+          ENG_CHECK(unary(rr, name + ".unary1", x, h, 2, nullptr, h_pos));
+        } else {
+          ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, rr.st));
+        }
+        Mat cn;
+        Mat sc = x;
+        ENG_CHECK(kpconv(rr, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, order,
+                         strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
+        if (e->params->lin.count(name + ".unary_shortcut.mlp")) {
+          Mat s2;
+          ENG_CHECK(unary(rr, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));
+          sc = s2;
+        }
+        ENG_CHECK(unary(rr, name + ".unary2", cn, y, 2, &sc, nullptr));
+      }
+      x = y;
+      tap(r, name.c_str(), x);
+      if (b == 1 || b == 4 || b == 7 || b == 10 || b == 13) feats[fi++] = x;
+    }
     return RDM_OK;
   };
   if (dd) {
@@ -974,45 +1140,6 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     }
   } else {
   // ---------------------------------------------------------------- collate (data.py:13-77)
-  lv[0].n = n0; lv[0].n_ref = n_ref;
-  lv[0].pts = e->alloc<float>(3 * n0);
-  lv[0].lengths = e->alloc<int64_t>(2);
-  ENG_ALLOC(lv[0].pts); ENG_ALLOC(lv[0].lengths);
-  ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, r.st, ref_points, n_ref, src_points, n_src, lv[0].pts,
-                     lv[0].lengths));
-  int64_t* all_len = e->alloc<int64_t>(8);  // device lengths of levels 1..4, contiguous for one read-back
-  ENG_ALLOC(all_len);
-  float voxel = c.init_voxel_size;
-  int64_t cap = n0;
-  // levels whose subsampling runs as the multi-launch pipeline (RDM_GS_MULTI_LEVELS, developer knob; default: the first)
-  static const int gs_multi_levels = [] { const char* v = ::rdm::dev_knob("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
-  for (int i = 1; i < 5; ++i) {
-    voxel *= 2.f;  // data.py:23-28
-    lv[i].pts = e->alloc<float>(3 * cap);
-    lv[i].lengths = all_len + 2 * (i - 1);
-    ENG_ALLOC(lv[i].pts);
-    // level 0 -> 1 (16-20 k points per cloud): phases spread over the GPU when the clouds are large; the later levels run at
-    // capacity `cap` with a few thousand real points: the single-workgroup kernel
-    RDM_DUP_LOOP("gs")
-    ENG_CHECK(grid_subsample_mode(lv[i - 1].pts, cap, lv[i - 1].lengths, 2, voxel, lv[i].pts, lv[i].lengths, r.ws, r.ws_bytes,
-                                  r.st, i <= gs_multi_levels ? 2 : 1));
-    // capacity of the next level is unknown on the host until the read-back; run it at full capacity
-  }
-  int64_t host_len[8];
-  // NOTE: each level was subsampled with n_points = cap (capacity): rows beyond the true count are
-  // never read because the kernels walk `lengths`.
-  ENG_CHECK(d2h(r, all_len, sizeof(host_len), host_len));
-  for (int i = 1; i < 5; ++i) {
-    lv[i].n_ref = host_len[2 * (i - 1)];
-    lv[i].n = host_len[2 * (i - 1)] + host_len[2 * (i - 1) + 1];
-    res->level_sizes[i] = lv[i].n;
-    res->level_ref_sizes[i] = lv[i].n_ref;
-  }
-  res->level_sizes[0] = n0;
-  res->level_ref_sizes[0] = n_ref;
-
-  float radius = c.init_radius;
-  ENG_CHECK(build_level_grids());
   // The forward consumes column 0 of upsampling[1..3] only (nearest_upsample, functional.py:6-22) and upsampling[0] not at all
   // (backbone.py:118-151 stops at the second level): a plain run skips that search (32 000 queries, a quarter of all) and keeps one
   // column of the others; the collate API and runs that keep their stage tensors build the reference's full tables.
@@ -1024,8 +1151,73 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // (33 MB less written and 65 MB less read per pair; the int64 layout of the reference stays wherever a table leaves the
   // engine: stage tensors, rdm_engine_collate, rdm_engine_forward's data_dict)
   const bool i32 = !full_up;
+  lv[0].n = n0; lv[0].n_ref = n_ref;
+  lv[0].pts = e->alloc<float>(3 * n0);
+  lv[0].lengths = e->alloc<int64_t>(2);
+  ENG_ALLOC(lv[0].pts); ENG_ALLOC(lv[0].lengths);
+  // (latency mode: each stream stacks the clouds for itself -- lv[0] is the side stream's copy, which everything but the
+  // subsampling chain reads; that chain reads the caller's stream's own)
+  float* pts0 = lv[0].pts;
+  int64_t* len0 = lv[0].lengths;
+  if (overlap_l0) {
+    pts0 = e->alloc<float>(3 * n0);
+    len0 = e->alloc<int64_t>(2);
+    ENG_ALLOC(pts0); ENG_ALLOC(len0);
+  }
+  if (overlap_l0) side_guard.pending++;  // (from here to the join an early return waits for the side stream)
+  ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, r.st, ref_points, n_ref, src_points, n_src, pts0, len0));
+  int64_t* all_len = e->alloc<int64_t>(8);  // device lengths of levels 1..4, contiguous for one read-back
+  ENG_ALLOC(all_len);
+  float voxel = c.init_voxel_size;
+  int64_t cap = n0;
+  // levels whose subsampling runs as the multi-launch pipeline (RDM_GS_MULTI_LEVELS, developer knob; default: the first)
+  static const int gs_multi_levels = [] { const char* v = ::rdm::dev_knob("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
+  std::vector<char> side_queue(radius_redo_queue_bytes());
+  for (int i = 1; i < 5; ++i) {
+    voxel *= 2.f;  // data.py:23-28
+    lv[i].pts = e->alloc<float>(3 * cap);
+    lv[i].lengths = all_len + 2 * (i - 1);
+    ENG_ALLOC(lv[i].pts);
+    // level 0 -> 1 (16-20 k points per cloud): phases spread over the GPU when the clouds are large; the later levels run at
+    // capacity `cap` with a few thousand real points: the single-workgroup kernel
+    RDM_DUP_LOOP("gs")
+    ENG_CHECK(grid_subsample_mode(i == 1 ? pts0 : lv[i - 1].pts, cap, i == 1 ? len0 : lv[i - 1].lengths, 2, voxel, lv[i].pts,
+                                  lv[i].lengths, r.ws, r.ws_bytes, r.st, i <= gs_multi_levels ? 2 : 1));
+    // capacity of the next level is unknown on the host until the read-back; run it at full capacity
+    if (i == 1 && overlap_l0) {
+      // beside that chain, on the side stream: everything that needs level 0 only.  Enqueued between the chain's first level
+      // (0.18 ms of GPU time) and the rest, so that neither stream waits for the host to get to it.
+      ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, rs.st, ref_points, n_ref, src_points, n_src, lv[0].pts,
+                         lv[0].lengths));
+      ENG_CHECK(build_level_grids(0, 1, rs.st));
+      radius_redo_queue_reset(side_queue.data());
+      ENG_CHECK(search(lv[0], grids[0], c.init_radius, c.neighbor_limits[0], nb[0], i32, side_queue.data(), rs.st));
+      ENG_CHECK(radius_redo_flush(side_queue.data(), rs.st));
+      ENG_CHECK(encoder_input(rs));
+      ENG_CHECK(encoder_blocks(rs, 0, 2));
+    }
+  }
+  int64_t host_len[8];
+  // NOTE: each level was subsampled with n_points = cap (capacity): rows beyond the true count are
+  // never read because the kernels walk `lengths`.
+  ENG_CHECK(d2h(r, all_len, sizeof(host_len), host_len));
+  if (overlap_l0) {  // host-side join (the caller's stream is idle here)
+    ENG_CHECK(wait_on(e, e->side));
+    side_guard.pending--;
+  }
+  for (int i = 1; i < 5; ++i) {
+    lv[i].n_ref = host_len[2 * (i - 1)];
+    lv[i].n = host_len[2 * (i - 1)] + host_len[2 * (i - 1) + 1];
+    res->level_sizes[i] = lv[i].n;
+    res->level_ref_sizes[i] = lv[i].n_ref;
+  }
+  res->level_sizes[0] = n0;
+  res->level_ref_sizes[0] = n_ref;
+
+  float radius = c.init_radius;
+  ENG_CHECK(build_level_grids(overlap_l0 ? 1 : 0, 5));
   for (int i = 0; i < 5; ++i) {
-    ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i], i32));
+    if (!(overlap_l0 && i == 0)) ENG_CHECK(search(lv[i], grids[i], radius, c.neighbor_limits[i], nb[i], i32));
     if (i < 4) ENG_CHECK(search(lv[i + 1], grids[i], radius, c.neighbor_limits[i], sub[i], i32));
     if (i > 0 && (full_up || i > 1)) ENG_CHECK(search(lv[i - 1], grids[i], radius, full_up ? c.neighbor_limits[i] : 1, up[i - 1]));
     radius *= 2.f;
@@ -1061,63 +1253,12 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     }
   }
 
-  // ---------------------------------------------------------------- encoder (backbone.py:72-107)
-  Mat x;
-  if (dd) {  // data_dict['features'] (model_infer.py:113), [N0, 1]
-    x.p = const_cast<float*>(dd->features); x.rows = n0; x.cols = 1; x.ld = dd->features_ld;
+  // ---------------------------------------------------------------- encoder (the callables above)
+  if (!overlap_l0) {
+    ENG_CHECK(encoder_input(r));
+    ENG_CHECK(encoder_blocks(r, 0, 14));
   } else {
-    x = e->mat(n0, 1);
-    ENG_ALLOC(x.p);
-  }
-  uint8_t* x_pos = e->alloc<uint8_t>(n0);
-  ENG_ALLOC(x_pos);
-  if (dd) ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, r.st));
-  else ENG_CHECK(launch1d("unit_features", unit_features_kernel, n0, r.st, x.p, n0, x.ld, x_pos));
-  Mat feats[5];
-  {
-    const char* names[14] = {"encoder1_1", "encoder1_2", "encoder2_1", "encoder2_2", "encoder2_3", "encoder3_1", "encoder3_2",
-                             "encoder3_3", "encoder4_1", "encoder4_2", "encoder4_3", "encoder5_1", "encoder5_2", "encoder5_3"};
-    const int level[14] = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4};
-    const bool strided[14] = {false, false, true, false, false, true, false, false, true, false, false, true, false, false};
-    int fi = 0;
-    for (int b = 0; b < 14; ++b) {
-      const std::string name = std::string("encoder.") + names[b];
-      const int lvl = level[b];
-      const Level& s = lv[lvl];
-      const Level& q = strided[b] ? lv[lvl + 1] : lv[lvl];
-      const Table& t = strided[b] ? sub[lvl] : nb[lvl];
-      const float sigma = c.init_sigma * static_cast<float>(1 << lvl);
-      // visit the queries in the cell order of their level's search grid: neighbouring queries share most
-      // neighbours, so gathered lines are re-used from L1 (results do not depend on the order)
-      const Grid& qg = grids[strided[b] ? lvl + 1 : lvl];
-      const float* order = qg.ws ? rdm_radius_grid_records(qg.ws, qg.bytes, qg.n_s) : nullptr;
-      Mat y;
-      if (b == 0) {
-        ENG_CHECK(kpconv(r, name + ".KPConv", x, x_pos, q, s, t, sigma, name + ".norm", y, order));
-      } else {
-        Mat h = x;
-        uint8_t* h_pos = e->alloc<uint8_t>(x.rows > 0 ? x.rows : 1);
-        ENG_ALLOC(h_pos);
-        if (e->params->lin.count(name + ".unary1.mlp")) {
-          ENG_CHECK(unary(r, name + ".unary1", x, h, 2, nullptr, h_pos));
-        } else {
-          ENG_CHECK(rdm_row_positive(x.p, x.rows, x.cols, x.ld, h_pos, r.st));
-        }
-        Mat cn;
-        Mat sc = x;
-        ENG_CHECK(kpconv(r, name + ".KPConv", h, h_pos, q, s, t, sigma, name + ".norm_conv", cn, order,
-                         strided[b] ? &x : nullptr, strided[b] ? &sc : nullptr));
-        if (e->params->lin.count(name + ".unary_shortcut.mlp")) {
-          Mat s2;
-          ENG_CHECK(unary(r, name + ".unary_shortcut", sc, s2, 0, nullptr, nullptr));
-          sc = s2;
-        }
-        ENG_CHECK(unary(r, name + ".unary2", cn, y, 2, &sc, nullptr));
-      }
-      x = y;
-      tap(r, name.c_str(), x);
-      if (b == 1 || b == 4 || b == 7 || b == 10 || b == 13) feats[fi++] = x;
-    }
+    ENG_CHECK(encoder_blocks(r, 2, 14));  // (input and blocks 0-1 ran on the side stream beside the subsampling)
   }
   const int64_t Nc = lv[4].n, nc_ref = lv[4].n_ref, Nf = lv[1].n, nf_ref = lv[1].n_ref;
   const int64_t D = c.out_dim;  // 256
@@ -1140,20 +1281,36 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   tap(r, "n2p_scores", n2p, Nc, 1, 1, 0);
 
   // ---------------------------------------------------------------- decoder (backbone.py:118-151)
-  Mat dec;
-  {
+  // Latency mode: the three wide GEMMs of the decoder run on the side stream beside the chain of small launches of the second
+  // transformer, the grouping and the coarse matching (~80 launches of a few workgroups each).  Fork and join sit at read-backs
+  // the host performs anyway (the NMS survivor counts, the coarse matching's correspondence count): once the host has seen the
+  // caller's stream idle, the side stream needs no device-side dependency on it, and the join is a host wait on the side
+  // stream next to the one on the caller's stream -- a device-side event pair between two busy streams costs ~0.15 ms per
+  // pair here (tools/overlap_probe.py, tools/xsync_probe.hip), more than the overlap wins.
+  Mat dec, feats_f;
+  float* p2p = nullptr;
+  auto run_decoder = [&](Run& rd) -> int {
     const std::string n4 = "decoder.decoder4.norm.norm", n3 = "decoder.decoder3.norm.norm";
     Mat l4, l3;
-    ENG_CHECK(decoder_stage(r, "decoder.decoder4.mlp", &n4, buf_c, up[3].idx, up[3].stride(), feats[3], lv[3].n, l4));
-    ENG_CHECK(decoder_stage(r, "decoder.decoder3.mlp", &n3, l4, up[2].idx, up[2].stride(), feats[2], lv[2].n, l3));
-    ENG_CHECK(decoder_stage(r, "decoder.decoder2.mlp", nullptr, l3, up[1].idx, up[1].stride(), feats[1], lv[1].n, dec));
-  }
-  tap(r, "decoder", dec);
-  Mat feats_f = dec.cols_from(0, D);
-  float* p2p = e->alloc<float>(Nf);
-  ENG_ALLOC(p2p);
-  ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, r.st));
-  tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
+    ENG_CHECK(decoder_stage(rd, "decoder.decoder4.mlp", &n4, buf_c, up[3].idx, up[3].stride(), feats[3], lv[3].n, l4));
+    ENG_CHECK(decoder_stage(rd, "decoder.decoder3.mlp", &n3, l4, up[2].idx, up[2].stride(), feats[2], lv[2].n, l3));
+    ENG_CHECK(decoder_stage(rd, "decoder.decoder2.mlp", nullptr, l3, up[1].idx, up[1].stride(), feats[1], lv[1].n, dec));
+    tap(r, "decoder", dec);
+    feats_f = dec.cols_from(0, D);
+    p2p = e->alloc<float>(Nf);
+    ENG_ALLOC(p2p);
+    ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, rd.st));
+    tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
+    return RDM_OK;
+  };
+  auto fork_decoder = [&]() -> int {  // call right after a host wait on the caller's stream
+    Run rd = r;
+    rd.st = e->side;
+    rd.ws = nullptr; rd.ws_bytes = 0;  // (decoder_stage then takes its scratch from the arena: r.ws belongs to the caller's stream)
+    side_guard.pending++;
+    return run_decoder(rd);
+  };
+  if (!overlap) ENG_CHECK(run_decoder(r));
 
   int64_t m_r = 0, m_s = 0, Mn = 0;
   float* nodes = nullptr;
@@ -1217,6 +1374,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       }
     m_r = host_flags[60]; m_s = host_flags[61]; Mn = m_r + m_s;
     RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
+    if (overlap) ENG_CHECK(fork_decoder());  // (the caller's stream is idle: everything the decoder reads is complete)
     nodes = e->alloc<float>(3 * Mn);
     ENG_ALLOC(nodes);
     Mat sel_feats = e->mat(Mn, D);
@@ -1254,6 +1412,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       }
     m_r = nc_ref; m_s = Nc - nc_ref; Mn = Nc;
     RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: a cloud has no superpoints");
+    if (overlap) ENG_CHECK(fork_decoder());
     nodes = const_cast<float*>(lv[4].pts);
     buf2 = x_c;
     tap(r, "nodes", nodes, Mn, 3, 3, 0);
@@ -1300,6 +1459,10 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   }
   int32_t tail[2];
   ENG_CHECK(d2h(r, flags + 62, sizeof(tail), tail));
+  if (overlap) {  // host-side join: the fine features are read from here on
+    ENG_CHECK(wait_on(e, e->side));
+    side_guard.pending--;
+  }
   if (tail[0] != 0) {
     set_error("rdm_engine_run: a superpoint owns more than 4096 points");
     return RDM_ERR_CAPACITY;

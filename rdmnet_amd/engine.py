@@ -132,6 +132,11 @@ class Engine:
         """Scheduling hint: how many pairs (engines / streams) share this GPU; from 3 the GEMM tiles keep two workgroups per CU."""
         _lib.check(self.L.rdm_engine_set_pairs_in_flight(self._h, int(n)), 'rdm_engine_set_pairs_in_flight')
 
+    def set_overlap(self, mode=1):
+        """Latency mode (rdm_engine_set_overlap): 0 = never run parts of a pair on the engine's side stream, 1 = when one pair is
+        in flight (default), 2 = always.  Results are bit-identical in every mode; not used on the null stream."""
+        _lib.check(self.L.rdm_engine_set_overlap(self._h, int(mode)), 'rdm_engine_set_overlap')
+
     def enable_profile(self, enable=True):
         _lib.check(self.L.rdm_engine_enable_profile(self._h, int(enable)), 'rdm_engine_enable_profile')
 

@@ -12,7 +12,8 @@ else that has a stream of pairs:
     falls behind takes fewer; all drain together at the end of the input),
   * staggered starts: worker k draws its first job k x `stagger_ms` after worker 0, so the in-flight pairs do
     not walk through the same stages in phase (four serial subsampling kernels, then four encoders contending),
-  * `rdm_engine_set_pairs_in_flight(N)` (GEMM residency hint from three pairs up),
+  * `rdm_engine_set_pairs_in_flight(N)` (GEMM residency hint from three pairs up; with N = 1 the engine runs in its latency
+    mode instead: the wide, independent parts of the pair on a side stream, `Engine.set_overlap`),
   * waits at the engines' size read-backs by spinning (`hipStreamSynchronize`) when the process owns two host
     cores per in-flight pair, by polling with 50 us sleeps otherwise (`cpu_budget`),
   * one hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware
@@ -115,9 +116,8 @@ class PairPipeline:
         self.wait_us = choose_wait_us(self.n, local_world) if wait_us is None or wait_us < 0 else int(wait_us)
         if streams is not None:
             self.streams = list(streams)
-        else:  # a single pair in flight runs on the caller's current stream
-            self.streams = ([torch.cuda.Stream(device=self.device) for _ in range(self.n)]
-                            if self.n > 1 and self._gpu else [None] * self.n)
+        else:  # (also for a single pair in flight: the engine's latency mode does not work on the null stream)
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)] if self._gpu else [None] * self.n
         self.engines = list(engines) if engines is not None else []
         if len(self.engines) < self.n:
             with torch.cuda.device(self.device):

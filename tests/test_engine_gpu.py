@@ -131,6 +131,44 @@ def test_pairs_in_flight_hint_changes_no_bit(ctx):
         eng.set_pairs_in_flight(1)
 
 
+def test_latency_mode_changes_no_bit(ctx):
+    """rdm_engine_set_overlap: with one pair in flight the engine runs the first level's grid / search / encoder blocks beside the
+    subsampling of the deeper levels, and the decoder beside the second transformer and the coarse matching, on a side stream of
+    its own.  Same kernels on the same operands: every stage tensor, the pose and the correspondences are the bits of the serial
+    run -- also when the caller's stream is still busy producing the inputs (the first half then stays serial), repeatedly."""
+    eng = ctx['eng']
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    names = ['points1', 'points4', 'neighbors0', 'subsampling0', 'neighbors4', 'encoder.encoder1_1', 'encoder.encoder1_2',
+             'encoder.encoder2_1', 'encoder.encoder5_3', 't1', 'decoder', 'p2p_scores', 'vote_feats', 't2', 'feats_c',
+             'matching_scores', 'search_flags']
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(st):
+            eng.set_overlap(0)
+            eng.run(rp, sp)
+            base = {k: eng.tensor(k).clone() for k in names}
+            T0, c0 = eng.transform(), [x.copy() for x in eng.host_corr()]
+            eng.set_overlap(2)
+            for rep in range(3):
+                if rep == 2:  # inputs still being produced on the stream when the run starts
+                    big = torch.randn(4096, 4096, device='cuda')
+                    for _ in range(4):
+                        big = big @ big * 1e-3
+                    r2, s2 = rp + 0 * big[0, 0], sp + 0 * big[0, 0]
+                else:
+                    r2, s2 = rp, sp
+                eng.run(r2, s2)
+                assert np.array_equal(eng.transform(), T0) and all(np.array_equal(a, b) for a, b in zip(eng.host_corr(), c0))
+                for k in names:
+                    assert torch.equal(eng.tensor(k), base[k]), k
+        # the null stream: latency mode is skipped (every blocking stream serialises with it), results as ever
+        eng.run(rp, sp)
+        assert np.array_equal(eng.transform(), T0)
+    finally:
+        eng.set_overlap(1)
+
+
 def test_full_size_pair_properties(ctx, golden_dir):
     """BASELINE-size workload (2 x 16k points): the engine equals the per-op mirror bit for bit, the pose
     is a proper rigid transform, correspondences are points of the fine level, neighbour tables are
