@@ -407,6 +407,23 @@ def test_model_forward_is_the_native_call_and_equals_engine_and_per_op_paths(ctx
         assert torch.equal(rc, out['ref_corr_points']) and torch.equal(cs, out['corr_scores'])
 
 
+def test_model_forward_in_latency_mode_changes_no_bit(ctx):
+    """model(data_dict) on a stream of the caller's (not the null stream) with one pair in flight runs its decoder on the engine's
+    side stream (rdm_engine_set_overlap, the default): all 31 outputs are the bits of the null-stream call."""
+    cfg, net = ctx['cfg'], ctx['net']
+    data = ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], cfg)
+    base = {k: v.clone() for k, v in net(data).items()}
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            out = net(data)
+            st.synchronize()
+            assert set(out) == set(base)
+            for k in out:
+                assert torch.equal(out[k], base[k]), k
+
+
 def test_model_is_a_torch_module_with_the_reference_checkpoint_layout(ctx):
     """nn.Module surface the reference's harness uses (engine/base_tester.py:97-113): strict load_state_dict with the 497
     checkpoint keys, .parameters(), .to(), .eval(); a wrong shape or a missing key raises RuntimeError."""
