@@ -11,6 +11,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_split_lab.hip -Lrdmnet_amd -lrdmnet_hip -Wl,-rpath,'$ORIGIN/../../rdmnet_amd' -o tools/bin/gemm_split_lab
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -276,6 +277,37 @@ int main(int argc, char** argv) {
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
       return ms * 1e3f / 20;
     };
+    if (argc > 1 && atoi(argv[1]) > 1) {
+      // the regime the path runs in: S products of this shape in flight on S streams (the runtime puts them on S hardware pipes);
+      // reported: wall time per product with S in flight (= 1 / aggregate rate), each form on its own buffers
+      const int S = atoi(argv[1]);
+      std::vector<hipStream_t> sts(S);
+      std::vector<float*> cs(S);
+      std::vector<void*> wss(S);
+      for (int i = 0; i < S; ++i) {
+        (void)hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking);
+        (void)hipMalloc(&cs[i], size_t(M) * N * 4);
+        (void)hipMalloc(&wss[i], wsb);
+      }
+      auto time_s = [&](auto fn) {
+        for (int i = 0; i < 3 * S; ++i) fn(i % S);
+        (void)hipDeviceSynchronize();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < 40 * S; ++i) fn(i % S);
+        (void)hipDeviceSynchronize();
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (40.0 * S);
+      };
+      const double a_ref = time_s([&](int i) { rdm_gemm(dA, K, 0, dB, N, 0, 0, cs[i], N, 0, M, N, K, 1, nullptr, nullptr, 0, wss[i], wsb, sts[i]); });
+      const double a6 = time_s([&](int i) { SplitArgs gi = g; gi.C = cs[i]; hipLaunchKernelGGL(gemm_split_kernel<6>, grid, dim3(256), 0, sts[i], gi); });
+      const double a6d = time_s([&](int i) { SplitArgs gi = g; gi.C = cs[i]; hipLaunchKernelGGL(gemm_split_direct_kernel<6>, grid, dim3(256), 0, sts[i], gi); });
+      const double flop = 2.0 * M * K * N;
+      printf("| %d x %d x %d (%s) | %d in flight: fp32 %.1f us (%.0f TF) | x6 LDS %.1f us (%.0f TF) | x6 direct %.1f us (%.0f TF) | %.2f |\n", M, K, N, s.what, S, a_ref,
+             flop / a_ref / 1e6, a6, flop / a6 / 1e6, a6d, flop / a6d / 1e6, a_ref / fmin(a6, a6d));
+      fflush(stdout);
+      for (int i = 0; i < S; ++i) { (void)hipStreamDestroy(sts[i]); (void)hipFree(cs[i]); (void)hipFree(wss[i]); }
+      (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dC2); (void)hipFree(dBT); (void)hipFree(ws);
+      continue;
+    }
     const float t_ref = time_it([&] { rdm_gemm(dA, K, 0, dB, N, 0, 0, dC, N, 0, M, N, K, 1, nullptr, nullptr, 0, ws, wsb, nullptr); });
     const float t6 = time_it([&] { hipLaunchKernelGGL(gemm_split_kernel<6>, grid, dim3(256), 0, 0, g); });
     const float t6d = time_it([&] { hipLaunchKernelGGL(gemm_split_direct_kernel<6>, grid, dim3(256), 0, 0, g); });
