@@ -220,6 +220,13 @@ size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c);
 int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx, int groups, const float* gamma,
                    const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y,
                    int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
+/* The same with the launch structure chosen by the caller (tests, A/B runs): form 0 = the library's choice -- up to 4 096 rows with
+ * whole 64-column slabs, finalize and apply are ONE launch (every workgroup recomputes the scale / shift of its slab from the few
+ * dozen partial rows: one dependent launch less on a pair's critical path, same bits) --, form 1 = statistics, finalize and apply
+ * as separate launches everywhere.  Applies to this call only.                                                                 */
+int rdm_group_norm_form(const float* x, int64_t n, int64_t c, int64_t ldx, int groups, const float* gamma,
+                        const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y, int64_t ldy,
+                        uint8_t* positive, void* ws, size_t ws_bytes, int form, void* stream);
 /* rdm_linear_group_norm: y = act(GroupNorm(x W + bias [/ rowdiv]) [+ residual]) -- UnaryBlock / the
  * KPConv weight contraction + norm_conv (modules/kpconv/modules.py:53-83, 196-207): the GEMM epilogue
  * emits the GroupNorm statistics, saving a pass over the activations.  lin_out [m, n] is scratch for

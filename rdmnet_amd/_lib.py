@@ -65,6 +65,8 @@ SIGNATURES = {
     'rdm_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_group_norm': (c_int, [c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_f32, c_void, c_i64, c_int,
                                c_void, c_i64, c_void, c_void, c_size, c_void]),
+    'rdm_group_norm_form': (c_int, [c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void, c_f32, c_void, c_i64, c_int,
+                                    c_void, c_i64, c_void, c_void, c_size, c_int, c_void]),
     'rdm_linear_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_linear_group_norm': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void,
                                       c_f32, c_void, c_i64, c_int, c_void, c_i64, c_void, c_i64, c_void, c_void, c_size, c_void]),

@@ -9,9 +9,12 @@ namespace rdm {
 namespace {
 thread_local char g_error[512] = "";
 thread_local bool g_index32 = false;
+thread_local int g_gn_form = 0;
 }
 bool index32() { return g_index32; }
 void set_index32(bool on) { g_index32 = on; }
+int gn_form() { return g_gn_form; }
+void set_gn_form(int form) { g_gn_form = form; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

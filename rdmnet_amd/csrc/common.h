@@ -35,6 +35,16 @@ struct Index32Scope {
   ~Index32Scope() { set_index32(before); }
 };
 
+// GroupNorm form of this thread's NEXT calls (rdm_group_norm_form, tests): 0 = the library's choice, 1 = statistics, finalize and
+// apply as separate launches everywhere.
+int gn_form();
+void set_gn_form(int form);
+struct GnFormScope {
+  int before;
+  explicit GnFormScope(int form) : before(gn_form()) { set_gn_form(form); }
+  ~GnFormScope() { set_gn_form(before); }
+};
+
 #define RDM_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \

@@ -57,15 +57,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, 
 // COLS = 64: the layout above.  COLS = 16 (64 lanes per column) for the fine levels, whose GEMMs leave hundreds of partial
 // rows for 32-128 columns: four times the workgroups and a quarter of the dependent load rounds per lane.  The per-column
 // sums differ between the two only in the (fixed) order of fp64 additions.
+// gn_scale_shift: the work of one such block (1024 threads, columns [col0, col0 + COLS)); the threads with lane == 0 return
+// their column's pair, the others zeros.  Shared by the finalize kernel and the one-launch finalize + apply form below, which
+// therefore produce the same scale / shift bits.
 template <int COLS>
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
-                                                            int c, int groups, const float* gamma,
-                                                            const float* beta, float eps, float* scale,
-                                                            float* shift) {
+struct GnFinalizeLds {
+  double sh[2][1024 / COLS][COLS];
+};
+template <int COLS>
+__device__ __forceinline__ float2 gn_scale_shift(GnFinalizeLds<COLS>& L, int col0, const double* partial, int nblk, int n, int c,
+                                                 int groups, const float* gamma, const float* beta, float eps) {
   constexpr int LANES = 1024 / COLS;
-  __shared__ double sh[2][LANES][COLS];
   const int ci = threadIdx.x % COLS, lane = threadIdx.x / COLS;
-  const int col = blockIdx.x * COLS + ci;
+  const int col = col0 + ci;
   double s = 0.0, ss = 0.0;
   if (col < c)
     for (int b0 = lane; b0 < nblk; b0 += 4 * LANES) {  // four partial rows in flight, added in ascending order
@@ -82,26 +86,27 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial
         ss += p1[u];
       }
     }
-  sh[0][lane][ci] = s;
-  sh[1][lane][ci] = ss;
+  L.sh[0][lane][ci] = s;
+  L.sh[1][lane][ci] = ss;
   __syncthreads();
   if (lane == 0) {
     double a = 0.0, b = 0.0;
     for (int k = 0; k < LANES; ++k) {
-      a += sh[0][k][ci];
-      b += sh[1][k][ci];
+      a += L.sh[0][k][ci];
+      b += L.sh[1][k][ci];
     }
-    sh[0][0][ci] = a;
-    sh[1][0][ci] = b;
+    L.sh[0][0][ci] = a;
+    L.sh[1][0][ci] = b;
   }
   __syncthreads();
+  float2 out = make_float2(0.f, 0.f);
   if (lane == 0 && col < c) {
     const int cpg = c / groups;
     const int g0 = (ci / cpg) * cpg;
     double gs = 0.0, gss = 0.0;
     for (int k = 0; k < cpg; ++k) {
-      gs += sh[0][0][g0 + k];
-      gss += sh[1][0][g0 + k];
+      gs += L.sh[0][0][g0 + k];
+      gss += L.sh[1][0][g0 + k];
     }
     const double cnt = static_cast<double>(n) * cpg;
     const double mean = gs / cnt;
@@ -109,8 +114,61 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + static_cast<double>(eps));
     const double gsc = rstd * static_cast<double>(gamma[col]);
-    scale[col] = static_cast<float>(gsc);
-    shift[col] = static_cast<float>(static_cast<double>(beta[col]) - mean * gsc);
+    out.x = static_cast<float>(gsc);
+    out.y = static_cast<float>(static_cast<double>(beta[col]) - mean * gsc);
+  }
+  return out;
+}
+template <int COLS>
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+                                                            int c, int groups, const float* gamma,
+                                                            const float* beta, float eps, float* scale,
+                                                            float* shift) {
+  __shared__ GnFinalizeLds<COLS> L;
+  const float2 v = gn_scale_shift<COLS>(L, blockIdx.x * COLS, partial, nblk, n, c, groups, gamma, beta, eps);
+  const int col = blockIdx.x * COLS + threadIdx.x % COLS;
+  if (threadIdx.x / COLS == 0 && col < c) {
+    scale[col] = v.x;
+    shift[col] = v.y;
+  }
+}
+
+// Finalize + apply in ONE launch for the coarse levels (a few thousand rows at most): workgroup (slab, chunk) computes the scale /
+// shift of its 64 columns exactly as gn_finalize_kernel<64> does (a few dozen partial rows: cheap enough to repeat per row chunk)
+// and applies them to 256 rows of that slab with gn_apply_wide_kernel's arithmetic -- same bits as the two launches, one
+// dependent launch (~4.5 us on a pair's critical path) less per GroupNorm.  No positive-row flag (a row spans several slabs).
+constexpr int kGnFusedRows = 256;
+__global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const double* partial, int nblk, const float* x, int n, int c, int ldx,
+                                                                  int groups, const float* gamma, const float* beta, float eps,
+                                                                  const float* res, int ldr, int act, float* y, int ldy) {
+  __shared__ GnFinalizeLds<64> L;
+  __shared__ float sc_l[64], sh_l[64];
+  const int col0 = blockIdx.x * 64;
+  const float2 v = gn_scale_shift<64>(L, col0, partial, nblk, n, c, groups, gamma, beta, eps);
+  if (threadIdx.x < 64) {  // (lane == 0: thread index = column within the slab)
+    sc_l[threadIdx.x] = v.x;
+    sh_l[threadIdx.x] = v.y;
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;  // 16 float4 per slab row, 64 rows per pass
+  const int col = col0 + 4 * q;
+  if (col >= c) return;
+  const float4 sc = *reinterpret_cast<const float4*>(sc_l + 4 * q), sh = *reinterpret_cast<const float4*>(sh_l + 4 * q);
+  const int r1 = min(n, (static_cast<int>(blockIdx.y) + 1) * kGnFusedRows);
+  for (int row = blockIdx.y * kGnFusedRows + rl; row < r1; row += 64) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(row) * ldx + col);
+    float o[4] = {__builtin_fmaf(xv.x, sc.x, sh.x), __builtin_fmaf(xv.y, sc.y, sh.y), __builtin_fmaf(xv.z, sc.z, sh.z),
+                  __builtin_fmaf(xv.w, sc.w, sh.w)};
+    if (res) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + static_cast<int64_t>(row) * ldr + col);
+      o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (act == 2) o[k] = o[k] > 0.f ? o[k] : 0.1f * o[k];
+      else if (act == 1) o[k] = o[k] > 0.f ? o[k] : 0.f;
+    }
+    *reinterpret_cast<float4*>(y + static_cast<int64_t>(row) * ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -153,7 +211,8 @@ __global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int 
   if (live) {
   const float4 xv = *reinterpret_cast<const float4*>(x + static_cast<int64_t>(row) * ldx + col);
   const float4 sc = *reinterpret_cast<const float4*>(scale + col), sh = *reinterpret_cast<const float4*>(shift + col);
-  float v[4] = {xv.x * sc.x + sh.x, xv.y * sc.y + sh.y, xv.z * sc.z + sh.z, xv.w * sc.w + sh.w};
+  float v[4] = {__builtin_fmaf(xv.x, sc.x, sh.x), __builtin_fmaf(xv.y, sc.y, sh.y), __builtin_fmaf(xv.z, sc.z, sh.z),
+                __builtin_fmaf(xv.w, sc.w, sh.w)};  // (what the compiler contracted x * scale + shift to since round 1)
   if (res) {
     const float4 rv = *reinterpret_cast<const float4*>(res + static_cast<int64_t>(row) * ldr + col);
     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
@@ -409,9 +468,21 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     use = partial;
     nblk = own_blk;
   }
+  const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+  static const bool fin64 = ::rdm::dev_knob("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
+  const bool narrow = !fin64 && nblk >= 128 && c / groups <= 16 && 16 % (c / groups) == 0;
+  // coarse levels: finalize + apply as one launch (see gn_finalize_apply_kernel); form 1 = always the separate launches
+  const int form = gn_form();
+  if (form != 1 && !narrow && !positive && vec_ok && c % 64 == 0 && n <= 4096) {
+    RDM_DUP_LOOP("gnfin")
+    hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(static_cast<unsigned>(c / 64), static_cast<unsigned>(ceil_div<int64_t>(n, kGnFusedRows))),
+                       dim3(1024), 0, st, use, nblk, x, static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), groups, gamma, beta,
+                       eps, residual, static_cast<int>(ldr), act, y, static_cast<int>(ldy));
+    return launch_status("gn_finalize_apply_kernel");
+  }
   {
-    static const bool fin64 = ::rdm::dev_knob("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
-    const bool narrow = !fin64 && nblk >= 128 && c / groups <= 16 && 16 % (c / groups) == 0;
     RDM_DUP_LOOP("gnfin")
     if (narrow)
       hipLaunchKernelGGL(gn_finalize_kernel<16>, dim3(ceil_div<int64_t>(c, 16)), dim3(1024), 0, st, use, nblk,
@@ -420,9 +491,6 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
     hipLaunchKernelGGL(gn_finalize_kernel<64>, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
                        static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
   }
-  const bool vec_ok = c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) &&
-                      (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
   // 16-byte accesses whenever the layout allows; with the positive-row flag only where a row lies inside one wavefront AND
   // gn_apply_kernel's summation tree can be reproduced (up to 128 columns: at most two values per lane there)
   static const bool narrow_rows = ::rdm::dev_knob("RDM_GN_APPLY_ROWS") != nullptr;  // developer knob (A/B): one wavefront per row below 256 columns
@@ -452,6 +520,14 @@ extern "C" int rdm_group_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
   if (n == 0) return RDM_OK;
   return group_norm_finish(nullptr, 0, x, n, c, ldx, groups, gamma, beta, eps, residual, ldr, act, y, ldy, positive, ws,
                            ws_bytes, stream);
+}
+
+extern "C" int rdm_group_norm_form(const float* x, int64_t n, int64_t c, int64_t ldx, int groups, const float* gamma,
+                                   const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y, int64_t ldy,
+                                   uint8_t* positive, void* ws, size_t ws_bytes, int form, void* stream) {
+  RDM_REQUIRE(form >= 0 && form <= 1, "rdm_group_norm_form: form must be 0 (the library's choice) or 1 (statistics, finalize, apply as three launches)");
+  rdm::GnFormScope scope(form);
+  return rdm_group_norm(x, n, c, ldx, groups, gamma, beta, eps, residual, ldr, act, y, ldy, positive, ws, ws_bytes, stream);
 }
 
 extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,

@@ -167,16 +167,17 @@ def kpconv_fused_group_norm(q_points, s_points, s_feats, s_positive, idx, kernel
     return y
 
 
-def group_norm(x, gamma, beta, groups, *, act=ACT_NONE, residual=None, want_positive=False, eps=1e-5):
+def group_norm(x, gamma, beta, groups, *, act=ACT_NONE, residual=None, want_positive=False, eps=1e-5, form=0):
+    """form: 0 = the library's launch structure (finalize + apply as one launch on the coarse levels), 1 = three launches."""
     L = _lib.lib()
     n, c = x.shape
     y = feat_empty(n, c, x.device)
     pos = torch.empty((max(n, 1),), dtype=torch.uint8, device=x.device) if want_positive else None
     ws_bytes = L.rdm_group_norm_workspace_bytes(n, c)
     ws = scratch(x.device, ws_bytes)
-    _lib.check(L.rdm_group_norm(x.data_ptr(), n, c, _ld(x), groups, gamma.data_ptr(), beta.data_ptr(), eps,
-                                _lib.ptr(residual), _ld(residual) if residual is not None else 0, act, y.data_ptr(),
-                                _ld(y), _lib.ptr(pos), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_group_norm')
+    _lib.check(L.rdm_group_norm_form(x.data_ptr(), n, c, _ld(x), groups, gamma.data_ptr(), beta.data_ptr(), eps,
+                                     _lib.ptr(residual), _ld(residual) if residual is not None else 0, act, y.data_ptr(),
+                                     _ld(y), _lib.ptr(pos), ws.data_ptr(), ws.numel(), int(form), _lib.stream_ptr()), 'rdm_group_norm')
     return (y, pos) if want_positive else y
 
 

@@ -211,6 +211,23 @@ def test_group_norm_matches_torch(ops, n, c):
     assert torch.equal(pos[:n].cpu().bool()[clear], (ref2.sum(1) > 0)[clear])
 
 
+@pytest.mark.parametrize('n,c', [(563, 2048), (563, 512), (1310, 1024), (1311, 256), (3879, 512), (4096, 128), (257, 64), (1, 64), (4097, 128)])
+def test_group_norm_one_launch_form_has_the_bits_of_the_three_launches(ops, n, c):
+    """On the coarse levels (up to 4 096 rows, whole 64-column slabs, no row flags) finalize and apply are one launch whose workgroups
+    recompute the scale / shift of their slab the way the finalize kernel does: same bits as the separate launches, with and without
+    residual and activation; and it matches torch's GroupNorm."""
+    g = torch.Generator().manual_seed(7 * n + c)
+    x, res = torch.randn(n, c, generator=g) * 2 - 0.5, torch.randn(n, c, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    xd, rd, gd, bd = padded(x), padded(res), gamma.cuda(), beta.cuda()
+    for act, r in ((ops.ACT_LEAKY, rd), (ops.ACT_NONE, None), (ops.ACT_RELU, rd)):
+        one = ops.group_norm(xd, gd, bd, 32, act=act, residual=r)
+        three = ops.group_norm(xd, gd, bd, 32, act=act, residual=r, form=1)
+        assert torch.equal(one, three)
+    ref = F.leaky_relu(F.group_norm(x.double().t()[None], 32, gamma.double(), beta.double(), 1e-5)[0].t() + res.double(), 0.1)
+    assert (ops.group_norm(xd, gd, bd, 32, act=ops.ACT_LEAKY, residual=rd).cpu().double() - ref).abs().max().item() <= 2e-5
+
+
 def test_layer_norm_matches_torch(ops):
     g = torch.Generator().manual_seed(5)
     for n, c in [(431, 128), (842, 512), (3, 256)]:
