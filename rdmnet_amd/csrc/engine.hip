@@ -14,6 +14,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -434,7 +435,10 @@ int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, M
 // are shared by both clouds (embedding, in/out projections, and in self layers the q|k|v projection,
 // rotary embedding and the whole tail) runs once on all rows; only the attention itself is per cloud.
 // Cross layers keep the reference's order: src attends to the UPDATED ref features (:244-245).
-int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out) {
+// `after_two` (optional) is called once two layers have been enqueued (latency mode: the host then has enough of a lead on the
+// caller's stream to enqueue the side stream's launches without stalling it).
+int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, int64_t n0, int num_layers, Mat out,
+                const std::function<int()>* after_two = nullptr) {
   rdm_engine* e = r.e;
   const int heads = e->cfg.num_heads;
   const int64_t N = x.rows, n1 = N - n0;
@@ -467,6 +471,7 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
       ENG_CHECK(attention_tail(r, p, hid.rows_from(n0, n1), f.rows_from(n0, n1), fnew.rows_from(n0, n1)));
     }
     f = fnew;
+    if (after_two && i == 1) ENG_CHECK((*after_two)());
   }
   return linear(r, name + ".out_proj", f, out, 0, false);
 }
@@ -1303,7 +1308,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
     return RDM_OK;
   };
-  auto fork_decoder = [&]() -> int {  // call right after a host wait on the caller's stream
+  auto fork_decoder = [&]() -> int {  // after a host wait on the caller's stream: what the decoder reads was complete then, and nothing enqueued since writes it
     Run rd = r;
     rd.st = e->side;
     rd.ws = nullptr; rd.ws_bytes = 0;  // (decoder_stage then takes its scratch from the arena: r.ws belongs to the caller's stream)
@@ -1374,7 +1379,6 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       }
     m_r = host_flags[60]; m_s = host_flags[61]; Mn = m_r + m_s;
     RDM_REQUIRE(m_r > 0 && m_s > 0, "rdm_engine_run: NMS left no superpoints");
-    if (overlap) ENG_CHECK(fork_decoder());  // (the caller's stream is idle: everything the decoder reads is complete)
     nodes = e->alloc<float>(3 * Mn);
     ENG_ALLOC(nodes);
     Mat sel_feats = e->mat(Mn, D);
@@ -1398,7 +1402,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     // ---------------------------------------------------------------- transformer #2, normalise
     buf2 = e->mat(Mn, D);
     ENG_ALLOC(buf2.p);
-    ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2));
+    // (latency mode: the decoder is forked once the first two layers are enqueued -- everything it reads was complete at the
+    // read-back above, and the host's 12 launches for it then do not hold up this chain)
+    const std::function<int()> fork = fork_decoder;
+    ENG_CHECK(thdroformer(r, "transformer2", nodes4, sel_feats, m_r, c.num_layers2, buf2, overlap ? &fork : nullptr));
+    if (overlap && 2 * c.num_layers2 < 2) ENG_CHECK(fork_decoder());
     tap(r, "t2", buf2);
   } else {
     // infer.py:119-120 (Mulran) switches the vote layer off and model_infer.py:179-246 then leaves the
