@@ -991,7 +991,13 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // ~0.4 ms) while the side stream builds the first level's grid, searches its neighbours and runs the encoder's first two
   // blocks (wide launches that need nothing but level 0).  No device-side dependency: taken only when the caller's stream is
   // idle at the call (the inputs are then complete), and joined by a host wait next to the read-back of the level sizes.
-  const bool overlap_l0 = overlap && !dd && hipStreamQuery(r.st) == hipSuccess;
+  bool overlap_l0 = false;
+  if (overlap && !dd) {  // (a hand-off event the caller just made the stream wait for -- dataset.PairStager -- takes it a few us)
+    const auto t_poll = std::chrono::steady_clock::now();
+    do {
+      overlap_l0 = hipStreamQuery(r.st) == hipSuccess;
+    } while (!overlap_l0 && std::chrono::steady_clock::now() - t_poll < std::chrono::microseconds(40));
+  }
   Run rs = r;  // the side stream's launches of the first level
   if (overlap_l0) {
     rs.st = e->side;

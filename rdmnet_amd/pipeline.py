@@ -162,6 +162,7 @@ class PairPipeline:
         def worker(k):
             stream = self.streams[k]
             import contextlib
+            torch.set_num_threads(1)  # this thread's CPU-side torch ops (small copies, metrics): no 128-thread OpenMP teams
             try:
                 with (torch.cuda.device(self.device) if self._gpu else contextlib.nullcontext()):
                     ctx = torch.cuda.stream(stream) if stream is not None else None

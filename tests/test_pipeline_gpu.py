@@ -72,6 +72,22 @@ def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):
             assert np.array_equal(za[k], zb[k]), k
 
 
+def test_one_pair_in_flight_through_the_stager_is_not_throttled(setup):
+    """Round 4: with two reader threads the stager's pinned-buffer fills went through torch's CPU copy_, whose OpenMP teams (one
+    per calling thread, as wide as the host) spin against a container's CPU quota: 30-70 ms per pair instead of 4.  The fills
+    are numpy copies now and the harness threads keep to one OpenMP thread; a generous bound catches the class of problem."""
+    import time
+    from rdmnet_amd import dataset, infer
+    cfg, state, distinct = setup
+    pairs = [distinct[i % 5] + (np.eye(4),) for i in range(40)]
+    t = infer.Tester(cfg, state, None, save_npz=False, pairs_in_flight=1)
+    t.run(dataset.PairStager(dataset.ArrayPairDataset(pairs[:8]), depth=2, workers=2))  # warm-up
+    t0 = time.perf_counter()
+    recs = t.run(dataset.PairStager(dataset.ArrayPairDataset(pairs), depth=2, workers=2))
+    ms = (time.perf_counter() - t0) * 1e3 / len(pairs)
+    assert len(recs) == 48 and ms < 15.0, ms
+
+
 def test_an_engine_error_inside_the_pipeline_reaches_the_caller(setup):
     from rdmnet_amd import pipeline
     cfg, state, distinct = setup
