@@ -4,7 +4,7 @@ source "$(dirname "${BASH_SOURCE[0]}")/lab_env.sh"  # developer knobs live in th
 # throughput regime -- the number that says where a faster kernel would pay (sums of kernel durations do not: small
 # kernels overlap with other pairs' work).  One pair in flight for comparison.
 run() {
-  python bench.py --streams $1 --steps 240 --warmup 16 --ramp-seconds 2 --no-cpu-baseline --host-steps 0 --api-steps 0 2>/dev/null | python -c "
+  python bench.py --streams $1 --steps 240 --warmup 16 --ramp-seconds 2 --no-cpu-baseline --host-steps 0 --api-steps 0 --full-steps 0 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
