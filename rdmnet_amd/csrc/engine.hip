@@ -585,10 +585,9 @@ int wait_stream(Run& r) { return wait_on(r.e, r.st); }
 // four compute pipes in creation order, and two queues of one pipe are served in turns -- their kernels never run side by side
 // (a process with four worker streams puts the sixth queue on the pipe of the second: measured, tools/overlap_probe.py).  There
 // is no query for that, so the engine tries it: two 60 us spin kernels, one per stream, take 60 us together or 120.
-__global__ void spin_kernel(long long ticks) {  // 100 MHz wall clock
+__global__ void spin_kernel(long long ticks) {  // 100 MHz wall clock; the pass count bounds it should the clock ever stand still
   const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) {
-  }
+  for (int pass = 0; pass < (1 << 20) && wall_clock64() - t0 < ticks; ++pass) __builtin_amdgcn_s_sleep(8);
 }
 bool runs_beside(hipStream_t a, hipStream_t b) {
   double best = 1e30;
