@@ -516,9 +516,9 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(SelectNodesArgs a) {
   } else if (t == 3) {
     a.nodes4[4 * j + 3] = 0.f;
   } else if (t == 4) {
-    a.scores[2 * j] = a.n2p[src];
+    if (a.n2p) a.scores[2 * j] = a.n2p[src];
   } else if (t == 5) {
-    a.scores[2 * j + 1] = a.n2n[src];
+    if (a.n2n) a.scores[2 * j + 1] = a.n2n[src];
   }
   for (int c = t; c < a.ldo; c += 64) a.out_feats[static_cast<int64_t>(j) * a.ldo + c] = c < a.d ? a.feats[static_cast<int64_t>(src) * a.ldf + c] : 0.f;
 }
@@ -1285,10 +1285,17 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   tap(r, "t1", x_c);
   Mat n2p_logit = buf_c.cols_from(D, 1);
   ENG_CHECK(linear(r, "proj_n2p_score", x_c, n2p_logit, 0, false));
-  float* n2p = e->alloc<float>(Nc);
-  ENG_ALLOC(n2p);
-  ENG_CHECK(rdm_sigmoid_column(n2p_logit.p, n2p_logit.ld, Nc, n2p, r.st));
-  tap(r, "n2p_scores", n2p, Nc, 1, 1, 0);
+  // The three score heads' sigmoids (and the n2n projection) feed output tensors only (model_infer.py:160-236: `n2p_scores`,
+  // `p2p_scores`, `node_scores`; the n2p LOGIT is an input of the decoder and stays): a plain run, which hands out no stage
+  // tensors, skips those four launches.
+  const bool want_scores = e->keep_taps;
+  float* n2p = nullptr;
+  if (want_scores) {
+    n2p = e->alloc<float>(Nc);
+    ENG_ALLOC(n2p);
+    ENG_CHECK(rdm_sigmoid_column(n2p_logit.p, n2p_logit.ld, Nc, n2p, r.st));
+    tap(r, "n2p_scores", n2p, Nc, 1, 1, 0);
+  }
 
   // ---------------------------------------------------------------- decoder (backbone.py:118-151)
   // Latency mode: the three wide GEMMs of the decoder run on the side stream beside the chain of small launches of the second
@@ -1307,10 +1314,12 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_CHECK(decoder_stage(rd, "decoder.decoder2.mlp", nullptr, l3, up[1].idx, up[1].stride(), feats[1], lv[1].n, dec));
     tap(r, "decoder", dec);
     feats_f = dec.cols_from(0, D);
-    p2p = e->alloc<float>(Nf);
-    ENG_ALLOC(p2p);
-    ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, rd.st));
-    tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
+    if (want_scores) {
+      p2p = e->alloc<float>(Nf);
+      ENG_ALLOC(p2p);
+      ENG_CHECK(rdm_sigmoid_column(dec.p + D, dec.ld, Nf, p2p, rd.st));
+      tap(r, "p2p_scores", p2p, Nf, 1, 1, 0);
+    }
     return RDM_OK;
   };
   auto fork_decoder = [&]() -> int {  // after a host wait on the caller's stream: what the decoder reads was complete then, and nothing enqueued since writes it
@@ -1343,11 +1352,14 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_CHECK(layer_norm(r, "vote.out_proj.0", x_c, &off_f, 0, vfeats));
     tap(r, "vote_xyz", shifted, Nc, 3, 3, 0);
     tap(r, "vote_feats", vfeats);
-    Mat n2n_logit;
-    ENG_CHECK(linear(r, "proj_n2n_score", vfeats, n2n_logit));
-    float* n2n = e->alloc<float>(Nc);
-    ENG_ALLOC(n2n);
-    ENG_CHECK(rdm_sigmoid_column(n2n_logit.p, n2n_logit.ld, Nc, n2n, r.st));
+    float* n2n = nullptr;
+    if (want_scores) {
+      Mat n2n_logit;
+      ENG_CHECK(linear(r, "proj_n2n_score", vfeats, n2n_logit));
+      n2n = e->alloc<float>(Nc);
+      ENG_ALLOC(n2n);
+      ENG_CHECK(rdm_sigmoid_column(n2n_logit.p, n2n_logit.ld, Nc, n2n, r.st));
+    }
 
     // ---------------------------------------------------------------- NMS (vote.py:13-40)
     Level nodes_all;
