@@ -256,6 +256,46 @@ def test_engine_handles_degenerate_clouds(ctx, n, scale):
     assert res.n_ref_nodes >= 1 and res.n_src_nodes >= 1 and res.n_correspondences >= 0
 
 
+def test_latency_mode_on_degenerate_clouds_and_after_an_error(ctx):
+    """The side-stream mode on the inputs that bend the path -- single points, a few points, every point its own voxel -- gives
+    the serial run's bits, and a run that fails between fork and join (a 4-point arena) leaves an engine that still works."""
+    from rdmnet_amd import engine
+    eng = ctx['eng']
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(st):
+            for n, scale in ((500, 20.0), (5, 1.0), (1, 1.0), (4000, 200.0)):
+                rng = np.random.default_rng(n)
+                a = torch.from_numpy((rng.uniform(-1, 1, (n, 3)) * np.array([scale, scale, 2.0])).astype(np.float32)).cuda()
+                b = torch.from_numpy((rng.uniform(-1, 1, (max(n - 3, 1), 3)) * np.array([scale, scale, 2.0])).astype(np.float32)).cuda()
+                st.synchronize()
+                outs = []
+                for mode in (0, 2):
+                    eng.set_overlap(mode)
+                    res = eng.run(a, b)
+                    outs.append((eng.transform(), [x.copy() for x in eng.host_corr()], list(res.level_sizes), eng.tensor('decoder').clone()))
+                assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+                assert all(np.array_equal(x, y) for x, y in zip(outs[0][1], outs[1][1])) and torch.equal(outs[0][3], outs[1][3])
+            # an arena too small for the pair, fixed by the caller: the run fails part-way (side stream busy), the next ones work
+            small = engine.Engine(ctx['cfg'], None, arena_bytes=160 << 20, share_with=eng)
+            small.set_overlap(2)
+            rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+            st.synchronize()
+            with pytest.raises(RuntimeError, match='arena'):
+                small.run(rp, sp)
+            with pytest.raises(RuntimeError, match='arena'):
+                small.run(rp, sp)
+            del small
+            eng.run(rp, sp)
+            T2 = eng.transform()
+            eng.set_overlap(0)
+            eng.run(rp, sp)
+            assert np.array_equal(eng.transform(), T2)
+    finally:
+        eng.set_overlap(1)
+
+
 def test_engine_deferred_large_buffer_pass_matches_per_op_searches(ctx):
     """6 000 points in a 6 x 6 x 4 m box: 300-500 points inside a level-0 search radius, more than the first pass's
     256-key buffer.  The engine defers the large-buffer pass of all 14 searches to one launch; the per-op path runs it
