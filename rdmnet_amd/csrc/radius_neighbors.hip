@@ -581,6 +581,19 @@ __device__ __forceinline__ void rn_query_one(const RnQueryArgs& a, int64_t qi, i
     __builtin_amdgcn_wave_barrier();
     const unsigned long long k0 = lane < n ? K[lane] : ~0ull;
     const unsigned long long k1 = 64 + lane < n ? K[64 + lane] : ~0ull;
+    if (width == 1) {
+      // one column (the nearest-neighbour tables of a plain engine run: up-sampling, functional.py:6-22): the smallest key is
+      // the first of the sorted row -- six exchange steps instead of the n-step rank sort
+      unsigned long long mn = k0 < k1 ? k0 : k1;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl_xor(static_cast<int>(mn >> 32), o, 64))) << 32) |
+                                         static_cast<unsigned>(__shfl_xor(static_cast<int>(mn & 0xffffffffull), o, 64));
+        mn = other < mn ? other : mn;
+      }
+      if (lane == 0) st_index(out_idx, qi, n > 0 ? static_cast<long long>(mn & 0xffffffffull) : ns, a.out32);
+      return;
+    }
     int r0 = 0, r1 = 0;
     if (n <= 64) {  // one key per lane: half the comparisons
       for (int i = 0; i < n; ++i) r0 += readlane64(k0, i) < k0 ? 1 : 0;

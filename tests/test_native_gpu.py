@@ -228,3 +228,21 @@ def test_grid_records_are_a_function_of_the_points_alone():
     key = np.stack([cloud, lin, rows.astype(np.int64)], 1)
     order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
     assert np.array_equal(order, np.arange(len(rows))), 'records are not in (cloud, cell, row) order'
+
+
+def test_one_column_search_is_the_first_column_of_the_full_row():
+    """A plain engine run builds its up-sampling tables one column wide (nearest neighbour only); the search then takes the
+    smallest (distance, index) key with a wavefront minimum instead of sorting the row.  Same column as the full search,
+    also for queries without any neighbour and with equidistant candidates (a lattice)."""
+    from rdmnet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    lattice = torch.stack(torch.meshgrid(*[torch.arange(12.0)] * 3, indexing='ij'), -1).reshape(-1, 3) * 0.5
+    for s_pts, radius in ((torch.rand(5000, 3, generator=g) * torch.tensor([20.0, 20.0, 4.0]), 1.1), (lattice, 0.8)):
+        q_pts = torch.cat([s_pts[::3] + 0.0, torch.rand(300, 3, generator=g) * 40.0 + 30.0])  # (the last 300: far from every support)
+        ql = torch.tensor([q_pts.shape[0] // 2, q_pts.shape[0] - q_pts.shape[0] // 2])
+        sl = torch.tensor([s_pts.shape[0] // 2, s_pts.shape[0] - s_pts.shape[0] // 2])
+        args = (q_pts.cuda(), s_pts.cuda(), ql.cuda(), sl.cuda(), radius)
+        full = ops.radius_search_device(*args, 40, torch.zeros(2, dtype=torch.int32, device='cuda'))
+        one = ops.radius_search_device(*args, 1, torch.zeros(2, dtype=torch.int32, device='cuda'))
+        assert one.shape[1] == 1 and torch.equal(one[:, 0], full[:, 0])
+        assert (one[:, 0] == s_pts.shape[0]).sum().item() >= 150  # queries with no neighbour hold the shadow index
