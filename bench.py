@@ -131,7 +131,9 @@ def spawn_ranks(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES', '8'),  # explicit in every rank's environment (one queue per in-flight pair)
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))  # dmabuf IPC: RCCL needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -194,6 +196,11 @@ def main():
     ap.add_argument('--pin', choices=['on', 'off'], default='on',
                     help='with several ranks on one host: pin rank r to the r-th contiguous slice of the CPUs this job may use')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
+    ap.add_argument('--dry-run', action='store_true',
+                    help='construct the communicator (RCCL for --dist-backend nccl), run the pre-flight -- the barrier, the ragged\n'
+                         'record gather and the timing reduction of a real run on dummy records -- print one JSON line and exit\n'
+                         'WITHOUT running a pair: everything a multi-GPU launch does besides the per-GPU work (needs no GPU with\n'
+                         '--dist-backend gloo)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -210,8 +217,12 @@ def main():
     pinned_cpus = pipeline.pin_rank(local_rank, local_world) if args.pin == 'on' else None
     if os.environ.get('RDM_BENCH_SHARE_DEVICE') == '1':
         local_rank = 0  # test hook: all ranks on one GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not (args.dry_run and args.dist_backend != 'nccl'):
+        raise SystemExit('bench.py needs a GPU (there is no CPU fallback; --dry-run --dist-backend gloo exercises the launcher alone)')
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank) if have_gpu else torch.device('cpu')
     dist = None
     force = args.force_dist and world == 1
     if world > 1 or force:
@@ -228,6 +239,36 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from rdmnet_amd import collate, config, engine, model, sharding, weights
+
+    # Pre-flight of the multi-rank half: the same calls a run ends with -- barrier, ragged gather of result
+    # records, max-reduction of the elapsed time + gather of the latencies -- on dummy records whose content is checked, BEFORE
+    # any pair runs: a broken communicator fails here, in the first second, and `--dry-run` stops after it.
+    comm_dev0 = dev if args.dist_backend == 'nccl' else torch.device('cpu')
+    preflight = None
+    if dist is not None:
+        tp = time.perf_counter()
+        dist.barrier()
+        dummy = torch.full((rank % 3 + 1, 5), float(rank), dtype=torch.float32)  # ragged: 1-3 rows per rank
+        got = sharding.gather_records(dummy.to(comm_dev0), world, dist, force)
+        assert len(got) == world and all(g.shape == (r % 3 + 1, 5) and bool((g.cpu() == float(r)).all()) for r, g in enumerate(got)), \
+            'pre-flight gather returned wrong records'
+        tmax, lats = sharding.reduce_timing(0.001 * (rank + 1), [float(rank)] * (rank % 2 + 1), world, dist, comm_dev0, force)
+        assert abs(tmax - 0.001 * world) < 1e-9 and lats == [float(r) for r in range(world) for _ in range(r % 2 + 1)], (tmax, lats)
+        dist.barrier()
+        preflight = {'ok': True, 'ms': (time.perf_counter() - tp) * 1e3, 'ops': 'barrier, all_gather (counts + ragged records), '
+                     'all_reduce(MAX), all_gather (latencies), barrier'}
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'n_gpus': world, 'backend': args.dist_backend if dist is not None else None,
+                              'library': (('RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version())) if args.dist_backend == 'nccl' and dist is not None
+                                          else ('gloo' if dist is not None else None)),
+                              'preflight': preflight, 'gpu_max_hw_queues': pipeline.hw_queues(),
+                              'host_cpus_per_rank': pipeline.rank_cpu_budget(local_world),
+                              'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None,
+                              'gpu_numa_nodes': pipeline.gpu_numa_nodes()}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     cfg = config.make_cfg()
     state = weights.synthetic_state_dict(cfg, seed=0)
     net = None
@@ -289,7 +330,7 @@ def main():
     # The scheduler is the PRODUCT's (rdmnet_amd.pipeline.PairPipeline, the one `python -m rdmnet_amd.infer` runs on): N engines
     # sharing one copy of the weights, N host threads / HIP streams drawing steps from one queue, staggered starts, the
     # pairs-in-flight hint, and spin-or-poll waits chosen from this rank's CPU budget.
-    budget = pipeline.cpu_budget() / max(local_world, 1)
+    budget = pipeline.rank_cpu_budget(local_world)
     pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
                                  stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams)
     wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
@@ -619,7 +660,8 @@ def main():
                                    'fp32, seeded random-init weights', 'searches_per_pair': 12 if args.path == 'engine' else 13,
                        'scheduler': 'rdmnet_amd.pipeline.PairPipeline', 'points_per_pair': n_points,
                        'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
-                       'host_cpus_per_rank': budget, 'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None, 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
+                       'host_cpus_per_rank': budget, 'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None,
+                       'gpu_max_hw_queues': pipeline.hw_queues(), 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},
             'p50_ms_per_pair': float(np.median(lat)),
             'one_pair_in_flight': ({'p50_ms_per_pair': float(np.median(iso_lat)), 'pairs': len(iso_lat),
@@ -635,7 +677,8 @@ def main():
                         'distinct_pairs': len({int(x) for g in gathered for x in g[:, 0].tolist()})},
             'collective': ({'backend': args.dist_backend, 'world': world, 'forced_single_rank': bool(force),
                             'library': ('RCCL ' + '.'.join(str(v) for v in torch.cuda.nccl.version())) if args.dist_backend == 'nccl' else 'gloo',
-                            'ops': 'barrier x2 per region, all_gather (counts + records), all_reduce(MAX) of the elapsed time'}
+                            'ops': 'barrier x2 per region, all_gather (counts + records), all_reduce(MAX) of the elapsed time',
+                            'preflight': preflight}
                            if dist is not None else None),
             'full_tables': full_tables,
             'host_to_host': host_to_host,

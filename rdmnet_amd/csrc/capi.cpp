@@ -1,4 +1,5 @@
-// Library-wide C-ABI plumbing: version and thread-local error text.
+// Library-wide C-ABI plumbing: version and thread-local error text (the library's only state: every mode of a kernel --
+// index width of a neighbour table, GroupNorm form -- is an argument of the call that uses it).
 #include <cstdarg>
 #include <cstdio>
 
@@ -8,13 +9,7 @@
 namespace rdm {
 namespace {
 thread_local char g_error[512] = "";
-thread_local bool g_index32 = false;
-thread_local int g_gn_form = 0;
 }
-bool index32() { return g_index32; }
-void set_index32(bool on) { g_index32 = on; }
-int gn_form() { return g_gn_form; }
-void set_gn_form(int form) { g_gn_form = form; }
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -22,29 +22,6 @@ enum : int {
 
 void set_error(const char* fmt, ...);
 
-// Width of the neighbour-index tables the NEXT calls of this thread read or write: false = int64 (the C-ABI's and the
-// reference's layout), true = int32 (rdm_engine_run keeps the tables it builds and consumes itself in 32 bits: half the bytes
-// written by the searches and read by every KPConv layer and shortcut pool; the int64 layout stays at the rdm_engine_forward /
-// rdm_engine_collate boundary).  Thread-local, set only by the engine around its own calls (Index32Scope); every public entry
-// point called from outside sees int64.
-bool index32();
-void set_index32(bool on);
-struct Index32Scope {
-  bool before;
-  explicit Index32Scope(bool on) : before(index32()) { set_index32(on); }
-  ~Index32Scope() { set_index32(before); }
-};
-
-// GroupNorm form of this thread's NEXT calls (rdm_group_norm_form, tests): 0 = the library's choice, 1 = statistics, finalize and
-// apply as separate launches everywhere.
-int gn_form();
-void set_gn_form(int form);
-struct GnFormScope {
-  int before;
-  explicit GnFormScope(int form) : before(gn_form()) { set_gn_form(form); }
-  ~GnFormScope() { set_gn_form(before); }
-};
-
 #define RDM_HIP_CHECK(expr)                                                              \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \

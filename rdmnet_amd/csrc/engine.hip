@@ -297,7 +297,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   }
   const Linear& W = it->second;
   const int64_t cin = x.cols, kdim = cin == 1 ? 16 : 15 * cin;
-  Index32Scope index_scope(t.i32);  // the convolution kernels and the shortcut pool read `t` in its own element width
+  const int i32 = t.i32 ? 1 : 0;  // the convolution kernels and the shortcut pool read `t` in its own element width
   if (W.packed && rdm_kpconv_fused_enabled()) {
     // fine levels (c_in = 1, 32, 64): the whole convolution is one kernel, the [M, 15 C] block never leaves the CU
     float* gam = vecp(r, norm_name + ".norm.weight");
@@ -317,8 +317,9 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, cin));
     double* gn_partial = static_cast<double*>(r.ws);
     const size_t stat_bytes = align_up(static_cast<size_t>(nblk) * 2 * W.out * sizeof(double));
-    ENG_CHECK(rdm_kpconv_fused(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
-                               vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, order, r.st));
+    ENG_CHECK(kpconv_fused_impl(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
+                                vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, order, 0,
+                                i32, r.st));
     if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
     ENG_CHECK(group_norm_finish(gn_partial, nblk, conv.p, q.n, W.out, conv.ld, r.groups, gam, bet, 1e-5f, nullptr, 0, 2, y.p, y.ld,
                                 nullptr, static_cast<char*>(r.ws) + stat_bytes, r.ws_bytes - stat_bytes, r.st));
@@ -326,7 +327,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
       *pool_out = e->mat(q.n, pool_src->cols);
       ENG_ALLOC(pool_out->p);
       ENG_CHECK(gather_max_ordered(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
-                                   t.flags, pool_out->p, pool_out->ld, order, r.st));
+                                   t.flags, pool_out->p, pool_out->ld, order, i32, r.st));
     }
     if (prof) {
       RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
@@ -347,8 +348,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   const int li = e->prof_layers;
   const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
-  ENG_CHECK(rdm_kpconv_gather_ordered(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
-                                      vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, order, r.st));
+  ENG_CHECK(kpconv_gather_impl(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
+                               vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, order, i32, r.st));
   if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
   Mat conv = e->mat(q.n, W.out);
   ENG_ALLOC(conv.p);
@@ -364,7 +365,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     *pool_out = e->mat(q.n, pool_src->cols);
     ENG_ALLOC(pool_out->p);
     ENG_CHECK(gather_max_ordered(pool_src->p, pool_src->rows, pool_src->cols, pool_src->ld, t.idx, q.n, t.width, t.stride(),
-                                   t.flags, pool_out->p, pool_out->ld, order, r.st));
+                                   t.flags, pool_out->p, pool_out->ld, order, i32, r.st));
   }
   if (prof) {
     RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
@@ -1023,12 +1024,11 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     t.i32 = i32;
     t.idx = reinterpret_cast<int64_t*>(e->alloc<char>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit * (i32 ? 4 : 8)));
     ENG_ALLOC(t.idx);
-    Index32Scope index_scope(i32);  // (the query's arguments are fixed here, also when it runs at the flush)
     // the large-buffer second pass of all 14 searches is one launch after the loop (radius_redo_flush)
     unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
     ENG_ALLOC(redo_flags);
     return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
-                                      t.flags + 1, redo_flags, queue ? queue : redo_queue.data(), qst ? qst : r.st);
+                                      t.flags + 1, redo_flags, queue ? queue : redo_queue.data(), i32 ? 1 : 0, qst ? qst : r.st);
   };
   // the five level grids with one set of launches (radius r_i = 2^i r_0): they serve the searches of the collate and, through
   // their cell-sorted records, the spatial query order of the KPConv kernels and the shortcut pools

@@ -36,10 +36,11 @@ inline int64_t gemm_stats_max_blocks(int64_t m) { return (m + 7) / 8 + 1; }
 int grid_subsample_mode(const float* points, int64_t n_points, const int64_t* lengths, int batch, float voxel_size,
                         float* out_points, int64_t* out_lengths, void* ws, size_t ws_bytes, void* stream, int mode);
 
-// GroupNorm given (optional) precomputed partials: nblk > 0 uses them, nblk == 0 computes them.
+// GroupNorm given (optional) precomputed partials: nblk > 0 uses them, nblk == 0 computes them.  form: 0 = the library's choice,
+// 1 = statistics, finalize and apply as separate launches everywhere (rdm_group_norm_form).
 int group_norm_finish(const double* partial, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx, int groups,
                       const float* gamma, const float* beta, float eps, const float* residual, int64_t ldr, int act,
-                      float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream);
+                      float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes, void* stream, int form = 0);
 
 // Radius searches batched: a call only records the search in `queue` (radius_redo_queue_bytes() bytes of host memory,
 // reset once; up to 16 searches -- further ones run at once); radius_redo_flush launches TWO kernels for all recorded
@@ -66,15 +67,27 @@ int compact_indices_pair(const uint8_t* keep, int64_t n_ref, int64_t n, int32_t*
 
 // rdm_gather_max visiting the queries in the order of `order_records` (the cell-sorted float4 records of the query level's
 // search grid, rdm_radius_grid_records; null = row order): same output, better L2 locality of the gathered rows.
+// i32 (here and below): the neighbour table `idx` holds int32 elements instead of the C-ABI's int64 -- rdm_engine_run keeps the
+// tables it builds AND consumes itself in 32 bits (half the bytes written by the searches and read by every KPConv layer and
+// shortcut pool); every public entry point passes 0, the int64 layout of the reference.
 int gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m, int64_t h, int64_t ldi,
-                       const int32_t* width, float* y, int64_t ldy, const float* order_records, void* stream);
+                       const int32_t* width, float* y, int64_t ldy, const float* order_records, int i32, void* stream);
+// rdm_kpconv_gather_ordered / rdm_kpconv_fused_form on a table of either element width
+int kpconv_gather_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                       int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                       const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
+                       int i32, void* stream);
+int kpconv_fused_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                      int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                      const float* kernel_points, float sigma, const float* w_packed, const float* bias, int64_t c_out, float* out,
+                      int64_t ldo, double* gn_partial, const float* order_records, int form, int i32, void* stream);
 
 size_t radius_redo_queue_bytes();
 void radius_redo_queue_reset(void* queue);
 int radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
                                const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
                                int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo_flags, void* queue,
-                               void* stream);
+                               int i32, void* stream);
 int radius_redo_flush(void* queue, void* stream);
 
 }  // namespace rdm

@@ -17,6 +17,7 @@
 // the WF stores are vector accesses.
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "internal.h"
 
 namespace {
 
@@ -277,11 +278,10 @@ extern "C" int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld
   return launch_status("row_positive_kernel");
 }
 
-extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
-                                         const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
-                                         const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
-                                         const float* kernel_points, float sigma, float* wf, int64_t ldw,
-                                         float* nn, const float* order_records, void* stream) {
+int rdm::kpconv_gather_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                            int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                            const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
+                            int i32, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
               "rdm_kpconv_gather: null pointer");
@@ -292,7 +292,7 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
   if (m == 0) return RDM_OK;
   KpArgs a;
   a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive;
-  a.idx = idx; a.i32 = index32() ? 1 : 0; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
+  a.idx = idx; a.i32 = i32 ? 1 : 0; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
   a.order = reinterpret_cast<const float4*>(order_records);
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
   a.C = static_cast<int>(c); a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi);
@@ -324,6 +324,15 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
       break;
   }
   return launch_status("kpconv_gather_kernel");
+}
+
+extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                         const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                         const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                         const float* kernel_points, float sigma, float* wf, int64_t ldw,
+                                         float* nn, const float* order_records, void* stream) {
+  return rdm::kpconv_gather_impl(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
+                                 wf, ldw, nn, order_records, 0, stream);
 }
 
 extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,

@@ -871,6 +871,14 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
                                      int64_t ldi, const int32_t* width, const float* kernel_points, float sigma,
                                      const float* w_packed, const float* bias, int64_t c_out, float* out, int64_t ldo,
                                      double* gn_partial, const float* order_records, int form, void* stream) {
+  return rdm::kpconv_fused_impl(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
+                                w_packed, bias, c_out, out, ldo, gn_partial, order_records, form, 0, stream);
+}
+
+int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                           int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                           const float* kernel_points, float sigma, const float* w_packed, const float* bias, int64_t c_out,
+                           float* out, int64_t ldo, double* gn_partial, const float* order_records, int form, int i32, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(form >= 0 && form <= 2, "rdm_kpconv_fused_form: form must be 0, 1 or 2");
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && w_packed && bias && out,
@@ -883,7 +891,7 @@ extern "C" int rdm_kpconv_fused_form(const float* q_points, int64_t m, const flo
               "rdm_kpconv_fused: features / packed weights must be 16-byte aligned with a row stride that is a multiple of 4");
   if (m == 0) return RDM_OK;
   FusedArgs a;
-  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.i32 = index32() ? 1 : 0;
+  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.i32 = i32 ? 1 : 0;
   a.kp = kernel_points;
   a.width = width; a.w = w_packed; a.bias = bias; a.out = out; a.stats = gn_partial;
   a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);

@@ -451,7 +451,7 @@ extern "C" size_t rdm_group_norm_workspace_bytes(int64_t n, int64_t c) {
 int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, int64_t n, int64_t c, int64_t ldx,
                            int groups, const float* gamma, const float* beta, float eps, const float* residual,
                            int64_t ldr, int act, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
-                           void* stream) {
+                           void* stream, int form) {
   Arena ar(ws, ws_bytes);
   const int own_blk = static_cast<int>(ceil_div<int64_t>(n, kGnRowsPerBlock));
   double* partial = ar.take<double>(static_cast<size_t>(own_blk) * 2 * c);
@@ -474,7 +474,6 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   static const bool fin64 = ::rdm::dev_knob("RDM_GN_FINALIZE_64") != nullptr;  // developer knob (A/B): always 64 columns per workgroup
   const bool narrow = !fin64 && nblk >= 128 && c / groups <= 16 && 16 % (c / groups) == 0;
   // coarse levels: finalize + apply as one launch (see gn_finalize_apply_kernel); form 1 = always the separate launches
-  const int form = gn_form();
   if (form != 1 && !narrow && !positive && vec_ok && c % 64 == 0 && n <= 4096) {
     RDM_DUP_LOOP("gnfin")
     hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(static_cast<unsigned>(c / 64), static_cast<unsigned>(ceil_div<int64_t>(n, kGnFusedRows))),
@@ -526,8 +525,13 @@ extern "C" int rdm_group_norm_form(const float* x, int64_t n, int64_t c, int64_t
                                    const float* beta, float eps, const float* residual, int64_t ldr, int act, float* y, int64_t ldy,
                                    uint8_t* positive, void* ws, size_t ws_bytes, int form, void* stream) {
   RDM_REQUIRE(form >= 0 && form <= 1, "rdm_group_norm_form: form must be 0 (the library's choice) or 1 (statistics, finalize, apply as three launches)");
-  rdm::GnFormScope scope(form);
-  return rdm_group_norm(x, n, c, ldx, groups, gamma, beta, eps, residual, ldr, act, y, ldy, positive, ws, ws_bytes, stream);
+  using namespace rdm;
+  RDM_REQUIRE(x && gamma && beta && y, "rdm_group_norm: null pointer");
+  RDM_REQUIRE(n >= 0 && c > 0 && groups > 0 && c % groups == 0 && c <= 4096 && 64 % (c / groups) == 0,
+              "rdm_group_norm: bad sizes (n=%lld c=%lld groups=%d)", (long long)n, (long long)c, groups);
+  if (n == 0) return RDM_OK;
+  return group_norm_finish(nullptr, 0, x, n, c, ldx, groups, gamma, beta, eps, residual, ldr, act, y, ldy, positive, ws, ws_bytes,
+                           stream, form);
 }
 
 extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
@@ -546,7 +550,7 @@ extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
 }
 
 int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m, int64_t h,
-                            int64_t ldi, const int32_t* width, float* y, int64_t ldy, const float* order_records, void* stream) {
+                            int64_t ldi, const int32_t* width, float* y, int64_t ldy, const float* order_records, int i32, void* stream) {
   RDM_REQUIRE(x && idx && y, "rdm_gather_max: null pointer");
   RDM_REQUIRE(c % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && h > 0, "rdm_gather_max: bad sizes");
   if (m == 0) return RDM_OK;
@@ -554,7 +558,6 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
   if (no_order) order_records = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const float4* ord = reinterpret_cast<const float4*>(order_records);
-  const int i32 = index32() ? 1 : 0;
   const int ns = static_cast<int>(n_s), ci = static_cast<int>(c), lx = static_cast<int>(ldx), mi = static_cast<int>(m), hi = static_cast<int>(h),
             li = static_cast<int>(ldi), ly = static_cast<int>(ldy);
   RDM_DUP_LOOP("pool") {
@@ -575,7 +578,7 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
 extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx,
                               int64_t m, int64_t h, int64_t ldi, const int32_t* width, float* y,
                               int64_t ldy, void* stream) {
-  return rdm::gather_max_ordered(x, n_s, c, ldx, idx, m, h, ldi, width, y, ldy, nullptr, stream);
+  return rdm::gather_max_ordered(x, n_s, c, ldx, idx, m, h, ldi, width, y, ldy, nullptr, 0, stream);
 }
 
 // The same with 16-byte accesses (c1, c2 and every row stride multiples of 4, 16-byte aligned bases): one wavefront per row.

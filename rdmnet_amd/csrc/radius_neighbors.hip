@@ -798,7 +798,7 @@ namespace {
 // appended to `queue` for rdm::radius_redo_flush
 int grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q, const int64_t* q_lengths,
                int batch, float radius, int width, int64_t* out_idx, int32_t* out_counts, int32_t* out_max, int32_t* status,
-               unsigned char* redo, RnRedoBatch* queue, hipStream_t st) {
+               unsigned char* redo, RnRedoBatch* queue, int out32, hipStream_t st) {
   using namespace rdm;
   RDM_REQUIRE(grid_ws && q_lengths && status, "rdm_radius_grid_query: null pointer");
   RDM_REQUIRE(n_q >= 0 && batch > 0 && batch <= kMaxBatch && radius > 0.f, "rdm_radius_grid_query: bad arguments");
@@ -811,7 +811,7 @@ int grid_query(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_
   RnQueryArgs a;
   a.q = q_points; a.nq = n_q; a.ns = n_s; a.q_lengths = q_lengths; a.batch = batch; a.radius = radius; a.meta = g.meta;
   a.cell_count = g.cell_count; a.cell_start = g.cell_start; a.sorted = g.sorted; a.width = width; a.out_idx = out_idx;
-  a.out32 = index32() ? 1 : 0;
+  a.out32 = out32 ? 1 : 0;
   a.out_counts = out_counts; a.out_max = out_max; a.status = status; a.redo = redo;
   const int qblocks = static_cast<int>(ceil_div<int64_t>(n_q, kWavesPerBlock));
   // small per-wavefront buffers keep many wavefronts resident; the rare query with more than 256
@@ -835,10 +835,10 @@ void rdm::radius_redo_queue_reset(void* queue) {
 int rdm::radius_grid_query_deferred(void* grid_ws, size_t grid_ws_bytes, int64_t n_s, const float* q_points, int64_t n_q,
                                     const int64_t* q_lengths, int batch, float radius, int width, int64_t* out_idx,
                                     int32_t* out_counts, int32_t* out_max, int32_t* status, unsigned char* redo_flags,
-                                    void* queue, void* stream) {
+                                    void* queue, int i32, void* stream) {
   RDM_REQUIRE(redo_flags && queue, "radius_grid_query_deferred: null redo storage");
   return grid_query(grid_ws, grid_ws_bytes, n_s, q_points, n_q, q_lengths, batch, radius, width, out_idx, out_counts, out_max,
-                    status, redo_flags, static_cast<RnRedoBatch*>(queue), static_cast<hipStream_t>(stream));
+                    status, redo_flags, static_cast<RnRedoBatch*>(queue), i32, static_cast<hipStream_t>(stream));
 }
 int rdm::radius_redo_flush(void* queue, void* stream) {
   RnRedoBatch* b = static_cast<RnRedoBatch*>(queue);
@@ -865,7 +865,7 @@ extern "C" int rdm_radius_grid_query(void* grid_ws, size_t grid_ws_bytes, int64_
     return RDM_ERR_WORKSPACE;
   }
   return grid_query(grid_ws, grid_ws_bytes, n_s, q_points, n_q, q_lengths, batch, radius, width, out_idx, out_counts, out_max,
-                    status, redo, nullptr, static_cast<hipStream_t>(stream));
+                    status, redo, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" const float* rdm_radius_grid_records(void* grid_ws, size_t grid_ws_bytes, int64_t n_s) {

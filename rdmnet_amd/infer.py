@@ -102,6 +102,9 @@ class Tester:
         return self._commit(self._work(self.engine, (item, ref_dev, src_dev)))
 
     def run(self, stager, log=None):
+        """Every pair of the stager, `pairs_in_flight` at a time, committed in dataset order.  If a pair fails, the pairs before
+        it are still committed (pose lines, records) before the error is raised; .npz files of later pairs that had already
+        finished on other workers may exist without a pose line."""
         for rec in self.pipeline.imap(stager, self._work):
             self._commit(rec)
             if log:
@@ -129,11 +132,12 @@ def main(argv=None):
     ap.add_argument('--pairs-in-flight', type=int, default=DEFAULT_PAIRS_IN_FLIGHT,
                     help='pairs on the GPU at a time (engines / host threads / HIP streams; rdmnet_amd.pipeline)')
     ap.add_argument('--no-ransac', action='store_true', help='skip the RANSAC estimate stored beside the LGR pose in the .npz')
+    ap.add_argument('--quiet', action='store_true', help='no per-pair log line (the reference prints one per iteration, infer.py:62-66)')
     args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local_rank, local_world = int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    pin_rank(local_rank, local_world)  # one contiguous slice of the host's CPUs per rank
+    pin_rank(local_rank, local_world)  # the CPUs of this rank's GPU's NUMA node (before the first HIP call)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -173,7 +177,7 @@ def main(argv=None):
     # scans are read and staged (pinned host -> HBM on a side stream) two pairs ahead of every in-flight pair
     stager = ds_mod.PairStager(data, mine, depth=2 * args.pairs_in_flight, workers=max(2, args.pairs_in_flight))
     t_run = time.perf_counter()
-    records = tester.run(stager, log=print if rank == 0 and len(mine) <= 64 else None)
+    records = tester.run(stager, log=print if rank == 0 and not args.quiet else None)
     torch.cuda.synchronize()
     t_run = time.perf_counter() - t_run
     # one gather of fixed-size records: ids, counts, time, errors, the pose (12 floats) and the pair's dataset index

@@ -19,7 +19,10 @@ else that has a stream of pairs:
   * one hardware queue per stream: the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware
     queues, and four worker streams + the default stream on four queues serialise two streams (345 instead of
     460 pairs/s); `rdmnet_amd/__init__.py` sets GPU_MAX_HW_QUEUES=8 unless the caller chose a value -- it must
-    be in the environment before the first HIP call of the process.
+    be in the environment before the first HIP call of the process (`hw_queues()` reports what is in effect and
+    warns when the default came too late); the launchers (`bench.py`, `python -m rdmnet_amd.infer`) put it into
+    the ranks' environment explicitly,
+  * one process per GPU: `pin_rank` keeps a rank on the CPUs of its GPU's NUMA node.
 
 Results come back in INPUT order whatever the completion order, and every engine is deterministic, so N pairs in
 flight give the bits of a serial run (tests/test_pipeline_gpu.py).
@@ -37,47 +40,145 @@ DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe wi
 DEFAULT_STAGGER_MS = 1.5
 
 
-def cpu_budget():
-    """Host CPUs this process may use: affinity mask capped by the cgroup quota (cpu.max / cfs_quota_us)."""
-    n = float(len(os.sched_getaffinity(0)))
+def _quota_cpus():
+    """The cgroup CPU quota alone (cpu.max / cfs_quota_us; inf when there is none)."""
     try:
         quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            n = min(n, float(quota) / float(period))
+        return float('inf') if quota == 'max' else float(quota) / float(period)
     except (OSError, ValueError):
         try:
             q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
             per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if q > 0:
-                n = min(n, q / per)
+            return q / per if q > 0 else float('inf')
         except (OSError, ValueError):
-            pass
-    return n
+            return float('inf')
 
 
-def pin_rank(local_rank, local_world):
-    """One process per GPU on a shared host: rank r keeps the r-th contiguous slice of the CPUs this process may run on
-    (its engines' worker threads and the runtime's helper threads then stay on one NUMA neighbourhood instead of
-    migrating over all sockets; with spinning waits that is 4 busy threads per rank).  No-op for a single rank, when
-    there are fewer CPUs than ranks, or where the platform has no affinity call.  Returns the CPU list it set (or None).
-    The same slice is what `torch.distributed.run` launches get: call this at the top of the rank's main()."""
+def cpu_budget():
+    """Host CPUs this process may use: affinity mask capped by the cgroup quota."""
+    return min(float(len(os.sched_getaffinity(0))), _quota_cpus())
+
+
+def _parse_cpulist(text):
+    """'0-15,32-47' -> [0..15, 32..47]"""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs='/sys', env=None):
+    """NUMA node of every GPU this process can see, in HIP device order, from sysfs alone (no HIP call: the affinity must be
+    set before the runtime starts its helper threads).  The KFD topology lists the agents in the order the ROCm runtime
+    enumerates them (`<sysfs>/class/kfd/kfd/topology/nodes/<i>/properties`: GPUs are the nodes with simd_count > 0;
+    `domain` and `location_id` = bus << 8 | devfn give the PCI address, whose `numa_node` file names the node);
+    ROCR_VISIBLE_DEVICES then HIP_VISIBLE_DEVICES re-index that list when they are plain index lists.  Returns a list of
+    node numbers (-1 = unknown), or None when the topology cannot be read or a visibility variable holds UUIDs."""
+    env = os.environ if env is None else env
+    root = os.path.join(sysfs, 'class', 'kfd', 'kfd', 'topology', 'nodes')
+    try:
+        ids = sorted(int(d) for d in os.listdir(root) if d.isdigit())
+    except OSError:
+        return None
+    gpus = []
+    for i in ids:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, str(i), 'properties')) if len(line.split()) >= 2)
+        except OSError:
+            continue  # (nodes of GPUs outside this container's device cgroup are unreadable)
+        if int(props.get('simd_count', '0')) <= 0:
+            continue
+        loc, dom = int(props.get('location_id', '0')), int(props.get('domain', '0'))
+        addr = f'{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}'
+        try:
+            node = int(open(os.path.join(sysfs, 'bus', 'pci', 'devices', addr, 'numa_node')).read())
+        except (OSError, ValueError):
+            node = -1
+        gpus.append(node)
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        val = env.get(var)
+        if val is None or val.strip() == '':
+            continue
+        toks = [t.strip() for t in val.split(',') if t.strip()]
+        if not all(t.isdigit() for t in toks):
+            return None
+        gpus = [gpus[int(t)] for t in toks if int(t) < len(gpus)]
+    return gpus or None
+
+
+_pinned = False  # pin_rank narrowed this process's affinity mask to its own share
+
+
+def pin_rank(local_rank, local_world, device_index=None, sysfs='/sys', force=False):
+    """One process per GPU on a shared host: the rank keeps a share of the CPUs OF ITS GPU'S NUMA NODE (round 4
+    handed rank r the r-th contiguous slice of the host, whatever socket the rank's GPU hangs off) -- the ranks whose GPUs
+    sit on the same node split that node's CPUs in rank order; its engines' worker threads, the stager's readers and the
+    runtime's helper threads then stay next to the GPU they feed (with spinning waits that is 4 busy threads per rank).
+    `device_index`: the rank's HIP device (default: local_rank).  Where the topology cannot be read (`gpu_numa_nodes`), or
+    the node's CPUs are not in this process's mask, the rank falls back to the r-th contiguous slice of the mask.
+
+    Pins only when the mask is still the whole host's: a launcher that already bound each rank to its own CPU
+    set (numactl, torchrun with binding, k8s cpusets) is left alone -- slicing a rank's own mask by local_world again would
+    leave it 1/local_world of its share; `force=True` slices whatever mask there is (all ranks must then share it).
+    No-op for a single rank, with fewer CPUs than ranks, or where the platform has no affinity call.  Returns the CPU list it
+    set (or None).  Call it at the top of the rank's main(), before the first HIP call."""
+    global _pinned
     if local_world <= 1 or not hasattr(os, 'sched_setaffinity'):
         return None
     cpus = sorted(os.sched_getaffinity(0))
+    if not force and len(cpus) < (os.cpu_count() or len(cpus)):
+        return None  # somebody chose this mask already
     per = len(cpus) // local_world
     if per < 1:
         return None
     mine = cpus[local_rank * per:(local_rank + 1) * per]
+    nodes = gpu_numa_nodes(sysfs)
+    dev = local_rank if device_index is None else device_index
+    if nodes is not None and len(nodes) >= local_world and 0 <= dev < len(nodes) and nodes[dev] >= 0:
+        try:
+            node_cpus = [c for c in _parse_cpulist(open(os.path.join(sysfs, 'devices', 'system', 'node', f'node{nodes[dev]}',
+                                                                     'cpulist')).read()) if c in set(cpus)]
+        except (OSError, ValueError):
+            node_cpus = []
+        # the ranks of this host that share the node (rank r drives device r unless the caller says otherwise: then only
+        # this rank's own device is known, and it is placed by its rank among the devices of the node)
+        peers = [r for r in range(local_world) if r < len(nodes) and nodes[r] == nodes[dev]]
+        me = peers.index(dev) if dev in peers else 0
+        share = len(node_cpus) // max(len(peers), 1)
+        if share >= 1:
+            mine = node_cpus[me * share:(me + 1) * share]
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
+    _pinned = True
     return mine
+
+
+def rank_cpu_budget(local_world=1):
+    """Host CPUs THIS RANK may use.  The cgroup quota is shared by the ranks of the host: always divided.  The affinity mask
+    is divided only while the ranks still share it -- after pin_rank (or a launcher's own binding: a mask smaller than the
+    host) it is this rank's share already (dividing it again made every multi-rank run poll instead of spin)."""
+    local_world = max(int(local_world), 1)
+    aff = float(len(os.sched_getaffinity(0))) if hasattr(os, 'sched_getaffinity') else float(os.cpu_count() or 1)
+    own_mask = _pinned or aff < float(os.cpu_count() or aff)
+    share = aff if own_mask else aff / local_world
+    return min(share, _quota_cpus() / local_world)
+
+
+def hw_queues():
+    """GPU_MAX_HW_QUEUES as this process's HIP runtime sees it (None = the runtime's default of 4: a fifth stream then
+    shares a queue, module docstring).  The variable only counts if it was in the environment at the first HIP call."""
+    v = os.environ.get('GPU_MAX_HW_QUEUES')
+    return int(v) if v and v.isdigit() else None
 
 
 def choose_wait_us(pairs_in_flight, local_world=1):
     """0 = spin at the read-backs (needs ~2 host cores per in-flight pair of this rank), else poll with 50 us sleeps."""
-    return 0 if cpu_budget() / max(local_world, 1) >= 2 * pairs_in_flight else 50
+    return 0 if rank_cpu_budget(local_world) >= 2 * pairs_in_flight else 50
 
 
 class PairResult:
@@ -162,7 +263,9 @@ class PairPipeline:
         def worker(k):
             stream = self.streams[k]
             import contextlib
-            torch.set_num_threads(1)  # this thread's CPU-side torch ops (small copies, metrics): no 128-thread OpenMP teams
+            # this thread's CPU-side torch ops (small copies, metrics): no 128-thread OpenMP teams.  (torch keeps the intra-op
+            # width per calling thread on OpenMP builds; the consumer restores the process's value after the run)
+            torch.set_num_threads(1)
             try:
                 with (torch.cuda.device(self.device) if self._gpu else contextlib.nullcontext()):
                     ctx = torch.cuda.stream(stream) if stream is not None else None
@@ -205,16 +308,17 @@ class PairPipeline:
                     cv.notify_all()
 
         threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(n)]
+        torch_threads = torch.get_num_threads()
         for t in threads:
             t.start()
         try:
             while True:
                 with cv:
                     while True:
+                        if state['next_out'] in done:  # (results completed in order are delivered before an error is raised:
+                            break                      # the consumer's output then ends at the first missing pair)
                         if state['error'] is not None:
                             raise state['error']
-                        if state['next_out'] in done:
-                            break
                         if state['alive'] == 0:  # every worker has left: nothing more will arrive
                             return
                         cv.wait(timeout=0.05)
@@ -228,6 +332,7 @@ class PairPipeline:
                 cv.notify_all()
             for t in threads:
                 t.join()
+            torch.set_num_threads(torch_threads)
             stats['wall_s'] = time.perf_counter() - t_begin
 
     def map(self, jobs, fn, stagger=True):

@@ -75,6 +75,11 @@ def np_(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
+def only_has_no(tag):
+    """True when the command line names cases and `tag` is not one of them (its ~20 s of ray casting are skipped)."""
+    return len(sys.argv) > 1 and tag not in sys.argv[1:]
+
+
 def main():
     cfg = ref_import.make_cfg()
     from model_infer import create_model
@@ -114,6 +119,13 @@ def main():
         'synth0': (synth['ref0'], synth['src0'], 0),   # BASELINE configs[1] shape; the reference's own 8- and 1-thread
         'synth3': (synth['ref3'], synth['src3'], 0),   # runs differ in a few point correspondences on 0, in nothing on 3
     }
+    # BASELINE configs[4] WORKLOAD (Mulran-shaped low overlap: 70 deg of the second scan's field of view removed, >= 10 m
+    # apart, arbitrary yaw) through the reference with the vote layer ON (model_infer.py:179-246 runs in that mode; only
+    # `inference_use_vote=False`, infer.py:119-120, breaks it).  The scans are stored in the fixture itself.
+    if not only_has_no('lowoverlap'):
+        from rdmnet_amd import synthetic
+        lo_ref, lo_src, _ = synthetic.make_low_overlap_pair(0)
+        cases['lowoverlap'] = (lo_ref, lo_src, 0)
     for i in os.environ.get('RDM_GOLDEN_EXTRA_SYNTH', '').split():  # probing other synthetic pairs, not committed
         cases[f'synth{i}'] = (synth[f'ref{i}'], synth[f'src{i}'], 0)
     only = [a for a in sys.argv[1:] if a in cases]

@@ -57,3 +57,13 @@ def test_single_rank_through_rccl():
     assert r['collective']['backend'] == 'nccl' and r['collective']['forced_single_rank'] and r['collective']['library'].startswith('RCCL')
     assert r['records'] == {'gathered': 8, 'distinct_steps': 8, 'distinct_pairs': 2}
     assert r['n_gpus'] == 1 and r['value'] > 0 and r['host_to_host']['value'] > 0
+    assert r['collective']['preflight']['ok'] and r['config']['gpu_max_hw_queues'] == 8
+
+
+def test_dry_run_builds_the_rccl_communicator_and_gathers_without_running_a_pair():
+    """`bench.py --dry-run` over RCCL (world of one: RCCL refuses two ranks on one device): communicator, pre-flight gather and
+    timing reduction, one line, no pair -- what an 8-GPU launch does before its first pair (tests/test_distributed.py runs the
+    same flag with two gloo ranks).  A real run reports the same pre-flight under `collective`."""
+    d = run_bench('--gpus', '1', '--force-dist', '--dry-run', timeout=300)
+    assert d['dry_run'] and d['backend'] == 'nccl' and d['library'].startswith('RCCL') and d['preflight']['ok']
+    assert d['gpu_max_hw_queues'] == 8 and d['host_cpus_per_rank'] > 0

