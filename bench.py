@@ -420,7 +420,7 @@ def main():
         return n_steps * world / t_pass
 
     # ---- the same engine path building ALL 13 search tables (a plain rdm_engine_run skips the up-sampling search of level 0,
-    # which nothing reads, and keeps one column of the other three: `value` times 12 searches).  Side key,
+    # which nothing reads, and keeps one column of the other three: `value` times 12 searches; docs/EXPERIMENTS.md 5d).  Side key,
     # never `value`: with the stage tensors kept the engine builds the reference's full tables.
     full_tables = None
     if args.path == 'engine' and args.full_steps > 0:

@@ -515,7 +515,7 @@ int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* data, rdm_engine_resu
 int rdm_engine_set_wait(rdm_engine* e, int sleep_us);
 /* How many scan pairs the caller keeps in flight on this GPU (one engine and stream each; default 1).  A scheduling hint, results do
  * not depend on it: from 3 the tiled GEMM leaves half of a CU's registers and LDS to the other pairs' kernels (two workgroups
- * per CU instead of four: +3 % pairs/s at four in flight, -2 % with one pair alone).                            */
+ * per CU instead of four: +3 % pairs/s at four in flight, -2 % with one pair alone, docs/EXPERIMENTS.md 5d).                            */
 int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n);
 /* Latency mode.  With one pair in flight most of the GPU idles while chains of one-workgroup kernels run, so the engine runs the
  * wide, independent parts of a pair -- the first level's grid, neighbour search and encoder blocks beside the subsampling of the

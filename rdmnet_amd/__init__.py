@@ -7,7 +7,7 @@ PyTorch is used for device memory and streams only.
 import os as _os
 
 # Several pairs in flight per GPU (rdmnet_amd.pipeline): one hardware queue per HIP stream.  The runtime reads this when the
-# process makes its first HIP call, so it is set at import unless the caller chose a value (four worker streams
+# process makes its first HIP call, so it is set at import unless the caller chose a value (docs/EXPERIMENTS.md 5b: four worker streams
 # + the default stream on the runtime's default of four queues run at 345 instead of 460 pairs/s).
 if 'GPU_MAX_HW_QUEUES' not in _os.environ:
     import sys as _sys

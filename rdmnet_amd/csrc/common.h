@@ -49,7 +49,7 @@ inline int launch_status(const char* what) {
   return RDM_OK;
 }
 
-// Developer knobs (A/B switches and tuning overrides behind the measurements in DESIGN.md 5) exist in the LAB build only
+// Developer knobs (A/B switches and tuning overrides behind the measurements in docs/EXPERIMENTS.md 5) exist in the LAB build only
 // (`make lab` -> librdmnet_hip_lab.so, compiled with -DRDM_DEV_KNOBS; tools/*.sh select it with RDM_LIB_PATH): the
 // product library never reads the environment.
 #ifdef RDM_DEV_KNOBS

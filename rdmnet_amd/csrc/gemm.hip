@@ -828,7 +828,7 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
 // Residency of the tiled GEMM for the calling thread's launches: `bytes` of unused dynamic LDS per workgroup.  A 64 x 64 tile
 // holds 34 KB and 128 VGPRs x 4 wavefronts, so four of its workgroups fill a CU; when several scan pairs share the GPU, 20 KB
 // of padding (two workgroups per CU) leaves registers and LDS for the other pairs' kernels: +3 % pairs/s at four in flight,
-// -2 % with one.  The engine sets it from rdm_engine_set_pairs_in_flight; results do not depend on it.
+// -2 % with one (docs/EXPERIMENTS.md 5d).  The engine sets it from rdm_engine_set_pairs_in_flight; results do not depend on it.
 void rdm::gemm_set_lds_pad(unsigned bytes) { g_lds_pad = bytes; }
 
 extern "C" size_t rdm_gemm_workspace_bytes(int64_t m, int64_t n, int batches) {

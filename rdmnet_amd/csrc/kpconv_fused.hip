@@ -16,12 +16,13 @@
 //   C = 64:  8 wavefronts x 2 queries, 4 column tiles x 2 K slices; 62 KB block + 16 KB staging -> 2 workgroups per CU
 //   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
 //   channel, 16 wavefronts x 4 queries per workgroup.
-// Measured (profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
+// Measured (docs/EXPERIMENTS.md 5b / 5d, profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
 // scan pair at the same pairs/s; the engine's default for these layers since round 3.  The kernel's time is the sum of its
 // phases' L2 -> CU traffic (neighbour lines + W re-read per 16 queries: tools/kpconv_bench.py, tools/lab/kpconv_fused_pc.hip
 // for the producer / consumer variant that overlaps the phases and measured the same).
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
 //           per CU (two of 16 wavefronts measured 65.6 against 59.4 us at the first level: the third workgroup's compute
 //           phases fill more of the other two's latency phases)
 //   C = 64: 8 wavefronts x 2 queries, tile of 240 rows (60 KB, the parked block needs 60.3 KB) -> 75 KB, two per CU
-// What bounds it (tools/tile_lab.py): inside the aggregation the CU's four matrix pipes are ~80 % busy (fp32 MFMA
+// What bounds it (tools/tile_lab.py, docs/EXPERIMENTS.md 5e): inside the aggregation the CU's four matrix pipes are ~80 % busy (fp32 MFMA
 // at 64 flop / clk / SIMD) -- points and rows now come from LDS, L2 -> CU traffic of the layer drops by the re-use factor --
 // while index rows, hash inserts, tile load and epilogue (half of a workgroup's residency) are serial latencies that two or
 // three resident workgroups only partly overlap; the layer lands within 15 % of the lock-step kernel either way.
@@ -289,10 +290,10 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
 // tools/tile_lab.py: s_memtime stamps (100 MHz) of wavefront 0 at the phase boundaries of every workgroup
 __device__ long long* rdm_tile_clk;  // [blocks][8]
 #define TILE_T0() long long tl_t = __builtin_amdgcn_s_memtime(); int tl_k = 0; const long long tl_rt0 = wall_clock64()
-#define TILE_PHASE() do { const long long now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[blockIdx.x * 8 + tl_k] = now - tl_t; tl_t = now; ++tl_k; } while (0)
+#define TILE_PHASE() do { const long long now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[tl_blk * 8 + tl_k] = now - tl_t; tl_t = now; ++tl_k; } while (0)
 // per-wavefront stamps inside the aggregation phase: [blocks][16 waves][4] = sum prologue, trips, (trips count), -
 __device__ long long* rdm_tile_wclk;
-#define TILE_W(slot, val) do { if ((threadIdx.x & 63) == 0 && rdm_tile_wclk) rdm_tile_wclk[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = (val); } while (0)
+#define TILE_W(slot, val) do { if ((threadIdx.x & 63) == 0 && rdm_tile_wclk) rdm_tile_wclk[(tl_blk * 16 + (threadIdx.x >> 6)) * 8 + (slot)] = (val); } while (0)
 #define TILE_NOW() __builtin_amdgcn_s_memtime()
 #ifdef RDM_TILE_TRIP_STAMPS  // serialising stamps inside a trip (diagnosis only: they change the schedule)
 #define TRIP_DECL() long long ts_a = 0, ts_b = 0, ts_c = 0, ts_d = 0, ts_t = 0
@@ -344,7 +345,7 @@ struct TileLds {
 
 // (two workgroups of 16 / three of 8 wavefronts per CU at C = 32, two of 8 at C = 64: 8 / 6 / 4 wavefronts per SIMD)
 template <int C>
-__global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order) {
+__global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order, int xcd_ranges) {
   using L = TileLds<C>;
   constexpr int NW = TileCfg<C>::NW, CAP = TileCfg<C>::CAP, NTH = 64 * NW, QB = kTileQB, QPW = QB / NW;
   constexpr int VEC = C / 16, NT = C / 16, TILES = NT, K16 = kKP * C / 16, LDW = L::LDW, PF = 4;
@@ -367,12 +368,22 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
   int* n_keys = reinterpret_cast<int*>(smem_raw + L::off_misc + 128);
   unsigned char* ppos = smem_raw + L::off_ppos;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, j = lane & 15;
-  const int q0 = blockIdx.x * QB;
+  // Block ids are dealt to the XCDs in contiguous ranges (workgroup b runs on XCD b % 8 -- observed placement,
+  // MI355X_MICROARCH.md: for speed only): neighbouring blocks of cell-ordered queries, whose support rows overlap, then meet in
+  // ONE L2 instead of eight (round 5: 65.7 against 68.4 us at the first level in the lab forms 5 / 3 of a persistent rewrite that
+  // was itself dropped -- static block assignment and software-pipelined index rows ran 57-80 us where this kernel runs 43-60,
+  // docs/EXPERIMENTS.md round 5).  The partial rows stay indexed by the BLOCK: same bits whatever the mapping.
+  const int per_xcd = gridDim.x / 8;
+  const int blk = (xcd_ranges && static_cast<int>(blockIdx.x) < 8 * per_xcd) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8 : blockIdx.x;
+  const int q0 = blk * QB;
   int H = a.H;
   if (a.width) H = min(H, *a.width);  // (<= kMaxH: checked by the host)
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
 
+#ifdef RDM_TILE_TIMING
+  const int tl_blk = blk;
+#endif
   TILE_T0();
   // ---------------------------------------------------------------- 0 / 1: index rows (in flight while the hash is emptied)
   int qm[QPW], qHq[QPW], qid[QPW][2], qpos[QPW][2];
@@ -420,6 +431,7 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
       bool entered = false;
       if (real) {
         unsigned p = (static_cast<unsigned>(id) * 2654435761u) >> 22;  // 10 bits
+#pragma unroll 1  // (unrolled 16 times the loop's exec masks spill 34 / 52 scalar registers)
         for (int t = 0; t < kTileProbes; ++t) {
           const int old = atomicCAS(&hkey[p], -1, id);
           if (old == -1) entered = true;  // this lane entered the id: it also numbers it below
@@ -685,81 +697,219 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
     st_s = (st_s + __shfl_xor(st_s, 16, 64)) + (__shfl_xor(st_s, 32, 64) + __shfl_xor(st_s, 48, 64));
     st_ss = (st_ss + __shfl_xor(st_ss, 16, 64)) + (__shfl_xor(st_ss, 32, 64) + __shfl_xor(st_ss, 48, 64));
     if (khg == 0 && g == 0) {
-      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * C + 16 * ct + j] = st_s;
-      a.stats[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * C + 16 * ct + j] = st_ss;
+      a.stats[(static_cast<int64_t>(blk) * 2 + 0) * C + 16 * ct + j] = st_s;
+      a.stats[(static_cast<int64_t>(blk) * 2 + 1) * C + 16 * ct + j] = st_ss;
     }
   }
   TILE_PHASE();  // 6: epilogue
 #ifdef RDM_TILE_TIMING
-  if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[blockIdx.x * 8 + 7] = n_slots + ((wall_clock64() - tl_rt0) << 16);  // (100 MHz clock)
+  if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[tl_blk * 8 + 7] = n_slots + ((wall_clock64() - tl_rt0) << 16);  // (100 MHz clock)
 #endif
 }
 
-// ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
-constexpr int kC1Out = 64, kC1Waves = 16, kC1Qpw = 4;  // 64 queries per workgroup, four per wavefront
-__global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArgs a) {
-  __shared__ float4 nb_all[kC1Waves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
+// ---- C_in = 1 (the first layer: kpconv.py:79-122 with one input channel, C' = 64)
+//
+// Round 5 form.  The round-3 / -4 kernel walked a wavefront's four queries one after the other, each a chain of dependent
+// round trips (index row -> three gathers per neighbour: point, feature, positive flag -> LDS -> a loop of one LDS read and
+// ~12 VALU instructions per neighbour with nothing in flight beside it -> six shuffles for the positive count): 24-29 us
+// for 32 000 queries, 0.23 of the HBM roofline, ~250 VALU instructions per query.  Now:
+//   * a wavefront's queries are software-pipelined: while query t is evaluated, the gathers of t+1 and the index row of t+2 are
+//     in flight (stages A / B / C of one loop below: the in-order vmcnt waits keep the younger loads flying),
+//   * two gathers per neighbour instead of three: with one input channel "row sum > 0" (kpconv.py:113-114) IS feature > 0,
+//     so the positive count is a ballot of the gathered feature -- no flag gather, no shuffles,
+//   * the staged neighbours lie in LDS as four planes (x, y, z, feature) in which the two neighbours a lane visits per step
+//     are adjacent: one 8-byte LDS read per plane feeds the packed-fp32 instructions directly (v_pk_add / v_pk_mul /
+//     v_pk_fma: two neighbours per instruction, IEEE roundings) -- ~6.5 VALU instructions per neighbour and lane instead of 12,
+//   * every slot of the planes is written (zero feature behind a row's last neighbour), so the loop runs without a tail test.
+// Lanes: (g = lane / 16, j = lane % 16): kernel point j over the neighbours h = g + 8 i (low half) and g + 8 i + 4 (high half).
+// The weights product out[c'] = sum_k WF[k] W[k][c'] stays on the VALU (15 readlane + fma per query, lane = output channel).
+constexpr int kC1Stage = 1;  // queries per pipeline stage (measured: 4 per stage 26.8 us against 23.2 -- the gathers' address processing, not their latency, bounds the kernel)
+constexpr int kC1Out = 64, kC1Waves = 8, kC1Qpw = 8;  // 64 queries per workgroup (= one GroupNorm partial row), eight per wavefront:
+// ~108 registers per lane allow 16 wavefronts per CU -- two workgroups, so that the first level's 500 workgroups are one round of the chip
+// plane index of neighbour slot h: [h / 8][h % 4][(h / 4) % 2]
+__device__ __forceinline__ int c1_plane_index(int h) { return ((h >> 3) << 3) + ((h & 3) << 1) + ((h >> 2) & 1); }
+
+template <bool I32, bool TWO>  // I32: int32 index table; TWO: rows of more than 64 slots (a second chunk per query)
+__global__ __launch_bounds__(64 * kC1Waves, 6) void kpconv_fused_c1_kernel(FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) float nb_all[kC1Waves][4][kMaxH];  // planes x, y, z (relative to the query), feature
   __shared__ double ex[kC1Waves][kC1Out][2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
-  float4* nb = nb_all[wave];
+  float* nbx = nb_all[wave][0];
+  float* nby = nb_all[wave][1];
+  float* nbz = nb_all[wave][2];
+  float* nbf = nb_all[wave][3];
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
-  int H = a.H;
-  if (a.width) H = min(H, *a.width);
-  float wcol[kKP];  // W[k][lane]
-#pragma unroll
-  for (int k = 0; k < kKP; ++k) wcol[k] = a.w[k * kC1Out + lane];
+  const int H = min(a.H, kMaxH);   // slots of the pipelined part; rows of more than 128 slots (beyond every KITTI limit) continue
+                                   // in chunks of the planes inside stage C, same lane -> neighbour assignment and summation order
+  constexpr bool two = TWO;
+  // W[k][lane] for the weights product: in LDS as [k / 4][lane] float4 (one conflict-free 16-byte read per four kernel points)
+  // instead of 15 registers per lane -- the kernel then fits six wavefronts per SIMD (three workgroups per CU)
+  __shared__ float4 wt[4][kC1Out];
+  if (wave < 4) wt[wave][lane] = make_float4(a.w[(4 * wave) * kC1Out + lane], a.w[(4 * wave + 1) * kC1Out + lane],
+                                             a.w[(4 * wave + 2) * kC1Out + lane], a.w[(4 * wave + 3) * kC1Out + lane]);  // (packed rows: 16, row 15 zero)
+  __syncthreads();
   const float bias_v = a.bias[lane];
+  const int Heff = a.width ? min(H, *a.width) : H;  // (needed only after the gathers: nothing waits for it)
   double st_s = 0.0, st_ss = 0.0;
-  const int m0 = (blockIdx.x * kC1Waves + wave) * kC1Qpw;
-  for (int qq = 0; qq < kC1Qpw; ++qq) {
-    const int m = m0 + qq;
-    if (m >= a.M) break;
-    const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
-    int positives = 0;
-    float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
-    for (int hc = 0; hc < H; hc += kMaxH) {  // chunks of the staging row
-      const int Hc = min(H - hc, kMaxH);
-      int Hq = 0;  // slots up to the last real neighbour
-      for (int hb = 0; hb < Hc; hb += 64) {
-        const int h = hb + lane;
-        const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
-        const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
-        if (rm) Hq = hb + 64 - __builtin_clzll(rm);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id >= 0 && id < a.Ns) {
-          v.x = a.s_points[3 * id] - qx;
-          v.y = a.s_points[3 * id + 1] - qy;
-          v.z = a.s_points[3 * id + 2] - qz;
-          v.w = a.s_feats[id * a.ldf];
-          positives += a.s_pos[id];
+  const int m0 = (blockIdx.x * kC1Waves + __builtin_amdgcn_readfirstlane(wave)) * kC1Qpw;  // (scalar: the query's own loads are s_loads)
+
+  // pipeline registers: raw index words of the U queries whose gathers are issued next; gathered point / feature of the U
+  // queries evaluated next (the validity test of an index is deferred to the stage that uses it: nothing waits for a load it
+  // has just issued).  U queries travel through the stages together: a wavefront's time is one memory round trip per stage
+  // (measured: with U = 1 the kernel ran at the old kernel's 23 us whatever its occupancy and instruction count -- eight
+  // dependent round trips of ~2.5 us per wavefront), so U queries per stage divide it by U.
+  constexpr int U = kC1Stage, STAGES = kC1Qpw / U;
+  using raw_t = typename std::conditional<I32, int32_t, int64_t>::type;
+  raw_t raw_a[U][2];
+  float px[U][2], py[U][2], pz[U][2], pf[U][2];
+  int id_b[U][2];
+  float qx_b[U], qy_b[U], qz_b[U];   // the query points travel with their gathers (wavefront-uniform: scalar loads)
+  float qx_a[U], qy_a[U], qz_a[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    qx_a[u] = qy_a[u] = qz_a[u] = qx_b[u] = qy_b[u] = qz_b[u] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { raw_a[u][k] = 0; px[u][k] = py[u][k] = pz[u][k] = pf[u][k] = 0.f; id_b[u][k] = -1; }
+  }
+  const f32x2 k2x = {kx, kx}, k2y = {ky, ky}, k2z = {kz, kz};
+#pragma unroll
+  for (int t = 0; t < STAGES + 2; ++t) {
+    // ---------------- stage C (first half): take over the gathers of queries (t - 2) U .. (issued one step ago)
+    float cpx[U][2], cpy[U][2], cpz[U][2], cpf[U][2], cqx[U], cqy[U], cqz[U];
+    int cid[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      cqx[u] = qx_b[u]; cqy[u] = qy_b[u]; cqz[u] = qz_b[u];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { cpx[u][k] = px[u][k]; cpy[u][k] = py[u][k]; cpz[u][k] = pz[u][k]; cpf[u][k] = pf[u][k]; cid[u][k] = id_b[u][k]; }
+    }
+    // ---------------- stage B: gathers of queries (t - 1) U .. (their index rows were requested one step ago).  Every load of
+    // stages A and B is unconditional -- rows and ids are clamped into range, what they return for a slot without a neighbour is
+    // masked in stage C -- so that the stream has no branch at which the compiler would drain the loads in flight.
+    if (t >= 1 && t <= STAGES) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k == 1 && !two) break;
+          const int h = 64 * k + lane;
+          const long long v = static_cast<long long>(raw_a[u][k]);
+          const int id = (h < H && v >= 0 && v < a.Ns) ? static_cast<int>(v) : -1;
+          id_b[u][k] = id;
+          const int idc = max(id, 0);
+          const float* pp = a.s_points + 3 * static_cast<int64_t>(idc);
+          px[u][k] = pp[0]; py[u][k] = pp[1]; pz[u][k] = pp[2];
+          pf[u][k] = a.s_feats[static_cast<int64_t>(idc) * a.ldf];
         }
-        if (h < Hc) nb[h] = v;
+        qx_b[u] = qx_a[u]; qy_b[u] = qy_a[u]; qz_b[u] = qz_a[u];
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    // ---------------- stage A: index rows and query points of queries t U ..
+    if (t < STAGES) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ma = min(m0 + t * U + u, a.M - 1);
+        const int64_t row = static_cast<int64_t>(ma) * a.ldi;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k == 1 && !two) break;
+          const int64_t off = row + min(64 * k + lane, H - 1);
+          raw_a[u][k] = reinterpret_cast<const raw_t*>(a.idx)[off];
+        }
+        qx_a[u] = a.q_points[3 * ma]; qy_a[u] = a.q_points[3 * ma + 1]; qz_a[u] = a.q_points[3 * ma + 2];
+      }
+    }
+    if (t < 2) continue;
+    // ---------------- stage C proper: the U queries one after the other through the wavefront's planes
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int mc = m0 + (t - 2) * U + u;
+    if (mc >= a.M) break;  // (uniform)
+    int positives = 0, Hq = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 1 && !two) break;
+      const int h = 64 * k + lane;
+      const bool real = cid[u][k] >= 0 && h < Heff;
+      const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
+      if (rm) Hq = 64 * k + 64 - __builtin_clzll(rm);
+      positives += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && cpf[u][k] > 0.f));
+      const int pi = c1_plane_index(h);
+      // shadow neighbours and the slots behind the row: a point at the query with a zero feature (their term is an exact zero)
+      nbx[pi] = real ? cpx[u][k] - cqx[u] : 0.f;
+      nby[pi] = real ? cpy[u][k] - cqy[u] : 0.f;
+      nbz[pi] = real ? cpz[u][k] - cqz[u] : 0.f;
+      nbf[pi] = real ? cpf[u][k] : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x2 acc2 = {0.f, 0.f};
+    auto accumulate = [&](int n_slots) __attribute__((always_inline)) {  // the staged planes, eight neighbours per step over the four lane groups
+#pragma clang fp contract(off)
+      const int steps = (n_slots + 7) >> 3;
+      const float2* X = reinterpret_cast<const float2*>(nbx) + g;
+      const float2* Y = reinterpret_cast<const float2*>(nby) + g;
+      const float2* Z = reinterpret_cast<const float2*>(nbz) + g;
+      const float2* F = reinterpret_cast<const float2*>(nbf) + g;
+#pragma unroll 2
+      for (int i = 0; i < steps; ++i) {
+        const float2 x2 = X[4 * i], y2 = Y[4 * i], z2 = Z[4 * i], f2 = F[4 * i];
+        const f32x2 w2 = kp_influence2(f32x2{x2.x, x2.y} - k2x, f32x2{y2.x, y2.y} - k2y, f32x2{z2.x, z2.y} - k2z, inv_sigma);
+        acc2 = __builtin_elementwise_fma(w2, f32x2{f2.x, f2.y}, acc2);
+      }
+    };
+    accumulate(Hq);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the planes are rewritten by the next chunk / query
+    __builtin_amdgcn_wave_barrier();
+    for (int hc = kMaxH; hc < a.H; hc += kMaxH) {  // (rows of more than 128 slots only: not pipelined)
+      int Hc = 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int h = hc + 64 * k + lane;
+        const long long v = h < a.H ? ld_index(a.idx, static_cast<int64_t>(mc) * a.ldi + h, I32 ? 1 : 0) : -1;
+        const bool real = v >= 0 && v < a.Ns && h < (a.width ? min(a.H, *a.width) : a.H);
+        const int idc = real ? static_cast<int>(v) : 0;
+        const float fx = a.s_points[3 * static_cast<int64_t>(idc)], fy = a.s_points[3 * static_cast<int64_t>(idc) + 1],
+                    fz = a.s_points[3 * static_cast<int64_t>(idc) + 2], ff = a.s_feats[static_cast<int64_t>(idc) * a.ldf];
+        const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
+        if (rm) Hc = 64 * k + 64 - __builtin_clzll(rm);
+        positives += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && ff > 0.f));
+        const int pi = c1_plane_index(64 * k + lane);
+        nbx[pi] = real ? fx - cqx[u] : 0.f;
+        nby[pi] = real ? fy - cqy[u] : 0.f;
+        nbz[pi] = real ? fz - cqz[u] : 0.f;
+        nbf[pi] = real ? ff : 0.f;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      for (int h = g; h < Hq; h += 4) {
-        const float4 v = nb[h];
-        const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
-        const float d2 = (dx * dx + dy * dy) + dz * dz;
-        acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next chunk / query
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      accumulate(Hc);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    positives = wave_sum_i(positives);
+    float acc = acc2.x + acc2.y;
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);  // every lane (., j) now holds WF[k = j]
     float o = 0.f;
 #pragma unroll
-    for (int k = 0; k < kKP; ++k)
-      o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k)), wcol[k], o);
+    for (int kg = 0; kg < 4; ++kg) {
+      const float4 w4 = wt[kg][lane];
+      const float wk[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * kg + e;
+        if (k < kKP) o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k)), wk[e], o);
+      }
+    }
     float v = o / static_cast<float>(positives > 1 ? positives : 1);
     v += bias_v;
-    a.out[static_cast<int64_t>(m) * a.ldo + lane] = v;
+    a.out[static_cast<int64_t>(mc) * a.ldo + lane] = v;
     st_s += static_cast<double>(v);
     st_ss += static_cast<double>(v) * static_cast<double>(v);
+    }  // queries of the stage
   }
   if (a.stats) {
     ex[wave][lane][0] = st_s;
@@ -817,7 +967,7 @@ bool use_tile(int64_t c_in, int64_t h, int64_t m, int64_t n_s, bool has_order, i
     return !(v != nullptr && v[0] == '0');
   }();
   if (!((c_in == 32 || c_in == 64) && h <= kMaxH)) return false;
-  if (form != 0) return form == 2;
+  if (form != 0) return form >= 2;
   return on && has_order && (c_in == 32 || 2 * m > n_s);
 }
 int64_t rows_per_block(int64_t c_in) {  // (the same in every form: the caller sizes the partial array before the form is chosen)
@@ -880,7 +1030,7 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
                            const float* kernel_points, float sigma, const float* w_packed, const float* bias, int64_t c_out,
                            float* out, int64_t ldo, double* gn_partial, const float* order_records, int form, int i32, void* stream) {
   using namespace rdm;
-  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_kpconv_fused_form: form must be 0, 1 or 2");
+  RDM_REQUIRE(form >= 0 && form <= 3, "rdm_kpconv_fused_form: form must be 0, 1 or 2 (3: lab variant of 2 without the XCD ranges)");
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && w_packed && bias && out,
               "rdm_kpconv_fused: null pointer");
   RDM_REQUIRE(rdm_kpconv_fused_supported(c, c_out), "rdm_kpconv_fused: unsupported channel counts %lld -> %lld", (long long)c,
@@ -903,18 +1053,23 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
     // (measured and dropped in round 4: the queries in cell order -- 28.2 against 26.8 us at the first level -- and the index rows
     // and gathers of a wavefront's four queries requested together -- 30.4 us: the kernel is bound by its ~250 VALU
     // instructions per query, not by its round trips)
-    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    const bool two = a.H > 64;  // (rows beyond 128 slots: the kernel's chunk loop)
+    if (a.i32 && two) hipLaunchKernelGGL((kpconv_fused_c1_kernel<true, true>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    else if (a.i32) hipLaunchKernelGGL((kpconv_fused_c1_kernel<true, false>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    else if (two) hipLaunchKernelGGL((kpconv_fused_c1_kernel<false, true>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    else hipLaunchKernelGGL((kpconv_fused_c1_kernel<false, false>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     continue;
   }
   if (use_tile(c, h, m, n_s, order_records != nullptr, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
     static std::atomic<uint64_t> tattr32{0}, tattr64{0};
     const float4* order = reinterpret_cast<const float4*>(order_records);
+    const int xcd_ranges = form == 3 ? 0 : 1;  // (form 3, lab: block ids in dispatch order, as in round 4)
     if (c == 32) {
       RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<32>), static_cast<int>(TileLds<32>::bytes), tattr32));
-      hipLaunchKernelGGL((kpconv_tile_kernel<32>), dim3(blocks), dim3(64 * TileCfg<32>::NW), TileLds<32>::bytes, st, a, order);
+      hipLaunchKernelGGL((kpconv_tile_kernel<32>), dim3(blocks), dim3(64 * TileCfg<32>::NW), TileLds<32>::bytes, st, a, order, xcd_ranges);
     } else {
       RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<64>), static_cast<int>(TileLds<64>::bytes), tattr64));
-      hipLaunchKernelGGL((kpconv_tile_kernel<64>), dim3(blocks), dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, st, a, order);
+      hipLaunchKernelGGL((kpconv_tile_kernel<64>), dim3(blocks), dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, st, a, order, xcd_ranges);
     }
     continue;
   }

@@ -2,7 +2,7 @@
 
 The reference's test loop (geotransformer/engine/single_tester.py:86-134) pushes one pair at a time through the
 model and synchronises after each; most kernels of one pair are far too small to fill 256 CUs, so a GPU driven
-like that idles (240 pairs/s with one pair in flight against 500+ with four).  `PairPipeline` is
+like that idles (docs/EXPERIMENTS.md 5: 240 pairs/s with one pair in flight against 500+ with four).  `PairPipeline` is
 what replaces that loop here -- used by `rdmnet_amd.infer.Tester`, by `bench.py`'s timed region and by anything
 else that has a stream of pairs:
 
@@ -36,7 +36,7 @@ import torch
 
 from .engine import Engine
 
-DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe with another one
+DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe with another one (docs/EXPERIMENTS.md 5b)
 DEFAULT_STAGGER_MS = 1.5
 
 

@@ -64,6 +64,9 @@ if __name__ == '__main__':
                 rows.append(('one kernel, LDS tile, row order', t))
                 t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=2, order=rec))
                 rows.append(('one kernel, LDS tile, cell order', t))
+                for f, tag in ((3, 'block ids in dispatch order (round 4)'),):
+                    t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=f, order=rec))
+                    rows.append((f'  lab form {f}: {tag}', t))
         t = timed(lambda: ops.kpconv_gather(q, s, feats, pos, idx, kp, sigma))
         rows.append(('gather alone', t))
         for name, t in rows:

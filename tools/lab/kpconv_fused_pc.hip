@@ -5,7 +5,7 @@
 // kernel that ships (graph-replayed, tools/kpconv_bench.py, us): 32->32 at 32 k queries 65.0 vs 61.3, 32->32 strided 28.4 vs
 // 31.0, 64->64 at 11 k 44.6 vs 48.5, 64->64 strided 19.7 vs 18.5-20.5 -- a wash.  The phase stamps say why: under the
 // gather's load every memory round trip takes 2.5-5 us, and the W operand (61 / 245 KB re-read from L2 per 16 queries) costs
-// the consumers 13 us per block; a later variant with W register-resident measured the same again, so neither the
+// the consumers 13 us per block; a later variant with W register-resident measured the same again (docs/EXPERIMENTS.md 5d), so neither the
 // phase structure nor W is what bounds these layers.  (A first version with read-modify-write LDS counters
 // dead-locked; single-writer counters with release stores / acquire loads are what works.)
 // a4 -- KPConv.forward as ONE kernel for the fine levels (C_in = 1, 32, 64): neighbourhood aggregation AND the
@@ -26,7 +26,7 @@
 //   C = 64:  8 wavefronts x 2 queries, 4 column tiles x 2 K slices; 62 KB block + 16 KB staging -> 2 workgroups per CU
 //   C_in = 1 (first layer, features == 1): no matrix core needed on either side; one wavefront per query, lane = output
 //   channel, 16 wavefronts x 4 queries per workgroup.
-// Measured (profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
+// Measured (docs/EXPERIMENTS.md §5b, profiles/r02_pmc_fused_kpconv.md): HBM-side writes of these layers drop from 200 MB to 24 MB per
 // scan pair, the time does not (the LDS block caps a CU at 16-32 queries in flight in lock-step phases), so the engine
 // uses it only when RDM_FUSED_KPCONV=1.
 #include <algorithm>

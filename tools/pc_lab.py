@@ -1,6 +1,6 @@
 """Phase timing of kpconv_fused_pc_kernel (shader-clock sums of workgroup 0's sixteen wavefronts): builds of kpconv_fused.hip
 with -DRDM_PC_TIMING export rdm_dbg_pc_timing(buffer).   RDM_LIB_PATH=.../librdmnet_hip_pctiming.so python tools/pc_lab.py
-The kernel is the lab copy tools/lab/kpconv_fused_pc.hip (measured a wash, not in the library): to reproduce, put it
+The kernel is the lab copy tools/lab/kpconv_fused_pc.hip (docs/EXPERIMENTS.md 5d: measured a wash, not in the library): to reproduce, put it
 in place of rdmnet_amd/csrc/kpconv_fused.hip, compile that file with -DRDM_PC_TIMING and link it with the other objects of
 rdmnet_amd/csrc/build into librdmnet_hip_pctiming.so."""
 import ctypes, os, sys
