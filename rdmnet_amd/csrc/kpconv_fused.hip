@@ -22,7 +22,6 @@
 // for the producer / consumer variant that overlaps the phases and measured the same).
 #include <atomic>
 #include <cstdlib>
-#include <type_traits>
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
@@ -707,209 +706,78 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
 #endif
 }
 
-// ---- C_in = 1 (the first layer: kpconv.py:79-122 with one input channel, C' = 64)
-//
-// Round 5 form.  The round-3 / -4 kernel walked a wavefront's four queries one after the other, each a chain of dependent
-// round trips (index row -> three gathers per neighbour: point, feature, positive flag -> LDS -> a loop of one LDS read and
-// ~12 VALU instructions per neighbour with nothing in flight beside it -> six shuffles for the positive count): 24-29 us
-// for 32 000 queries, 0.23 of the HBM roofline, ~250 VALU instructions per query.  Now:
-//   * a wavefront's queries are software-pipelined: while query t is evaluated, the gathers of t+1 and the index row of t+2 are
-//     in flight (stages A / B / C of one loop below: the in-order vmcnt waits keep the younger loads flying),
-//   * two gathers per neighbour instead of three: with one input channel "row sum > 0" (kpconv.py:113-114) IS feature > 0,
-//     so the positive count is a ballot of the gathered feature -- no flag gather, no shuffles,
-//   * the staged neighbours lie in LDS as four planes (x, y, z, feature) in which the two neighbours a lane visits per step
-//     are adjacent: one 8-byte LDS read per plane feeds the packed-fp32 instructions directly (v_pk_add / v_pk_mul /
-//     v_pk_fma: two neighbours per instruction, IEEE roundings) -- ~6.5 VALU instructions per neighbour and lane instead of 12,
-//   * every slot of the planes is written (zero feature behind a row's last neighbour), so the loop runs without a tail test.
-// Lanes: (g = lane / 16, j = lane % 16): kernel point j over the neighbours h = g + 8 i (low half) and g + 8 i + 4 (high half).
-// The weights product out[c'] = sum_k WF[k] W[k][c'] stays on the VALU (15 readlane + fma per query, lane = output channel).
-constexpr int kC1Stage = 1;  // queries per pipeline stage (measured: 4 per stage 26.8 us against 23.2 -- the gathers' address processing, not their latency, bounds the kernel)
-constexpr int kC1Out = 64, kC1Waves = 8, kC1Qpw = 8;  // 64 queries per workgroup (= one GroupNorm partial row), eight per wavefront:
-// ~108 registers per lane allow 16 wavefronts per CU -- two workgroups, so that the first level's 500 workgroups are one round of the chip
-// plane index of neighbour slot h: [h / 8][h % 4][(h / 4) % 2]
-__device__ __forceinline__ int c1_plane_index(int h) { return ((h >> 3) << 3) + ((h & 3) << 1) + ((h >> 2) & 1); }
-
-template <bool I32, bool TWO>  // I32: int32 index table; TWO: rows of more than 64 slots (a second chunk per query)
-__global__ __launch_bounds__(64 * kC1Waves, 6) void kpconv_fused_c1_kernel(FusedArgs a) {
-  __shared__ __attribute__((aligned(16))) float nb_all[kC1Waves][4][kMaxH];  // planes x, y, z (relative to the query), feature
+// (Round 5 measured a rewrite of this kernel -- a wavefront's queries software-pipelined (index row of query t + 2 and the two
+// gathers of t + 1 in flight while t is evaluated), the positive count as a ballot of the gathered feature, the staged
+// neighbours in four LDS planes feeding packed-fp32 instructions, ~6.5 VALU instructions per neighbour instead of 12: 22.8-23.2 us
+// against 26.8-27.1 for 32 000 queries, 19.5 with {x, y, z, f} records gathered in one access -- and did NOT adopt it: its
+// summation order moves the first layer's features by 1e-7, which is enough to make another local hypothesis win the
+// registration of the two near-tie golden cases (9 m crop: margin 1; pair 0<->7: margin 0), i.e. to leave the set of poses the
+// REFERENCE returns for them.  A 4 us kernel is not worth a weaker parity statement; docs/EXPERIMENTS.md 5f.)
+// ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
+constexpr int kC1Out = 64, kC1Waves = 16, kC1Qpw = 4;  // 64 queries per workgroup, four per wavefront
+__global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArgs a) {
+  __shared__ float4 nb_all[kC1Waves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
   __shared__ double ex[kC1Waves][kC1Out][2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = lane >> 4, j = lane & 15;
-  float* nbx = nb_all[wave][0];
-  float* nby = nb_all[wave][1];
-  float* nbz = nb_all[wave][2];
-  float* nbf = nb_all[wave][3];
+  float4* nb = nb_all[wave];
   const float kx = j < kKP ? a.kp[3 * j] : 0.f, ky = j < kKP ? a.kp[3 * j + 1] : 0.f, kz = j < kKP ? a.kp[3 * j + 2] : 0.f;
   const float inv_sigma = 1.0f / a.sigma;
-  const int H = min(a.H, kMaxH);   // slots of the pipelined part; rows of more than 128 slots (beyond every KITTI limit) continue
-                                   // in chunks of the planes inside stage C, same lane -> neighbour assignment and summation order
-  constexpr bool two = TWO;
-  // W[k][lane] for the weights product: in LDS as [k / 4][lane] float4 (one conflict-free 16-byte read per four kernel points)
-  // instead of 15 registers per lane -- the kernel then fits six wavefronts per SIMD (three workgroups per CU)
-  __shared__ float4 wt[4][kC1Out];
-  if (wave < 4) wt[wave][lane] = make_float4(a.w[(4 * wave) * kC1Out + lane], a.w[(4 * wave + 1) * kC1Out + lane],
-                                             a.w[(4 * wave + 2) * kC1Out + lane], a.w[(4 * wave + 3) * kC1Out + lane]);  // (packed rows: 16, row 15 zero)
-  __syncthreads();
+  int H = a.H;
+  if (a.width) H = min(H, *a.width);
+  float wcol[kKP];  // W[k][lane]
+#pragma unroll
+  for (int k = 0; k < kKP; ++k) wcol[k] = a.w[k * kC1Out + lane];
   const float bias_v = a.bias[lane];
-  const int Heff = a.width ? min(H, *a.width) : H;  // (needed only after the gathers: nothing waits for it)
   double st_s = 0.0, st_ss = 0.0;
-  const int m0 = (blockIdx.x * kC1Waves + __builtin_amdgcn_readfirstlane(wave)) * kC1Qpw;  // (scalar: the query's own loads are s_loads)
-
-  // pipeline registers: raw index words of the U queries whose gathers are issued next; gathered point / feature of the U
-  // queries evaluated next (the validity test of an index is deferred to the stage that uses it: nothing waits for a load it
-  // has just issued).  U queries travel through the stages together: a wavefront's time is one memory round trip per stage
-  // (measured: with U = 1 the kernel ran at the old kernel's 23 us whatever its occupancy and instruction count -- eight
-  // dependent round trips of ~2.5 us per wavefront), so U queries per stage divide it by U.
-  constexpr int U = kC1Stage, STAGES = kC1Qpw / U;
-  using raw_t = typename std::conditional<I32, int32_t, int64_t>::type;
-  raw_t raw_a[U][2];
-  float px[U][2], py[U][2], pz[U][2], pf[U][2];
-  int id_b[U][2];
-  float qx_b[U], qy_b[U], qz_b[U];   // the query points travel with their gathers (wavefront-uniform: scalar loads)
-  float qx_a[U], qy_a[U], qz_a[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    qx_a[u] = qy_a[u] = qz_a[u] = qx_b[u] = qy_b[u] = qz_b[u] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { raw_a[u][k] = 0; px[u][k] = py[u][k] = pz[u][k] = pf[u][k] = 0.f; id_b[u][k] = -1; }
-  }
-  const f32x2 k2x = {kx, kx}, k2y = {ky, ky}, k2z = {kz, kz};
-#pragma unroll
-  for (int t = 0; t < STAGES + 2; ++t) {
-    // ---------------- stage C (first half): take over the gathers of queries (t - 2) U .. (issued one step ago)
-    float cpx[U][2], cpy[U][2], cpz[U][2], cpf[U][2], cqx[U], cqy[U], cqz[U];
-    int cid[U][2];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      cqx[u] = qx_b[u]; cqy[u] = qy_b[u]; cqz[u] = qz_b[u];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) { cpx[u][k] = px[u][k]; cpy[u][k] = py[u][k]; cpz[u][k] = pz[u][k]; cpf[u][k] = pf[u][k]; cid[u][k] = id_b[u][k]; }
-    }
-    // ---------------- stage B: gathers of queries (t - 1) U .. (their index rows were requested one step ago).  Every load of
-    // stages A and B is unconditional -- rows and ids are clamped into range, what they return for a slot without a neighbour is
-    // masked in stage C -- so that the stream has no branch at which the compiler would drain the loads in flight.
-    if (t >= 1 && t <= STAGES) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (k == 1 && !two) break;
-          const int h = 64 * k + lane;
-          const long long v = static_cast<long long>(raw_a[u][k]);
-          const int id = (h < H && v >= 0 && v < a.Ns) ? static_cast<int>(v) : -1;
-          id_b[u][k] = id;
-          const int idc = max(id, 0);
-          const float* pp = a.s_points + 3 * static_cast<int64_t>(idc);
-          px[u][k] = pp[0]; py[u][k] = pp[1]; pz[u][k] = pp[2];
-          pf[u][k] = a.s_feats[static_cast<int64_t>(idc) * a.ldf];
+  const int m0 = (blockIdx.x * kC1Waves + wave) * kC1Qpw;
+  for (int qq = 0; qq < kC1Qpw; ++qq) {
+    const int m = m0 + qq;
+    if (m >= a.M) break;
+    const float qx = a.q_points[3 * m], qy = a.q_points[3 * m + 1], qz = a.q_points[3 * m + 2];
+    int positives = 0;
+    float acc = 0.f;  // lane (g, j): kernel point j over neighbours g, g+4, ...
+    for (int hc = 0; hc < H; hc += kMaxH) {  // chunks of the staging row
+      const int Hc = min(H - hc, kMaxH);
+      int Hq = 0;  // slots up to the last real neighbour
+      for (int hb = 0; hb < Hc; hb += 64) {
+        const int h = hb + lane;
+        const int64_t id = h < Hc ? ld_index(a.idx, static_cast<int64_t>(m) * a.ldi + hc + h, a.i32) : -1;
+        const unsigned long long rm = __builtin_amdgcn_ballot_w64(id >= 0 && id < a.Ns);
+        if (rm) Hq = hb + 64 - __builtin_clzll(rm);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id >= 0 && id < a.Ns) {
+          v.x = a.s_points[3 * id] - qx;
+          v.y = a.s_points[3 * id + 1] - qy;
+          v.z = a.s_points[3 * id + 2] - qz;
+          v.w = a.s_feats[id * a.ldf];
+          positives += a.s_pos[id];
         }
-        qx_b[u] = qx_a[u]; qy_b[u] = qy_a[u]; qz_b[u] = qz_a[u];
+        if (h < Hc) nb[h] = v;
       }
-    }
-    // ---------------- stage A: index rows and query points of queries t U ..
-    if (t < STAGES) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int ma = min(m0 + t * U + u, a.M - 1);
-        const int64_t row = static_cast<int64_t>(ma) * a.ldi;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (k == 1 && !two) break;
-          const int64_t off = row + min(64 * k + lane, H - 1);
-          raw_a[u][k] = reinterpret_cast<const raw_t*>(a.idx)[off];
-        }
-        qx_a[u] = a.q_points[3 * ma]; qy_a[u] = a.q_points[3 * ma + 1]; qz_a[u] = a.q_points[3 * ma + 2];
-      }
-    }
-    if (t < 2) continue;
-    // ---------------- stage C proper: the U queries one after the other through the wavefront's planes
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-    const int mc = m0 + (t - 2) * U + u;
-    if (mc >= a.M) break;  // (uniform)
-    int positives = 0, Hq = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k == 1 && !two) break;
-      const int h = 64 * k + lane;
-      const bool real = cid[u][k] >= 0 && h < Heff;
-      const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
-      if (rm) Hq = 64 * k + 64 - __builtin_clzll(rm);
-      positives += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && cpf[u][k] > 0.f));
-      const int pi = c1_plane_index(h);
-      // shadow neighbours and the slots behind the row: a point at the query with a zero feature (their term is an exact zero)
-      nbx[pi] = real ? cpx[u][k] - cqx[u] : 0.f;
-      nby[pi] = real ? cpy[u][k] - cqy[u] : 0.f;
-      nbz[pi] = real ? cpz[u][k] - cqz[u] : 0.f;
-      nbf[pi] = real ? cpf[u][k] : 0.f;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    f32x2 acc2 = {0.f, 0.f};
-    auto accumulate = [&](int n_slots) __attribute__((always_inline)) {  // the staged planes, eight neighbours per step over the four lane groups
-#pragma clang fp contract(off)
-      const int steps = (n_slots + 7) >> 3;
-      const float2* X = reinterpret_cast<const float2*>(nbx) + g;
-      const float2* Y = reinterpret_cast<const float2*>(nby) + g;
-      const float2* Z = reinterpret_cast<const float2*>(nbz) + g;
-      const float2* F = reinterpret_cast<const float2*>(nbf) + g;
-#pragma unroll 2
-      for (int i = 0; i < steps; ++i) {
-        const float2 x2 = X[4 * i], y2 = Y[4 * i], z2 = Z[4 * i], f2 = F[4 * i];
-        const f32x2 w2 = kp_influence2(f32x2{x2.x, x2.y} - k2x, f32x2{y2.x, y2.y} - k2y, f32x2{z2.x, z2.y} - k2z, inv_sigma);
-        acc2 = __builtin_elementwise_fma(w2, f32x2{f2.x, f2.y}, acc2);
-      }
-    };
-    accumulate(Hq);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the planes are rewritten by the next chunk / query
-    __builtin_amdgcn_wave_barrier();
-    for (int hc = kMaxH; hc < a.H; hc += kMaxH) {  // (rows of more than 128 slots only: not pipelined)
-      int Hc = 0;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int h = hc + 64 * k + lane;
-        const long long v = h < a.H ? ld_index(a.idx, static_cast<int64_t>(mc) * a.ldi + h, I32 ? 1 : 0) : -1;
-        const bool real = v >= 0 && v < a.Ns && h < (a.width ? min(a.H, *a.width) : a.H);
-        const int idc = real ? static_cast<int>(v) : 0;
-        const float fx = a.s_points[3 * static_cast<int64_t>(idc)], fy = a.s_points[3 * static_cast<int64_t>(idc) + 1],
-                    fz = a.s_points[3 * static_cast<int64_t>(idc) + 2], ff = a.s_feats[static_cast<int64_t>(idc) * a.ldf];
-        const unsigned long long rm = __builtin_amdgcn_ballot_w64(real);
-        if (rm) Hc = 64 * k + 64 - __builtin_clzll(rm);
-        positives += __builtin_popcountll(__builtin_amdgcn_ballot_w64(real && ff > 0.f));
-        const int pi = c1_plane_index(64 * k + lane);
-        nbx[pi] = real ? fx - cqx[u] : 0.f;
-        nby[pi] = real ? fy - cqy[u] : 0.f;
-        nbz[pi] = real ? fz - cqz[u] : 0.f;
-        nbf[pi] = real ? ff : 0.f;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      accumulate(Hc);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      for (int h = g; h < Hq; h += 4) {
+        const float4 v = nb[h];
+        const float dx = v.x - kx, dy = v.y - ky, dz = v.z - kz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        acc += fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(d2) * inv_sigma) * v.w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // nb is rewritten by the next chunk / query
       __builtin_amdgcn_wave_barrier();
     }
-    float acc = acc2.x + acc2.y;
+    positives = wave_sum_i(positives);
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);  // every lane (., j) now holds WF[k = j]
     float o = 0.f;
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const float4 w4 = wt[kg][lane];
-      const float wk[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = 4 * kg + e;
-        if (k < kKP) o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k)), wk[e], o);
-      }
-    }
+    for (int k = 0; k < kKP; ++k)
+      o = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), k)), wcol[k], o);
     float v = o / static_cast<float>(positives > 1 ? positives : 1);
     v += bias_v;
-    a.out[static_cast<int64_t>(mc) * a.ldo + lane] = v;
+    a.out[static_cast<int64_t>(m) * a.ldo + lane] = v;
     st_s += static_cast<double>(v);
     st_ss += static_cast<double>(v) * static_cast<double>(v);
-    }  // queries of the stage
   }
   if (a.stats) {
     ex[wave][lane][0] = st_s;
@@ -1051,13 +919,10 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
   RDM_DUP_LOOP("fused") {
   if (c == 1) {
     // (measured and dropped in round 4: the queries in cell order -- 28.2 against 26.8 us at the first level -- and the index rows
-    // and gathers of a wavefront's four queries requested together -- 30.4 us: the kernel is bound by its ~250 VALU
-    // instructions per query, not by its round trips)
-    const bool two = a.H > 64;  // (rows beyond 128 slots: the kernel's chunk loop)
-    if (a.i32 && two) hipLaunchKernelGGL((kpconv_fused_c1_kernel<true, true>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
-    else if (a.i32) hipLaunchKernelGGL((kpconv_fused_c1_kernel<true, false>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
-    else if (two) hipLaunchKernelGGL((kpconv_fused_c1_kernel<false, true>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
-    else hipLaunchKernelGGL((kpconv_fused_c1_kernel<false, false>), dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    // and gathers of a wavefront's four queries requested together -- 30.4 us; round 5: halving the instruction count and
+    // pipelining the queries buys 15 %, four queries per pipeline stage lose it again: the address processing of the
+    // scattered gathers bounds the kernel, see the note above kpconv_fused_c1_kernel)
+    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
     continue;
   }
   if (use_tile(c, h, m, n_s, order_records != nullptr, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS

@@ -234,16 +234,32 @@ __global__ void rn_scatter_kernel(RnBuildBatch bb) {
   it.cell_list[it.cell_start[c] + it.pt_slot[i]] = static_cast<int>(i);
 }
 
-// records in (cell, index) order: a point's place inside its cell is the number of members with a smaller index
+// records in (cell, index) order: a point's place inside its cell is the number of members with a smaller index.
+// Cells of up to 32 members (every cell of a voxel-subsampled level) are counted by the point's own lane; the members of a
+// crowded cell -- raw scans, coincident points, the kMaxCells clamp on a huge extent -- are counted by the whole wavefront for one
+// such point at a time (coalesced reads of the member list, 64 comparisons per trip): n / 64 trips per point instead of n
+// dependent loads, so a degenerate cloud of 32 k points in ONE cell costs 16 M coalesced reads, not 10^9 serial ones.
 __global__ void rn_rank_kernel(RnBuildBatch bb) {
   const RnBuildItem& it = bb.item[blockIdx.y];
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= it.ns) return;
-  const int c = it.pt_cell[i];
-  if (c < 0) return;
-  const int start = it.cell_start[c], n = it.cell_count[c];
+  const int lane = threadIdx.x & 63;
+  const int c = i < it.ns ? it.pt_cell[i] : -1;
+  const int start = c >= 0 ? it.cell_start[c] : 0, n = c >= 0 ? it.cell_count[c] : 0;
   int rank = 0;
-  for (int k = 0; k < n; ++k) rank += it.cell_list[start + k] < static_cast<int>(i) ? 1 : 0;
+  if (n <= 32)
+    for (int k = 0; k < n; ++k) rank += it.cell_list[start + k] < static_cast<int>(i) ? 1 : 0;
+  unsigned long long crowded = __builtin_amdgcn_ballot_w64(n > 32);
+  while (crowded) {  // (wavefront-uniform)
+    const int src = __builtin_ctzll(crowded);
+    crowded &= crowded - 1;
+    const int s0 = __builtin_amdgcn_readlane(start, src), sn = __builtin_amdgcn_readlane(n, src);
+    const int si = __builtin_amdgcn_readlane(static_cast<int>(i), src);
+    int cnt = 0;
+    for (int k = lane; k < sn; k += 64) cnt += it.cell_list[s0 + k] < si ? 1 : 0;
+    cnt = wave_sum_i(cnt);
+    if (lane == src) rank = cnt;
+  }
+  if (c < 0) return;
   const float* s = it.s;
   float4 v;
   v.x = s[3 * i];

@@ -126,6 +126,12 @@ def main():
         from rdmnet_amd import synthetic
         lo_ref, lo_src, _ = synthetic.make_low_overlap_pair(0)
         cases['lowoverlap'] = (lo_ref, lo_src, 0)
+    # BASELINE configs[3] WORKLOAD (KITTI-360 / Apollo-shaped: denser scans, ~20 k points each) through the reference in fp32 --
+    # the reference has no bf16 switch; the bf16 mode's deviation from THIS run is measured by test_reference_goldens_gpu.py
+    if not only_has_no('dense20k'):
+        from rdmnet_amd import synthetic
+        d_ref, d_src, _ = synthetic.make_pair(40, target_points=20000)
+        cases['dense20k'] = (d_ref, d_src, 0)
     for i in os.environ.get('RDM_GOLDEN_EXTRA_SYNTH', '').split():  # probing other synthetic pairs, not committed
         cases[f'synth{i}'] = (synth[f'ref{i}'], synth[f'src{i}'], 0)
     only = [a for a in sys.argv[1:] if a in cases]

@@ -193,6 +193,29 @@ def test_multi_launch_subsampling_equals_single_workgroup_form_and_oracle(scans,
             assert np.array_equal(p, rp), (lens, voxel)
 
 
+def test_grid_build_of_a_degenerate_cloud_is_not_quadratic():
+    """rn_rank_kernel placed a record by a serial loop over all members of its cell -- fine for voxel-subsampled levels
+    (tens of points per cell), 10^9 dependent loads for 32 k points in ONE cell (raw scans, coincident points, a clamped cell
+    grid).  Crowded cells are now counted by the whole wavefront: the build of such a cloud stays in the milliseconds and the
+    records come out in (cloud, cell, row) order as for any other cloud."""
+    import time
+    from rdmnet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n = 32768
+    pts = (torch.rand(2 * n, 3, generator=g) * 0.05).cuda()  # every point of a cloud inside one cell of a 1 m grid
+    lengths = torch.tensor([n, n], dtype=torch.int64).cuda()
+    ops.radius_grid_records(pts[:64], torch.tensor([32, 32]).cuda(), 1.0)  # (first-call costs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = ops.radius_grid_records(pts, lengths, 1.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rows = rec[:, 3].contiguous().view(torch.int32).cpu().numpy()
+    assert np.array_equal(rows, np.arange(2 * n)), 'one cell per cloud: the records are the rows in order'
+    assert torch.equal(rec[:, :3], pts)
+    assert dt < 0.25, f'grid build of a one-cell cloud took {dt * 1e3:.1f} ms'
+
+
 def test_grid_records_are_a_function_of_the_points_alone():
     """Round 4: the cell-sorted records of a search grid (rdm_radius_grid_records) also order the queries of the KPConv tile
     kernel, whose GroupNorm partials follow its workgroups -- so the order must not depend on how the build's atomics raced:

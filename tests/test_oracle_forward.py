@@ -33,7 +33,7 @@ def close(a, b, rtol=2e-5, atol=2e-5):
     assert err <= atol * scale + rtol * scale, f'max err {err} (scale {scale})'
 
 
-TAGS = ['small', 'crop9', 'pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'lowoverlap']
+TAGS = ['small', 'crop9', 'pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'lowoverlap', 'dense20k']
 
 
 @pytest.mark.parametrize('tag', TAGS)

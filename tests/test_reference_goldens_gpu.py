@@ -46,7 +46,7 @@ def npy(x):
 rre_rte = tie_aware.rre_rte
 
 
-TAGS = ['pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'small', 'crop9', 'lowoverlap']
+TAGS = ['pair04', 'pair07', 'pair04_seed1', 'synth0', 'synth3', 'small', 'crop9', 'lowoverlap', 'dense20k']
 
 
 @pytest.fixture(scope='module')
@@ -239,7 +239,7 @@ def test_coarse_matching_reproduces_reference_indices_teacher_forced(golden_dir,
     assert err <= 4e-6  # the reference's scores carry their own fp32 rounding (measured: <= 2.2e-6 on seven cases, 3.02e-6 on `lowoverlap`)
 
 
-@pytest.mark.parametrize('tag', ['synth0', 'synth3'])
+@pytest.mark.parametrize('tag', ['synth0', 'synth3', 'dense20k'])
 def test_bf16_attention_deviation_from_the_fp32_reference_goldens(setup, golden_dir, tag):
     """BASELINE configs[3] (bf16 operands in QK^T and PV, fp32 softmax / accumulators / pose solve) has no counterpart in
     the reference; test_full_size_configs_gpu.py compares it with the oracle's bf16 restatement.  Here the same mode runs on
