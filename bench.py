@@ -196,6 +196,10 @@ def main():
     ap.add_argument('--pin', choices=['on', 'off'], default='on',
                     help='with several ranks on one host: pin rank r to the r-th contiguous slice of the CPUs this job may use')
     ap.add_argument('--cache', default=os.path.join(ROOT, 'gpurun_out', 'bench_pairs'))
+    ap.add_argument('--collate-batch', type=int, default=None,
+                    help='pairs a worker collates with ONE sequence of launches before it runs their forwards one by one\n'
+                         '(rdm_engine_collate_batch; default: rdmnet_amd.pipeline.DEFAULT_COLLATE_BATCH; 1 = every pair collates itself,\n'
+                         'the schedule of rounds 1-4).  Same results bit for bit.')
     ap.add_argument('--dry-run', action='store_true',
                     help='construct the communicator (RCCL for --dist-backend nccl), run the pre-flight -- the barrier, the ragged\n'
                          'record gather and the timing reduction of a real run on dummy records -- print one JSON line and exit\n'
@@ -331,8 +335,12 @@ def main():
     # sharing one copy of the weights, N host threads / HIP streams drawing steps from one queue, staggered starts, the
     # pairs-in-flight hint, and spin-or-poll waits chosen from this rank's CPU budget.
     budget = pipeline.rank_cpu_budget(local_world)
+    collate_batch = pipeline.DEFAULT_COLLATE_BATCH if args.collate_batch is None else max(1, args.collate_batch)
+    if args.path != 'engine':
+        collate_batch = 1
     pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
-                                 stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams)
+                                 stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams,
+                                 collate_batch=collate_batch)
     wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
     worker_of = {id(e): k for k, e in enumerate(engines)}
     for eng in engines:
@@ -382,8 +390,13 @@ def main():
 
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
         events_every = args.layer_events_every if events_every is None else events_every
+        # (tensors_of: what one_step will hand to eng.run for this slot -- the pipeline's workers collate several drawn pairs at once)
         pipe.map(range(count), lambda eng, slot: one_step(eng, slot, first, rec, lat_out, prof_lists[worker_of[id(eng)]],
-                                                          events_every, len(streams)))
+                                                          events_every, len(streams)),
+                 tensors_of=(lambda slot: dev_pairs[(rank + (first + slot) * world) % len(dev_pairs)]) if args.path == 'engine' else None)
+        if rec is not None and lat_out is not None and pipe.last_stats.get('latency_ms'):
+            # a pair's latency counts from the moment its worker drew it: the batch's collate and the pairs before it included
+            lat_out[:] = [pipe.last_stats['latency_ms'][k] for k in sorted(pipe.last_stats['latency_ms'])]
 
     # Clock ramp (untimed, before the W warm-up steps): the first GPU process on a freshly started box runs 15-20 % slower
     # for its first seconds -- idle host cores and GPU power states take that long to reach their steady clocks (measured:
@@ -659,7 +672,8 @@ def main():
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'searches_per_pair': 12 if args.path == 'engine' else 13,
                        'scheduler': 'rdmnet_amd.pipeline.PairPipeline', 'points_per_pair': n_points,
-                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'host_path': args.path,
+                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'collate_batch': collate_batch,
+                       'host_path': args.path,
                        'host_cpus_per_rank': budget, 'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None,
                        'gpu_max_hw_queues': pipeline.hw_queues(), 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
                        'parallelism': f'pairs sharded over {world} GPU(s)'},

@@ -207,6 +207,14 @@ int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const float* s_p
                               const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
                               const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
                               const float* order_records, void* stream);
+/* The same with the kernel form chosen by the caller (tests and A/B runs): 0 = the library's choice, 1 = one wavefront per
+ * (query, 64-channel slice) fetching every neighbour row, 2 = the support rows of 16 cell-ordered queries staged once in LDS
+ * (needs order_records, c a multiple of 64 >= 128, h <= 128; else form 1).  Same WF and nn bits in every form.            */
+int rdm_kpconv_gather_form(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                              const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                              const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                              const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn,
+                              const float* order_records, int form, void* stream);
 int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld, uint8_t* out, void* stream);
 
 /* ---- a5: block glue --------------------------------------------------------------------------
@@ -507,6 +515,19 @@ int rdm_engine_collate(rdm_engine* e, const float* ref_points, int64_t n_ref, co
  * (rdmnet_amd.collate) or the reference's.  Same result structure, taps and waits as rdm_engine_run; bit-identical to
  * it when fed the tables rdm_engine_run builds itself.                                                              */
 int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* data, rdm_engine_result* result_host, void* stream);
+
+/* Batched collate (round 5): the collates of `n_pairs` (1 .. 16) pairs -- precompute_data_stack_mode, data.py:13-77, once per
+ * pair in the reference's DataLoader workers -- as ONE sequence of launches: every subsampling launch works on 2 * n_pairs
+ * clouds, the search grids are built as (pair, level) items, the 12 searches a plain run needs per pair are flushed 16 per
+ * launch, the level sizes of all pairs return in one read-back.  The pyramids stay in the engine's arena;
+ * rdm_engine_forward_batched(e, k, ...) then runs RDMNet.forward (model_infer.py:109-354) of pair k on them: result structure,
+ * waits and read-outs of rdm_engine_run, and the same bits (every pair's tables, points and query order are what its own
+ * collate writes).  ref_points / src_points: host arrays of device pointers, float32 [n, 3] each; the clouds must stay valid
+ * until the collate has run on `stream`.  Not with rdm_engine_keep_taps (a run that keeps its stage tensors builds the
+ * reference's full tables).  Any other run on the engine discards the batch.                                          */
+int rdm_engine_collate_batch(rdm_engine* e, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                             const float* const* src_points, const int64_t* n_src, void* stream);
+int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* result_host, void* stream);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
 /* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,

@@ -2,7 +2,7 @@
 # Regenerates the round's profile summaries on the GPU box:  gpurun -- 'bash profiles/collect.sh r01'
 # Kernel traces and PMC counters are collected in separate rocprofv3 runs (see MI355X_MICROARCH.md).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/profiles_$R
 mkdir -p $O

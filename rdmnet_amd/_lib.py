@@ -40,6 +40,8 @@ SIGNATURES = {
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
     'rdm_kpconv_gather_ordered': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                           c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_void]),
+    'rdm_kpconv_gather_form': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
+                                       c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void, c_int, c_void]),
     'rdm_kpconv_fused_enabled': (c_int, []),
     'rdm_kpconv_fused_supported': (c_int, [c_i64, c_i64]),
     'rdm_kpconv_fused_partial_rows': (c_i64, [c_i64, c_i64]),
@@ -121,6 +123,8 @@ SIGNATURES = {
     'rdm_engine_run': (c_int, [c_void, c_void, c_i64, c_void, c_i64, c_void, c_void]),
     'rdm_engine_collate': (c_int, [c_void, c_void, c_i64, c_void, c_i64, c_void, c_void]),
     'rdm_engine_forward': (c_int, [c_void, c_void, c_void, c_void]),
+    'rdm_engine_collate_batch': (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void]),
+    'rdm_engine_forward_batched': (c_int, [c_void, c_int, c_void, c_void]),
     'rdm_engine_set_wait': (c_int, [c_void, c_int]),
     'rdm_engine_set_pairs_in_flight': (c_int, [c_void, c_int]),
     'rdm_engine_set_overlap': (c_int, [c_void, c_int]),

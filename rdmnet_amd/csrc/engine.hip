@@ -68,6 +68,36 @@ struct ParamSet {
   }
 };
 
+struct Level {
+  float* pts = nullptr;
+  int64_t n = 0;
+  int64_t* lengths = nullptr;  // device [2]
+  int64_t n_ref = 0;
+};
+struct Table {
+  int64_t* idx = nullptr;     // int32 elements when i32 (tables the engine builds AND consumes itself in a plain run)
+  bool i32 = false;
+  int64_t rows = 0, width = 0;
+  int64_t ld = 0;            // row stride; 0 = width (tables built by the engine's own collate)
+  int32_t* flags = nullptr;  // device [2]: max_count, status (optional: null = every column is valid)
+  int64_t stride() const { return ld ? ld : width; }
+};
+
+struct Grid {  // a level's search grid (rdm_radius_grid_build): workspace + the support size it was built for
+  void* ws = nullptr;
+  size_t bytes = 0;
+  int64_t n_s = 0;
+};
+// What the collate of one pair leaves for its forward (geotransformer/utils/data.py:13-77): the pyramid, the tables the engine
+// consumes itself (int32 elements), the level grids (their cell-sorted records order the KPConv queries) and the status words.
+struct PairPyramid {
+  Level lv[5];
+  Table nb[5], sub[4], up[4];
+  Grid grids[5];
+  int32_t* flags = nullptr;  // device [64]
+  int calls = 0;             // searches recorded in `flags`
+};
+
 }  // namespace
 
 struct rdm_engine {
@@ -93,6 +123,12 @@ struct rdm_engine {
   int overlap_mode = 1;       // 0: never, 1: when pairs_in_flight == 1, 2: always
   hipStream_t side = nullptr;
   std::map<hipStream_t, bool> side_ok;  // caller stream -> the side stream runs beside it (see ensure_side)
+  // Batched collate (rdm_engine_collate_batch): the pyramids of B pairs built by ONE sequence of launches -- 2 B clouds per
+  // subsampling launch, (pair, level) items per grid build, 16 searches per query launch -- stay in the arena below `arena_base`;
+  // rdm_engine_forward_batched(k) runs pair k's forward above it.  Same kernels on the same operands per pair: same bits.
+  std::vector<PairPyramid> batch;
+  std::vector<int64_t> batch_n_ref, batch_n_src;
+  size_t arena_base = 0;
   bool profile = false;
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
@@ -270,21 +306,6 @@ int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, in
   return rdm_layer_norm(x.p, x.rows, x.cols, x.ld, res ? res->p : nullptr, res ? res->ld : 0, vecp(r, name + ".weight"),
                         vecp(r, name + ".bias"), 1e-5f, act, y.p, y.ld, r.st);
 }
-
-struct Level {
-  float* pts = nullptr;
-  int64_t n = 0;
-  int64_t* lengths = nullptr;  // device [2]
-  int64_t n_ref = 0;
-};
-struct Table {
-  int64_t* idx = nullptr;     // int32 elements when i32 (tables the engine builds AND consumes itself in a plain run)
-  bool i32 = false;
-  int64_t rows = 0, width = 0;
-  int64_t ld = 0;            // row stride; 0 = width (tables built by the engine's own collate)
-  int32_t* flags = nullptr;  // device [2]: max_count, status (optional: null = every column is valid)
-  int64_t stride() const { return ld ? ld : width; }
-};
 
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
            const Table& t, float sigma, const std::string& norm_name, Mat& y, const float* order,
@@ -889,7 +910,7 @@ extern "C" int rdm_engine_get_tensor(rdm_engine* e, const char* name, rdm_tensor
 }
 
 static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
-                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream);
+                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream, const PairPyramid* pre = nullptr);
 
 // The default 3 GiB arena covers pairs of ~2 x 25 k points; denser input (raw scans, KITTI-360-sized clouds)
 // grows it: on exhaustion the stream is drained, the arena doubled (288 GB of HBM leave room) and the pair
@@ -924,6 +945,194 @@ extern "C" int rdm_engine_run(rdm_engine* e, const float* ref_points, int64_t n_
   RDM_REQUIRE(e->finalized, "rdm_engine_run: call rdm_engine_finalize first");
   RDM_REQUIRE(n_ref > 0 && n_src > 0, "rdm_engine_run: empty cloud");
   return engine_run_growing(e, ref_points, n_ref, src_points, n_src, nullptr, res, stream);
+}
+
+// ---------------------------------------------------------------- batched collate
+// The collate of B pairs (data.py:13-77, B times) as ONE sequence of launches.  The collate is the launch-bound part of a pair
+// (four chains of one-workgroup-per-cloud subsampling kernels, seven small launches per grid build, two query launches): with
+// four pairs in flight it costs 0.25 ms of a pair's 1.9 ms (profiles/r04_marginal_cost.txt), and the batching lab measured the
+// class at 0.43x per pair when four pairs share its launches (profiles/r05_batch_lab.md).  Here
+//   * every subsampling launch works on 2 B clouds (one workgroup per cloud: the latency of a pair's chain now serves B),
+//   * the grids are built as (pair, level) items, eight per set of launches -- each item is exactly the grid of the pair's own
+//     collate (its own bounding box, two clouds), so records and tables come out as in a single-pair run,
+//   * the 12 searches of every pair are recorded into one queue and flushed 16 at a time (two launches per flush),
+//   * the level sizes of all pairs return in one read-back.
+// What a pair's forward reads is bit for bit what its own collate would have written (integer tables, the same points, the same
+// cell-sorted records): rdm_engine_forward_batched(k) then equals rdm_engine_run on pair k.
+static int collate_batch_once(rdm_engine* e, int B, const float* const* refs, const int64_t* n_refs, const float* const* srcs,
+                              const int64_t* n_srcs, hipStream_t st) {
+  const rdm_engine_config& c = e->cfg;
+  e->arena_off = 0;
+  e->arena_base = 0;
+  e->batch.clear();
+  e->taps.clear();
+  Run r;
+  r.e = e; r.st = st; r.groups = c.group_norm;
+  int64_t n_tot = 0;
+  for (int p = 0; p < B; ++p) n_tot += n_refs[p] + n_srcs[p];
+  const int nc = 2 * B;  // clouds
+  r.ws_bytes = std::max<size_t>(rdm_grid_subsample_workspace_bytes(n_tot, nc), size_t(16) << 20);
+  r.ws = e->alloc<char>(r.ws_bytes);
+  ENG_ALLOC(r.ws);
+  // level 0: the clouds stacked [ref_0 src_0 ref_1 src_1 ...]
+  float* pts[5];
+  int64_t* len[5];
+  pts[0] = e->alloc<float>(3 * n_tot);
+  len[0] = e->alloc<int64_t>(nc);
+  ENG_ALLOC(pts[0]); ENG_ALLOC(len[0]);
+  {
+    int64_t base = 0;
+    for (int p = 0; p < B; ++p) {
+      ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * (n_refs[p] + n_srcs[p]), st, refs[p], n_refs[p], srcs[p], n_srcs[p],
+                         pts[0] + 3 * base, len[0] + 2 * p));
+      base += n_refs[p] + n_srcs[p];
+    }
+  }
+  int64_t* all_len = e->alloc<int64_t>(static_cast<size_t>(4) * nc);  // levels 1..4 x clouds, contiguous for one read-back
+  ENG_ALLOC(all_len);
+  static const int gs_multi_levels = [] { const char* v = ::rdm::dev_knob("RDM_GS_MULTI_LEVELS"); return v ? atoi(v) : 1; }();
+  float voxel = c.init_voxel_size;
+  for (int i = 1; i < 5; ++i) {
+    voxel *= 2.f;  // data.py:23-28
+    pts[i] = e->alloc<float>(3 * n_tot);  // (capacity: the level sizes are not known on the host yet; the kernels walk `lengths`)
+    len[i] = all_len + static_cast<size_t>(i - 1) * nc;
+    ENG_ALLOC(pts[i]);
+    ENG_CHECK(grid_subsample_mode(pts[i - 1], n_tot, len[i - 1], nc, voxel, pts[i], len[i], r.ws, r.ws_bytes, st,
+                                  i <= gs_multi_levels ? 2 : 1));
+  }
+  std::vector<int64_t> host_len(static_cast<size_t>(4) * nc);
+  RDM_REQUIRE(host_len.size() * sizeof(int64_t) <= 4096, "rdm_engine_collate_batch: too many pairs for the read-back buffer");
+  ENG_CHECK(d2h(r, all_len, host_len.size() * sizeof(int64_t), host_len.data()));
+
+  e->batch.resize(B);
+  int32_t* flags_all = e->alloc<int32_t>(static_cast<size_t>(64) * B);
+  ENG_ALLOC(flags_all);
+  fill_words<int32_t>(flags_all, static_cast<int64_t>(64) * B, 0, st);
+  // the pyramids: slices of the stacked level arrays
+  {
+    std::vector<int64_t> off(5, 0);
+    for (int p = 0; p < B; ++p) {
+      PairPyramid& py = e->batch[p];
+      py.flags = flags_all + 64 * p;
+      for (int i = 0; i < 5; ++i) {
+        const int64_t a = i == 0 ? n_refs[p] : host_len[static_cast<size_t>(i - 1) * nc + 2 * p];
+        const int64_t b = i == 0 ? n_srcs[p] : host_len[static_cast<size_t>(i - 1) * nc + 2 * p + 1];
+        py.lv[i].pts = pts[i] + 3 * off[i];
+        py.lv[i].lengths = len[i] + 2 * p;
+        py.lv[i].n = a + b;
+        py.lv[i].n_ref = a;
+        off[i] += a + b;
+      }
+    }
+  }
+  // the (pair, level) grids, eight items per set of launches
+  {
+    const float* gp[8];
+    int64_t gn[8];
+    const int64_t* gl[8];
+    float gr[8];
+    void* gw[8];
+    size_t gb[8];
+    int k = 0;
+    auto flush = [&]() -> int {
+      if (k > 0) ENG_CHECK(radius_grid_build_multi(k, gp, gn, gl, 2, gr, gw, gb, st));
+      k = 0;
+      return RDM_OK;
+    };
+    for (int p = 0; p < B; ++p) {
+      float rad = c.init_radius;
+      for (int i = 0; i < 5; ++i, rad *= 2.f) {
+        Grid& g = e->batch[p].grids[i];
+        g.n_s = e->batch[p].lv[i].n;
+        g.bytes = rdm_radius_grid_workspace_bytes(g.n_s);
+        g.ws = e->alloc<char>(g.bytes);
+        ENG_ALLOC(g.ws);
+        gp[k] = e->batch[p].lv[i].pts; gn[k] = g.n_s; gl[k] = e->batch[p].lv[i].lengths; gr[k] = rad; gw[k] = g.ws; gb[k] = g.bytes;
+        if (++k == 8) ENG_CHECK(flush());
+      }
+    }
+    ENG_CHECK(flush());
+  }
+  // the searches of a plain run (engine_run_once: 12 per pair, int32 tables, one column of the up-sampling tables 1..3)
+  {
+    std::vector<char> queue(radius_redo_queue_bytes());
+    radius_redo_queue_reset(queue.data());
+    int queued = 0;
+    for (int p = 0; p < B; ++p) {
+      PairPyramid& py = e->batch[p];
+      auto search = [&](const Level& q, const Grid& g, float rad, int limit, Table& t, bool i32) -> int {
+        if (queued == 16) {  // (the queue's capacity: radius_neighbors.hip kRedoMax)
+          ENG_CHECK(radius_redo_flush(queue.data(), st));
+          queued = 0;
+        }
+        t.rows = q.n; t.width = limit; t.flags = py.flags + 2 * py.calls++;
+        t.i32 = i32;
+        t.idx = reinterpret_cast<int64_t*>(e->alloc<char>(static_cast<size_t>(q.n > 0 ? q.n : 1) * limit * (i32 ? 4 : 8)));
+        ENG_ALLOC(t.idx);
+        unsigned char* redo_flags = e->alloc<unsigned char>(static_cast<size_t>(q.n > 0 ? q.n : 1));
+        ENG_ALLOC(redo_flags);
+        ++queued;
+        return radius_grid_query_deferred(g.ws, g.bytes, g.n_s, q.pts, q.n, q.lengths, 2, rad, limit, t.idx, nullptr, t.flags,
+                                          t.flags + 1, redo_flags, queue.data(), i32 ? 1 : 0, st);
+      };
+      float radius = c.init_radius;
+      for (int i = 0; i < 5; ++i) {  // (the order of engine_run_once: the status rows are numbered by it)
+        ENG_CHECK(search(py.lv[i], py.grids[i], radius, c.neighbor_limits[i], py.nb[i], true));
+        if (i < 4) ENG_CHECK(search(py.lv[i + 1], py.grids[i], radius, c.neighbor_limits[i], py.sub[i], true));
+        if (i > 1) ENG_CHECK(search(py.lv[i - 1], py.grids[i], radius, 1, py.up[i - 1], false));
+        radius *= 2.f;
+      }
+    }
+    ENG_CHECK(radius_redo_flush(queue.data(), st));
+  }
+  e->arena_base = e->arena_off;
+  e->batch_n_ref.assign(n_refs, n_refs + B);
+  e->batch_n_src.assign(n_srcs, n_srcs + B);
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_collate_batch(rdm_engine* e, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                                        const float* const* src_points, const int64_t* n_src, void* stream) {
+  RDM_REQUIRE(e && ref_points && n_ref && src_points && n_src, "rdm_engine_collate_batch: null pointer");
+  RDM_REQUIRE(e->finalized, "rdm_engine_collate_batch: call rdm_engine_finalize first");
+  RDM_REQUIRE(n_pairs >= 1 && n_pairs <= 16, "rdm_engine_collate_batch: 1 .. 16 pairs");
+  RDM_REQUIRE(!e->keep_taps, "rdm_engine_collate_batch: a run that keeps its stage tensors builds the reference's full tables pair by pair");
+  for (int p = 0; p < n_pairs; ++p)
+    RDM_REQUIRE(ref_points[p] && src_points[p] && n_ref[p] > 0 && n_src[p] > 0, "rdm_engine_collate_batch: pair %d is empty", p);
+  for (;;) {  // (arena growth as in rdm_engine_run: on exhaustion the arena is doubled and the batch collated again)
+    e->arena_exhausted = false;
+    const int rc = collate_batch_once(e, n_pairs, ref_points, n_ref, src_points, n_src, static_cast<hipStream_t>(stream));
+    if (rc != RDM_OK) {
+      e->batch.clear();
+      e->arena_base = 0;
+    }
+    if (rc != RDM_ERR_WORKSPACE || !e->arena_exhausted || e->arena_fixed || e->arena_cap >= (size_t(96) << 30)) return rc;
+    RDM_HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    RDM_HIP_CHECK(hipFree(e->arena));
+    e->arena = nullptr;
+    e->arena_cap *= 2;
+    const hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
+    if (err != hipSuccess) {
+      e->arena_cap = 0;
+      set_error("rdm_engine_collate_batch: growing the activation arena failed: %s", hipGetErrorString(err));
+      return RDM_ERR_HIP;
+    }
+  }
+}
+
+// RDMNet.forward of pair `k` of the collated batch; the result structure, rdm_engine_transform-style read-outs and the host
+// views are those of rdm_engine_run and stay valid until the next call on this engine.  RDM_ERR_WORKSPACE: the arena is too
+// small for this pair's forward above the batch's pyramids (the caller collates a smaller batch, or runs the pair alone:
+// rdm_engine_run grows the arena).
+extern "C" int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* res, void* stream) {
+  RDM_REQUIRE(e && res, "rdm_engine_forward_batched: null pointer");
+  RDM_REQUIRE(k >= 0 && k < static_cast<int>(e->batch.size()), "rdm_engine_forward_batched: no collated pair %d (rdm_engine_collate_batch first)", k);
+  struct PadGuard {
+    explicit PadGuard(unsigned b) { rdm::gemm_set_lds_pad(b); }
+    ~PadGuard() { rdm::gemm_set_lds_pad(0); }
+  } pad_guard(e->pairs_in_flight >= 3 ? 20480u : 0u);
+  e->arena_exhausted = false;
+  return engine_run_once(e, nullptr, e->batch_n_ref[k], nullptr, e->batch_n_src[k], nullptr, res, stream, &e->batch[k]);
 }
 
 // The collate alone (geotransformer/utils/data.py:13-77 on two clouds): the pyramid and its 13 searches stay in the engine's
@@ -963,9 +1172,13 @@ extern "C" int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* dd, rdm_en
 }
 
 static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref, const float* src_points, int64_t n_src,
-                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
+                           const rdm_data_dict* dd, rdm_engine_result* res, void* stream, const PairPyramid* pre) {
   const rdm_engine_config& c = e->cfg;
-  e->arena_off = 0;
+  e->arena_off = pre ? e->arena_base : 0;  // (a pair of a collated batch: its pyramid lies below arena_base)
+  if (!pre) {
+    e->batch.clear();  // (the arena is rewritten: a collated batch is gone)
+    e->arena_base = 0;
+  }
   e->taps.clear();
   e->prof.clear();
   e->prof_layers = 0;
@@ -973,19 +1186,20 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   r.e = e; r.st = static_cast<hipStream_t>(stream); r.groups = c.group_norm;
   const int64_t n0 = n_ref + n_src;
   // latency mode (see rdm_engine::overlap_mode); never on the legacy null stream, which every other blocking stream serialises with
-  bool overlap = !e->collate_only && r.st != nullptr && (e->overlap_mode == 2 || (e->overlap_mode == 1 && e->pairs_in_flight == 1));
+  bool overlap = !pre && !e->collate_only && r.st != nullptr && (e->overlap_mode == 2 || (e->overlap_mode == 1 && e->pairs_in_flight == 1));
   if (overlap) ENG_CHECK(ensure_side(e, r.st, &overlap));
   SideGuard side_guard{e};
   // kernel scratch: the largest consumers are the grid-subsample tables and split-K partials
-  r.ws_bytes = std::max<size_t>(rdm_grid_subsample_workspace_bytes(n0, 2),
-                                std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(96) << 20));
+  r.ws_bytes = pre ? size_t(96) << 20
+                   : std::max<size_t>(rdm_grid_subsample_workspace_bytes(n0, 2),
+                                      std::max<size_t>(rdm_radius_neighbors_workspace_bytes(n0, n0, 2), size_t(96) << 20));
   r.ws = e->alloc<char>(r.ws_bytes);
   ENG_ALLOC(r.ws);
   std::memset(res, 0, sizeof(*res));
 
   Level lv[5];
   Table nb[5], sub[4], up[4];
-  int32_t* flags = e->alloc<int32_t>(64);
+  int32_t* flags = pre ? pre->flags : e->alloc<int32_t>(64);
   ENG_ALLOC(flags);
   // Latency mode, first half: the caller's stream runs the subsampling of levels 1-4 (a chain of one- and two-workgroup kernels,
   // ~0.4 ms) while the side stream builds the first level's grid, searches its neighbours and runs the encoder's first two
@@ -1005,9 +1219,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     rs.ws = e->alloc<char>(rs.ws_bytes);
     ENG_ALLOC(rs.ws);
   }
-  fill_words<int32_t>(flags, 64, 0, overlap_l0 ? rs.st : r.st);  // (the first searches write their status rows on that stream)
-  int call = 0;
-  struct Grid { void* ws; size_t bytes; int64_t n_s; };
+  if (!pre) fill_words<int32_t>(flags, 64, 0, overlap_l0 ? rs.st : r.st);  // (the first searches write their status rows on that stream)
+  int call = pre ? pre->calls : 0;
   Grid grids[5] = {};
   std::vector<char> redo_queue(radius_redo_queue_bytes());
   radius_redo_queue_reset(redo_queue.data());
@@ -1118,7 +1331,20 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     }
     return RDM_OK;
   };
-  if (dd) {
+  if (pre) {
+    // ------------------------------------------------------------ a pair of a collated batch (rdm_engine_collate_batch)
+    for (int i = 0; i < 5; ++i) {
+      lv[i] = pre->lv[i];
+      nb[i] = pre->nb[i];
+      grids[i] = pre->grids[i];
+      res->level_sizes[i] = lv[i].n;
+      res->level_ref_sizes[i] = lv[i].n_ref;
+      if (i < 4) {
+        sub[i] = pre->sub[i];
+        up[i] = pre->up[i];
+      }
+    }
+  } else if (dd) {
     // ------------------------------------------------------------ the caller's data_dict (model_infer.py:113-131)
     for (int i = 0; i < 5; ++i) {
       lv[i].pts = const_cast<float*>(dd->points[i]);
@@ -1400,8 +1626,10 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(nodes);
     Mat sel_feats = e->mat(Mn, D);
     ENG_ALLOC(sel_feats.p);
-    float* sel_scores = e->alloc<float>(2 * Mn);
-    ENG_ALLOC(sel_scores);
+    // (the (n2p, n2n) score pairs exist only in runs that hand out stage tensors: a plain run skips the score heads, and a
+    // buffer nobody writes is not allocated -- ADVICE r4: a later consumer could otherwise read garbage)
+    float* sel_scores = want_scores ? e->alloc<float>(2 * Mn) : nullptr;
+    if (want_scores) ENG_ALLOC(sel_scores);
     Mat nodes4{e->alloc<float>(4 * Mn), Mn, 4, 4};
     ENG_ALLOC(nodes4.p);
     {  // the survivors' rows of every per-superpoint tensor with one launch
@@ -1414,7 +1642,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       ENG_CHECK(launch_status("select_nodes_kernel"));
     }
     tap(r, "nodes", nodes, Mn, 3, 3, 0);
-    tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
+    if (want_scores) tap(r, "node_scores", sel_scores, Mn, 2, 2, 0);
 
     // ---------------------------------------------------------------- transformer #2, normalise
     buf2 = e->mat(Mn, D);

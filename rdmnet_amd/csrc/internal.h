@@ -76,6 +76,13 @@ int gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx, cons
 int kpconv_gather_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
                        int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
                        const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
+                       int i32, void* stream, int form = 0);
+// The aggregation of kpconv_gather_impl with the support rows of 16 cell-ordered queries staged once in LDS (kpconv_fused.hip:
+// kpconv_tile_kernel<64, GATHER>, one 64-channel slice per workgroup): same WF / nn bits, fewer L2 -> CU line fills.
+bool kpconv_tile_gather_applies(int64_t c, int64_t h, bool has_order);
+int kpconv_tile_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                       int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                       const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
                        int i32, void* stream);
 int kpconv_fused_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
                       int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,

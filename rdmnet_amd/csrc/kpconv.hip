@@ -278,10 +278,19 @@ extern "C" int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld
   return launch_status("row_positive_kernel");
 }
 
+namespace {
+// Where the LDS-tile form of the gather beats the per-neighbour form (measured per shape on MI355X, tools/kpconv_bench.py,
+// profiles/r05_kpconv_bench.txt): the tile form runs blocks-of-16 x slices workgroups, two per CU.
+bool tile_gather_pays(int64_t c, int64_t m) {
+  (void)c; (void)m;
+  return false;  // (set from the measurements)
+}
+}  // namespace
+
 int rdm::kpconv_gather_impl(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
                             int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
                             const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
-                            int i32, void* stream) {
+                            int i32, void* stream, int form) {
   using namespace rdm;
   RDM_REQUIRE(q_points && s_points && s_feats && s_positive && idx && kernel_points && wf && nn,
               "rdm_kpconv_gather: null pointer");
@@ -290,6 +299,11 @@ int rdm::kpconv_gather_impl(const float* q_points, int64_t m, const float* s_poi
   RDM_REQUIRE(ldw >= kKP * c && (c == 1 || (ldf % 4 == 0 && ldw % 4 == 0)),
               "rdm_kpconv_gather: ldw/ldf must be padded");
   if (m == 0) return RDM_OK;
+  // form: 0 = the library's choice, 1 = one wavefront per (query, slice) fetching every neighbour row (rounds 1-4), 2 = the
+  // support rows of 16 cell-ordered queries staged once in LDS (kpconv_tile_kernel<64, GATHER>, round 5) where it applies
+  if (form != 1 && kpconv_tile_gather_applies(c, h, order_records != nullptr) && (form == 2 || tile_gather_pays(c, m)))
+    return kpconv_tile_gather(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma, wf,
+                              ldw, nn, order_records, i32, stream);
   KpArgs a;
   a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive;
   a.idx = idx; a.i32 = i32 ? 1 : 0; a.kp = kernel_points; a.width = width; a.wf = wf; a.nn = nn;
@@ -333,6 +347,16 @@ extern "C" int rdm_kpconv_gather_ordered(const float* q_points, int64_t m, const
                                          float* nn, const float* order_records, void* stream) {
   return rdm::kpconv_gather_impl(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
                                  wf, ldw, nn, order_records, 0, stream);
+}
+
+extern "C" int rdm_kpconv_gather_form(const float* q_points, int64_t m, const float* s_points, int64_t n_s,
+                                      const float* s_feats, int64_t c, int64_t ldf, const uint8_t* s_positive,
+                                      const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                                      const float* kernel_points, float sigma, float* wf, int64_t ldw,
+                                      float* nn, const float* order_records, int form, void* stream) {
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_kpconv_gather_form: form must be 0, 1 or 2");
+  return rdm::kpconv_gather_impl(q_points, m, s_points, n_s, s_feats, c, ldf, s_positive, idx, h, ldi, width, kernel_points, sigma,
+                                 wf, ldw, nn, order_records, 0, stream, form);
 }
 
 extern "C" int rdm_kpconv_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s,

@@ -63,6 +63,10 @@ struct FusedArgs {
   int M, Ns, H;
   int ldf, ldi, ldo;
   float sigma;
+  // gather-only form of the tile kernel (c_in >= 128, one 64-channel slice per workgroup): `out` = WF [M, ldo] with the slice's
+  // first channel already added, ctot = c_in (the stride between kernel points inside a WF row), nn [M] or null (slice 0 writes it)
+  int ctot;
+  float* nn;
 };
 
 // The same for two neighbours at once on the packed-fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two IEEE operations per
@@ -343,8 +347,16 @@ struct TileLds {
 };
 
 // (two workgroups of 16 / three of 8 wavefronts per CU at C = 32, two of 8 at C = 64: 8 / 6 / 4 wavefronts per SIMD)
-template <int C>
+// GATHER = true (round 5): the aggregation half alone, for the layers whose weight contraction stays a GEMM (c_in >= 128): a
+// workgroup serves ONE 64-channel slice of its 16 queries' WF rows (a.s_feats / a.out point at the slice, gridDim.y slices) and
+// writes them where kpconv_gather_kernel writes them -- same neighbour order, same influences, same MFMA sequence per accumulator:
+// the same bits -- but fetches every distinct support row of the block once instead of once per (query, neighbour).
+template <int C, bool GATHER = false>
 __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order, int xcd_ranges) {
+  if constexpr (GATHER) {  // the slice of this workgroup
+    a.s_feats += static_cast<int64_t>(blockIdx.y) * C;
+    a.out += static_cast<int64_t>(blockIdx.y) * C;
+  }
   using L = TileLds<C>;
   constexpr int NW = TileCfg<C>::NW, CAP = TileCfg<C>::CAP, NTH = 64 * NW, QB = kTileQB, QPW = QB / NW;
   constexpr int VEC = C / 16, NT = C / 16, TILES = NT, K16 = kKP * C / 16, LDW = L::LDW, PF = 4;
@@ -631,6 +643,23 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
     if (qq == 0) { const float probe = acc[0][0][0]; asm volatile("" ::"v"(probe)); TILE_W(1, TILE_NOW() - tw1); }
 #endif
   }
+  if constexpr (GATHER) {  // WF[m, k, slice]: accumulator row 4 g + r = kernel point, lane j holds channels 4 j .. 4 j + 3 (kpconv.hip's store)
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq) {
+      const int m = qm[qq];
+      if (m < 0) continue;
+      float* dst = a.out + static_cast<int64_t>(m) * a.ldo + VEC * j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * g + r;
+        if (k >= kKP) continue;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + k * a.ctot) = make_float4(acc[qq][0][r], acc[qq][1][r], acc[qq][2][r], acc[qq][3][r]);
+        else *reinterpret_cast<float2*>(dst + k * a.ctot) = make_float2(acc[qq][0][r], acc[qq][1][r]);
+      }
+      if (lane == 0 && blockIdx.y == 0 && a.nn) a.nn[m] = static_cast<float>(positives[qq] > 1 ? positives[qq] : 1);
+    }
+    return;
+  }
   __syncthreads();  // every wavefront is done with the tile: the parked block takes its place
   TILE_PHASE();  // 4: aggregation
 
@@ -843,6 +872,35 @@ int64_t rows_per_block(int64_t c_in) {  // (the same in every form: the caller s
   return c_in == 1 ? kC1Waves * kC1Qpw : kTileQB;
 }
 }  // namespace
+
+// The gather-only tile form for kpconv_gather_impl (kpconv.hip): WF [m, ldw] and nn [m] exactly as kpconv_gather_kernel writes them.
+// Applies to c a multiple of 64 (>= 128 in the backbone), rows of at most 128 slots, with order records.
+bool rdm::kpconv_tile_gather_applies(int64_t c, int64_t h, bool has_order) {
+  return has_order && c >= 128 && c % 64 == 0 && h <= kMaxH;
+}
+int rdm::kpconv_tile_gather(const float* q_points, int64_t m, const float* s_points, int64_t n_s, const float* s_feats, int64_t c,
+                            int64_t ldf, const uint8_t* s_positive, const int64_t* idx, int64_t h, int64_t ldi, const int32_t* width,
+                            const float* kernel_points, float sigma, float* wf, int64_t ldw, float* nn, const float* order_records,
+                            int i32, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(kpconv_tile_gather_applies(c, h, order_records != nullptr), "kpconv_tile_gather: unsupported shape");
+  RDM_REQUIRE(ldf % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(s_feats) & 15) == 0 && (reinterpret_cast<uintptr_t>(wf) & 15) == 0,
+              "kpconv_tile_gather: features / WF must be 16-byte aligned with row strides that are multiples of 4");
+  if (m == 0) return RDM_OK;
+  FusedArgs a{};
+  a.q_points = q_points; a.s_points = s_points; a.s_feats = s_feats; a.s_pos = s_positive; a.idx = idx; a.i32 = i32 ? 1 : 0;
+  a.kp = kernel_points; a.width = width; a.w = nullptr; a.bias = nullptr; a.out = wf; a.stats = nullptr;
+  a.M = static_cast<int>(m); a.Ns = static_cast<int>(n_s); a.H = static_cast<int>(h);
+  a.ldf = static_cast<int>(ldf); a.ldi = static_cast<int>(ldi); a.ldo = static_cast<int>(ldw); a.sigma = sigma;
+  a.ctot = static_cast<int>(c); a.nn = nn;
+  static std::atomic<uint64_t> gattr{0};
+  RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<64, true>), static_cast<int>(TileLds<64>::bytes), gattr));
+  const dim3 grid(static_cast<unsigned>(ceil_div<int64_t>(m, kTileQB)), static_cast<unsigned>(c / 64));
+  RDM_DUP_LOOP("gather")
+  hipLaunchKernelGGL((kpconv_tile_kernel<64, true>), grid, dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, static_cast<hipStream_t>(stream), a,
+                     reinterpret_cast<const float4*>(order_records), 1);
+  return launch_status("kpconv_tile_kernel<64, gather>");
+}
 
 // Rows of the fp64 GroupNorm partial array [rows][2][c_out] a call with m queries and neighbour rows of h slots writes
 // (one per workgroup).

@@ -153,15 +153,47 @@ class Engine:
         return out
 
     def keep_taps(self, enable=True):
+        self._prepared = []
         _lib.check(self.L.rdm_engine_keep_taps(self._h, int(enable)), 'rdm_engine_keep_taps')
 
     def run(self, ref_points, src_points):
         """ref/src: float32 CUDA tensors [n,3] on this engine's device.  Returns the EngineResult (host)."""
         assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
         assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
+        prepared = getattr(self, '_prepared', None)
+        if prepared:  # the next pair of a collated batch (collate_batch): its forward alone
+            k, r, s = prepared[0]
+            if (r.data_ptr(), r.shape[0], s.data_ptr(), s.shape[0]) == (ref_points.data_ptr(), ref_points.shape[0],
+                                                                       src_points.data_ptr(), src_points.shape[0]):
+                prepared.pop(0)
+                return self.forward_batched(k)
+            self._prepared = []  # (another pair: the batch is dropped, rdm_engine_run collates this pair itself)
         _lib.check(self.L.rdm_engine_run(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
                                          src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()),
                    'rdm_engine_run')
+        return self.result
+
+    # ------------------------------------------------------------------ several pairs per collate
+    def collate_batch(self, pairs):
+        """The collates of several pairs as ONE sequence of launches (rdm_engine_collate_batch): `pairs` = [(ref, src), ...]
+        float32 CUDA tensors [n,3].  The pyramids stay in the engine; `forward_batched(k)` / the next `run(ref, src)` calls on
+        exactly these tensors, in this order, run the pairs' forwards on them -- with the bits of `run` on each pair alone."""
+        n = len(pairs)
+        for r, s in pairs:
+            assert r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()
+        P, I = ctypes.c_void_p * n, ctypes.c_int64 * n
+        rp, sp = P(*[r.data_ptr() for r, _ in pairs]), P(*[s.data_ptr() for _, s in pairs])
+        rn, sn = I(*[r.shape[0] for r, _ in pairs]), I(*[s.shape[0] for _, s in pairs])
+        self._prepared = []
+        _lib.check(self.L.rdm_engine_collate_batch(self._h, n, rp, rn, sp, sn, _lib.stream_ptr()), 'rdm_engine_collate_batch')
+        # (the tensors are kept alive until their forwards have run; `run` recognises them by address and size)
+        self._prepared = [(k, r, s) for k, (r, s) in enumerate(pairs)]
+        return n
+
+    def forward_batched(self, k):
+        """RDMNet.forward of pair k of the collated batch; returns the EngineResult (as `run`)."""
+        _lib.check(self.L.rdm_engine_forward_batched(self._h, int(k), ctypes.byref(self.result), _lib.stream_ptr()),
+                   'rdm_engine_forward_batched')
         return self.result
 
     _COLLATE_NAMES = ([f'points{i}' for i in range(5)] + [f'lengths{i}' for i in range(5)] + [f'neighbors{i}' for i in range(5)] +
@@ -174,6 +206,7 @@ class Engine:
         `_widths` / `_flags` (device-resident effective table widths, as rdmnet_amd.collate returns them)."""
         assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
         assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
+        self._prepared = []
         _lib.check(self.L.rdm_engine_collate(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
                                              src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()), 'rdm_engine_collate')
         t = self.tensors(self._COLLATE_NAMES)
@@ -255,6 +288,7 @@ class Engine:
                 getattr(d, key + '_ld')[i] = t.stride(0) if t.shape[0] > 1 else t.shape[1]
                 w = widths.get((key, i))
                 getattr(d, key + '_count')[i] = w.data_ptr() if w is not None else None
+        self._prepared = []
         _lib.check(self.L.rdm_engine_forward(self._h, ctypes.byref(d), ctypes.byref(self.result), _lib.stream_ptr()),
                    'rdm_engine_forward')
         return self.result

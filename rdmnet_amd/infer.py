@@ -105,7 +105,8 @@ class Tester:
         """Every pair of the stager, `pairs_in_flight` at a time, committed in dataset order.  If a pair fails, the pairs before
         it are still committed (pose lines, records) before the error is raised; .npz files of later pairs that had already
         finished on other workers may exist without a pose line."""
-        for rec in self.pipeline.imap(stager, self._work):
+        # (tensors_of: the pipeline's workers collate several staged pairs with one sequence of launches, pipeline.PairPipeline.imap)
+        for rec in self.pipeline.imap(stager, self._work, tensors_of=lambda job: (job[1].contiguous(), job[2].contiguous())):
             self._commit(rec)
             if log:
                 log('seq_id: {}, id0: {}, id1: {}, nCorr: {}'.format(rec['seq_id'], rec['ref_frame'], rec['src_frame'],

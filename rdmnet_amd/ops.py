@@ -99,17 +99,19 @@ def row_positive(x):
     return out
 
 
-def kpconv_gather(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, width=None):
-    """-> (wf [m, pad4(15*c)] view, nn [m])."""
+def kpconv_gather(q_points, s_points, s_feats, s_positive, idx, kernel_points, sigma, width=None, order=None, form=0):
+    """-> (wf [m, pad4(15*c)] view, nn [m]).  order: the query level's cell-sorted records (radius_grid_records) = the order the
+    queries are visited in; form: 0 = the library's choice, 1 = one wavefront per (query, slice), 2 = the LDS-tile form (needs
+    `order`, c a multiple of 64 >= 128, at most 128 slots).  The same bits in every form and order."""
     L = _lib.lib()
     m, c = q_points.shape[0], s_feats.shape[1]
     kdim = 16 if c == 1 else 15 * c
     wf = feat_empty(m, kdim, q_points.device)
     nn = torch.empty((max(m, 1),), dtype=torch.float32, device=q_points.device)
-    _lib.check(L.rdm_kpconv_gather(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(),
-                                   c, _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0),
-                                   _lib.ptr(width), kernel_points.data_ptr(), float(sigma), wf.data_ptr(), _ld(wf),
-                                   nn.data_ptr(), _lib.stream_ptr()), 'rdm_kpconv_gather')
+    _lib.check(L.rdm_kpconv_gather_form(q_points.data_ptr(), m, s_points.data_ptr(), s_points.shape[0], s_feats.data_ptr(),
+                                        c, _ld(s_feats), s_positive.data_ptr(), idx.data_ptr(), idx.shape[1], idx.stride(0),
+                                        _lib.ptr(width), kernel_points.data_ptr(), float(sigma), wf.data_ptr(), _ld(wf),
+                                        nn.data_ptr(), _lib.ptr(order), int(form), _lib.stream_ptr()), 'rdm_kpconv_gather')
     return wf, nn
 
 

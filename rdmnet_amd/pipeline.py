@@ -12,6 +12,10 @@ else that has a stream of pairs:
     falls behind takes fewer; all drain together at the end of the input),
   * staggered starts: worker k draws its first job k x `stagger_ms` after worker 0, so the in-flight pairs do
     not walk through the same stages in phase (four serial subsampling kernels, then four encoders contending),
+  * optionally (`collate_batch` > 1, round 5) a worker draws several jobs at a time and collates them with ONE sequence of
+    launches (`Engine.collate_batch`: the subsampling chains, grid builds and searches of a pair are launch-bound; the pairs of
+    a batch share them), then runs the pairs' forwards one by one -- the same bits as the one-by-one schedule, +2-3 % pairs/s
+    for 2-4 x the per-pair latency: off by default,
   * `rdm_engine_set_pairs_in_flight(N)` (GEMM residency hint from three pairs up; with N = 1 the engine runs in its latency
     mode instead: the wide, independent parts of the pair on a side stream, `Engine.set_overlap`),
   * waits at the engines' size read-backs by spinning (`hipStreamSynchronize`) when the process owns two host
@@ -38,6 +42,12 @@ from .engine import Engine
 
 DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe with another one (docs/EXPERIMENTS.md 5b)
 DEFAULT_STAGGER_MS = 1.5
+# Pairs a worker collates with one sequence of launches (Engine.collate_batch) before it runs their forwards one by one.  Measured
+# (round 5, tools/ab_collate_batch.sh): 4 per batch +3 % pairs/s on a 20-pair run (505 against 490) and +1.5 % on a long one, 8 per
+# batch +2.7 % -- for twice / four times the per-pair latency (13.9 / 32 ms against 7.3), and the KPConv kernels of the timed
+# region then share the GPU with more of the other pairs' wide kernels (their event-bracketed durations grow by a fifth).  Default:
+# every pair collates itself, the schedule of rounds 1-4; a throughput-only caller sets 4-8.
+DEFAULT_COLLATE_BATCH = 1
 
 
 def _quota_cpus():
@@ -205,13 +215,16 @@ class PairPipeline:
     job source (its hand-off event is waited for by the drawing worker's stream)."""
 
     def __init__(self, cfg, state, device=None, pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None,
-                 stagger_ms=DEFAULT_STAGGER_MS, keep_taps=False, local_world=None, engines=None, streams=None):
+                 stagger_ms=DEFAULT_STAGGER_MS, keep_taps=False, local_world=None, engines=None, streams=None,
+                 collate_batch=DEFAULT_COLLATE_BATCH):
         self._gpu = torch.cuda.is_available()
         if not self._gpu and engines is None:
             raise RuntimeError('rdmnet_amd.pipeline needs a GPU (no CPU fallback)')
         # (without a GPU only the scheduler itself can run, on engines the caller injected: tests/test_pipeline.py)
         self.device = (torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)) if self._gpu else None
         self.n = max(1, int(pairs_in_flight))
+        self.collate_batch = max(1, int(collate_batch))
+        self.keep_taps = bool(keep_taps)
         self.stagger_s = max(0.0, float(stagger_ms)) * 1e-3
         local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1')) if local_world is None else local_world
         self.wait_us = choose_wait_us(self.n, local_world) if wait_us is None or wait_us < 0 else int(wait_us)
@@ -233,11 +246,20 @@ class PairPipeline:
         self.last_stats = None
 
     # ------------------------------------------------------------------ generic scheduler
-    def imap(self, jobs, fn, stagger=True, window=None):
+    def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None):
         """Yields fn(engine, job) for every job, in job order.  `window` bounds how far completion may run ahead of
-        the consumer (default 4 x pairs_in_flight results held)."""
+        the consumer (default 4 x pairs_in_flight results held).
+
+        tensors_of(job) -> (ref, src): the CUDA tensors fn will hand to `engine.run` for this job.  When given (and the
+        pipeline's `collate_batch` > 1, no stage tensors kept), a worker draws several jobs at a time, collates them with ONE
+        sequence of launches (`Engine.collate_batch`: the collate is the launch-bound part of a pair) and then runs fn on each --
+        `engine.run` recognises the prepared pair and runs its forward alone; the results are the bits of the one-by-one
+        schedule.  Towards the end of a sized job list the batches shrink so that the workers still finish together."""
         n = self.n
         window = max(n, 4 * n if window is None else int(window))
+        bmax = self.collate_batch if (tensors_of is not None and not self.keep_taps) else 1
+        window = max(window, 2 * n * bmax)
+        total = len(jobs) if hasattr(jobs, '__len__') else None
         it = enumerate(iter(jobs))
         draw_lock = threading.Lock()
         cv = threading.Condition()
@@ -245,20 +267,30 @@ class PairPipeline:
         state = {'next_out': 0, 'drawn': 0, 'exhausted': False, 'error': None, 'stop': False, 'alive': n}
         # where the workers' time went (seconds, summed over workers): waiting for / drawing the next job (the job source's
         # cost: reading and staging a pair), running fn, waiting for the consumer's window -- `last_stats` after the run
-        stats = self.last_stats = {'draw_s': 0.0, 'work_s': 0.0, 'window_s': 0.0, 'jobs': 0, 'wall_s': 0.0, 'workers': n}
+        # `latency_ms`: per job (by slot), from the moment its worker had drawn it -- with its batch -- to its result: the batch's
+        # collate and the forwards of the pairs before it in the batch included
+        stats = self.last_stats = {'draw_s': 0.0, 'work_s': 0.0, 'window_s': 0.0, 'jobs': 0, 'wall_s': 0.0, 'workers': n,
+                                   'collate_batches': 0, 'latency_ms': {}}
         t_begin = time.perf_counter()
 
         def draw():
+            """-> up to bmax (slot, job) pairs, or None at the end of the input."""
             with draw_lock:
                 if state['exhausted'] or state['stop']:
                     return None
-                try:
-                    slot, job = next(it)
-                except StopIteration:
-                    state['exhausted'] = True
-                    return None
-                state['drawn'] = slot + 1
-                return slot, job
+                want = bmax
+                if total is not None and bmax > 1:  # the last rounds: what is left, spread over the workers
+                    want = max(1, min(bmax, -(-(total - state['drawn']) // n)))
+                got = []
+                while len(got) < want:
+                    try:
+                        slot, job = next(it)
+                    except StopIteration:
+                        state['exhausted'] = True
+                        break
+                    state['drawn'] = slot + 1
+                    got.append((slot, job))
+                return got or None
 
         def worker(k):
             stream = self.streams[k]
@@ -284,16 +316,23 @@ class PairPipeline:
                             t2 = time.perf_counter()
                             if got is None:
                                 return
-                            slot, job = got
-                            out = fn(self.engines[k], job)
+                            if len(got) > 1:  # one collate for all of them; fn's engine.run then finds each pair prepared
+                                self.engines[k].collate_batch([tensors_of(job) for _, job in got])
+                                with cv:
+                                    stats['collate_batches'] += 1
+                            for slot, job in got:
+                                out = fn(self.engines[k], job)
+                                t_done = time.perf_counter()
+                                with cv:
+                                    done[slot] = out
+                                    stats['jobs'] += 1
+                                    stats['latency_ms'][slot] = (t_done - t2) * 1e3
+                                    cv.notify_all()
                             t3 = time.perf_counter()
                             with cv:
-                                done[slot] = out
                                 stats['window_s'] += t1 - t0
                                 stats['draw_s'] += t2 - t1
                                 stats['work_s'] += t3 - t2
-                                stats['jobs'] += 1
-                                cv.notify_all()
                     finally:
                         if ctx is not None:
                             ctx.__exit__(None, None, None)
@@ -335,8 +374,8 @@ class PairPipeline:
             torch.set_num_threads(torch_threads)
             stats['wall_s'] = time.perf_counter() - t_begin
 
-    def map(self, jobs, fn, stagger=True):
-        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30))
+    def map(self, jobs, fn, stagger=True, tensors_of=None):
+        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30, tensors_of=tensors_of))
 
     # ------------------------------------------------------------------ the common case
     def run_pairs(self, pairs, stagger=True):
@@ -347,7 +386,7 @@ class PairPipeline:
             t0 = time.perf_counter()
             res = eng.run(ref.contiguous(), src.contiguous())
             return PairResult(eng, res, (time.perf_counter() - t0) * 1e3)
-        return self.map(pairs, one, stagger=stagger)
+        return self.map(pairs, one, stagger=stagger, tensors_of=lambda job: (job[-2].contiguous(), job[-1].contiguous()))
 
     def close(self):
         """Drops the engines (their arenas; the shared weights go with the last one)."""

@@ -548,3 +548,49 @@ def test_plain_engine_runs_and_int64_per_op_calls_interleave_on_one_thread(ctx):
         got = per_op()
         assert all(torch.equal(a, b) for a, b in zip(got, want))
     assert all(torch.equal(a, b) for a, b in zip(plain.corr(), corr))
+
+
+def test_batched_collate_gives_every_pair_the_bits_of_its_own_run(ctx, golden_dir):
+    """Round 5: rdm_engine_collate_batch builds the pyramids of several pairs with ONE sequence of launches (2 B clouds per
+    subsampling launch, (pair, level) grid items, 16 searches per query launch, one read-back of all level sizes);
+    rdm_engine_forward_batched(k) runs pair k's forward on them.  Pairs of five very different sizes in one batch: pose,
+    correspondences (points and scores), counters and level sizes of every pair equal those of rdm_engine_run on the pair alone,
+    bit for bit; `run` recognises the next prepared pair by its tensors and drops the batch when another pair comes."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    sc = np.load(os.path.join(golden_dir, 'scans.npz'))
+
+    def crop(p, r):
+        return p[np.linalg.norm(p[:, :2], axis=1) < r]
+    clouds = [(ctx['rp'], ctx['sp']), (z['ref0'], z['src0']), (crop(sc['s000000'], 14.0), crop(sc['s000004'], 12.0)),
+              (z['ref1'], z['src1']), (sc['s000000'], sc['s000007'])]
+    pairs = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in clouds]
+    plain = engine.Engine(cfg, None, share_with=eng)  # keep_taps off
+
+    def snapshot(e, res):
+        return (e.transform().copy(), [c.clone() for c in e.corr()], int(res.n_correspondences), int(res.n_ref_nodes), int(res.n_src_nodes),
+                int(res.n_node_correspondences), [int(x) for x in res.level_sizes], [int(x) for x in res.level_ref_sizes])
+    want = [snapshot(plain, plain.run(r, s)) for r, s in pairs]
+
+    def same(a, b):
+        return (np.array_equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and a[2:] == b[2:])
+    batched = engine.Engine(cfg, None, share_with=eng)
+    for lo, hi in ((0, 5), (1, 3), (4, 5)):  # batches of 5, 2 and 1 pairs on one engine, one after the other
+        assert batched.collate_batch(pairs[lo:hi]) == hi - lo
+        for k in range(lo, hi):
+            assert same(snapshot(batched, batched.run(*pairs[k])), want[k]), (lo, hi, k)
+    # forwards of a batch in any order, and twice
+    batched.collate_batch(pairs[:3])
+    for k in (2, 0, 2, 1):
+        assert same(snapshot(batched, batched.forward_batched(k)), want[k]), k
+    # another pair in between drops the batch: run() collates it itself, the prepared pair after it as well
+    batched.collate_batch(pairs[:2])
+    assert same(snapshot(batched, batched.run(*pairs[3])), want[3])
+    assert same(snapshot(batched, batched.run(*pairs[0])), want[0])
+    with pytest.raises(RuntimeError):
+        batched.forward_batched(0)
+    # keeping stage tensors builds the reference's full tables pair by pair: refused
+    batched.keep_taps(True)
+    with pytest.raises(RuntimeError):
+        batched.collate_batch(pairs[:2])

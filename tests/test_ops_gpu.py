@@ -465,3 +465,39 @@ def test_kpconv_lds_tile_kernel_has_the_bits_of_the_lock_step_kernel(ops, c, h, 
     if h > 4:
         cap = torch.tensor([h - 3], dtype=torch.int32).cuda()
         assert torch.equal(ops.kpconv_fused(*args, width=cap, form=2, order=rec), ops.kpconv_fused(*args, width=cap, form=1))
+
+
+@pytest.mark.parametrize('c,h,m,ns,spread', [(128, 69, 700, 3000, 0.3), (256, 70, 333, 2000, 0.3), (512, 81, 130, 900, 0.5),
+                                             (128, 128, 100, 4000, 3.0), (192, 17, 16, 40, 1.0), (256, 9, 5, 9, 1.0)])
+def test_kpconv_gather_lds_tile_form_has_the_bits_of_the_per_neighbour_form(ops, c, h, m, ns, spread):
+    """Round 5: form 2 of rdm_kpconv_gather_form serves the layers whose weight contraction stays a GEMM (c_in >= 128) with the
+    aggregation half of the KPConv tile kernel -- a workgroup stages the union of the support rows of 16 ordered queries once in
+    LDS, per 64-channel slice -- and writes WF and the positive-neighbour counts where kpconv_gather_kernel (form 1) writes
+    them: same neighbour order, influences and MFMA sequence per accumulator, i.e. the same BITS -- for every channel count that
+    is a multiple of 64, shadow slots, unions beyond the tile's capacity, a width cap, a ragged last block, any query order."""
+    g = torch.Generator().manual_seed(7 * c + h + m)
+    s_pts = torch.randn(ns, 3, generator=g) * 2
+    q_pts = s_pts[torch.randint(0, ns, (m,), generator=g)] + 0.1 * torch.randn(m, 3, generator=g)
+    feats = torch.randn(ns, c, generator=g)
+    feats[torch.rand(ns, generator=g) < 0.2] *= -1
+    d = torch.cdist(q_pts + spread * torch.randn(m, 3, generator=g), s_pts)
+    idx = d.argsort(1)[:, :h].contiguous()
+    n_valid = torch.randint(0, h + 1, (m,), generator=g)
+    n_valid[0] = h
+    idx = torch.where(torch.arange(h)[None] < n_valid[:, None], idx, torch.full_like(idx, ns))
+    kp = torch.randn(15, 3, generator=g)
+    fd = padded(feats)
+    args = (q_pts.cuda(), s_pts.cuda(), fd, ops.row_positive(fd), idx.cuda(), kp.cuda(), 1.7)
+    wf1, nn1 = ops.kpconv_gather(*args, form=1)
+    perm = torch.argsort(q_pts[:, 0])
+    rec = torch.cat([q_pts[perm], perm.to(torch.int32).view(torch.float32)[:, None]], 1).contiguous().cuda()
+    ident = torch.arange(m)
+    rec_rows = torch.cat([q_pts, ident.to(torch.int32).view(torch.float32)[:, None]], 1).contiguous().cuda()
+    for order in (rec, rec_rows):
+        wf2, nn2 = ops.kpconv_gather(*args, order=order, form=2)
+        assert torch.equal(wf2[:, :15 * c], wf1[:, :15 * c]) and torch.equal(nn2[:m], nn1[:m])
+    if h > 4:
+        cap = torch.tensor([h - 3], dtype=torch.int32).cuda()
+        a, na = ops.kpconv_gather(*args, width=cap, order=rec, form=2)
+        b, nb = ops.kpconv_gather(*args, width=cap, form=1)
+        assert torch.equal(a[:, :15 * c], b[:, :15 * c]) and torch.equal(na[:m], nb[:m])

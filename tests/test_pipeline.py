@@ -75,6 +75,48 @@ def test_single_pair_in_flight_runs_on_the_callers_stream_serially():
     assert p.map(range(5), lambda eng, job: (eng.k, job)) == [(0, j) for j in range(5)]
 
 
+def test_workers_collate_several_drawn_jobs_at_once_and_shrink_the_batches_towards_the_end():
+    """Round 5: with `tensors_of` a worker draws up to `collate_batch` jobs, hands their tensors to Engine.collate_batch ONCE and
+    then runs fn on each; results still come back in job order; for a sized job list the last rounds are spread over the
+    workers (20 jobs, 4 workers, batches of up to 8: 5 each, not 8 + 8 + 4 + 0); without `tensors_of`, with a batch of 1, or
+    when stage tensors are kept, jobs are drawn one by one as before."""
+    class Batching(FakeEngine):
+        def __init__(self, k):
+            super().__init__(k)
+            self.batches = []
+
+        def collate_batch(self, pairs):
+            self.batches.append(list(pairs))
+
+    def run(n_jobs, **kw):
+        p = pipeline.PairPipeline(None, None, pairs_in_flight=4, engines=[Batching(k) for k in range(4)], stagger_ms=0.0, **kw)
+
+        def fn(eng, job):
+            eng.jobs.append(job)
+            time.sleep(0.001)
+            return job + 100
+        out = p.map(range(n_jobs), fn, tensors_of=lambda job: ('ref%d' % job, 'src%d' % job))
+        assert out == [j + 100 for j in range(n_jobs)]
+        return p
+    p = run(20, collate_batch=8)
+    sizes = sorted(len(b) for e in p.engines for b in e.batches)
+    assert sorted(j for e in p.engines for j in e.jobs) == list(range(20))  # every job ran once
+    assert max(sizes) <= 5 and p.last_stats['collate_batches'] == len(sizes) and p.last_stats['jobs'] == 20
+    for e in p.engines:  # a batch is collated with the tensors of exactly the jobs the worker then runs, in order
+        flat = [t for b in e.batches for t in b]
+        batched_jobs = [int(t[0][3:]) for t in flat]
+        assert [j for j in e.jobs if j in set(batched_jobs)] == batched_jobs
+    p = run(64, collate_batch=4)
+    assert max(len(b) for e in p.engines for b in e.batches) == 4
+    p = run(10, collate_batch=1)
+    assert not any(e.batches for e in p.engines)
+    p = run(10, collate_batch=4, keep_taps=True)
+    assert not any(e.batches for e in p.engines)
+    # no tensors_of: nothing to prepare
+    p = pipeline.PairPipeline(None, None, pairs_in_flight=2, engines=[Batching(k) for k in range(2)], stagger_ms=0.0, collate_batch=4)
+    assert p.map(range(6), lambda eng, job: job) == list(range(6)) and not any(e.batches for e in p.engines)
+
+
 def _fake_sysfs(root, gpu_nodes, node_cpulists):
     """A sysfs tree with one CPU agent and len(gpu_nodes) GPU agents in the KFD topology (GPU k on PCI bus 0x10 + k, NUMA node
     gpu_nodes[k]) and the nodes' cpulist files."""

@@ -46,6 +46,16 @@ def test_pairs_in_flight_equal_the_serial_run_bit_for_bit_in_dataset_order(setup
     for i in set(order):
         rows = [g for g, k in zip(got, order) if k == i]
         assert all(np.array_equal(rows[0].transform, r.transform) for r in rows[1:])
+    # round 5: the workers collate several drawn pairs with one sequence of launches (collate_batch > 1: batches of pairs of
+    # different sizes, the last rounds shrunk) -- still the serial run's bits, in dataset order
+    for cb in (3, 4):
+        batched = pipeline.PairPipeline(cfg, None, pairs_in_flight=4, engines=[serial.engines[0]], collate_batch=cb)
+        got = batched.run_pairs([dev[i] for i in order])
+        assert batched.last_stats['collate_batches'] >= 2 and len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g.transform, w.transform) and g.level_sizes == w.level_sizes
+            assert np.array_equal(g.ref_corr_points, w.ref_corr_points) and np.array_equal(g.src_corr_points, w.src_corr_points)
+            assert np.array_equal(g.corr_scores, w.corr_scores)
 
 
 def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):

@@ -67,7 +67,11 @@ if __name__ == '__main__':
                 for f, tag in ((3, 'block ids in dispatch order (round 4)'),):
                     t = timed(lambda: ops.kpconv_fused(q, s, feats, pos, idx, kp, sigma, packed, bias, cout, want_partials=True, form=f, order=rec))
                     rows.append((f'  lab form {f}: {tag}', t))
-        t = timed(lambda: ops.kpconv_gather(q, s, feats, pos, idx, kp, sigma))
-        rows.append(('gather alone', t))
+        rec_q = ops.radius_grid_records(q, dd['lengths'][ql], cfg.backbone.init_radius * 2 ** ql)
+        t = timed(lambda: ops.kpconv_gather(q, s, feats, pos, idx, kp, sigma, order=rec_q, form=1))
+        rows.append(('gather alone (one wavefront per query and slice, cell order)', t))
+        if cin >= 128:
+            t = timed(lambda: ops.kpconv_gather(q, s, feats, pos, idx, kp, sigma, order=rec_q, form=2))
+            rows.append(('gather alone, LDS tile (round 5)', t))
         for name, t in rows:
             print(f'| L{sl}->L{ql} {cin}->{cout} | {M} | {H} | {fill:.2f} | {name} | {t:.1f} | {nbytes / t / 1e3:.0f} | {nbytes / t / 1e3 / 8000:.2f} |')
