@@ -619,7 +619,7 @@ def main():
 
     n_layers = max(len(prof), 1)
     traffic, traffic_note = None, None
-    for tag in ('r04', 'r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
+    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
         pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_kpconv_gather.json')
         if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
