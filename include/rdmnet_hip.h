@@ -528,6 +528,16 @@ int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* data, rdm_engine_resu
 int rdm_engine_collate_batch(rdm_engine* e, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
                              const float* const* src_points, const int64_t* n_src, void* stream);
 int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* result_host, void* stream);
+
+/* Lock step (round 5, experimental): rdm_engine_run of `n_pairs` (1 .. 8) pairs on as many engines -- one arena and one
+ * result buffer each, the weights shared (rdm_engine_share_params) -- on ONE stream: the runs advance together on the calling
+ * thread, the launches of the same kernel of all pairs go out as one grouped launch, the size read-backs of the pairs become
+ * waits of the group.  What the reference does pair after pair (engine/single_tester.py:86-134) and this library otherwise does on
+ * one stream per pair.  Every pair: the bits of rdm_engine_run on it alone.  RDM_ERR_WORKSPACE: a pair exhausted its arena (run it
+ * with rdm_engine_run, which grows the arena).                                                                              */
+int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                            const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
+                            int collate_batched, void* stream);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
 /* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,

@@ -16,6 +16,7 @@
 //   tokens the op is latency- not throughput-bound.
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -24,8 +25,9 @@ using namespace rdm;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHeadDim = 32;
 
-__global__ void rope_kernel(float* q, int ldq, float* k, int ldk, const float* emb, int lde, int n,
-                            int pairs) {
+__device__ __forceinline__ void rope_body(const dim3 blockIdx, const dim3 gridDim, float* q, int ldq, float* k, int ldk,
+                                          const float* emb, int lde, int n, int pairs) {
+  (void)gridDim;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * pairs) return;
   const int row = i / pairs, p = i % pairs;
@@ -43,6 +45,9 @@ __global__ void rope_kernel(float* q, int ldq, float* k, int ldk, const float* e
     b[0] = k0 * c + (-k1) * s;
     b[1] = k1 * c + k0 * s;
   }
+}
+__global__ __launch_bounds__(256) void rope_kernel(float* q, int ldq, float* k, int ldk, const float* emb, int lde, int n, int pairs) {
+  rope_body(blockIdx, gridDim, q, ldq, k, ldk, emb, lde, n, pairs);
 }
 
 struct AttnArgs {
@@ -78,7 +83,8 @@ __device__ __forceinline__ bf16x4_t pack_bf16(float a, float b, float c, float d
 // Q, K, V and the probabilities are rounded to bf16 in registers and contracted on the 16x16x16 bf16 MFMA;
 // logits, softmax statistics and both accumulators stay fp32.  HBM tensors are fp32 either way.
 template <bool BF16>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a_in) {
+__device__ __forceinline__ void attention_body(const dim3 blockIdx, const dim3 gridDim, AttnArgs a_in) {
+  (void)gridDim;
   AttnArgs a = a_in;
   int bx = blockIdx.x;
   if (a.seg0_blocks > 0 && bx >= a.seg0_blocks) {  // block-uniform: the second cloud's rows
@@ -218,10 +224,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a_in) {
       *reinterpret_cast<float2*>(a.out + static_cast<int64_t>(qi) * a.ldo + hoff + dd) = make_float2(a0 / lt, a1 / lt);
   }
 }
+template <bool BF16>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) { attention_body<BF16>(blockIdx, gridDim, a); }
 
 // vote.py:98-108: xyz + clamp(offset, -limit, +limit)
-__global__ void vote_shift_kernel(const float* xyz, const float* off, int ldo, int n, float lx, float ly,
+__device__ __forceinline__ void vote_shift_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* xyz, const float* off, int ldo, int n, float lx, float ly,
                                   float lz, float* out) {
+  (void)blockIdx; (void)gridDim;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * 3) return;
   const int row = i / 3, d = i % 3;
@@ -231,17 +240,24 @@ __global__ void vote_shift_kernel(const float* xyz, const float* off, int ldo, i
   o = o < -lim ? -lim : o;
   out[i] = xyz[i] + o;
 }
+__global__ void vote_shift_kernel(const float* xyz, const float* off, int ldo, int n, float lx, float ly,
+                                  float lz, float* out) { vote_shift_kernel_body(blockIdx, gridDim, xyz, off, ldo, n, lx, ly, lz, out); }
+
 
 // sigmoid + clamp[0,1] of a strided column (model_infer.py:161-162, 171-172, 199-202)
-__global__ void sigmoid_kernel(const float* x, int ldx, int n, float* out) {
+__device__ __forceinline__ void sigmoid_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int ldx, int n, float* out) {
+  (void)blockIdx; (void)gridDim;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 1.0f / (1.0f + expf(-x[static_cast<int64_t>(i) * ldx]));
   out[i] = fminf(fmaxf(s, 0.f), 1.f);
 }
+__global__ void sigmoid_kernel(const float* x, int ldx, int n, float* out) { sigmoid_kernel_body(blockIdx, gridDim, x, ldx, n, out); }
+
 
 // F.normalize(p=2, dim=1) (model_infer.py:248-249); one wavefront per row
-__global__ void l2_normalize_kernel(const float* x, int ldx, int n, int c, float* y, int ldy) {
+__device__ __forceinline__ void l2_normalize_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int ldx, int n, int c, float* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
@@ -253,6 +269,8 @@ __global__ void l2_normalize_kernel(const float* x, int ldx, int n, int c, float
   const float nrm = fmaxf(__fsqrt_rn(wave_sum(s)), 1e-12f);
   for (int i = lane; i < c; i += 64) y[static_cast<int64_t>(row) * ldy + i] = x[static_cast<int64_t>(row) * ldx + i] / nrm;
 }
+__global__ void l2_normalize_kernel(const float* x, int ldx, int n, int c, float* y, int ldy) { l2_normalize_kernel_body(blockIdx, gridDim, x, ldx, n, c, y, ldy); }
+
 
 }  // namespace
 
@@ -262,9 +280,8 @@ extern "C" int rdm_rope(float* q, int64_t ldq, float* k, int64_t ldk, const floa
   RDM_REQUIRE(q && emb && n >= 0 && d_model % 2 == 0, "rdm_rope: bad arguments");
   if (n == 0) return RDM_OK;
   const int pairs = static_cast<int>(d_model / 2);
-  hipLaunchKernelGGL(rope_kernel, dim3(ceil_div<int64_t>(n * pairs, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), q, static_cast<int>(ldq), k, static_cast<int>(ldk), emb,
-                     static_cast<int>(lde), static_cast<int>(n), pairs);
+  launch<rope_body, rope_kernel, 256>(dim3(ceil_div<int64_t>(n * pairs, 256)), 0, static_cast<hipStream_t>(stream), q,
+                                      static_cast<int>(ldq), k, static_cast<int>(ldk), emb, static_cast<int>(lde), static_cast<int>(n), pairs);
   return launch_status("rope_kernel");
 }
 
@@ -287,9 +304,9 @@ static int attention_launch(const float* q, int64_t ldq, const float* k, int64_t
   const dim3 grid(ceil_div<int64_t>(n_q, 16), heads);
   RDM_DUP_LOOP("attn")
   if (bf16)
-    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    launch<attention_body<true>, attention_kernel<true>, 256>(grid, 0, static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    launch<attention_body<false>, attention_kernel<false>, 256>(grid, 0, static_cast<hipStream_t>(stream), a);
   return launch_status("attention_kernel");
 }
 
@@ -326,9 +343,9 @@ extern "C" int rdm_attention_self_pair(const float* q, int64_t ldq, const float*
   const dim3 grid(a.seg0_blocks + ceil_div<int64_t>(n1, 16), heads);
   RDM_DUP_LOOP("attn")
   if (bf16)
-    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    launch<attention_body<true>, attention_kernel<true>, 256>(grid, 0, static_cast<hipStream_t>(stream), a);
   else
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    launch<attention_body<false>, attention_kernel<false>, 256>(grid, 0, static_cast<hipStream_t>(stream), a);
   return launch_status("attention_kernel");
 }
 
@@ -343,8 +360,7 @@ extern "C" int rdm_vote_shift(const float* xyz, const float* offsets, int64_t ld
   using namespace rdm;
   RDM_REQUIRE(xyz && offsets && out && n >= 0, "rdm_vote_shift: bad arguments");
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(vote_shift_kernel, dim3(ceil_div<int64_t>(3 * n, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), xyz, offsets, static_cast<int>(ldo), static_cast<int>(n), lx,
+  ::rdm::launch<vote_shift_kernel_body, vote_shift_kernel, 256>(dim3(ceil_div<int64_t>(3 * n, 256)), 0, static_cast<hipStream_t>(stream), xyz, offsets, static_cast<int>(ldo), static_cast<int>(n), lx,
                      ly, lz, out);
   return launch_status("vote_shift_kernel");
 }
@@ -353,8 +369,7 @@ extern "C" int rdm_sigmoid_column(const float* x, int64_t ldx, int64_t n, float*
   using namespace rdm;
   RDM_REQUIRE(x && out && n >= 0, "rdm_sigmoid_column: bad arguments");
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(sigmoid_kernel, dim3(ceil_div<int64_t>(n, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n), out);
+  ::rdm::launch<sigmoid_kernel_body, sigmoid_kernel, 256>(dim3(ceil_div<int64_t>(n, 256)), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n), out);
   return launch_status("sigmoid_kernel");
 }
 
@@ -363,8 +378,7 @@ extern "C" int rdm_l2_normalize(const float* x, int64_t ldx, int64_t n, int64_t 
   using namespace rdm;
   RDM_REQUIRE(x && y && n >= 0 && c > 0, "rdm_l2_normalize: bad arguments");
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(l2_normalize_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n),
+  ::rdm::launch<l2_normalize_kernel_body, l2_normalize_kernel, 256>(dim3(ceil_div<int64_t>(n, 4)), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(ldx), static_cast<int>(n),
                      static_cast<int>(c), y, static_cast<int>(ldy));
   return launch_status("l2_normalize_kernel");
 }

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -152,9 +153,9 @@ struct rdm_engine {
 
 namespace {
 
-#define ENG_CHECK(call)            \
+#define ENG_CHECK(...)             \
   do {                             \
-    int _rc = (call);              \
+    int _rc = (__VA_ARGS__);       \
     if (_rc != 0) return _rc;      \
   } while (0)
 #define ENG_ALLOC(ptr)                                             \
@@ -499,7 +500,8 @@ int thdroformer(Run& r, const std::string& name, const Mat& pts4, const Mat& x, 
 }
 
 // [n,3] -> [n,4] zero padded
-__global__ void pad_points_kernel(const float* p, int64_t n, float* out) {
+__device__ __forceinline__ void pad_points_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* p, int64_t n, float* out) {
+  (void)blockIdx; (void)gridDim;
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
   out[4 * i] = p[3 * i];
@@ -507,17 +509,22 @@ __global__ void pad_points_kernel(const float* p, int64_t n, float* out) {
   out[4 * i + 2] = p[3 * i + 2];
   out[4 * i + 3] = 0.f;
 }
+__global__ void pad_points_kernel(const float* p, int64_t n, float* out) { pad_points_kernel_body(blockIdx, gridDim, p, n, out); }
+
 __global__ void fill_kernel(float* p, int64_t n, float v) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i < n) p[i] = v;
 }
 // features = 1 (dataset.py:187-188) and the "row sum > 0" flag the first KPConv needs (kpconv.py:113-114), one launch
-__global__ void unit_features_kernel(float* x, int64_t n, int64_t ld, uint8_t* positive) {
+__device__ __forceinline__ void unit_features_kernel_body(const dim3 blockIdx, const dim3 gridDim, float* x, int64_t n, int64_t ld, uint8_t* positive) {
+  (void)blockIdx; (void)gridDim;
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
   for (int64_t c = 0; c < ld; ++c) x[i * ld + c] = 1.0f;  // (the pad columns as the separate fill wrote them)
   positive[i] = 1;
 }
+__global__ void unit_features_kernel(float* x, int64_t n, int64_t ld, uint8_t* positive) { unit_features_kernel_body(blockIdx, gridDim, x, n, ld, positive); }
+
 // The NMS survivors' rows (vote.py:36-40 boolean-mask selects; model_infer.py:206-216): nodes, their zero-padded [n,4]
 // copy for the positional Linear, features and the (n2p, n2n) score pairs -- one launch instead of seven gathers.
 struct SelectNodesArgs {
@@ -527,7 +534,8 @@ struct SelectNodesArgs {
   int d, ldf, ldo;
   float *nodes, *nodes4, *out_feats, *scores;
 };
-__global__ __launch_bounds__(64) void select_nodes_kernel(SelectNodesArgs a) {
+__device__ __forceinline__ void select_nodes_kernel_body(const dim3 blockIdx, const dim3 gridDim, SelectNodesArgs a) {
+  (void)blockIdx; (void)gridDim;
   const int j = blockIdx.x;
   const int src = j < a.m_r ? a.order[j] : a.order[a.nc_ref + (j - a.m_r)];
   const int t = threadIdx.x;
@@ -544,7 +552,10 @@ __global__ __launch_bounds__(64) void select_nodes_kernel(SelectNodesArgs a) {
   }
   for (int c = t; c < a.ldo; c += 64) a.out_feats[static_cast<int64_t>(j) * a.ldo + c] = c < a.d ? a.feats[static_cast<int64_t>(src) * a.ldf + c] : 0.f;
 }
-__global__ void concat_points_kernel(const float* a, int64_t na, const float* b, int64_t nb, float* out, int64_t* lengths) {
+__global__ __launch_bounds__(64) void select_nodes_kernel(SelectNodesArgs a) { select_nodes_kernel_body(blockIdx, gridDim, a); }
+
+__device__ __forceinline__ void concat_points_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* a, int64_t na, const float* b, int64_t nb, float* out, int64_t* lengths) {
+  (void)blockIdx; (void)gridDim;
   const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i == 0) {
     lengths[0] = na;
@@ -553,36 +564,49 @@ __global__ void concat_points_kernel(const float* a, int64_t na, const float* b,
   if (i < 3 * na) out[i] = a[i];
   else if (i < 3 * (na + nb)) out[i] = b[i - 3 * na];
 }
+__global__ void concat_points_kernel(const float* a, int64_t na, const float* b, int64_t nb, float* out, int64_t* lengths) { concat_points_kernel_body(blockIdx, gridDim, a, na, b, nb, out, lengths); }
+
 
 // The host half of a pair's result in one launch: pose + counters (19 words) and the first n correspondences
 // ([ref points 3n | src points 3n | scores n]) go straight into the mapped pinned buffer.
-__global__ __launch_bounds__(256) void export_result_kernel(const float* T, const float* rc, const float* sc, const float* cs,
+__device__ __forceinline__ void export_result_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* T, const float* rc, const float* sc, const float* cs,
                                                             uint32_t* head, float* corr, int cap) {
+  (void)blockIdx; (void)gridDim;
   const int n = min(reinterpret_cast<const int32_t*>(T)[16], cap);
   const int tid = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
   if (tid < 19) head[tid] = reinterpret_cast<const uint32_t*>(T)[tid];
   for (int i = tid; i < 7 * n; i += nt) corr[i] = i < 3 * n ? rc[i] : (i < 6 * n ? sc[i - 3 * n] : cs[i - 6 * n]);
 }
+__global__ __launch_bounds__(256) void export_result_kernel(const float* T, const float* rc, const float* sc, const float* cs,
+                                                            uint32_t* head, float* corr, int cap) { export_result_kernel_body(blockIdx, gridDim, T, rc, sc, cs, head, corr, cap); }
+
 
 // dst = OR of the status words of n {max count, status} pairs (one wavefront)
-__global__ __launch_bounds__(64) void or_status_kernel(const int32_t* pairs, int n, int32_t* dst) {
+__device__ __forceinline__ void or_status_kernel_body(const dim3 blockIdx, const dim3 gridDim, const int32_t* pairs, int n, int32_t* dst) {
+  (void)blockIdx; (void)gridDim;
   int v = 0;
   for (int i = threadIdx.x; i < n; i += 64) v |= pairs[2 * i + 1];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
   if (threadIdx.x == 0) *dst = v;
 }
+__global__ __launch_bounds__(64) void or_status_kernel(const int32_t* pairs, int n, int32_t* dst) { or_status_kernel_body(blockIdx, gridDim, pairs, n, dst); }
 
-template <typename K, typename... A>
-int launch1d(const char* what, K kernel, int64_t n, hipStream_t st, A... args) {
+
+template <auto Body, auto Kernel, typename... A>
+int launch1d(const char* what, int64_t n, hipStream_t st, A... args) {
   if (n <= 0) return RDM_OK;
-  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(n, 256))), dim3(256), 0, st, args...);
+  ::rdm::launch<Body, Kernel, 256>(dim3(static_cast<unsigned>(ceil_div<int64_t>(n, 256))), 0, st, args...);
   return launch_status(what);
 }
 
 // Wait for the engine's stream at a size read-back.  The runtime's synchronize busy-waits: with several pairs in
 // flight per GPU and 8 ranks per node that is 32 spinning cores; hosts with a small CPU quota poll instead.
 int wait_on(rdm_engine* e, hipStream_t st) {
+  if (lockstep_active()) {  // a pair of a lock-step group: parked until every pair of the group waits; the group waits once
+    lockstep_sync();
+    return RDM_OK;
+  }
   if (e->wait_sleep_us <= 0) {
     RDM_HIP_CHECK(hipStreamSynchronize(st));
     return RDM_OK;
@@ -983,7 +1007,7 @@ static int collate_batch_once(rdm_engine* e, int B, const float* const* refs, co
   {
     int64_t base = 0;
     for (int p = 0; p < B; ++p) {
-      ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * (n_refs[p] + n_srcs[p]), st, refs[p], n_refs[p], srcs[p], n_srcs[p],
+      ENG_CHECK(launch1d<concat_points_kernel_body, concat_points_kernel>("concat_points", 3 * (n_refs[p] + n_srcs[p]), st, refs[p], n_refs[p], srcs[p], n_srcs[p],
                          pts[0] + 3 * base, len[0] + 2 * p));
       base += n_refs[p] + n_srcs[p];
     }
@@ -1135,6 +1159,87 @@ extern "C" int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_resul
   return engine_run_once(e, nullptr, e->batch_n_ref[k], nullptr, e->batch_n_src[k], nullptr, res, stream, &e->batch[k]);
 }
 
+// ---------------------------------------------------------------- lock step: several pairs, one stream, grouped launches
+// rdm_engine_run of n pairs on n engines (one arena and one result buffer each, the weights shared) on ONE stream, in lock step
+// (lockstep.h): the runs are contexts of the calling thread; launches of converted kernels are recorded and the same kernel of
+// all pairs goes out as one grouped launch; the four size read-backs of the pairs become four waits of the group.  Every pair gets
+// the bits of rdm_engine_run on it alone (same kernel bodies, arguments and grids).
+namespace {
+struct LockstepJob {
+  rdm_engine* const* engines;
+  const float* const* refs;
+  const int64_t* n_refs;
+  const float* const* srcs;
+  const int64_t* n_srcs;
+  rdm_engine_result* const* results;
+  void* stream;
+  bool collated;  // the pyramids of all pairs lie in engines[0]'s arena (rdm_engine_collate_batch)
+};
+int lockstep_pair(int k, void* user) {
+  const LockstepJob& j = *static_cast<const LockstepJob*>(user);
+  rdm_engine* e = j.engines[k];
+  e->arena_exhausted = false;
+  if (j.collated) {  // (engines 1.. read the pyramid in engines[0]'s arena and keep their activations in their own)
+    if (k > 0) {
+      e->batch.clear();
+      e->arena_base = 0;
+    }
+    return engine_run_once(e, nullptr, j.n_refs[k], nullptr, j.n_srcs[k], nullptr, j.results[k], j.stream, &j.engines[0]->batch[k]);
+  }
+  return engine_run_once(e, j.refs[k], j.n_refs[k], j.srcs[k], j.n_srcs[k], nullptr, j.results[k], j.stream);
+}
+int lockstep_wait(hipStream_t st, void* user) {
+  rdm_engine* e = static_cast<rdm_engine*>(user);
+  if (e->wait_sleep_us <= 0) {
+    RDM_HIP_CHECK(hipStreamSynchronize(st));
+    return RDM_OK;
+  }
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return RDM_OK;
+    if (q != hipErrorNotReady) {
+      set_error("hipStreamQuery failed: %s", hipGetErrorString(q));
+      return RDM_ERR_HIP;
+    }
+    timespec ts{0, static_cast<long>(e->wait_sleep_us) * 1000};
+    nanosleep(&ts, nullptr);
+  }
+}
+}  // namespace
+
+extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                                       const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
+                                       int collate_batched, void* stream) {
+  RDM_REQUIRE(engines && ref_points && n_ref && src_points && n_src && results, "rdm_engine_run_lockstep: null pointer");
+  RDM_REQUIRE(n_pairs >= 1 && n_pairs <= kGroupMax, "rdm_engine_run_lockstep: 1 .. %d pairs", kGroupMax);
+  for (int k = 0; k < n_pairs; ++k) {
+    RDM_REQUIRE(engines[k] && results[k] && ref_points[k] && src_points[k] && n_ref[k] > 0 && n_src[k] > 0,
+                "rdm_engine_run_lockstep: pair %d is incomplete", k);
+    RDM_REQUIRE(engines[k]->finalized && !engines[k]->profile, "rdm_engine_run_lockstep: engine %d is not finalized (or profiles its layers)", k);
+    for (int j = 0; j < k; ++j) RDM_REQUIRE(engines[j] != engines[k], "rdm_engine_run_lockstep: every pair needs an engine of its own");
+  }
+  struct PadGuard {
+    explicit PadGuard(unsigned b) { rdm::gemm_set_lds_pad(b); }
+    ~PadGuard() { rdm::gemm_set_lds_pad(0); }
+  } pad_guard(engines[0]->pairs_in_flight >= 3 ? 20480u : 0u);
+  // the collates of all pairs as one launch sequence on engines[0] (exact, tests/test_engine_gpu.py), then the forwards in lock step
+  const bool collated = collate_batched != 0 && n_pairs > 1 && !engines[0]->keep_taps;
+  if (collated) ENG_CHECK(rdm_engine_collate_batch(engines[0], n_pairs, ref_points, n_ref, src_points, n_src, stream));
+  LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, collated};
+  int rcs[kGroupMax] = {};
+  const int wrc = lockstep_run(n_pairs, lockstep_pair, &job, static_cast<hipStream_t>(stream), lockstep_wait, engines[0], rcs);
+  if (wrc != 0) return wrc;
+  // a pair that exhausted its arena runs again on its own: rdm_engine_run grows the arena (engines[0] last: that rewrites the
+  // arena the other pairs' pyramids lie in -- they are done by then)
+  for (int k = n_pairs - 1; k >= 0; --k) {
+    if (rcs[k] == RDM_ERR_WORKSPACE && engines[k]->arena_exhausted && !engines[k]->arena_fixed)
+      rcs[k] = engine_run_growing(engines[k], ref_points[k], n_ref[k], src_points[k], n_src[k], nullptr, results[k], stream);
+  }
+  for (int k = 0; k < n_pairs; ++k)
+    if (rcs[k] != RDM_OK) return rcs[k];
+  return RDM_OK;
+}
+
 // The collate alone (geotransformer/utils/data.py:13-77 on two clouds): the pyramid and its 13 searches stay in the engine's
 // arena as stage tensors ("points0".."points4", "lengths0".., "neighbors0".., "subsampling0".."subsampling3",
 // "upsampling0".., "search_flags") for rdm_engine_export; level sizes in result_host.  Stage tensors are kept for this call
@@ -1186,7 +1291,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   r.e = e; r.st = static_cast<hipStream_t>(stream); r.groups = c.group_norm;
   const int64_t n0 = n_ref + n_src;
   // latency mode (see rdm_engine::overlap_mode); never on the legacy null stream, which every other blocking stream serialises with
-  bool overlap = !pre && !e->collate_only && r.st != nullptr && (e->overlap_mode == 2 || (e->overlap_mode == 1 && e->pairs_in_flight == 1));
+  bool overlap = !pre && !lockstep_active() && !e->collate_only && r.st != nullptr && (e->overlap_mode == 2 || (e->overlap_mode == 1 && e->pairs_in_flight == 1));
   if (overlap) ENG_CHECK(ensure_side(e, r.st, &overlap));
   SideGuard side_guard{e};
   // kernel scratch: the largest consumers are the grid-subsample tables and split-K partials
@@ -1283,7 +1388,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     x_pos = e->alloc<uint8_t>(n0);
     ENG_ALLOC(x_pos);
     if (dd) ENG_CHECK(rdm_row_positive(x.p, n0, 1, x.ld, x_pos, rr.st));
-    else ENG_CHECK(launch1d("unit_features", unit_features_kernel, n0, rr.st, x.p, n0, x.ld, x_pos));
+    else ENG_CHECK(launch1d<unit_features_kernel_body, unit_features_kernel>("unit_features", n0, rr.st, x.p, n0, x.ld, x_pos));
     return RDM_OK;
   };
   auto encoder_blocks = [&](Run& rr, int b0, int b1) -> int {
@@ -1369,7 +1474,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     // grids the per-op mirror builds (rdmnet_amd/model.py: run_encoder), so both give the same GroupNorm partials
     ENG_CHECK(build_level_grids());
     if (dd->collate_status && dd->n_collate_status > 0) {  // the collate's status words join the engine's own (checked below)
-      hipLaunchKernelGGL(or_status_kernel, dim3(1), dim3(64), 0, r.st, dd->collate_status, static_cast<int>(dd->n_collate_status),
+      ::rdm::launch<or_status_kernel_body, or_status_kernel, 64>(dim3(1), 0, r.st, dd->collate_status, static_cast<int>(dd->n_collate_status),
                          flags + 2 * call + 1);
       ENG_CHECK(launch_status("or_status_kernel"));
       call++;
@@ -1401,7 +1506,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     ENG_ALLOC(pts0); ENG_ALLOC(len0);
   }
   if (overlap_l0) side_guard.pending++;  // (from here to the join an early return waits for the side stream)
-  ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, r.st, ref_points, n_ref, src_points, n_src, pts0, len0));
+  ENG_CHECK(launch1d<concat_points_kernel_body, concat_points_kernel>("concat_points", 3 * n0, r.st, ref_points, n_ref, src_points, n_src, pts0, len0));
   int64_t* all_len = e->alloc<int64_t>(8);  // device lengths of levels 1..4, contiguous for one read-back
   ENG_ALLOC(all_len);
   float voxel = c.init_voxel_size;
@@ -1423,7 +1528,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     if (i == 1 && overlap_l0) {
       // beside that chain, on the side stream: everything that needs level 0 only.  Enqueued between the chain's first level
       // (0.18 ms of GPU time) and the rest, so that neither stream waits for the host to get to it.
-      ENG_CHECK(launch1d("concat_points", concat_points_kernel, 3 * n0, rs.st, ref_points, n_ref, src_points, n_src, lv[0].pts,
+      ENG_CHECK(launch1d<concat_points_kernel_body, concat_points_kernel>("concat_points", 3 * n0, rs.st, ref_points, n_ref, src_points, n_src, lv[0].pts,
                          lv[0].lengths));
       ENG_CHECK(build_level_grids(0, 1, rs.st));
       radius_redo_queue_reset(side_queue.data());
@@ -1503,7 +1608,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
   // ---------------------------------------------------------------- transformer #1 + heads
   Mat pts_c4{e->alloc<float>(4 * (Nc > 0 ? Nc : 1)), Nc, 4, 4};
   ENG_ALLOC(pts_c4.p);
-  ENG_CHECK(launch1d("pad_points", pad_points_kernel, Nc, r.st, lv[4].pts, Nc, pts_c4.p));
+  ENG_CHECK(launch1d<pad_points_kernel_body, pad_points_kernel>("pad_points", Nc, r.st, lv[4].pts, Nc, pts_c4.p));
   Mat buf_c = e->mat(Nc, D + 1);
   ENG_ALLOC(buf_c.p);
   Mat x_c = buf_c.cols_from(0, D);
@@ -1638,7 +1743,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
       sa.xyz = shifted; sa.feats = vfeats.p; sa.n2p = n2p; sa.n2n = n2n;
       sa.d = static_cast<int>(D); sa.ldf = static_cast<int>(vfeats.ld); sa.ldo = static_cast<int>(sel_feats.ld);
       sa.nodes = nodes; sa.nodes4 = nodes4.p; sa.out_feats = sel_feats.p; sa.scores = sel_scores;
-      hipLaunchKernelGGL(select_nodes_kernel, dim3(static_cast<unsigned>(Mn)), dim3(64), 0, r.st, sa);
+      ::rdm::launch<select_nodes_kernel_body, select_nodes_kernel, 64>(dim3(static_cast<unsigned>(Mn)), 0, r.st, sa);
       ENG_CHECK(launch_status("select_nodes_kernel"));
     }
     tap(r, "nodes", nodes, Mn, 3, 3, 0);
@@ -1790,7 +1895,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     int32_t counts[4];
   } tailbuf;
   float* host_corr = reinterpret_cast<float*>(static_cast<char*>(e->pinned) + 4096);
-  hipLaunchKernelGGL(export_result_kernel, dim3(16), dim3(256), 0, r.st, T, rc, sc, cs, static_cast<uint32_t*>(e->pinned_dev),
+  ::rdm::launch<export_result_kernel_body, export_result_kernel, 256>(dim3(16), 0, r.st, T, rc, sc, cs, static_cast<uint32_t*>(e->pinned_dev),
                      reinterpret_cast<float*>(static_cast<char*>(e->pinned_dev) + 4096), static_cast<int>(e->host_corr_cap));
   ENG_CHECK(launch_status("export_result_kernel"));
   ENG_CHECK(wait_stream(r));

@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -71,7 +72,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // flight): the skinny products of this path run a handful of blocks per CU and a block covers part of the load
 // latency itself.
 template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF, bool CAT = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g) {
+  (void)blockIdx; (void)gridDim;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   static_assert(WM * WN == 4 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
   // transposed-staged tiles use an odd row stride (scalar LDS writes of one k-column hit distinct
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
   GEMM_STAMP(3);
 }
+template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF, bool CAT = false>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) { gemm_kernel_body<BM, BN, WM, WN, BK, TRANS_B, PF, CAT>(blockIdx, gridDim, g); }
+
 
 // Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
 // one workgroup = ONE 32 x 32 output tile, its four wavefronts split K four ways, operands go straight
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // 128-B coalesced), and the four partial tiles are added through LDS in a fixed order.  The dependent
 // MFMA chain per wavefront is K/8 instructions instead of K/2, which is what bounds a 350 x 128 x 128
 // projection, not bandwidth.
-__device__ __forceinline__ void gemm_small_body(const GemmArgs& g, float (*red)[32][33]) {
+__device__ __forceinline__ void gemm_small_body(const dim3 blockIdx, const GemmArgs& g, float (*red)[32][33]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -453,17 +458,21 @@ __device__ __forceinline__ void gemm_small_body(const GemmArgs& g, float (*red)[
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_small_entry(const dim3 blockIdx, const dim3 gridDim, GemmArgs g) {
+  (void)gridDim;
   __shared__ float red[4][32][33];
-  gemm_small_body(g, red);
+  gemm_small_body(blockIdx, g, red);
 }
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs g) { gemm_small_entry(blockIdx, gridDim, g); }
 // two independent products in one launch (blockIdx.z): the q and the k|v projection of a cross-attention layer
-__global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs g0, GemmArgs g1) {
+__device__ __forceinline__ void gemm_small_pair_entry(const dim3 blockIdx, const dim3 gridDim, GemmArgs g0, GemmArgs g1) {
+  (void)gridDim;
   __shared__ float red[4][32][33];
   const GemmArgs& g = blockIdx.z ? g1 : g0;
   if (static_cast<int>(blockIdx.y) * 32 >= g.M || static_cast<int>(blockIdx.x) * 32 >= g.N) return;  // whole workgroup
-  gemm_small_body(g, red);
+  gemm_small_body(blockIdx, g, red);
 }
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(GemmArgs g0, GemmArgs g1) { gemm_small_pair_entry(blockIdx, gridDim, g0, g1); }
 
 // y = act(LayerNorm(x W + bias + residual)) for the transformer width (N = 128) in ONE launch: a workgroup owns
 // 16 complete rows (wavefront w the columns 32w..32w+31 over the whole K on the 16x16x4 MFMA, operands straight from
@@ -477,7 +486,8 @@ struct LinLnArgs {
   float eps;
 };
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
+__device__ __forceinline__ void linear_ln128_body(const dim3 blockIdx, const dim3 gridDim, LinLnArgs a) {
+  (void)gridDim;
   __shared__ float red[2][4][16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kb = lane >> 4;
@@ -554,6 +564,7 @@ __global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) {
     a.out[static_cast<long long>(row) * a.ldo + c1] = o1;
   }
 }
+__global__ __launch_bounds__(256) void linear_ln128_kernel(LinLnArgs a) { linear_ln128_body(blockIdx, gridDim, a); }
 
 // Everything of an attention layer after softmax(QK^T)V in ONE launch (thdroformer.py:142-173,
 // vanilla_transformer.py:69-103, output_layer.py:6-21), at the transformer width 128 with a 256-wide FFN:
@@ -580,7 +591,8 @@ struct TailArgs {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
+__device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, const dim3 gridDim, TailArgs a) {
+  (void)gridDim;
   __shared__ __attribute__((aligned(16))) float ys[16][132];
   __shared__ __attribute__((aligned(16))) float zs[16][260];
   __shared__ float red[4][8][16];
@@ -723,8 +735,10 @@ __global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) {
     if (row < a.M) a.out[static_cast<long long>(row) * a.ldo + c] = o[r];
   }
 }
+__global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) { attention_tail128_body(blockIdx, gridDim, a); }
 
-__global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
+__device__ __forceinline__ void splitk_reduce_kernel_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g, int batches) {
+  (void)blockIdx; (void)gridDim;
   const long long total = static_cast<long long>(batches) * g.M * g.N;
   for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
        i += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -740,6 +754,8 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
     g.C[b * g.sc + static_cast<long long>(m) * g.ldc + n] = apply_act(v, g.act);
   }
 }
+__global__ void splitk_reduce_kernel(GemmArgs g, int batches) { splitk_reduce_kernel_body(blockIdx, gridDim, g, batches); }
+
 
 // Split-K reduce that also emits the GroupNorm column partials of its row block (layout of gn_partial_kernel
 // in norm.hip, whose separate pass it replaces): grid = (row blocks, column chunks of 256); cw = min(N, 256)
@@ -747,7 +763,8 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int batches) {
 // element costs `splits` dependent-latency loads and the matrices are small (M in the hundreds).
 constexpr int kStatRowsPerLane = 8;
 inline int stat_rows_per_block(long long n) { return kStatRowsPerLane * (256 / static_cast<int>(n < 256 ? n : 256)); }
-__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, double* stats) {
+__device__ __forceinline__ void splitk_reduce_stats_kernel_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g, double* stats) {
+  (void)blockIdx; (void)gridDim;
   __shared__ double red[2][256];
   const int cw = g.N < 256 ? g.N : 256;
   const int lanes = 256 / cw;
@@ -798,6 +815,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, do
     stats[(static_cast<long long>(blockIdx.x) * 2 + 1) * g.N + col] = b;
   }
 }
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(GemmArgs g, double* stats) { splitk_reduce_stats_kernel_body(blockIdx, gridDim, g, stats); }
+
 
 thread_local unsigned g_lds_pad = 0;  // see rdm::gemm_set_lds_pad
 
@@ -809,18 +828,18 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   const unsigned pad = pad_env >= 0 ? static_cast<unsigned>(pad_env) : g_lds_pad;
   if constexpr (BM == 64 && BN == 64 && BK == 32 && PF == 2) {
     if (g.aidx && g.bidx) {  // gathered rows on both sides (patch scores)
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>), grid, dim3(256), pad, st, g);
+      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>, 256>(grid, pad, st, g);
       return;
     }
     if (g.aidx) {  // virtual [upsample | skip] A operand
-      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>), grid, dim3(256), pad, st, g);
+      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>, 256>(grid, pad, st, g);
       return;
     }
   }
   if (trans_b)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, true, PF>), grid, dim3(256), pad, st, g);
+    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF>, gemm_kernel<BM, BN, WM, WN, BK, true, PF>, 256>(grid, pad, st, g);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BK, false, PF>), grid, dim3(256), pad, st, g);
+    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF>, gemm_kernel<BM, BN, WM, WN, BK, false, PF>, 256>(grid, pad, st, g);
 }
 
 }  // namespace
@@ -851,7 +870,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     if (stat_blocks) *stat_blocks = 0;
     g_last_plan[0] = 32; g_last_plan[1] = 32; g_last_plan[2] = static_cast<int>(k / 4); g_last_plan[3] = 4;  // K over four wavefronts
     RDM_DUP_LOOP("gemmsmall")
-    hipLaunchKernelGGL(gemm_small_kernel, dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), dim3(256), 0, st, g);
+    ::rdm::launch<gemm_small_entry, gemm_small_kernel, 256>(dim3(ceil_div<long long>(n, 32), ceil_div<long long>(m, 32)), 0, st, g);
     return launch_status("gemm_small_kernel");
   }
   // Tile shape and split-K factor from a small cost model fitted to tools/gemm_sweep_graph.py (HIP-graph-replayed
@@ -982,14 +1001,13 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   if (int e = launch_status("gemm_kernel")) return e;
   if (g.splits > 1 && reduce_stats) {
     RDM_DUP_LOOP("splitk")
-    hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(ceil_div<long long>(m, stat_rows_per_block(n)), ceil_div<long long>(n, 256)), dim3(256),
-                       0, st, g, reduce_stats);
+    ::rdm::launch<splitk_reduce_stats_kernel_body, splitk_reduce_stats_kernel, 256>(dim3(ceil_div<long long>(m, stat_rows_per_block(n)), ceil_div<long long>(n, 256)), 0, st, g, reduce_stats);
     return launch_status("splitk_reduce_stats_kernel");
   }
   if (g.splits > 1) {
     const long long total = static_cast<long long>(batches) * m * n;
     const int blocks = static_cast<int>(std::min<long long>(ceil_div<long long>(total, 256), 2048));
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, batches);
+    ::rdm::launch<splitk_reduce_kernel_body, splitk_reduce_kernel, 256>(dim3(blocks), 0, st, g, batches);
     return launch_status("splitk_reduce_kernel");
   }
   return RDM_OK;
@@ -1055,7 +1073,7 @@ int rdm::gemm_pair(const float* a0, int64_t lda0, const float* b0, int64_t ldb0,
       g[i].A2 = nullptr; g[i].aidx = nullptr; g[i].lda2 = g[i].ldi = g[i].c1 = g[i].n_coarse = 0; g[i].bidx = nullptr; g[i].n_b = 0;
     }
     const long long gx = ceil_div<long long>(std::max(n0, n1), 32), gy = ceil_div<long long>(std::max(m0, m1), 32);
-    hipLaunchKernelGGL(gemm_small_pair_kernel, dim3(gx, gy, 2), dim3(256), 0, static_cast<hipStream_t>(stream), g[0], g[1]);
+    ::rdm::launch<gemm_small_pair_entry, gemm_small_pair_kernel, 256>(dim3(gx, gy, 2), 0, static_cast<hipStream_t>(stream), g[0], g[1]);
     return launch_status("gemm_small_pair_kernel");
   }
   if (m0 > 0)
@@ -1217,8 +1235,7 @@ extern "C" int rdm_linear_layer_norm(const float* x, int64_t ldx, const float* w
   a.A = x; a.B = w; a.bias = bias; a.res = residual; a.gamma = gamma; a.beta = beta; a.out = y;
   a.M = static_cast<int>(m); a.K = static_cast<int>(k); a.lda = static_cast<int>(ldx); a.ldb = static_cast<int>(ldw);
   a.ldr = static_cast<int>(ldr); a.ldo = static_cast<int>(ldy); a.act = act; a.eps = eps;
-  hipLaunchKernelGGL(linear_ln128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a);
+  ::rdm::launch<linear_ln128_body, linear_ln128_kernel, 256>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), 0, static_cast<hipStream_t>(stream), a);
   return launch_status("linear_ln128_kernel");
 }
 
@@ -1245,8 +1262,7 @@ extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const 
   a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
   a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
   RDM_DUP_LOOP("tail")
-  hipLaunchKernelGGL(attention_tail128_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), dim3(512), 0,
-                     static_cast<hipStream_t>(stream), a);
+  ::rdm::launch<attention_tail128_body, attention_tail128_kernel, 512>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), 0, static_cast<hipStream_t>(stream), a);
   return launch_status("attention_tail128_kernel");
 }
 

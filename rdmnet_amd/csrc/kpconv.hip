@@ -18,6 +18,7 @@
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -53,7 +54,8 @@ struct KpArgs {
 // coarse levels (few hundred queries, 256-512 channels) still fill the chip; PF neighbour groups of
 // four are fetched before the first is consumed (the gather -> MFMA chain is latency-bound otherwise).
 template <int VEC, int U, int SPLIT, int PF>
-__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
+__device__ __forceinline__ void kpconv_gather_kernel_body(const dim3 blockIdx, const dim3 gridDim, KpArgs a) {
+  (void)blockIdx; (void)gridDim;
   __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = bit pattern of the support row (or -1)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // Work distribution.  Large levels: a workgroup owns `qpb` consecutive work units (= queries in the
@@ -192,10 +194,14 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) {
   if (lane == 0 && slice == 0) a.nn[m] = static_cast<float>(positives > 1 ? positives : 1);
   }  // unit loop
 }
+template <int VEC, int U, int SPLIT, int PF>
+__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_kernel(KpArgs a) { kpconv_gather_kernel_body<VEC, U, SPLIT, PF>(blockIdx, gridDim, a); }
+
 
 // First layer (C_in = 1, features == 1 for every real point, reference dataset.py:187-188 and
 // model_infer.py:113): WF[m,k] = sum_h w[h,k] * f[idx], no matrix core needed.
-__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a) {
+__device__ __forceinline__ void kpconv_gather_c1_kernel_body(const dim3 blockIdx, const dim3 gridDim, KpArgs a) {
+  (void)blockIdx; (void)gridDim;
   // one wavefront per query: phase 1 stages (relative position, feature) of every neighbour in LDS with
   // coalesced index reads; phase 2: lane (g, j) walks neighbours g, g+4, ... for kernel point j
   __shared__ float4 nb[kWaves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
@@ -253,9 +259,12 @@ __global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a)
     }
   }
 }
+__global__ __launch_bounds__(64 * kWaves) void kpconv_gather_c1_kernel(KpArgs a) { kpconv_gather_c1_kernel_body(blockIdx, gridDim, a); }
+
 
 // 1 iff the row sum is positive (kpconv.py:113-114); one wavefront per row, fixed summation order.
-__global__ void row_positive_kernel(const float* x, int n, int c, int ld, unsigned char* out) {
+__device__ __forceinline__ void row_positive_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int n, int c, int ld, unsigned char* out) {
+  (void)blockIdx; (void)gridDim;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
@@ -264,6 +273,8 @@ __global__ void row_positive_kernel(const float* x, int n, int c, int ld, unsign
   s = wave_sum(s);
   if (lane == 0) out[row] = s > 0.f ? 1 : 0;
 }
+__global__ void row_positive_kernel(const float* x, int n, int c, int ld, unsigned char* out) { row_positive_kernel_body(blockIdx, gridDim, x, n, c, ld, out); }
+
 
 }  // namespace
 
@@ -272,8 +283,7 @@ extern "C" int rdm_row_positive(const float* x, int64_t n, int64_t c, int64_t ld
   using namespace rdm;
   RDM_REQUIRE(x && out && n >= 0 && c > 0, "rdm_row_positive: bad arguments");
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(row_positive_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
+  ::rdm::launch<row_positive_kernel_body, row_positive_kernel, 256>(dim3(ceil_div<int64_t>(n, 4)), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
                      static_cast<int>(ld), out);
   return launch_status("row_positive_kernel");
 }
@@ -314,7 +324,6 @@ int rdm::kpconv_gather_impl(const float* q_points, int64_t m, const float* s_poi
   static const bool xcd_env = ::rdm::dev_knob("RDM_GATHER_XCD") != nullptr;  // developer knob (A/B)
   a.xcd_remap = (xcd_env && order_records) ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 block(64 * kWaves);
   // one work unit per wavefront.  Measured on MI355X: letting a workgroup own 16 or 64 consecutive
   // (cell-ordered) queries for L1 re-use does not help (64: too few wavefronts per CU, 16: neutral)
   auto grid = [&](int split) {
@@ -326,15 +335,15 @@ int rdm::kpconv_gather_impl(const float* q_points, int64_t m, const float* s_poi
   // fills from L2 (feature row + point + flag per neighbour), not by the dependent-load chain.
   RDM_DUP_LOOP("gather")
   switch (c) {
-    case 1: hipLaunchKernelGGL(kpconv_gather_c1_kernel, dim3(ceil_div<int64_t>(m, kWaves)), block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 1, 4>), grid(1), block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 1, 4>), grid(1), block, 0, st, a); break;
-    case 128: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 2, 4>), grid(2), block, 0, st, a); break;
-    case 256: hipLaunchKernelGGL((kpconv_gather_kernel<4, 1, 4, 4>), grid(4), block, 0, st, a); break;
-    case 512: hipLaunchKernelGGL((kpconv_gather_kernel<4, 2, 4, 2>), grid(4), block, 0, st, a); break;
+    case 1: ::rdm::launch<kpconv_gather_c1_kernel_body, kpconv_gather_c1_kernel, 64 * kWaves>(dim3(ceil_div<int64_t>(m, kWaves)), 0, st, a); break;
+    case 32: ::rdm::launch<kpconv_gather_kernel_body<2, 1, 1, 4>, kpconv_gather_kernel<2, 1, 1, 4>, 64 * kWaves>(grid(1), 0, st, a); break;
+    case 64: ::rdm::launch<kpconv_gather_kernel_body<4, 1, 1, 4>, kpconv_gather_kernel<4, 1, 1, 4>, 64 * kWaves>(grid(1), 0, st, a); break;
+    case 128: ::rdm::launch<kpconv_gather_kernel_body<4, 1, 2, 4>, kpconv_gather_kernel<4, 1, 2, 4>, 64 * kWaves>(grid(2), 0, st, a); break;
+    case 256: ::rdm::launch<kpconv_gather_kernel_body<4, 1, 4, 4>, kpconv_gather_kernel<4, 1, 4, 4>, 64 * kWaves>(grid(4), 0, st, a); break;
+    case 512: ::rdm::launch<kpconv_gather_kernel_body<4, 2, 4, 2>, kpconv_gather_kernel<4, 2, 4, 2>, 64 * kWaves>(grid(4), 0, st, a); break;
     default:  // any other multiple of 32 (the backbone's widths are 32 * 2^k; the reference takes any init_dim): 32-channel slices
       a.split = static_cast<int>(c / 32);
-      hipLaunchKernelGGL((kpconv_gather_kernel<2, 1, 0, 4>), grid(a.split), block, 0, st, a);
+      ::rdm::launch<kpconv_gather_kernel_body<2, 1, 0, 4>, kpconv_gather_kernel<2, 1, 0, 4>, 64 * kWaves>(grid(a.split), 0, st, a);
       break;
   }
   return launch_status("kpconv_gather_kernel");

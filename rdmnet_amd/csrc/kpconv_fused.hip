@@ -26,6 +26,7 @@
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -84,7 +85,8 @@ __device__ __forceinline__ f32x2 kp_influence2(f32x2 dx, f32x2 dy, f32x2 dz, flo
 
 // ---- C_in in {32, 64}
 template <int C, int QB, int NW, int ITERS>
-__global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
+__device__ __forceinline__ void kpconv_fused_kernel_body(const dim3 blockIdx, const dim3 gridDim, FusedArgs a) {
+  (void)blockIdx; (void)gridDim;
   constexpr int VEC = C / 16;           // channels per lane and gather tile pass (channel = VEC*j + e)
   constexpr int NT = C / 16;            // output column tiles (C' = C)
   constexpr int RT = QB / 16;           // output row tiles
@@ -262,6 +264,9 @@ __global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) {
     }
   }
 }
+template <int C, int QB, int NW, int ITERS>
+__global__ __launch_bounds__(64 * NW) void kpconv_fused_kernel(FusedArgs a) { kpconv_fused_kernel_body<C, QB, NW, ITERS>(blockIdx, gridDim, a); }
+
 
 // ---- C_in in {32, 64}, neighbour rows of at most 128 slots: the support rows of a block of queries staged ONCE in LDS
 //
@@ -352,7 +357,8 @@ struct TileLds {
 // writes them where kpconv_gather_kernel writes them -- same neighbour order, same influences, same MFMA sequence per accumulator:
 // the same bits -- but fetches every distinct support row of the block once instead of once per (query, neighbour).
 template <int C, bool GATHER = false>
-__global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order, int xcd_ranges) {
+__device__ __forceinline__ void kpconv_tile_kernel_body(const dim3 blockIdx, const dim3 gridDim, FusedArgs a, const float4* __restrict__ order, int xcd_ranges) {
+  (void)blockIdx; (void)gridDim;
   if constexpr (GATHER) {  // the slice of this workgroup
     a.s_feats += static_cast<int64_t>(blockIdx.y) * C;
     a.out += static_cast<int64_t>(blockIdx.y) * C;
@@ -734,6 +740,9 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
   if (threadIdx.x == 0 && rdm_tile_clk) rdm_tile_clk[tl_blk * 8 + 7] = n_slots + ((wall_clock64() - tl_rt0) << 16);  // (100 MHz clock)
 #endif
 }
+template <int C, bool GATHER = false>
+__global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 8 ? 3 : 2) * TileCfg<C>::NW / 4) void kpconv_tile_kernel(FusedArgs a, const float4* __restrict__ order, int xcd_ranges) { kpconv_tile_kernel_body<C, GATHER>(blockIdx, gridDim, a, order, xcd_ranges); }
+
 
 // (Round 5 measured a rewrite of this kernel -- a wavefront's queries software-pipelined (index row of query t + 2 and the two
 // gathers of t + 1 in flight while t is evaluated), the positive count as a ballot of the gathered feature, the staged
@@ -744,7 +753,8 @@ __global__ __launch_bounds__(64 * TileCfg<C>::NW, (C == 32 && TileCfg<C>::NW == 
 // REFERENCE returns for them.  A 4 us kernel is not worth a weaker parity statement; docs/EXPERIMENTS.md 5f.)
 // ---- C_in = 1: one wavefront per query, lane = output channel (C' = 64); QPW queries per wavefront
 constexpr int kC1Out = 64, kC1Waves = 16, kC1Qpw = 4;  // 64 queries per workgroup, four per wavefront
-__global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArgs a) {
+__device__ __forceinline__ void kpconv_fused_c1_kernel_body(const dim3 blockIdx, const dim3 gridDim, FusedArgs a) {
+  (void)blockIdx; (void)gridDim;
   __shared__ float4 nb_all[kC1Waves][kMaxH];  // rel.xyz, w = feature (0 for shadow neighbours)
   __shared__ double ex[kC1Waves][kC1Out][2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -824,6 +834,8 @@ __global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArg
     }
   }
 }
+__global__ __launch_bounds__(64 * kC1Waves) void kpconv_fused_c1_kernel(FusedArgs a) { kpconv_fused_c1_kernel_body(blockIdx, gridDim, a); }
+
 
 template <int C, int QB, int NW>
 constexpr size_t fused_lds_bytes() { return sizeof(float) * (static_cast<size_t>(QB) * (kKP * C + 4) + NW * kMaxH * 4 + QB); }
@@ -897,7 +909,7 @@ int rdm::kpconv_tile_gather(const float* q_points, int64_t m, const float* s_poi
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<64, true>), static_cast<int>(TileLds<64>::bytes), gattr));
   const dim3 grid(static_cast<unsigned>(ceil_div<int64_t>(m, kTileQB)), static_cast<unsigned>(c / 64));
   RDM_DUP_LOOP("gather")
-  hipLaunchKernelGGL((kpconv_tile_kernel<64, true>), grid, dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, static_cast<hipStream_t>(stream), a,
+  ::rdm::launch<kpconv_tile_kernel_body<64, true>, kpconv_tile_kernel<64, true>, 64 * TileCfg<64>::NW, 2 * TileCfg<64>::NW / 4>(grid, TileLds<64>::bytes, static_cast<hipStream_t>(stream), a,
                      reinterpret_cast<const float4*>(order_records), 1);
   return launch_status("kpconv_tile_kernel<64, gather>");
 }
@@ -980,7 +992,7 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
     // and gathers of a wavefront's four queries requested together -- 30.4 us; round 5: halving the instruction count and
     // pipelining the queries buys 15 %, four queries per pipeline stage lose it again: the address processing of the
     // scattered gathers bounds the kernel, see the note above kpconv_fused_c1_kernel)
-    hipLaunchKernelGGL(kpconv_fused_c1_kernel, dim3(blocks), dim3(64 * kC1Waves), 0, st, a);
+    ::rdm::launch<kpconv_fused_c1_kernel_body, kpconv_fused_c1_kernel, 64 * kC1Waves>(dim3(blocks), 0, st, a);
     continue;
   }
   if (use_tile(c, h, m, n_s, order_records != nullptr, form)) {  // the support rows of 16 cell-ordered queries staged once in LDS
@@ -989,10 +1001,10 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
     const int xcd_ranges = form == 3 ? 0 : 1;  // (form 3, lab: block ids in dispatch order, as in round 4)
     if (c == 32) {
       RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<32>), static_cast<int>(TileLds<32>::bytes), tattr32));
-      hipLaunchKernelGGL((kpconv_tile_kernel<32>), dim3(blocks), dim3(64 * TileCfg<32>::NW), TileLds<32>::bytes, st, a, order, xcd_ranges);
+      ::rdm::launch<kpconv_tile_kernel_body<32>, kpconv_tile_kernel<32>, 64 * TileCfg<32>::NW, (TileCfg<32>::NW == 8 ? 3 : 2) * TileCfg<32>::NW / 4>(dim3(blocks), TileLds<32>::bytes, st, a, order, xcd_ranges);
     } else {
       RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(kpconv_tile_kernel<64>), static_cast<int>(TileLds<64>::bytes), tattr64));
-      hipLaunchKernelGGL((kpconv_tile_kernel<64>), dim3(blocks), dim3(64 * TileCfg<64>::NW), TileLds<64>::bytes, st, a, order, xcd_ranges);
+      ::rdm::launch<kpconv_tile_kernel_body<64>, kpconv_tile_kernel<64>, 64 * TileCfg<64>::NW, 2 * TileCfg<64>::NW / 4>(dim3(blocks), TileLds<64>::bytes, st, a, order, xcd_ranges);
     }
     continue;
   }
@@ -1004,9 +1016,9 @@ int rdm::kpconv_fused_impl(const float* q_points, int64_t m, const float* s_poin
                                     static_cast<int>(fused_lds_bytes<64, kQb64, kNw64>()), attr64));
   const size_t lds32 = fused_lds_bytes<32, kQb32, kNw32>(), lds64 = fused_lds_bytes<64, kQb64, kNw64>();
   if (c == 32)
-    hipLaunchKernelGGL((kpconv_fused_kernel<32, kQb32, kNw32, kIters32>), dim3(blocks), dim3(64 * kNw32), lds32, st, a);
+    ::rdm::launch<kpconv_fused_kernel_body<32, kQb32, kNw32, kIters32>, kpconv_fused_kernel<32, kQb32, kNw32, kIters32>, 64 * kNw32>(dim3(blocks), lds32, st, a);
   else
-    hipLaunchKernelGGL((kpconv_fused_kernel<64, kQb64, kNw64, kIters64>), dim3(blocks), dim3(64 * kNw64), lds64, st, a);
+    ::rdm::launch<kpconv_fused_kernel_body<64, kQb64, kNw64, kIters64>, kpconv_fused_kernel<64, kQb64, kNw64, kIters64>, 64 * kNw64>(dim3(blocks), lds64, st, a);
   }
   return launch_status("kpconv_fused_kernel");
 }

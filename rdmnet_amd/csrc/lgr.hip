@@ -20,6 +20,7 @@
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 #include "procrustes.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -45,9 +46,10 @@ struct LgrBuffers {
 // holds fl(-1e12), i.e. exp() = 0 exactly, while a real row (column) of exp(scores) sums to 1, so its maximum is positive
 // and a masked entry never wins nor ties a top-1 -- the compacted search returns the indices of the full 129 x 129 one.  A
 // patch holds a few dozen real points of 128: 1-2 k exponentials per patch instead of 16.6 k.
-__global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_scores, int side,
+__device__ __forceinline__ void lgr_extract_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* log_scores, int side,
                                                           const unsigned char* ref_mask,
                                                           const unsigned char* src_mask, LgrBuffers w) {
+  (void)blockIdx; (void)gridDim;
   extern __shared__ float S[];  // compacted [(nr+1)][(nc+1)], row stride ldc (odd)
   __shared__ int rows[kSide + 1], cols[kSide + 1];  // original index of every compacted line, dustbin (= side) last
   __shared__ int rowarg[kSide + 1], colarg[kSide + 1];
@@ -136,11 +138,16 @@ __global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_score
       }
   }
 }
+__global__ __launch_bounds__(256) void lgr_extract_kernel(const float* log_scores, int side,
+                                                          const unsigned char* ref_mask,
+                                                          const unsigned char* src_mask, LgrBuffers w) { lgr_extract_kernel_body(blockIdx, gridDim, log_scores, side, ref_mask, src_mask, w); }
+
 
 // ------------------------------------------------------------------------------------------ layout
 // One wavefront: exclusive prefix of the per-patch correspondence counts (= offsets in nonzero order) and the
 // ordered list of patches with >= min_corr correspondences.  Lane l owns patches 4l .. 4l+3 of each 256-patch chunk.
-__global__ __launch_bounds__(64) void lgr_layout_kernel(int batch, int min_corr, LgrBuffers w) {
+__device__ __forceinline__ void lgr_layout_kernel_body(const dim3 blockIdx, const dim3 gridDim, int batch, int min_corr, LgrBuffers w) {
+  (void)blockIdx; (void)gridDim;
   const int lane = threadIdx.x;
   int acc = 0, chunks = 0;  // running totals, identical in all lanes
   for (int base = 0; base < batch; base += 256) {
@@ -180,9 +187,12 @@ __global__ __launch_bounds__(64) void lgr_layout_kernel(int batch, int min_corr,
     w.meta[2] = -1;
   }
 }
+__global__ __launch_bounds__(64) void lgr_layout_kernel(int batch, int min_corr, LgrBuffers w) { lgr_layout_kernel_body(blockIdx, gridDim, batch, min_corr, w); }
 
-__global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, int side, LgrBuffers w,
+
+__device__ __forceinline__ void lgr_gather_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* ref_knn, const float* src_knn, int side, LgrBuffers w,
                                   float* ref_corr, float* src_corr, float* corr_scores) {
+  (void)blockIdx; (void)gridDim;
   const int b = blockIdx.x;
   const int cnt = w.patch_count[b], off = w.patch_offset[b];
   for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
@@ -196,6 +206,9 @@ __global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, in
     corr_scores[off + t] = w.local_s[o];
   }
 }
+__global__ void lgr_gather_kernel(const float* ref_knn, const float* src_knn, int side, LgrBuffers w,
+                                  float* ref_corr, float* src_corr, float* corr_scores) { lgr_gather_kernel_body(blockIdx, gridDim, ref_knn, src_knn, side, w, ref_corr, src_corr, corr_scores); }
+
 
 // ------------------------------------------------------------------------------------------ Procrustes
 // Sum N values per thread over the block (fixed order); red must hold N * 16 doubles.
@@ -295,8 +308,9 @@ __device__ __forceinline__ bool is_inlier(const float* T, const float* src, cons
 }
 
 // one 64-thread block per chunk: local Procrustes, then inlier count over ALL correspondences
-__global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, const float* src_corr,
+__device__ __forceinline__ void lgr_local_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* ref_corr, const float* src_corr,
                                                         const float* scores, float radius, LgrBuffers w) {
+  (void)blockIdx; (void)gridDim;
   __shared__ double red[9 * 16];
   __shared__ float Tf[12];
   __shared__ int cnt_sh;
@@ -320,13 +334,17 @@ __global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, c
   __syncthreads();
   if (threadIdx.x == 0) w.chunk_inliers[chunk] = cnt_sh;
 }
+__global__ __launch_bounds__(256) void lgr_local_kernel(const float* ref_corr, const float* src_corr,
+                                                        const float* scores, float radius, LgrBuffers w) { lgr_local_kernel_body(blockIdx, gridDim, ref_corr, src_corr, scores, radius, w); }
+
 
 // single block: pick the hypothesis, refine globally
 constexpr int kRefineStage = 4608;  // correspondences staged in LDS: 4608 * 29 B = 131 KB
-__global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
+__device__ __forceinline__ void lgr_refine_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* ref_corr, const float* src_corr,
                                                           const float* scores, float radius, int steps,
                                                           LgrBuffers w, unsigned char* gate, float* out_T,
                                                           int32_t* counts) {
+  (void)blockIdx; (void)gridDim;
   __shared__ double red[9 * 16];
   __shared__ float Tf[12];
   extern __shared__ float stage[];
@@ -388,6 +406,11 @@ __global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, 
     counts[2] = best_out;
   }
 }
+__global__ __launch_bounds__(256) void lgr_refine_kernel(const float* ref_corr, const float* src_corr,
+                                                          const float* scores, float radius, int steps,
+                                                          LgrBuffers w, unsigned char* gate, float* out_T,
+                                                          int32_t* counts) { lgr_refine_kernel_body(blockIdx, gridDim, ref_corr, src_corr, scores, radius, steps, w, gate, out_T, counts); }
+
 
 }  // namespace
 
@@ -437,12 +460,12 @@ extern "C" int rdm_lgr(const float* log_scores, const float* ref_knn_points, con
   static std::atomic<uint64_t> attr_extract{0}, attr_refine{0};  // per device (rdm::set_max_dynamic_lds)
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(lgr_extract_kernel), 160 * 1024 - 4096, attr_extract));
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(lgr_refine_kernel), 160 * 1024 - 4096, attr_refine));
-  hipLaunchKernelGGL(lgr_extract_kernel, dim3(B), dim3(256), lds, st, log_scores, S, ref_knn_masks, src_knn_masks, w);
-  hipLaunchKernelGGL(lgr_layout_kernel, dim3(1), dim3(64), 0, st, B, correspondence_threshold, w);
-  hipLaunchKernelGGL(lgr_gather_kernel, dim3(B), dim3(64), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,
+  ::rdm::launch<lgr_extract_kernel_body, lgr_extract_kernel, 256>(dim3(B), lds, st, log_scores, S, ref_knn_masks, src_knn_masks, w);
+  ::rdm::launch<lgr_layout_kernel_body, lgr_layout_kernel, 64>(dim3(1), 0, st, B, correspondence_threshold, w);
+  ::rdm::launch<lgr_gather_kernel_body, lgr_gather_kernel, 64>(dim3(B), 0, st, ref_knn_points, src_knn_points, S, w, ref_corr,
                      src_corr, corr_scores);
-  hipLaunchKernelGGL(lgr_local_kernel, dim3(B), dim3(256), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
-  hipLaunchKernelGGL(lgr_refine_kernel, dim3(1), dim3(256), kRefineStage * 29 + 64, st, ref_corr, src_corr, corr_scores,
+  ::rdm::launch<lgr_local_kernel_body, lgr_local_kernel, 256>(dim3(B), 0, st, ref_corr, src_corr, corr_scores, acceptance_radius, w);
+  ::rdm::launch<lgr_refine_kernel_body, lgr_refine_kernel, 256>(dim3(1), kRefineStage * 29 + 64, st, ref_corr, src_corr, corr_scores,
                      acceptance_radius, num_refinement_steps, w, gate, transform, counts);
   return launch_status("lgr kernels");
 }

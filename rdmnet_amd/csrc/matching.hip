@@ -11,6 +11,7 @@
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -22,8 +23,9 @@ using namespace rdm;
 // only, which makes it the lexicographically-first maximal independent set; it is resolved in
 // parallel rounds (a node is final once a lower neighbour is kept, or all lower neighbours are
 // final and none is kept).  One workgroup; rounds <= longest dependency chain.
-__global__ __launch_bounds__(1024) void nms_kernel(const int64_t* idx, int n, int h, int ldi,
+__device__ __forceinline__ void nms_kernel_body(const dim3 blockIdx, const dim3 gridDim, const int64_t* idx, int n, int h, int ldi,
                                                    const int32_t* width, unsigned char* keep) {
+  (void)blockIdx; (void)gridDim;
   extern __shared__ unsigned char state[];  // 0 undecided, 1 kept, 2 suppressed
   __shared__ int pending;
   int H = h;
@@ -54,10 +56,14 @@ __global__ __launch_bounds__(1024) void nms_kernel(const int64_t* idx, int n, in
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) keep[i] = state[i] == 1 ? 1 : 0;
 }
+__global__ __launch_bounds__(1024) void nms_kernel(const int64_t* idx, int n, int h, int ldi,
+                                                   const int32_t* width, unsigned char* keep) { nms_kernel_body(blockIdx, gridDim, idx, n, h, ldi, width, keep); }
+
 
 // order-preserving compaction of kept rows: dst row = number of kept rows before it
-__global__ __launch_bounds__(1024) void compact_index_kernel(const unsigned char* keep, int begin, int end,
+__device__ __forceinline__ void compact_index_kernel_body(const dim3 blockIdx, const dim3 gridDim, const unsigned char* keep, int begin, int end,
                                                              int32_t* order, int32_t* count) {
+  (void)blockIdx; (void)gridDim;
   __shared__ int wsum[17];
   __shared__ int base;
   if (threadIdx.x == 0) base = 0;
@@ -90,13 +96,17 @@ __global__ __launch_bounds__(1024) void compact_index_kernel(const unsigned char
   }
   if (threadIdx.x == 0) *count = base;
 }
+__global__ __launch_bounds__(1024) void compact_index_kernel(const unsigned char* keep, int begin, int end,
+                                                             int32_t* order, int32_t* count) { compact_index_kernel_body(blockIdx, gridDim, keep, begin, end, order, count); }
+
 
 // Both clouds' compactions in one launch (workgroup b: rows [b ? n_ref : 0, b ? n : n_ref), indices from order + begin,
 // count in counts[b]), and -- for the engine's size read-back -- a copy of the `mirror_words` status words at mirror_src
 // into mirror_dst (mapped host memory) with the two counts stored directly into their slots: no separate copy launch.
-__global__ __launch_bounds__(1024) void compact_index_pair_kernel(const unsigned char* keep, int n_ref, int n, int32_t* order,
+__device__ __forceinline__ void compact_index_pair_kernel_body(const dim3 blockIdx, const dim3 gridDim, const unsigned char* keep, int n_ref, int n, int32_t* order,
                                                                   int32_t* counts, const int32_t* mirror_src,
                                                                   int32_t* mirror_dst, int mirror_words) {
+  (void)blockIdx; (void)gridDim;
   __shared__ int wsum[17];
   __shared__ int base;
   const int begin = blockIdx.x ? n_ref : 0, end = blockIdx.x ? n : n_ref;
@@ -140,6 +150,10 @@ __global__ __launch_bounds__(1024) void compact_index_pair_kernel(const unsigned
       if (t != s0 && t != s0 + 1) mirror_dst[t] = mirror_src[t];
   }
 }
+__global__ __launch_bounds__(1024) void compact_index_pair_kernel(const unsigned char* keep, int n_ref, int n, int32_t* order,
+                                                                  int32_t* counts, const int32_t* mirror_src,
+                                                                  int32_t* mirror_dst, int mirror_words) { compact_index_pair_kernel_body(blockIdx, gridDim, keep, n_ref, n, order, counts, mirror_src, mirror_dst, mirror_words); }
+
 
 // ---------------------------------------------------------------------------------------------
 // point_to_node_partition (modules/ops/pointcloud_partition.py:60-107)
@@ -180,10 +194,14 @@ __device__ __forceinline__ void p2n_assign_body(const float* points, int n, cons
   atomicAdd(&node_count[arg], 1);
 }
 
-__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
+__device__ __forceinline__ void p2n_assign_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* points, int n, const float* nodes, int m,
                                                          int32_t* owner, float* d_own, int32_t* node_count) {
+  (void)blockIdx; (void)gridDim;
   p2n_assign_body(points, n, nodes, m, owner, d_own, node_count);
 }
+__global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
+                                                         int32_t* owner, float* d_own, int32_t* node_count) { p2n_assign_kernel_body(blockIdx, gridDim, points, n, nodes, m, owner, d_own, node_count); }
+
 
 // Both clouds of a pair in one launch (blockIdx.y = cloud): the two assignments are independent.
 struct P2nSeg {
@@ -203,11 +221,14 @@ struct P2nPair {
   int k;
   int32_t* status;
 };
-__global__ __launch_bounds__(256) void p2n_assign_pair_kernel(P2nPair p) {
+__device__ __forceinline__ void p2n_assign_pair_kernel_body(const dim3 blockIdx, const dim3 gridDim, P2nPair p) {
+  (void)blockIdx; (void)gridDim;
   const P2nSeg& s = p.seg[blockIdx.y];
   if (static_cast<int>(blockIdx.x) * 256 >= s.n) return;  // whole workgroup
   p2n_assign_body(s.points, s.n, s.nodes, s.m, s.owner, s.d_own, s.node_count);
 }
+__global__ __launch_bounds__(256) void p2n_assign_pair_kernel(P2nPair p) { p2n_assign_pair_kernel_body(blockIdx, gridDim, p); }
+
 
 // one wavefront per node: its points sorted by (d, index), first k kept (topk largest=False)
 template <int CAP>
@@ -268,26 +289,38 @@ __device__ __forceinline__ void p2n_select_body(unsigned long long* keys, int no
 }
 
 template <int CAP>
-__global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, const float* d_own, int n, int m,
+__device__ __forceinline__ void p2n_select_kernel_body(const dim3 blockIdx, const dim3 gridDim, const int32_t* owner, const float* d_own, int n, int m,
                                                         int k, const int32_t* node_count, int64_t* knn_idx,
                                                         unsigned char* knn_mask, unsigned char* node_mask,
                                                         int32_t* status) {
+  (void)blockIdx; (void)gridDim;
   __shared__ unsigned long long keys[CAP];
   p2n_select_body<CAP>(keys, blockIdx.x, owner, d_own, n, m, k, node_count, knn_idx, knn_mask, node_mask, status);
 }
 template <int CAP>
-__global__ __launch_bounds__(64) void p2n_select_pair_kernel(P2nPair p) {
+__global__ __launch_bounds__(64) void p2n_select_kernel(const int32_t* owner, const float* d_own, int n, int m,
+                                                        int k, const int32_t* node_count, int64_t* knn_idx,
+                                                        unsigned char* knn_mask, unsigned char* node_mask,
+                                                        int32_t* status) { p2n_select_kernel_body<CAP>(blockIdx, gridDim, owner, d_own, n, m, k, node_count, knn_idx, knn_mask, node_mask, status); }
+
+template <int CAP>
+__device__ __forceinline__ void p2n_select_pair_kernel_body(const dim3 blockIdx, const dim3 gridDim, P2nPair p) {
+  (void)blockIdx; (void)gridDim;
   __shared__ unsigned long long keys[CAP];
   const P2nSeg& s = p.seg[blockIdx.y];
   if (static_cast<int>(blockIdx.x) >= s.m) return;
   p2n_select_body<CAP>(keys, blockIdx.x, s.owner, s.d_own, s.n, s.m, p.k, s.node_count, s.knn_idx, s.knn_mask, s.node_mask, p.status);
 }
+template <int CAP>
+__global__ __launch_bounds__(64) void p2n_select_pair_kernel(P2nPair p) { p2n_select_pair_kernel_body<CAP>(blockIdx, gridDim, p); }
+
 
 // ---------------------------------------------------------------------------------------------
 // SuperPointMatching (modules/geotransformer/superpoint_matching.py:14-61)
 // scores = exp(-clamp(2 - 2*xy, 1e-12)) over non-empty nodes, rows/cols of empty nodes are 0
-__global__ void coarse_scores_kernel(float* s, int m, int n, int ld, const unsigned char* rmask,
+__device__ __forceinline__ void coarse_scores_kernel_body(const dim3 blockIdx, const dim3 gridDim, float* s, int m, int n, int ld, const unsigned char* rmask,
                                      const unsigned char* cmask) {
+  (void)blockIdx; (void)gridDim;
   const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (t >= static_cast<int64_t>(m) * n) return;
   const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
@@ -299,8 +332,12 @@ __global__ void coarse_scores_kernel(float* s, int m, int n, int ld, const unsig
   }
   s[static_cast<int64_t>(i) * ld + j] = v;
 }
+__global__ void coarse_scores_kernel(float* s, int m, int n, int ld, const unsigned char* rmask,
+                                     const unsigned char* cmask) { coarse_scores_kernel_body(blockIdx, gridDim, s, m, n, ld, rmask, cmask); }
+
 // rsum[i] = sum_j s[i,j] (one wavefront per row); csum[j] = sum_i s[i,j] (one thread per column)
-__global__ void coarse_rowsum_kernel(const float* s, int m, int n, int ld, float* rsum) {
+__device__ __forceinline__ void coarse_rowsum_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* s, int m, int n, int ld, float* rsum) {
+  (void)blockIdx; (void)gridDim;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= m) return;
   float acc = 0.f;
@@ -308,7 +345,10 @@ __global__ void coarse_rowsum_kernel(const float* s, int m, int n, int ld, float
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) rsum[i] = acc;
 }
-__global__ void coarse_colsum_kernel(const float* s, int m, int n, int ld, float* csum) {
+__global__ void coarse_rowsum_kernel(const float* s, int m, int n, int ld, float* rsum) { coarse_rowsum_kernel_body(blockIdx, gridDim, s, m, n, ld, rsum); }
+
+__device__ __forceinline__ void coarse_colsum_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* s, int m, int n, int ld, float* csum) {
+  (void)blockIdx; (void)gridDim;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   float acc = 0.f;  // rows are added in ascending order (as the reference's sum over dim 0), 8 loads in flight
@@ -323,8 +363,11 @@ __global__ void coarse_colsum_kernel(const float* s, int m, int n, int ld, float
   for (; i < m; ++i) acc += s[static_cast<int64_t>(i) * ld + j];
   csum[j] = acc;
 }
-__global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* rsum, const float* csum,
+__global__ void coarse_colsum_kernel(const float* s, int m, int n, int ld, float* csum) { coarse_colsum_kernel_body(blockIdx, gridDim, s, m, n, ld, csum); }
+
+__device__ __forceinline__ void coarse_dual_kernel_body(const dim3 blockIdx, const dim3 gridDim, float* s, int m, int n, int ld, const float* rsum, const float* csum,
                                    const unsigned char* rmask, const unsigned char* cmask) {
+  (void)blockIdx; (void)gridDim;
   const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (t >= static_cast<int64_t>(m) * n) return;
   const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
@@ -335,6 +378,9 @@ __global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* 
   }
   s[static_cast<int64_t>(i) * ld + j] = v;
 }
+__global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* rsum, const float* csum,
+                                   const unsigned char* rmask, const unsigned char* cmask) { coarse_dual_kernel_body(blockIdx, gridDim, s, m, n, ld, rsum, csum, rmask, cmask); }
+
 
 // ---- the same stage from the FEATURES, evaluated in fp64 (rdm_coarse_matching_features).
 // Why fp64: the reference's top-k order is decided by relative score gaps down to 4e-7 (tests/golden/
@@ -342,9 +388,10 @@ __global__ void coarse_dual_kernel(float* s, int m, int n, int ld, const float* 
 // score by that much, the exact value does not (the reference's own fp32 evaluation agrees with fp64 at every position
 // on both golden cases).  The stage is tiny (m*n*d = 26 MFLOP), so exactness costs nothing measurable.
 // One workgroup per 16 x 16 tile of pairs; feature rows staged in LDS (row stride d+1: conflict-free column walks).
-__global__ __launch_bounds__(256) void coarse_scores64_kernel(const float* fr, int ldr, int m, const float* fs, int lds_, int n,
+__device__ __forceinline__ void coarse_scores64_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* fr, int ldr, int m, const float* fs, int lds_, int n,
                                                               int d, const unsigned char* rmask, const unsigned char* cmask,
                                                               double* s, int ld) {
+  (void)blockIdx; (void)gridDim;
   extern __shared__ float tile[];
   float* a = tile;                    // [16][d+1]
   float* b = tile + 16 * (d + 1);     // [16][d+1]
@@ -374,7 +421,12 @@ __global__ __launch_bounds__(256) void coarse_scores64_kernel(const float* fr, i
   }
   s[static_cast<int64_t>(i) * ld + j] = v;
 }
-__global__ void coarse_rowsum64_kernel(const double* s, int m, int n, int ld, double* rsum) {
+__global__ __launch_bounds__(256) void coarse_scores64_kernel(const float* fr, int ldr, int m, const float* fs, int lds_, int n,
+                                                              int d, const unsigned char* rmask, const unsigned char* cmask,
+                                                              double* s, int ld) { coarse_scores64_kernel_body(blockIdx, gridDim, fr, ldr, m, fs, lds_, n, d, rmask, cmask, s, ld); }
+
+__device__ __forceinline__ void coarse_rowsum64_kernel_body(const dim3 blockIdx, const dim3 gridDim, const double* s, int m, int n, int ld, double* rsum) {
+  (void)blockIdx; (void)gridDim;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= m) return;
   double acc = 0.0;
@@ -382,7 +434,10 @@ __global__ void coarse_rowsum64_kernel(const double* s, int m, int n, int ld, do
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) rsum[i] = acc;
 }
-__global__ void coarse_colsum64_kernel(const double* s, int m, int n, int ld, double* csum) {
+__global__ void coarse_rowsum64_kernel(const double* s, int m, int n, int ld, double* rsum) { coarse_rowsum64_kernel_body(blockIdx, gridDim, s, m, n, ld, rsum); }
+
+__device__ __forceinline__ void coarse_colsum64_kernel_body(const dim3 blockIdx, const dim3 gridDim, const double* s, int m, int n, int ld, double* csum) {
+  (void)blockIdx; (void)gridDim;
   // one wavefront per 64 columns x a slice of rows would need a second pass; the matrix is small: 4 row slices per column
   // block reduced through LDS in a fixed order
   __shared__ double part[4][64];
@@ -394,8 +449,11 @@ __global__ void coarse_colsum64_kernel(const double* s, int m, int n, int ld, do
   __syncthreads();
   if (slice == 0 && j < n) csum[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-__global__ void coarse_dual64_kernel(const double* s, int m, int n, int ld, const double* rsum, const double* csum,
+__global__ void coarse_colsum64_kernel(const double* s, int m, int n, int ld, double* csum) { coarse_colsum64_kernel_body(blockIdx, gridDim, s, m, n, ld, csum); }
+
+__device__ __forceinline__ void coarse_dual64_kernel_body(const dim3 blockIdx, const dim3 gridDim, const double* s, int m, int n, int ld, const double* rsum, const double* csum,
                                      const unsigned char* rmask, const unsigned char* cmask, float* out, int ldo) {
+  (void)blockIdx; (void)gridDim;
   const int64_t t = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (t >= static_cast<int64_t>(m) * n) return;
   const int i = static_cast<int>(t / n), j = static_cast<int>(t % n);
@@ -406,13 +464,17 @@ __global__ void coarse_dual64_kernel(const double* s, int m, int n, int ld, cons
   }
   out[static_cast<int64_t>(i) * ldo + j] = v;
 }
+__global__ void coarse_dual64_kernel(const double* s, int m, int n, int ld, const double* rsum, const double* csum,
+                                     const unsigned char* rmask, const unsigned char* cmask, float* out, int ldo) { coarse_dual64_kernel_body(blockIdx, gridDim, s, m, n, ld, rsum, csum, rmask, cmask, out, ldo); }
+
 
 // Global top-k (k <= 1024) of an m x n matrix, descending, ties by ascending flat index.
 // One workgroup: three radix-select passes on the float bit pattern, then a bitonic sort.
 // `gate` (optional, a TopkState): run only if its fallback flag is set, i.e. as the fallback of the multi-workgroup path below.
-__global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n, int ld, int k,
+__device__ __forceinline__ void topk_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* s, int m, int n, int ld, int k,
                                                     int64_t* out_row, int64_t* out_col, float* out_val,
                                                     int32_t* out_count, const unsigned* gate) {
+  (void)blockIdx; (void)gridDim;
   if (gate && gate[5] == 0) return;  // TopkState::fallback
   __shared__ unsigned hist[4096];
   __shared__ unsigned long long cand[2048];
@@ -598,6 +660,10 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n
   }
   if (threadIdx.x == 0) *out_count = kk;
 }
+__global__ __launch_bounds__(1024) void topk_kernel(const float* s, int m, int n, int ld, int k,
+                                                    int64_t* out_row, int64_t* out_col, float* out_val,
+                                                    int32_t* out_count, const unsigned* gate) { topk_kernel_body(blockIdx, gridDim, s, m, n, ld, k, out_row, out_col, out_val, out_count, gate); }
+
 
 }  // namespace
 
@@ -607,7 +673,7 @@ extern "C" int rdm_nms(const int64_t* idx, int64_t n, int64_t h, int64_t ldi, co
   RDM_REQUIRE(idx && keep && n >= 0 && h > 0, "rdm_nms: bad arguments");
   RDM_REQUIRE(n <= 150000, "rdm_nms: at most 150000 nodes (LDS-resident state)");
   if (n == 0) return RDM_OK;
-  hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), static_cast<size_t>(n), static_cast<hipStream_t>(stream),
+  ::rdm::launch<nms_kernel_body, nms_kernel, 1024>(dim3(1), static_cast<size_t>(n), static_cast<hipStream_t>(stream),
                      idx, static_cast<int>(n), static_cast<int>(h), static_cast<int>(ldi), width, keep);
   return launch_status("nms_kernel");
 }
@@ -616,7 +682,7 @@ extern "C" int rdm_compact_indices(const uint8_t* keep, int64_t begin, int64_t e
                                    int32_t* count, void* stream) {
   using namespace rdm;
   RDM_REQUIRE(keep && order && count && begin >= 0 && end >= begin, "rdm_compact_indices: bad arguments");
-  hipLaunchKernelGGL(compact_index_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), keep,
+  ::rdm::launch<compact_index_kernel_body, compact_index_kernel, 1024>(dim3(1), 0, static_cast<hipStream_t>(stream), keep,
                      static_cast<int>(begin), static_cast<int>(end), order, count);
   return launch_status("compact_index_kernel");
 }
@@ -626,7 +692,7 @@ int rdm::compact_indices_pair(const uint8_t* keep, int64_t n_ref, int64_t n, int
   RDM_REQUIRE(keep && order && counts && n_ref >= 0 && n >= n_ref, "compact_indices_pair: bad arguments");
   RDM_REQUIRE(!mirror_dst || (mirror_src && counts >= mirror_src && counts + 2 <= mirror_src + mirror_words),
               "compact_indices_pair: the counts must lie inside the mirrored words");
-  hipLaunchKernelGGL(compact_index_pair_kernel, dim3(2), dim3(1024), 0, static_cast<hipStream_t>(stream), keep,
+  ::rdm::launch<compact_index_pair_kernel_body, compact_index_pair_kernel, 1024>(dim3(2), 0, static_cast<hipStream_t>(stream), keep,
                      static_cast<int>(n_ref), static_cast<int>(n), order, counts, mirror_src, mirror_dst, mirror_words);
   return launch_status("compact_index_pair_kernel");
 }
@@ -656,10 +722,9 @@ extern "C" int rdm_point_to_node(const float* points, int64_t n_points, const fl
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   fill_words<int32_t>(node_count, n_nodes, 0, st);
-  hipLaunchKernelGGL(p2n_assign_kernel, dim3(ceil_div<int64_t>(n_points, 256)), dim3(256),
-                     static_cast<size_t>(n_nodes) * 16, st, points, static_cast<int>(n_points), nodes,
+  ::rdm::launch<p2n_assign_kernel_body, p2n_assign_kernel, 256>(dim3(ceil_div<int64_t>(n_points, 256)), static_cast<size_t>(n_nodes) * 16, st, points, static_cast<int>(n_points), nodes,
                      static_cast<int>(n_nodes), owner, d_own, node_count);
-  hipLaunchKernelGGL(p2n_select_kernel<4096>, dim3(static_cast<unsigned>(n_nodes)), dim3(64), 0, st, owner, d_own,
+  ::rdm::launch<p2n_select_kernel_body<4096>, p2n_select_kernel<4096>, 64>(dim3(static_cast<unsigned>(n_nodes)), 0, st, owner, d_own,
                      static_cast<int>(n_points), static_cast<int>(n_nodes), k, node_count, knn_idx, knn_mask,
                      node_mask, status);
   return launch_status("point_to_node kernels");
@@ -692,8 +757,8 @@ extern "C" int rdm_point_to_node_pair(const float* points_a, int64_t n_a, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t n_max = n_a > n_b ? n_a : n_b, m_max = m_a > m_b ? m_a : m_b;
   fill_words<int32_t>(counts, m_a + m_b, 0, st);
-  hipLaunchKernelGGL(p2n_assign_pair_kernel, dim3(ceil_div<int64_t>(n_max, 256), 2), dim3(256), static_cast<size_t>(m_max) * 16, st, p);
-  hipLaunchKernelGGL(p2n_select_pair_kernel<4096>, dim3(static_cast<unsigned>(m_max), 2), dim3(64), 0, st, p);
+  ::rdm::launch<p2n_assign_pair_kernel_body, p2n_assign_pair_kernel, 256>(dim3(ceil_div<int64_t>(n_max, 256), 2), static_cast<size_t>(m_max) * 16, st, p);
+  ::rdm::launch<p2n_select_pair_kernel_body<4096>, p2n_select_pair_kernel<4096>, 64>(dim3(static_cast<unsigned>(m_max), 2), 0, st, p);
   return launch_status("point_to_node kernels");
 }
 
@@ -721,8 +786,9 @@ struct TopkState {  // device scratch
 
 // LEVEL 0: histogram of bits [31:20] of all eligible scores; LEVEL 1: bits [19:8] of the scores inside bin0
 template <int LEVEL>
-__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ s, int m, int n, int ld,
+__device__ __forceinline__ void topk_hist_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* __restrict__ s, int m, int n, int ld,
                                                          const TopkState* __restrict__ st, unsigned* __restrict__ ghist) {
+  (void)blockIdx; (void)gridDim;
   __shared__ unsigned hist[kTopkBins];
   for (int i = threadIdx.x; i < kTopkBins; i += 256) hist[i] = 0;
   __syncthreads();
@@ -740,10 +806,15 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < kTopkBins; i += 256)
     if (hist[i]) atomicAdd(&ghist[i], hist[i]);
 }
+template <int LEVEL>
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ s, int m, int n, int ld,
+                                                         const TopkState* __restrict__ st, unsigned* __restrict__ ghist) { topk_hist_kernel_body<LEVEL>(blockIdx, gridDim, s, m, n, ld, st, ghist); }
+
 
 // the bin that holds the need-th largest entry of the histogram, and how many entries of that bin are needed
 template <int LEVEL>
-__global__ __launch_bounds__(64) void topk_pick_kernel(const unsigned* __restrict__ ghist, int k, TopkState* st) {
+__device__ __forceinline__ void topk_pick_kernel_body(const dim3 blockIdx, const dim3 gridDim, const unsigned* __restrict__ ghist, int k, TopkState* st) {
+  (void)blockIdx; (void)gridDim;
   const int lane = threadIdx.x, per = kTopkBins / 64;
   const int hi = kTopkBins - 1 - lane * per;  // this lane owns bins hi, hi-1, ..., hi-per+1
   unsigned mine = 0;
@@ -781,10 +852,14 @@ __global__ __launch_bounds__(64) void topk_pick_kernel(const unsigned* __restric
     }
   }
 }
+template <int LEVEL>
+__global__ __launch_bounds__(64) void topk_pick_kernel(const unsigned* __restrict__ ghist, int k, TopkState* st) { topk_pick_kernel_body<LEVEL>(blockIdx, gridDim, ghist, k, st); }
+
 
 // every score above the 24-bit threshold prefix (bin0, bin1) or sharing it is a candidate
-__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int m, int n, int ld, TopkState* st,
+__device__ __forceinline__ void topk_collect_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* __restrict__ s, int m, int n, int ld, TopkState* st,
                                                             unsigned long long* __restrict__ cand) {
+  (void)blockIdx; (void)gridDim;
   const unsigned thr = (st->bin0 << 12) | (st->bin1 & 0xfffu);
   const bool none = st->bin0 >= kTopkBins;
   const int r0 = blockIdx.x * kTopkRows, r1 = min(m, r0 + kTopkRows);
@@ -799,10 +874,14 @@ __global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restri
       }
     }
 }
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float* __restrict__ s, int m, int n, int ld, TopkState* st,
+                                                            unsigned long long* __restrict__ cand) { topk_collect_kernel_body(blockIdx, gridDim, s, m, n, ld, st, cand); }
 
-__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ cand, TopkState* st, int n,
+
+__device__ __forceinline__ void topk_final_kernel_body(const dim3 blockIdx, const dim3 gridDim, const unsigned long long* __restrict__ cand, TopkState* st, int n,
                                                            int k, int64_t* out_row, int64_t* out_col, float* out_val,
                                                            int32_t* out_count) {
+  (void)blockIdx; (void)gridDim;
   __shared__ unsigned long long keys[kTopkCand];
   const unsigned nc = st->n_cand;
   if (nc > kTopkCand) {  // thousands of scores share their top 24 bits: the single-workgroup kernel runs instead
@@ -837,6 +916,10 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long lo
   }
   if (threadIdx.x == 0) *out_count = kk;
 }
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ cand, TopkState* st, int n,
+                                                           int k, int64_t* out_row, int64_t* out_col, float* out_val,
+                                                           int32_t* out_count) { topk_final_kernel_body(blockIdx, gridDim, cand, st, n, k, out_row, out_col, out_val, out_count); }
+
 
 }  // namespace
 
@@ -848,13 +931,13 @@ void launch_topk(const float* scores, int M, int N, int LD, int k, unsigned* ghi
   TopkState* ts = reinterpret_cast<TopkState*>(ghist + 2 * kTopkBins);
   const int tb = ceil_div(M, kTopkRows);
   fill_words<unsigned>(ghist, 2 * kTopkBins + 8, 0u, st);
-  hipLaunchKernelGGL(topk_hist_kernel<0>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist);
-  hipLaunchKernelGGL(topk_pick_kernel<0>, dim3(1), dim3(64), 0, st, ghist, k, ts);
-  hipLaunchKernelGGL(topk_hist_kernel<1>, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, ghist + kTopkBins);
-  hipLaunchKernelGGL(topk_pick_kernel<1>, dim3(1), dim3(64), 0, st, ghist + kTopkBins, k, ts);
-  hipLaunchKernelGGL(topk_collect_kernel, dim3(tb), dim3(256), 0, st, scores, M, N, LD, ts, cand);
-  hipLaunchKernelGGL(topk_final_kernel, dim3(1), dim3(1024), 0, st, cand, ts, N, k, ref_idx, src_idx, out_scores, out_count);
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(1024), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
+  ::rdm::launch<topk_hist_kernel_body<0>, topk_hist_kernel<0>, 256>(dim3(tb), 0, st, scores, M, N, LD, ts, ghist);
+  ::rdm::launch<topk_pick_kernel_body<0>, topk_pick_kernel<0>, 64>(dim3(1), 0, st, ghist, k, ts);
+  ::rdm::launch<topk_hist_kernel_body<1>, topk_hist_kernel<1>, 256>(dim3(tb), 0, st, scores, M, N, LD, ts, ghist + kTopkBins);
+  ::rdm::launch<topk_pick_kernel_body<1>, topk_pick_kernel<1>, 64>(dim3(1), 0, st, ghist + kTopkBins, k, ts);
+  ::rdm::launch<topk_collect_kernel_body, topk_collect_kernel, 256>(dim3(tb), 0, st, scores, M, N, LD, ts, cand);
+  ::rdm::launch<topk_final_kernel_body, topk_final_kernel, 1024>(dim3(1), 0, st, cand, ts, N, k, ref_idx, src_idx, out_scores, out_count);
+  ::rdm::launch<topk_kernel_body, topk_kernel, 1024>(dim3(1), 0, st, scores, M, N, LD, k, ref_idx, src_idx, out_scores,
                      out_count, reinterpret_cast<const unsigned*>(ts));  // only runs if the candidate list overflowed
 }
 }  // namespace
@@ -889,12 +972,12 @@ extern "C" int rdm_coarse_matching(float* scores, int64_t m, int64_t n, int64_t 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int M = static_cast<int>(m), N = static_cast<int>(n), LD = static_cast<int>(ld);
   const int eb = static_cast<int>(ceil_div<int64_t>(m * n, 256));
-  hipLaunchKernelGGL(coarse_scores_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD, ref_mask, src_mask);
+  ::rdm::launch<coarse_scores_kernel_body, coarse_scores_kernel, 256>(dim3(eb), 0, st, scores, M, N, LD, ref_mask, src_mask);
   if (dual_normalization) {
-    hipLaunchKernelGGL(coarse_rowsum_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, scores, M, N, LD, rsum);
-    hipLaunchKernelGGL(coarse_colsum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, scores, M, N, LD, csum);
+    ::rdm::launch<coarse_rowsum_kernel_body, coarse_rowsum_kernel, 256>(dim3(ceil_div(M, 4)), 0, st, scores, M, N, LD, rsum);
+    ::rdm::launch<coarse_colsum_kernel_body, coarse_colsum_kernel, 256>(dim3(ceil_div(N, 256)), 0, st, scores, M, N, LD, csum);
   }
-  hipLaunchKernelGGL(coarse_dual_kernel, dim3(eb), dim3(256), 0, st, scores, M, N, LD,
+  ::rdm::launch<coarse_dual_kernel_body, coarse_dual_kernel, 256>(dim3(eb), 0, st, scores, M, N, LD,
                      dual_normalization ? rsum : static_cast<const float*>(nullptr),
                      dual_normalization ? csum : static_cast<const float*>(nullptr), ref_mask, src_mask);
   launch_topk(scores, M, N, LD, k, ghist, cand, ref_idx, src_idx, out_scores, out_count, st);
@@ -938,13 +1021,13 @@ extern "C" int rdm_coarse_matching_features(const float* ref_feats, int64_t ld_r
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int M = static_cast<int>(m), N = static_cast<int>(n), LD = static_cast<int>(ld), D = static_cast<int>(d);
   const size_t lds = sizeof(float) * 2 * 16 * (D + 1);
-  hipLaunchKernelGGL(coarse_scores64_kernel, dim3(ceil_div(N, 16), ceil_div(M, 16)), dim3(256), lds, st, ref_feats,
+  ::rdm::launch<coarse_scores64_kernel_body, coarse_scores64_kernel, 256>(dim3(ceil_div(N, 16), ceil_div(M, 16)), lds, st, ref_feats,
                      static_cast<int>(ld_ref), M, src_feats, static_cast<int>(ld_src), N, D, ref_mask, src_mask, s64, LD);
   if (dual_normalization) {
-    hipLaunchKernelGGL(coarse_rowsum64_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, s64, M, N, LD, rsum);
-    hipLaunchKernelGGL(coarse_colsum64_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, st, s64, M, N, LD, csum);
+    ::rdm::launch<coarse_rowsum64_kernel_body, coarse_rowsum64_kernel, 256>(dim3(ceil_div(M, 4)), 0, st, s64, M, N, LD, rsum);
+    ::rdm::launch<coarse_colsum64_kernel_body, coarse_colsum64_kernel, 256>(dim3(ceil_div(N, 64)), 0, st, s64, M, N, LD, csum);
   }
-  hipLaunchKernelGGL(coarse_dual64_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m * n, 256))), dim3(256), 0, st, s64, M, N, LD,
+  ::rdm::launch<coarse_dual64_kernel_body, coarse_dual64_kernel, 256>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m * n, 256))), 0, st, s64, M, N, LD,
                      dual_normalization ? rsum : static_cast<const double*>(nullptr),
                      dual_normalization ? csum : static_cast<const double*>(nullptr), ref_mask, src_mask, s32, LD);
   launch_topk(s32, M, N, LD, k, ghist, cand, ref_idx, src_idx, out_scores, out_count, st);

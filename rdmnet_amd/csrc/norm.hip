@@ -11,6 +11,7 @@
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
 #include "internal.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -22,8 +23,9 @@ constexpr int kGnRowsPerBlock = 64;
 // grid = (row blocks, column chunks of 256).  256 threads cover cw = min(C,256) columns x (256/cw)
 // row lanes so that every wavefront reads whole contiguous row segments; the row lanes of a column
 // are combined through LDS in fixed order (fp64 throughout).
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, int c, int ld,
+__device__ __forceinline__ void gn_partial_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int n, int c, int ld,
                                                          double* partial) {
+  (void)blockIdx; (void)gridDim;
   __shared__ double red[2][256];
   const int r0 = blockIdx.x * kGnRowsPerBlock;
   const int r1 = min(n, r0 + kGnRowsPerBlock);
@@ -51,6 +53,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, 
     partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * c + col] = b;
   }
 }
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* x, int n, int c, int ld,
+                                                         double* partial) { gn_partial_kernel_body(blockIdx, gridDim, x, n, c, ld, partial); }
+
 
 // One block per 64 columns (whole groups: C/groups divides 64): 16 lanes per column add the row-block
 // partials in a fixed order, then scale[c] = rstd*gamma, shift[c] = beta - mean*rstd*gamma.
@@ -120,10 +125,11 @@ __device__ __forceinline__ float2 gn_scale_shift(GnFinalizeLds<COLS>& L, int col
   return out;
 }
 template <int COLS>
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+__device__ __forceinline__ void gn_finalize_kernel_body(const dim3 blockIdx, const dim3 gridDim, const double* partial, int nblk, int n,
                                                             int c, int groups, const float* gamma,
                                                             const float* beta, float eps, float* scale,
                                                             float* shift) {
+  (void)blockIdx; (void)gridDim;
   __shared__ GnFinalizeLds<COLS> L;
   const float2 v = gn_scale_shift<COLS>(L, blockIdx.x * COLS, partial, nblk, n, c, groups, gamma, beta, eps);
   const int col = blockIdx.x * COLS + threadIdx.x % COLS;
@@ -132,15 +138,22 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial
     shift[col] = v.y;
   }
 }
+template <int COLS>
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const double* partial, int nblk, int n,
+                                                            int c, int groups, const float* gamma,
+                                                            const float* beta, float eps, float* scale,
+                                                            float* shift) { gn_finalize_kernel_body<COLS>(blockIdx, gridDim, partial, nblk, n, c, groups, gamma, beta, eps, scale, shift); }
+
 
 // Finalize + apply in ONE launch for the coarse levels (a few thousand rows at most): workgroup (slab, chunk) computes the scale /
 // shift of its 64 columns exactly as gn_finalize_kernel<64> does (a few dozen partial rows: cheap enough to repeat per row chunk)
 // and applies them to 256 rows of that slab with gn_apply_wide_kernel's arithmetic -- same bits as the two launches, one
 // dependent launch (~4.5 us on a pair's critical path) less per GroupNorm.  No positive-row flag (a row spans several slabs).
 constexpr int kGnFusedRows = 256;
-__global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const double* partial, int nblk, const float* x, int n, int c, int ldx,
+__device__ __forceinline__ void gn_finalize_apply_kernel_body(const dim3 blockIdx, const dim3 gridDim, const double* partial, int nblk, const float* x, int n, int c, int ldx,
                                                                   int groups, const float* gamma, const float* beta, float eps,
                                                                   const float* res, int ldr, int act, float* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   __shared__ GnFinalizeLds<64> L;
   __shared__ float sc_l[64], sh_l[64];
   const int col0 = blockIdx.x * 64;
@@ -171,12 +184,17 @@ __global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const double* p
     *reinterpret_cast<float4*>(y + static_cast<int64_t>(row) * ldy + col) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
+__global__ __launch_bounds__(1024) void gn_finalize_apply_kernel(const double* partial, int nblk, const float* x, int n, int c, int ldx,
+                                                                  int groups, const float* gamma, const float* beta, float eps,
+                                                                  const float* res, int ldr, int act, float* y, int ldy) { gn_finalize_apply_kernel_body(blockIdx, gridDim, partial, nblk, x, n, c, ldx, groups, gamma, beta, eps, res, ldr, act, y, ldy); }
+
 
 // y = act(x*scale + shift (+ res)); optional positive-row flag.  One wavefront per row.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, int c, int ldx,
+__device__ __forceinline__ void gn_apply_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int n, int c, int ldx,
                                                        const float* scale, const float* shift,
                                                        const float* res, int ldr, int act, float* y,
                                                        int ldy, unsigned char* positive) {
+  (void)blockIdx; (void)gridDim;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
@@ -194,15 +212,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, in
     if (lane == 0) positive[row] = rs > 0.f ? 1 : 0;
   }
 }
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* x, int n, int c, int ldx,
+                                                       const float* scale, const float* shift,
+                                                       const float* res, int ldr, int act, float* y,
+                                                       int ldy, unsigned char* positive) { gn_apply_kernel_body(blockIdx, gridDim, x, n, c, ldx, scale, shift, res, ldr, act, y, ldy, positive); }
+
 
 // Same without the row flag, for wide matrices with few rows (coarse levels: 800 x 2048): one thread per
 // float4, grid over (rows, column quads) so that the launch has enough wavefronts to cover the latency.
 // `positive` (optional, needs c4 a power of two <= 64 so that a row lies inside one wavefront): the row-sum flag of
 // gn_apply_kernel with the SAME summation tree (column index bits from high to low: gn_apply_kernel's lane-strided partial
 // sums and xor-butterfly), so both kernels set the same flags bit for bit.
-__global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int n, int c4, int ldx, const float* scale,
+__device__ __forceinline__ void gn_apply_wide_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int n, int c4, int ldx, const float* scale,
                                                             const float* shift, const float* res, int ldr, int act,
                                                             float* y, int ldy, unsigned char* positive) {
+  (void)blockIdx; (void)gridDim;
   const int64_t t = blockIdx.x * 256ll + threadIdx.x;
   const bool live = t < static_cast<int64_t>(n) * c4;
   if (!live && !positive) return;
@@ -234,12 +258,17 @@ __global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int 
     if (live && col == 0) positive[row] = rs > 0.f ? 1 : 0;
   }
 }
+__global__ __launch_bounds__(256) void gn_apply_wide_kernel(const float* x, int n, int c4, int ldx, const float* scale,
+                                                            const float* shift, const float* res, int ldr, int act,
+                                                            float* y, int ldy, unsigned char* positive) { gn_apply_wide_kernel_body(blockIdx, gridDim, x, n, c4, ldx, scale, shift, res, ldr, act, y, ldy, positive); }
+
 
 // y = act(LayerNorm(x (+ res)) * gamma + beta); one wavefront per row, c <= 2048
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, int c, int ldx,
+__device__ __forceinline__ void layernorm_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int n, int c, int ldx,
                                                         const float* res, int ldr,
                                                         const float* gamma, const float* beta,
                                                         float eps, int act, float* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
@@ -276,6 +305,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, i
     }
   }
 }
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, int c, int ldx,
+                                                        const float* res, int ldr,
+                                                        const float* gamma, const float* beta,
+                                                        float eps, int act, float* y, int ldy) { layernorm_kernel_body(blockIdx, gridDim, x, n, c, ldx, res, ldr, gamma, beta, eps, act, y, ldy); }
+
 
 // out[m, c] = max_h x[idx[m,h], c], pad rows count as zeros.  One wavefront per (row, 256 channels).
 // `order` (optional): cell-sorted query records of the level's search grid (query row = int bits of .w).  Queries are
@@ -291,9 +325,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int n, i
 // the kernel's time): the four wavefronts of a workgroup share ONE (query, 256-channel chunk), each takes every fourth
 // group of slots, and the four partial maxima meet in LDS (max is exact: the result does not depend on the split).
 template <int LPR, bool SPLIT = false>
-__global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
+__device__ __forceinline__ void gather_max_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* x, int ns, int c, int ldx,
                                                          const int64_t* idx, int m_total, int h, int ldi,
                                                          const int32_t* width, float* y, int ldy, const float4* order, int i32) {
+  (void)blockIdx; (void)gridDim;
   constexpr int QPW = 64 / LPR, U = SPLIT ? 8 : 16;
   static_assert(!SPLIT || LPR == 64, "the slot split is for one query per wavefront");
   __shared__ float4 part[SPLIT ? 3 * 64 : 1];
@@ -356,11 +391,17 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns,
   }
   if (active && c0 < c) *reinterpret_cast<float4*>(y + static_cast<int64_t>(m) * ldy + c0) = best;
 }
+template <int LPR, bool SPLIT = false>
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* x, int ns, int c, int ldx,
+                                                         const int64_t* idx, int m_total, int h, int ldi,
+                                                         const int32_t* width, float* y, int ldy, const float4* order, int i32) { gather_max_kernel_body<LPR, SPLIT>(blockIdx, gridDim, x, ns, c, ldx, idx, m_total, h, ldi, width, y, ldy, order, i32); }
+
 
 // y[m, 0:c1] = coarse[idx[m,0]] (pad -> 0), y[m, c1:c1+c2] = skip[m], y[m, c1+c2:ldy] = 0
-__global__ void upsample_concat_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+__device__ __forceinline__ void upsample_concat_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* coarse, int n_coarse, int c1, int ld1,
                                        const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
                                        int m_total, float* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   const int m = blockIdx.x;
   const int64_t id = idx[static_cast<int64_t>(m) * ldi];
   const bool ok = id >= 0 && id < n_coarse;
@@ -371,16 +412,24 @@ __global__ void upsample_concat_kernel(const float* coarse, int n_coarse, int c1
     y[static_cast<int64_t>(m) * ldy + col] = v;
   }
 }
+__global__ void upsample_concat_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+                                       const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
+                                       int m_total, float* y, int ldy) { upsample_concat_kernel_body(blockIdx, gridDim, coarse, n_coarse, c1, ld1, idx, ldi, skip, c2, ld2, m_total, y, ldy); }
+
 
 // y[i, :] = x[idx[i], :] as raw 32-bit words; rows with idx outside [0, n_src) become zeros
-__global__ void gather_rows_kernel(const uint32_t* x, int n_src, int c, int ldx, const int64_t* idx, int m,
+__device__ __forceinline__ void gather_rows_kernel_body(const dim3 blockIdx, const dim3 gridDim, const uint32_t* x, int n_src, int c, int ldx, const int64_t* idx, int m,
                                    uint32_t* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   const int row = blockIdx.x;
   const int64_t id = idx[row];
   const bool ok = id >= 0 && id < n_src;
   for (int col = threadIdx.x; col < c; col += blockDim.x)
     y[static_cast<int64_t>(row) * ldy + col] = ok ? x[id * ldx + col] : 0u;
 }
+__global__ void gather_rows_kernel(const uint32_t* x, int n_src, int c, int ldx, const int64_t* idx, int m,
+                                   uint32_t* y, int ldy) { gather_rows_kernel_body(blockIdx, gridDim, x, n_src, c, ldx, idx, m, y, ldy); }
+
 
 // Up to four independent row gathers in one launch: a 1-D grid, workgroup -> (gather, row) through first_row.
 struct GatherItem {
@@ -395,7 +444,8 @@ struct GatherBatch {
   int first_row[5];
   int n;
 };
-__global__ void gather_rows_multi_kernel(GatherBatch b) {
+__device__ __forceinline__ void gather_rows_multi_kernel_body(const dim3 blockIdx, const dim3 gridDim, GatherBatch b) {
+  (void)blockIdx; (void)gridDim;
   int it = 0;
 #pragma unroll
   for (int k = 1; k < 4; ++k) it += (k < b.n && static_cast<int>(blockIdx.x) >= b.first_row[k]) ? 1 : 0;
@@ -406,6 +456,8 @@ __global__ void gather_rows_multi_kernel(GatherBatch b) {
   for (int col = threadIdx.x; col < g.c; col += blockDim.x)
     g.y[static_cast<int64_t>(row) * g.ldy + col] = ok ? g.x[id * g.ldx + col] : 0u;
 }
+__global__ void gather_rows_multi_kernel(GatherBatch b) { gather_rows_multi_kernel_body(blockIdx, gridDim, b); }
+
 
 }  // namespace
 
@@ -425,8 +477,11 @@ int rdm::gather_rows_multi(int n, const void* const* x, const int64_t* n_src, co
   }
   if (b.first_row[n] == 0) return RDM_OK;
   const int threads = max_words >= 256 ? 256 : (max_words >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(static_cast<unsigned>(b.first_row[n])), dim3(threads), 0,
-                     static_cast<hipStream_t>(stream), b);
+  const dim3 grid(static_cast<unsigned>(b.first_row[n]));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (threads == 256) ::rdm::launch<gather_rows_multi_kernel_body, gather_rows_multi_kernel, 256>(grid, 0, st, b);
+  else if (threads == 128) ::rdm::launch<gather_rows_multi_kernel_body, gather_rows_multi_kernel, 128>(grid, 0, st, b);
+  else ::rdm::launch<gather_rows_multi_kernel_body, gather_rows_multi_kernel, 64>(grid, 0, st, b);
   return launch_status("gather_rows_multi_kernel");
 }
 
@@ -436,8 +491,13 @@ extern "C" int rdm_gather_rows(const void* x, int64_t n_src, int64_t words, int6
   RDM_REQUIRE(x && idx && y && words > 0, "rdm_gather_rows: bad arguments");
   if (m == 0) return RDM_OK;
   const int threads = words >= 256 ? 256 : (words >= 128 ? 128 : 64);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>(m)), dim3(threads), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<int>(n_src),
+  if (threads == 256) ::rdm::launch<gather_rows_kernel_body, gather_rows_kernel, 256>(dim3(static_cast<unsigned>(m)), 0, static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<int>(n_src),
+                     static_cast<int>(words), static_cast<int>(ldx), idx, static_cast<int>(m),
+                     static_cast<uint32_t*>(y), static_cast<int>(ldy));
+  else if (threads == 128) ::rdm::launch<gather_rows_kernel_body, gather_rows_kernel, 128>(dim3(static_cast<unsigned>(m)), 0, static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<int>(n_src),
+                     static_cast<int>(words), static_cast<int>(ldx), idx, static_cast<int>(m),
+                     static_cast<uint32_t*>(y), static_cast<int>(ldy));
+  else ::rdm::launch<gather_rows_kernel_body, gather_rows_kernel, 64>(dim3(static_cast<unsigned>(m)), 0, static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(x), static_cast<int>(n_src),
                      static_cast<int>(words), static_cast<int>(ldx), idx, static_cast<int>(m),
                      static_cast<uint32_t*>(y), static_cast<int>(ldy));
   return launch_status("gather_rows_kernel");
@@ -463,7 +523,7 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double* use = partial_in;
   if (nblk <= 0) {
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(own_blk, ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x,
+    ::rdm::launch<gn_partial_kernel_body, gn_partial_kernel, 256>(dim3(own_blk, ceil_div<int64_t>(c, 256)), 0, st, x,
                        static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), partial);
     use = partial;
     nblk = own_blk;
@@ -476,18 +536,17 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   // coarse levels: finalize + apply as one launch (see gn_finalize_apply_kernel); form 1 = always the separate launches
   if (form != 1 && !narrow && !positive && vec_ok && c % 64 == 0 && n <= 4096) {
     RDM_DUP_LOOP("gnfin")
-    hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(static_cast<unsigned>(c / 64), static_cast<unsigned>(ceil_div<int64_t>(n, kGnFusedRows))),
-                       dim3(1024), 0, st, use, nblk, x, static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), groups, gamma, beta,
+    ::rdm::launch<gn_finalize_apply_kernel_body, gn_finalize_apply_kernel, 1024>(dim3(static_cast<unsigned>(c / 64), static_cast<unsigned>(ceil_div<int64_t>(n, kGnFusedRows))), 0, st, use, nblk, x, static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), groups, gamma, beta,
                        eps, residual, static_cast<int>(ldr), act, y, static_cast<int>(ldy));
     return launch_status("gn_finalize_apply_kernel");
   }
   {
     RDM_DUP_LOOP("gnfin")
     if (narrow)
-      hipLaunchKernelGGL(gn_finalize_kernel<16>, dim3(ceil_div<int64_t>(c, 16)), dim3(1024), 0, st, use, nblk,
+      ::rdm::launch<gn_finalize_kernel_body<16>, gn_finalize_kernel<16>, 1024>(dim3(ceil_div<int64_t>(c, 16)), 0, st, use, nblk,
                          static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
     else
-    hipLaunchKernelGGL(gn_finalize_kernel<64>, dim3(ceil_div<int64_t>(c, 64)), dim3(1024), 0, st, use, nblk,
+    ::rdm::launch<gn_finalize_kernel_body<64>, gn_finalize_kernel<64>, 1024>(dim3(ceil_div<int64_t>(c, 64)), 0, st, use, nblk,
                        static_cast<int>(n), static_cast<int>(c), groups, gamma, beta, eps, ss, ss + c);
   }
   // 16-byte accesses whenever the layout allows; with the positive-row flag only where a row lies inside one wavefront AND
@@ -498,11 +557,11 @@ int rdm::group_norm_finish(const double* partial_in, int nblk, const float* x, i
   const bool wide = vec_ok && (narrow_rows ? (!positive && c >= 256) : (!positive || flag_ok));
   RDM_DUP_LOOP("gnapply")
   if (wide)
-    hipLaunchKernelGGL(gn_apply_wide_kernel, dim3(ceil_div<int64_t>(n * (c / 4), 256)), dim3(256), 0, st, x, static_cast<int>(n),
+    ::rdm::launch<gn_apply_wide_kernel_body, gn_apply_wide_kernel, 256>(dim3(ceil_div<int64_t>(n * (c / 4), 256)), 0, st, x, static_cast<int>(n),
                        static_cast<int>(c / 4), static_cast<int>(ldx), ss, ss + c, residual, static_cast<int>(ldr), act, y,
                        static_cast<int>(ldy), positive);
   else
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0, st, x,
+    ::rdm::launch<gn_apply_kernel_body, gn_apply_kernel, 256>(dim3(ceil_div<int64_t>(n, 4)), 0, st, x,
                        static_cast<int>(n), static_cast<int>(c), static_cast<int>(ldx), ss, ss + c, residual,
                        static_cast<int>(ldr), act, y, static_cast<int>(ldy), positive);
   return launch_status("group_norm kernels");
@@ -542,8 +601,7 @@ extern "C" int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx,
   RDM_REQUIRE(n >= 0 && c > 0 && c <= 2048, "rdm_layer_norm: bad sizes");
   if (n == 0) return RDM_OK;
   RDM_DUP_LOOP("ln")
-  hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div<int64_t>(n, 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
+  ::rdm::launch<layernorm_kernel_body, layernorm_kernel, 256>(dim3(ceil_div<int64_t>(n, 4)), 0, static_cast<hipStream_t>(stream), x, static_cast<int>(n), static_cast<int>(c),
                      static_cast<int>(ldx), residual, static_cast<int>(ldr), gamma, beta, eps, act, y,
                      static_cast<int>(ldy));
   return launch_status("layernorm_kernel");
@@ -562,14 +620,14 @@ int rdm::gather_max_ordered(const float* x, int64_t n_s, int64_t c, int64_t ldx,
             li = static_cast<int>(ldi), ly = static_cast<int>(ldy);
   RDM_DUP_LOOP("pool") {
     if (c <= 64)  // four queries per wavefront
-      hipLaunchKernelGGL(gather_max_kernel<16>, dim3(ceil_div<int64_t>(m, 16), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
+      ::rdm::launch<gather_max_kernel_body<16>, gather_max_kernel<16>, 256>(dim3(ceil_div<int64_t>(m, 16), 1), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
     else if (c <= 128)
-      hipLaunchKernelGGL(gather_max_kernel<32>, dim3(ceil_div<int64_t>(m, 8), 1), dim3(256), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
+      ::rdm::launch<gather_max_kernel_body<32>, gather_max_kernel<32>, 256>(dim3(ceil_div<int64_t>(m, 8), 1), 0, st, x, ns, ci, lx, idx, mi, hi, li, width, y, ly, ord, i32);
     else if (m * ceil_div<int64_t>(c, 256) <= 4096)  // coarse levels: a workgroup per (query, chunk), slots split over its wavefronts
-      hipLaunchKernelGGL((gather_max_kernel<64, true>), dim3(static_cast<unsigned>(m), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx,
+      ::rdm::launch<gather_max_kernel_body<64, true>, gather_max_kernel<64, true>, 256>(dim3(static_cast<unsigned>(m), ceil_div<int64_t>(c, 256)), 0, st, x, ns, ci, lx,
                          idx, mi, hi, li, width, y, ly, ord, i32);
     else
-      hipLaunchKernelGGL(gather_max_kernel<64>, dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)), dim3(256), 0, st, x, ns, ci, lx, idx, mi,
+      ::rdm::launch<gather_max_kernel_body<64>, gather_max_kernel<64>, 256>(dim3(ceil_div<int64_t>(m, 4), ceil_div<int64_t>(c, 256)), 0, st, x, ns, ci, lx, idx, mi,
                          hi, li, width, y, ly, ord, i32);
   }
   return launch_status("gather_max_kernel");
@@ -582,9 +640,10 @@ extern "C" int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ld
 }
 
 // The same with 16-byte accesses (c1, c2 and every row stride multiples of 4, 16-byte aligned bases): one wavefront per row.
-__global__ __launch_bounds__(256) void upsample_concat_vec_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+__device__ __forceinline__ void upsample_concat_vec_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* coarse, int n_coarse, int c1, int ld1,
                                                                   const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
                                                                   int m_total, float* y, int ldy) {
+  (void)blockIdx; (void)gridDim;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= m_total) return;
   const int lane = threadIdx.x & 63;
@@ -604,6 +663,10 @@ __global__ __launch_bounds__(256) void upsample_concat_vec_kernel(const float* c
     dst[q] = v;
   }
 }
+__global__ __launch_bounds__(256) void upsample_concat_vec_kernel(const float* coarse, int n_coarse, int c1, int ld1,
+                                                                  const int64_t* idx, int ldi, const float* skip, int c2, int ld2,
+                                                                  int m_total, float* y, int ldy) { upsample_concat_vec_kernel_body(blockIdx, gridDim, coarse, n_coarse, c1, ld1, idx, ldi, skip, c2, ld2, m_total, y, ldy); }
+
 
 extern "C" int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1,
                                    const int64_t* idx, int64_t ldi, const float* skip, int64_t c2,
@@ -616,13 +679,11 @@ extern "C" int rdm_upsample_concat(const float* coarse, int64_t n_coarse, int64_
                    ((reinterpret_cast<uintptr_t>(coarse) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   RDM_DUP_LOOP("ups")
   if (vec)
-    hipLaunchKernelGGL(upsample_concat_vec_kernel, dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 4))), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse), static_cast<int>(c1),
+    ::rdm::launch<upsample_concat_vec_kernel_body, upsample_concat_vec_kernel, 256>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 4))), 0, static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse), static_cast<int>(c1),
                        static_cast<int>(ld1), idx, static_cast<int>(ldi), skip, static_cast<int>(c2), static_cast<int>(ld2),
                        static_cast<int>(m), y, static_cast<int>(ldy));
   else
-  hipLaunchKernelGGL(upsample_concat_kernel, dim3(static_cast<unsigned>(m)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse),
+  ::rdm::launch<upsample_concat_kernel_body, upsample_concat_kernel, 256>(dim3(static_cast<unsigned>(m)), 0, static_cast<hipStream_t>(stream), coarse, static_cast<int>(n_coarse),
                      static_cast<int>(c1), static_cast<int>(ld1), idx, static_cast<int>(ldi), skip,
                      static_cast<int>(c2), static_cast<int>(ld2), static_cast<int>(m), y,
                      static_cast<int>(ldy));

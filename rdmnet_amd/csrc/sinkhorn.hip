@@ -17,6 +17,7 @@
 
 #include "../../include/rdmnet_hip.h"
 #include "common.h"
+#include "lockstep.h"
 
 namespace {
 
@@ -145,10 +146,11 @@ __device__ __forceinline__ void sinkhorn_iterate(const float* Z, int ldz, int nr
 // float2 pairs: the adds, the shift by the maximum and the scaling by log2(e) are packed-fp32 instructions
 // (v_pk_add_f32 / v_pk_mul_f32, two entries per issue slot) -- the loop is VALU-issue bound (per entry: add, max,
 // subtract, multiply, v_exp_f32 at quarter rate, add), not LDS or latency bound.
-__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int m, int n,
+__device__ __forceinline__ void sinkhorn_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* scores, int m, int n,
                                                        const unsigned char* row_mask,
                                                        const unsigned char* col_mask, const float* alpha_p,
                                                        int iters, float* out) {
+  (void)blockIdx; (void)gridDim;
   extern __shared__ float lds[];
   __shared__ int rows[kMaxSide + 2], cols[kMaxSide + 2];
   __shared__ __attribute__((aligned(8))) float u[2 * kHalf], v[2 * kHalf];
@@ -195,6 +197,11 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int 
   else if (side <= 100) sinkhorn_iterate<25>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
   else sinkhorn_iterate<33>(Z, ldz, nr, nc, norm, iters, u, v, rows, cols, m, n, O);
 }
+__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* scores, int m, int n,
+                                                       const unsigned char* row_mask,
+                                                       const unsigned char* col_mask, const float* alpha_p,
+                                                       int iters, float* out) { sinkhorn_kernel_body(blockIdx, gridDim, scores, m, n, row_mask, col_mask, alpha_p, iters, out); }
+
 
 }  // namespace
 
@@ -210,8 +217,7 @@ extern "C" int rdm_sinkhorn(const float* scores, int64_t batch, int64_t m, int64
   static std::atomic<uint64_t> attr_set{0};
   RDM_HIP_CHECK(set_max_dynamic_lds(reinterpret_cast<const void*>(sinkhorn_kernel), 160 * 1024 - 4096, attr_set));
   RDM_DUP_LOOP("sinkhorn")
-  hipLaunchKernelGGL(sinkhorn_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), lds,
-                     static_cast<hipStream_t>(stream), scores, static_cast<int>(m), static_cast<int>(n), row_mask,
+  ::rdm::launch<sinkhorn_kernel_body, sinkhorn_kernel, 256>(dim3(static_cast<unsigned>(batch)), lds, static_cast<hipStream_t>(stream), scores, static_cast<int>(m), static_cast<int>(n), row_mask,
                      col_mask, alpha, iters, out);
   return launch_status("sinkhorn_kernel");
 }

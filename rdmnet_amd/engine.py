@@ -190,6 +190,25 @@ class Engine:
         self._prepared = [(k, r, s) for k, (r, s) in enumerate(pairs)]
         return n
 
+    @staticmethod
+    def run_lockstep(engines, pairs, collate_batched=True):
+        """rdm_engine_run of len(pairs) pairs on as many engines (sharing one copy of the weights) on the CURRENT stream, in lock
+        step: launches of the same kernel of all pairs go out as one grouped launch (rdm_engine_run_lockstep, experimental).
+        Returns the engines' EngineResults; every engine then holds its pair's result as after `run`."""
+        n = len(pairs)
+        assert 1 <= n <= len(engines)
+        for r, s in pairs:
+            assert r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()
+        P, I = ctypes.c_void_p * n, ctypes.c_int64 * n
+        for e in engines[:n]:
+            e._prepared = []
+        hs = P(*[e._h.value if hasattr(e._h, 'value') else e._h for e in engines[:n]])
+        rp, sp = P(*[r.data_ptr() for r, _ in pairs]), P(*[s.data_ptr() for _, s in pairs])
+        rn, sn = I(*[r.shape[0] for r, _ in pairs]), I(*[s.shape[0] for _, s in pairs])
+        res = P(*[ctypes.addressof(e.result) for e in engines[:n]])
+        _lib.check(engines[0].L.rdm_engine_run_lockstep(hs, n, rp, rn, sp, sn, res, int(bool(collate_batched)), _lib.stream_ptr()), 'rdm_engine_run_lockstep')
+        return [e.result for e in engines[:n]]
+
     def forward_batched(self, k):
         """RDMNet.forward of pair k of the collated batch; returns the EngineResult (as `run`)."""
         _lib.check(self.L.rdm_engine_forward_batched(self._h, int(k), ctypes.byref(self.result), _lib.stream_ptr()),

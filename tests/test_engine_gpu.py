@@ -594,3 +594,37 @@ def test_batched_collate_gives_every_pair_the_bits_of_its_own_run(ctx, golden_di
     batched.keep_taps(True)
     with pytest.raises(RuntimeError):
         batched.collate_batch(pairs[:2])
+
+
+def test_lockstep_runs_give_every_pair_the_bits_of_its_own_run(ctx, golden_dir):
+    """Round 5 (experimental): rdm_engine_run_lockstep runs several pairs on as many engines on ONE stream -- stackful contexts of
+    the calling thread, launches of converted kernels recorded and issued as one grouped launch per kernel, one host wait per
+    read-back for the whole group.  Pairs of very different sizes (so that their grids, and the points at which they wait, differ):
+    pose, correspondences and counters of every pair equal rdm_engine_run on the pair alone, bit for bit; group sizes 1 .. 5."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    sc = np.load(os.path.join(golden_dir, 'scans.npz'))
+
+    def crop(p, r):
+        return p[np.linalg.norm(p[:, :2], axis=1) < r]
+    clouds = [(ctx['rp'], ctx['sp']), (z['ref0'], z['src0']), (crop(sc['s000000'], 14.0), crop(sc['s000004'], 12.0)),
+              (z['ref1'], z['src1']), (sc['s000000'], sc['s000007'])]
+    pairs = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in clouds]
+    engines = [engine.Engine(cfg, None, share_with=eng) for _ in range(5)]
+
+    def snapshot(e, res):
+        return (e.transform().copy(), [c.clone() for c in e.corr()], int(res.n_correspondences), int(res.n_ref_nodes), int(res.n_src_nodes),
+                int(res.n_node_correspondences), [int(x) for x in res.level_sizes])
+    want = [snapshot(engines[0], engines[0].run(r, s)) for r, s in pairs]
+
+    def same(a, b):
+        return np.array_equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and a[2:] == b[2:]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        # (collates of the group as one launch sequence on the first engine -- rdm_engine_collate_batch -- or pair by pair in lock step)
+        for collated, lo, hi in ((True, 0, 5), (False, 1, 3), (True, 3, 4), (False, 0, 4), (True, 2, 5)):
+            res = engine.Engine.run_lockstep(engines, pairs[lo:hi], collate_batched=collated)
+            for k in range(lo, hi):
+                assert same(snapshot(engines[k - lo], res[k - lo]), want[k]), (collated, lo, hi, k)
+        # an engine of a group runs alone again afterwards
+        assert same(snapshot(engines[2], engines[2].run(*pairs[4])), want[4])
