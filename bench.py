@@ -200,6 +200,11 @@ def main():
                     help='pairs a worker collates with ONE sequence of launches before it runs their forwards one by one\n'
                          '(rdm_engine_collate_batch; default: rdmnet_amd.pipeline.DEFAULT_COLLATE_BATCH; 1 = every pair collates itself,\n'
                          'the schedule of rounds 1-4).  Same results bit for bit.')
+    ap.add_argument('--lockstep', type=int, default=None,
+                    help='pairs a worker runs as ONE lock-step group on its stream (rdm_engine_run_lockstep: identical kernels of the\n'
+                         'pairs of a group go out as one grouped launch, their collates as one launch sequence; default:\n'
+                         'rdmnet_amd.pipeline.DEFAULT_LOCKSTEP; 1 = one pair per engine call, the schedule of rounds 1-4).  A step is then\n'
+                         'one group: --steps K times this many pairs.  Same results bit for bit.')
     ap.add_argument('--dry-run', action='store_true',
                     help='construct the communicator (RCCL for --dist-backend nccl), run the pre-flight -- the barrier, the ragged\n'
                          'record gather and the timing reduction of a real run on dummy records -- print one JSON line and exit\n'
@@ -336,13 +341,16 @@ def main():
     # pairs-in-flight hint, and spin-or-poll waits chosen from this rank's CPU budget.
     budget = pipeline.rank_cpu_budget(local_world)
     collate_batch = pipeline.DEFAULT_COLLATE_BATCH if args.collate_batch is None else max(1, args.collate_batch)
+    lockstep = pipeline.DEFAULT_LOCKSTEP if args.lockstep is None else max(1, min(8, args.lockstep))
     if args.path != 'engine':
-        collate_batch = 1
+        collate_batch = lockstep = 1
+    pps = lockstep  # pairs per step: one step = one pass of the hot path over one batch = one engine call (a lock-step group)
+    n_timed, n_warm = args.steps * pps, args.warmup * pps
     pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
                                  stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams,
-                                 collate_batch=collate_batch)
+                                 collate_batch=collate_batch, lockstep=lockstep)
     wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
-    worker_of = {id(e): k for k, e in enumerate(engines)}
+    worker_of = {id(e): k for k, grp in enumerate(pipe.groups) for e in grp}
     for eng in engines:
         eng.enable_profile(False)
 
@@ -360,22 +368,33 @@ def main():
     iso_lat = []  # per-pair latencies of the one-pair-in-flight pass after the timed region
     iso_serial = []  # the same with the engine's latency mode off
 
-    def one_step(eng, slot, first, rec, lat_out, prof_out, events_every, n_workers):
-        """One step of the hot path on the worker thread / stream the pipeline hands it to."""
+    grouped = lockstep > 1 and args.path == 'engine'  # the pipeline runs the drawn pairs as a lock-step group BEFORE one_step sees them
+
+    def layer_records(eng, pid, role):
+        """The KPConv layer records of the engine's last run.  role 1: with event-bracketed durations; role 2: shapes only -- another
+        pair of a lock-step group whose launches (and durations) are those of the group's first engine."""
+        out = eng.kpconv_profile()
+        for li, layer_rec in enumerate(out):
+            layer_rec['pid'], layer_rec['layer'], layer_rec['launches'] = pid, li, 1 if role == 1 else 0
+        return out
+
+    def one_step(eng, slot, first, rec, lat_out, prof_out, events_every, n_workers, prepared=False):
+        """One pair of the hot path on the worker thread / stream the pipeline hands it to."""
         i = first + slot
         ts = time.perf_counter()
         pid = (rank + i * world) % len(dev_pairs)
         if net is None or args.path == 'engine':
-            sampled = prof_out is not None and events_every > 0 and (slot // max(n_workers, 1)) % events_every == 0
-            eng.enable_profile(sampled)
+            if prepared:  # (set_profile below chose before the group ran)
+                role = eng._bench_prof if prof_out is not None else 0
+            else:
+                role = 1 if prof_out is not None and events_every > 0 and (slot // max(n_workers, 1)) % events_every == 0 else 0
+                eng.enable_profile(role)
             res = eng.run(*dev_pairs[pid])  # returns with pose AND correspondences in host memory
             T, n_corr = eng.transform(), res.n_correspondences
             rc_h, sc_h, cs_h = eng.host_corr()  # SURVEY 8d: "... to estimated_transform + correspondences on the host"
             assert rc_h.shape[0] == n_corr
-            if sampled:
-                for li, layer_rec in enumerate(eng.kpconv_profile()):
-                    layer_rec['pid'], layer_rec['layer'] = pid, li
-                    prof_out.append(layer_rec)
+            if role:
+                prof_out.extend(layer_records(eng, pid, role))
         else:
             net.set_thread_profile(prof_out)
             try:
@@ -390,10 +409,22 @@ def main():
 
     def run_all(first, count, rec, lat_out, prof_lists, events_every=None):
         events_every = args.layer_events_every if events_every is None else events_every
-        # (tensors_of: what one_step will hand to eng.run for this slot -- the pipeline's workers collate several drawn pairs at once)
+        n_workers = len(streams)
+
+        def set_profile(eng, slot, i, n):
+            """Lock step: every events_every-th group of a stream records its layer events -- on its first engine; the others report
+            their layers' shapes (the grouped launches serve all of them)."""
+            on = prof_lists[worker_of[id(eng)]] is not None and events_every > 0
+            if i == 0:  # (one engine of pps records events: the rate per PAIR stays what --layer-events-every says)
+                eng._bench_sampled = on and ((slot // pps) // max(n_workers, 1)) % max(1, events_every // pps) == 0
+            sampled = pipe.groups[worker_of[id(eng)]][0]._bench_sampled
+            eng._bench_prof = (1 if i == 0 else 2) if sampled else 0
+            eng.enable_profile(eng._bench_prof)
+        # (tensors_of: what one_step will hand to eng.run for this slot -- the pipeline's workers collate / run several drawn pairs at once)
         pipe.map(range(count), lambda eng, slot: one_step(eng, slot, first, rec, lat_out, prof_lists[worker_of[id(eng)]],
-                                                          events_every, len(streams)),
-                 tensors_of=(lambda slot: dev_pairs[(rank + (first + slot) * world) % len(dev_pairs)]) if args.path == 'engine' else None)
+                                                          events_every, n_workers, prepared=grouped),
+                 tensors_of=(lambda slot: dev_pairs[(rank + (first + slot) * world) % len(dev_pairs)]) if args.path == 'engine' else None,
+                 prepare=set_profile if grouped else None)
         if rec is not None and lat_out is not None and pipe.last_stats.get('latency_ms'):
             # a pair's latency counts from the moment its worker drew it: the batch's collate and the pairs before it included
             lat_out[:] = [pipe.last_stats['latency_ms'][k] for k in sorted(pipe.last_stats['latency_ms'])]
@@ -407,13 +438,13 @@ def main():
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < args.ramp_seconds:
         run_all(0, 16 * len(streams), None, [], [[] for _ in streams], events_every=2 if args.layer_events_every > 0 else 0)
-    run_all(0, args.warmup, None, [], [None] * len(streams))
+    run_all(0, n_warm, None, [], [None] * len(streams))
     lat = []
     prof_lists = [[] for _ in streams]
-    records = torch.zeros((args.steps, 5), dtype=torch.float32)  # [pair_id, rre_deg, rte_m, n_corr, global step index]
+    records = torch.zeros((n_timed, 5), dtype=torch.float32)  # [pair_id, rre_deg, rte_m, n_corr, global step index]
     fence()
     t0 = time.perf_counter()
-    run_all(args.warmup, args.steps, records, lat, prof_lists)
+    run_all(n_warm, n_timed, records, lat, prof_lists)
     # the path's only collective: one gather of per-pair result records (RCCL)
     comm_dev = dev if args.dist_backend == 'nccl' else torch.device('cpu')  # gloo gathers CPU tensors
     gathered = sharding.gather_records(records.to(comm_dev), world, dist, force)
@@ -451,6 +482,18 @@ def main():
         finally:
             for eng in engines:
                 eng.keep_taps(False)
+
+    # ---- the schedule of rounds 1-4 beside the lock-step groups: the same engines, streams and pairs, one pair per engine call
+    one_by_one = None
+    if grouped and args.full_steps > 0:
+        def single_step(eng, i):
+            eng.enable_profile(False)
+            res = eng.run(*dev_pairs[(rank + i * world) % len(dev_pairs)])
+            assert eng.host_corr()[0].shape[0] == res.n_correspondences
+        pipe.map(range(4 * len(streams)), single_step)
+        one_by_one = {'value': timed_pass(2 * args.full_steps, single_step), 'unit': 'pairs/s', 'steps': 2 * args.full_steps,
+                      'note': f'rdm_engine_run, one pair per call, {len(streams)} pairs in flight (the schedule `value` was measured on up to '
+                              'round 4; --lockstep 1 makes it the timed region)'}
 
     # ---- host-to-host rate (SURVEY §8d's definition of a pair: two clouds in HOST memory -> transform + correspondences
     # in HOST memory).  Never `value`: a second, shorter region after the timed one.  Each in-flight pair copies its scans
@@ -533,13 +576,13 @@ def main():
             tg, tt = rec['gather_ms'] * 1e-3, rec['total_ms'] * 1e-3
             tot['t_total'] += tt
             tot['b_total'] += rec['bytes']
-            tot['n'] += 1
+            tot['n'] += rec.get('launches', 1)
             f = forms['fused' if rec.get('fused') else 'gather']
             f['t'] += tg
             f['b'] += rec['gather_bytes']
             f['b_real'] += rec.get('real_bytes', 0.0)
             f['flops'] += 2.0 * rec['m'] * (16 if rec['cin'] == 1 else 15 * rec['cin']) * rec['cout'] if rec.get('fused') else 0.0
-            f['n'] += 1
+            f['n'] += rec.get('launches', 1)  # (lock step: one launch serves the group; the other pairs' records add their bytes)
             key = rec.get('name') or f"kpconv M={rec['m']} H={rec['h']} C={rec['cin']}->{rec['cout']}"
             d = per_layer.setdefault(key, {'t': 0.0, 'tg': 0.0, 'bytes': rec['bytes'], 'n': 0, 'm': rec['m'], 'fused': rec.get('fused', 0),
                                            'h': rec['h'], 'cin': rec['cin'], 'cout': rec['cout'], 'real_bytes': rec.get('real_bytes')})
@@ -587,15 +630,28 @@ def main():
         engines[0].set_pairs_in_flight(1)  # (these passes ARE one pair in flight: no GEMM residency cap)
         with torch.cuda.stream(streams[0] if streams[0] is not None else torch.cuda.Stream()):  # (never the null stream)
             engines[0].set_overlap(0)
-            for k in range(min(8, args.steps)):
-                one_step(engines[0], k, args.warmup, None, [], iso_prof, 1, 1)
-            for k in range(min(16, args.steps)):  # serial, no events: the figure comparable with earlier rounds' (minus their events)
-                one_step(engines[0], k, args.warmup, None, iso_serial, None, 0, 1)
+            if grouped:  # the timed region's launches are lock-step groups: 6 groups alone on the GPU, events on the first engine
+                from rdmnet_amd.engine import Engine
+                grp = pipe.groups[0]
+                for g in range(6):
+                    pids = [(rank + (n_warm + g * pps + i) * world) % len(dev_pairs) for i in range(pps)]
+                    for i, e in enumerate(grp):
+                        e.enable_profile(1 if i == 0 else 2)
+                    Engine.run_lockstep(grp, [dev_pairs[p] for p in pids])
+                    for i, e in enumerate(grp):
+                        iso_prof.extend(layer_records(e, pids[i], 1 if i == 0 else 2))
+                for e in grp:
+                    e.enable_profile(0)
+            else:
+                for k in range(min(8, n_timed)):
+                    one_step(engines[0], k, n_warm, None, [], iso_prof, 1, 1)
+            for k in range(min(16, n_timed)):  # serial, no events: the figure comparable with earlier rounds' (minus their events)
+                one_step(engines[0], k, n_warm, None, iso_serial, None, 0, 1)
             engines[0].set_overlap(1)
-            for k in range(min(4, args.steps)):  # (the first latency-mode run picks the side stream)
-                one_step(engines[0], k, args.warmup, None, [], None, 0, 1)
-            for k in range(min(24, args.steps)):
-                one_step(engines[0], k, args.warmup, None, iso_lat, None, 0, 1)
+            for k in range(min(4, n_timed)):  # (the first latency-mode run picks the side stream)
+                one_step(engines[0], k, n_warm, None, [], None, 0, 1)
+            for k in range(min(24, n_timed)):
+                one_step(engines[0], k, n_warm, None, iso_lat, None, 0, 1)
         engines[0].set_pairs_in_flight(args.streams)
         fence()
     for rec in iso_prof:
@@ -638,9 +694,11 @@ def main():
                 'traffic': traffic, 'traffic_scope': traffic_note,
                 'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / '
                           'kpconv_fused_kernel<64> (6: gather + weight contraction in one launch) and kpconv_gather_kernel<*> (8)',
-                'region': f'timed region, {len(streams)} pair(s) in flight',
+                'region': f'timed region, {len(streams) * lockstep} pair(s) in flight' + (f' ({len(streams)} streams x lock-step groups of {lockstep}: a launch serves '
+                                                                                           f'the {lockstep} pairs of its group, bytes and duration are the group\'s)' if grouped else ''),
                 'pairs_with_layer_events': len(prof) // 14,
-                'one_pair_in_flight': ({**roofline_of(iforms), 'note': 'same kernels, 8 pairs on one stream after the timed region'}
+                'one_pair_in_flight': ({**roofline_of(iforms), 'note': ('same launches, 6 lock-step groups on one stream after the timed region' if grouped else
+                                                                            'same kernels, 8 pairs on one stream after the timed region')}
                                        if iso_prof else None),
                 # the whole KPConv layer (+ weight GEMM / GroupNorm passes + shortcut pool) against the same HBM peak, as round 1 reported it
                 'whole_layer': {'definition': 'SURVEY 8d bytes of the WHOLE KPConv layer (gather + 4 M C_out output + the strided blocks\' pool) / the '
@@ -666,13 +724,14 @@ def main():
 
     if rank == 0:
         result = {
-            'metric': 'scan-pairs/sec (whole node)', 'value': args.steps * world / elapsed, 'unit': 'pairs/s',
+            'metric': 'scan-pairs/sec (whole node)', 'value': n_timed * world / elapsed, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'KITTI-shaped synthetic pair (~16k pts/scan), full pipeline (GPU collate + forward), '
                                    'fp32, seeded random-init weights', 'searches_per_pair': 12 if args.path == 'engine' else 13,
                        'scheduler': 'rdmnet_amd.pipeline.PairPipeline', 'points_per_pair': n_points,
-                       'pairs_per_gpu': args.steps, 'pairs_in_flight_per_gpu': args.streams, 'collate_batch': collate_batch,
+                       'pairs_per_step': pps, 'pairs_per_gpu': n_timed, 'pairs_in_flight_per_gpu': args.streams * lockstep,
+                       'streams_per_gpu': args.streams, 'lockstep_pairs_per_stream': lockstep, 'collate_batch': collate_batch,
                        'host_path': args.path,
                        'host_cpus_per_rank': budget, 'host_cpus_pinned': len(pinned_cpus) if pinned_cpus else None,
                        'gpu_max_hw_queues': pipeline.hw_queues(), 'clock_ramp_s': args.ramp_seconds, 'wait': 'spin' if wait_us == 0 else f'poll+sleep {wait_us}us',
@@ -694,6 +753,7 @@ def main():
                             'ops': 'barrier x2 per region, all_gather (counts + records), all_reduce(MAX) of the elapsed time',
                             'preflight': preflight}
                            if dist is not None else None),
+            'one_pair_per_call': one_by_one,
             'full_tables': full_tables,
             'host_to_host': host_to_host,
             'drop_in_api': api,
@@ -707,7 +767,7 @@ def main():
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(ROOT, 'gpurun_out', 'bench_layers.json'), 'w') as f:
             json.dump({k: {**v, 'us': v['t'] / v['n'] * 1e6, 'gather_us': v['tg'] / v['n'] * 1e6,
-                           'GBps': v['bytes'] * v['n'] / v['t'] / 1e9} for k, v in per_layer.items()}, f, indent=1)
+                           'GBps': v['bytes'] * v['n'] / v['t'] / 1e9} for k, v in per_layer.items() if v['t'] > 0}, f, indent=1)
         print(json.dumps(_no_nan(result)))
     if dist is not None:
         dist.destroy_process_group()

@@ -533,8 +533,9 @@ int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* result_h
  * result buffer each, the weights shared (rdm_engine_share_params) -- on ONE stream: the runs advance together on the calling
  * thread, the launches of the same kernel of all pairs go out as one grouped launch, the size read-backs of the pairs become
  * waits of the group.  What the reference does pair after pair (engine/single_tester.py:86-134) and this library otherwise does on
- * one stream per pair.  Every pair: the bits of rdm_engine_run on it alone.  RDM_ERR_WORKSPACE: a pair exhausted its arena (run it
- * with rdm_engine_run, which grows the arena).                                                                              */
+ * one stream per pair.  Every pair: the bits of rdm_engine_run on it alone.  collate_batched != 0: the collates of the group run
+ * as one launch sequence on engines[0] (rdm_engine_collate_batch) before the forwards run in lock step (not when engines[0] keeps
+ * its stage tensors).  A pair that exhausts its arena is run again on its own (the arena grows as in rdm_engine_run).        */
 int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
                             const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
                             int collate_batched, void* stream);
@@ -558,6 +559,9 @@ int rdm_engine_set_pairs_in_flight(rdm_engine* e, int n);
  * spin kernels the first time it sees a caller stream (a few hundred microseconds, once) and stays serial where no such stream exists.
  * The reference has no counterpart (its loop is synchronous: geotransformer/engine/single_tester.py:86-134).                    */
 int rdm_engine_set_overlap(rdm_engine* e, int mode);
+/* Per-KPConv-layer profile of the next runs: 0 = off, 1 = HIP events around every layer's neighbourhood kernel and around the
+ * whole layer (rdm_engine_get_profile: sizes + milliseconds), 2 = the layers' sizes only, no events -- for the other pairs of a
+ * lock-step group whose first engine records the events: the launches (and durations) are the group's.                     */
 int rdm_engine_enable_profile(rdm_engine* e, int enable);
 int rdm_engine_get_profile(rdm_engine* e, rdm_kpconv_profile* out, int cap);
 int rdm_engine_keep_taps(rdm_engine* e, int enable);

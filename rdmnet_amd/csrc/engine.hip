@@ -131,6 +131,7 @@ struct rdm_engine {
   std::vector<int64_t> batch_n_ref, batch_n_src;
   size_t arena_base = 0;
   bool profile = false;
+  bool profile_shapes_only = false;  // (enable = 2: the layer records without events -- the other pairs of a profiled lock-step group)
   std::vector<hipEvent_t> events;      // 3 per KPConv layer: before gather, between, after GEMM
   std::vector<rdm_kpconv_profile> prof;  // filled at the end of a run
   int prof_layers = 0;
@@ -308,6 +309,19 @@ int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, in
                         vecp(r, name + ".bias"), 1e-5f, act, y.p, y.ld, r.st);
 }
 
+// A KPConv layer's profile event k (rdm_engine_enable_profile).  In a lock-step group the launches around it are deferred: the
+// event is too (lockstep_event: recorded right before this pair's next recorded launch goes out -- after the grouped launch the
+// layer's kernel became, which serves every pair of the group: the record's durations are the GROUP's).
+int layer_event(rdm_engine* e, int k, hipStream_t st) {
+  if (e->profile_shapes_only) return RDM_OK;
+  if (lockstep_active()) {
+    lockstep_event(e->events[k], st);
+    return RDM_OK;
+  }
+  RDM_HIP_CHECK(hipEventRecord(e->events[k], st));
+  return RDM_OK;
+}
+
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
            const Table& t, float sigma, const std::string& norm_name, Mat& y, const float* order,
            const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
@@ -333,8 +347,8 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     ENG_ALLOC(conv.p); ENG_ALLOC(y.p);
     RDM_REQUIRE(rdm_kpconv_fused_workspace_bytes(q.n, cin, W.out) <= r.ws_bytes, "rdm_engine: scratch too small");
     const int li = e->prof_layers;
-    const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
-    if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
+    const bool prof = e->profile && (e->profile_shapes_only ? li < 16 : 3 * li + 2 < static_cast<int>(e->events.size()));
+    if (prof) ENG_CHECK(layer_event(e, 3 * li, r.st));
     // (rdm_kpconv_fused_group_norm's two halves, so that the layer events bracket the convolution kernel alone)
     const int nblk = static_cast<int>(rdm_kpconv_fused_partial_rows(q.n, cin));
     double* gn_partial = static_cast<double*>(r.ws);
@@ -342,7 +356,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
     ENG_CHECK(kpconv_fused_impl(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
                                 vecp(r, name + ".kernel_points"), sigma, W.packed, W.bias, W.out, conv.p, conv.ld, gn_partial, order, 0,
                                 i32, r.st));
-    if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
+    if (prof) ENG_CHECK(layer_event(e, 3 * li + 1, r.st));
     ENG_CHECK(group_norm_finish(gn_partial, nblk, conv.p, q.n, W.out, conv.ld, r.groups, gam, bet, 1e-5f, nullptr, 0, 2, y.p, y.ld,
                                 nullptr, static_cast<char*>(r.ws) + stat_bytes, r.ws_bytes - stat_bytes, r.st));
     if (pool_src) {
@@ -352,7 +366,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
                                    t.flags, pool_out->p, pool_out->ld, order, i32, r.st));
     }
     if (prof) {
-      RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
+      ENG_CHECK(layer_event(e, 3 * li + 2, r.st));
       rdm_kpconv_profile p;
       p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
       p.gather_ms = p.total_ms = 0.f;
@@ -368,11 +382,11 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
   float* nn = e->alloc<float>(q.n > 0 ? q.n : 1);
   ENG_ALLOC(nn);
   const int li = e->prof_layers;
-  const bool prof = e->profile && 3 * li + 2 < static_cast<int>(e->events.size());
-  if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li], r.st));
+  const bool prof = e->profile && (e->profile_shapes_only ? li < 16 : 3 * li + 2 < static_cast<int>(e->events.size()));
+  if (prof) ENG_CHECK(layer_event(e, 3 * li, r.st));
   ENG_CHECK(kpconv_gather_impl(q.pts, q.n, s.pts, s.n, x.p, cin, x.ld, x_pos, t.idx, t.width, t.stride(), t.flags,
                                vecp(r, name + ".kernel_points"), sigma, wf.p, wf.ld, nn, order, i32, r.st));
-  if (prof) RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 1], r.st));
+  if (prof) ENG_CHECK(layer_event(e, 3 * li + 1, r.st));
   Mat conv = e->mat(q.n, W.out);
   ENG_ALLOC(conv.p);
   // scratch split: [GEMM split-K partials | GroupNorm partials | GroupNorm finish]
@@ -390,7 +404,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
                                    t.flags, pool_out->p, pool_out->ld, order, i32, r.st));
   }
   if (prof) {
-    RDM_HIP_CHECK(hipEventRecord(e->events[3 * li + 2], r.st));
+    ENG_CHECK(layer_event(e, 3 * li + 2, r.st));
     rdm_kpconv_profile p;
     p.m = q.n; p.h = t.width; p.c_in = cin; p.c_out = W.out; p.pooled_channels = pool_src ? pool_src->cols : 0;
     p.gather_ms = p.total_ms = 0.f;
@@ -883,8 +897,10 @@ extern "C" int rdm_engine_share_params(rdm_engine* e, const rdm_engine* src) {
 
 extern "C" int rdm_engine_enable_profile(rdm_engine* e, int enable) {
   RDM_REQUIRE(e, "rdm_engine_enable_profile: null engine");
+  RDM_REQUIRE(enable >= 0 && enable <= 2, "rdm_engine_enable_profile: 0 (off), 1 (events) or 2 (layer shapes only)");
   e->profile = enable != 0;
-  if (e->profile && e->events.empty()) {
+  e->profile_shapes_only = enable == 2;
+  if (enable == 1 && e->events.empty()) {
     e->events.resize(3 * 16);
     for (auto& ev : e->events) RDM_HIP_CHECK(hipEventCreate(&ev));
   }
@@ -1215,7 +1231,7 @@ extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, 
   for (int k = 0; k < n_pairs; ++k) {
     RDM_REQUIRE(engines[k] && results[k] && ref_points[k] && src_points[k] && n_ref[k] > 0 && n_src[k] > 0,
                 "rdm_engine_run_lockstep: pair %d is incomplete", k);
-    RDM_REQUIRE(engines[k]->finalized && !engines[k]->profile, "rdm_engine_run_lockstep: engine %d is not finalized (or profiles its layers)", k);
+    RDM_REQUIRE(engines[k]->finalized, "rdm_engine_run_lockstep: engine %d is not finalized", k);
     for (int j = 0; j < k; ++j) RDM_REQUIRE(engines[j] != engines[k], "rdm_engine_run_lockstep: every pair needs an engine of its own");
   }
   struct PadGuard {
@@ -1920,7 +1936,7 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     res->host_corr_scores = host_corr + 6 * nh;
   }
   res->arena_used = e->arena_off;
-  for (int i = 0; i < e->prof_layers; ++i) {  // the stream is idle here (read-back above synchronised it)
+  for (int i = 0; i < e->prof_layers && !e->profile_shapes_only; ++i) {  // the stream is idle here (read-back above synchronised it)
     RDM_HIP_CHECK(hipEventElapsedTime(&e->prof[i].gather_ms, e->events[3 * i], e->events[3 * i + 1]));
     RDM_HIP_CHECK(hipEventElapsedTime(&e->prof[i].total_ms, e->events[3 * i], e->events[3 * i + 2]));
   }

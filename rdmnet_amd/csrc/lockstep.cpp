@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <utility>
 #include <vector>
 
 namespace rdm {
@@ -18,6 +19,11 @@ struct Context {
   State state = State::Ready;
   LaunchRecord rec;
   int rc = 0;
+  std::vector<std::pair<hipEvent_t, hipStream_t>> events;  // lockstep_event: waiting for the context's next launch
+  void flush_events() {
+    for (auto& ev : events) (void)hipEventRecord(ev.first, ev.second);
+    events.clear();
+  }
 };
 
 struct Group {
@@ -70,6 +76,8 @@ void lockstep_submit(const LaunchRecord& rec) {
 
 void lockstep_sync() { yield_to_scheduler(State::Sync); }
 
+void lockstep_event(hipEvent_t ev, hipStream_t stream) { g_group->ctx[g_group->cur].events.emplace_back(ev, stream); }
+
 int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, int (*wait)(hipStream_t, void*), void* wait_user,
                  int* rcs) {
   if (n < 1 || n > kGroupMax || g_group != nullptr) return -1;
@@ -114,6 +122,7 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
         if (g.ctx[j].state != State::Launch) continue;  // (contexts that wait or ended do not break a group)
         if (g.ctx[j].rec.fire != g.ctx[k].rec.fire || g.ctx[j].rec.lds != g.ctx[k].rec.lds) break;
         recs[m++] = &g.ctx[j].rec;
+        g.ctx[j].flush_events();
       }
       g.ctx[k].rec.fire(recs, m);
       g_stats[3] += 1;
@@ -126,7 +135,10 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
     if (launched > 0) continue;
     // nothing to issue: the contexts still alive all wait for the stream
     bool waiting = false;
-    for (int k = 0; k < n; ++k) waiting |= g.ctx[k].state == State::Sync;
+    for (int k = 0; k < n; ++k) {
+      waiting |= g.ctx[k].state == State::Sync;
+      g.ctx[k].flush_events();  // (contexts that wait or have ended)
+    }
     if (waiting) {
       const long long t_w = now_ns();
       const int rc = wait(stream, wait_user);

@@ -85,6 +85,9 @@ struct LaunchRecord {
 bool lockstep_active();
 void lockstep_submit(const LaunchRecord& rec);  // records the launch of the running context and yields until it has been issued
 void lockstep_sync();                           // parks the running context until the group's stream is idle
+// An event of the running context: recorded on `stream` right before the context's next recorded launch is issued (or before
+// the group waits / the context ends) -- i.e. after everything the context has launched so far, without making it yield.
+void lockstep_event(hipEvent_t ev, hipStream_t stream);
 // Runs fn(0) .. fn(n - 1) as the contexts of one lock-step group on `stream`; wait(stream) is the group's host wait.
 int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, int (*wait)(hipStream_t, void*), void* wait_user,
                  int* rcs);

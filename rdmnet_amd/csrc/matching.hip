@@ -165,7 +165,7 @@ __device__ __forceinline__ float ref_sq_dist(float x0, float x1, float x2, float
 }
 
 // one thread per point: owner = argmin over nodes (first minimum), d_own = that distance
-__device__ __forceinline__ void p2n_assign_body(const float* points, int n, const float* nodes, int m, int32_t* owner,
+__device__ __forceinline__ void p2n_assign_body(unsigned block_x, const float* points, int n, const float* nodes, int m, int32_t* owner,
                                                 float* d_own, int32_t* node_count) {
   extern __shared__ float sn[];  // [m][4]: x, y, z, |node|^2
   for (int j = threadIdx.x; j < m; j += blockDim.x) {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void p2n_assign_body(const float* points, int n, cons
     sn[4 * j + 3] = (a * a + b * b) + c * c;
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = block_x * blockDim.x + threadIdx.x;  // (the caller's block index: a grouped launch carries its own, lockstep.h)
   if (i >= n) return;
   const float y0 = points[3 * i], y1 = points[3 * i + 1], y2 = points[3 * i + 2];
   const float yn = (y0 * y0 + y1 * y1) + y2 * y2;
@@ -196,8 +196,8 @@ __device__ __forceinline__ void p2n_assign_body(const float* points, int n, cons
 
 __device__ __forceinline__ void p2n_assign_kernel_body(const dim3 blockIdx, const dim3 gridDim, const float* points, int n, const float* nodes, int m,
                                                          int32_t* owner, float* d_own, int32_t* node_count) {
-  (void)blockIdx; (void)gridDim;
-  p2n_assign_body(points, n, nodes, m, owner, d_own, node_count);
+  (void)gridDim;
+  p2n_assign_body(blockIdx.x, points, n, nodes, m, owner, d_own, node_count);
 }
 __global__ __launch_bounds__(256) void p2n_assign_kernel(const float* points, int n, const float* nodes, int m,
                                                          int32_t* owner, float* d_own, int32_t* node_count) { p2n_assign_kernel_body(blockIdx, gridDim, points, n, nodes, m, owner, d_own, node_count); }
@@ -225,7 +225,7 @@ __device__ __forceinline__ void p2n_assign_pair_kernel_body(const dim3 blockIdx,
   (void)blockIdx; (void)gridDim;
   const P2nSeg& s = p.seg[blockIdx.y];
   if (static_cast<int>(blockIdx.x) * 256 >= s.n) return;  // whole workgroup
-  p2n_assign_body(s.points, s.n, s.nodes, s.m, s.owner, s.d_own, s.node_count);
+  p2n_assign_body(blockIdx.x, s.points, s.n, s.nodes, s.m, s.owner, s.d_own, s.node_count);
 }
 __global__ __launch_bounds__(256) void p2n_assign_pair_kernel(P2nPair p) { p2n_assign_pair_kernel_body(blockIdx, gridDim, p); }
 

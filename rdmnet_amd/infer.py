@@ -37,11 +37,11 @@ class Tester:
     records, pose lines and the report come out in dataset order whatever the completion order."""
 
     def __init__(self, cfg, state, output_dir=None, save_npz=True, ransac=True, write_poses=True,
-                 pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None):
+                 pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None, lockstep=None):
         self.cfg, self.output_dir, self.save_npz, self.ransac = cfg, output_dir, save_npz, ransac
         self.write_poses = write_poses  # False under several ranks: rank 0 writes all poses, in pair order, at the end
         self.pipeline = PairPipeline(cfg, state, pairs_in_flight=pairs_in_flight, wait_us=wait_us,
-                                     keep_taps=bool(save_npz and output_dir))
+                                     keep_taps=bool(save_npz and output_dir), lockstep=lockstep)
         self.engine = self.pipeline.engines[0]  # (the serial entry point `step` runs on this one)
         if output_dir:
             os.makedirs(output_dir, exist_ok=True)
@@ -132,6 +132,9 @@ def main(argv=None):
     ap.add_argument('--synthetic-cache', default=os.path.join('gpurun_out', 'bench_pairs'))
     ap.add_argument('--pairs-in-flight', type=int, default=DEFAULT_PAIRS_IN_FLIGHT,
                     help='pairs on the GPU at a time (engines / host threads / HIP streams; rdmnet_amd.pipeline)')
+    ap.add_argument('--lockstep', type=int, default=None,
+                    help='pairs a stream runs as one lock-step group (identical kernels of the group as one grouped launch; default: '
+                         'rdmnet_amd.pipeline.DEFAULT_LOCKSTEP with two or more pairs in flight and no .npz outputs; 1 = one pair per engine call)')
     ap.add_argument('--no-ransac', action='store_true', help='skip the RANSAC estimate stored beside the LGR pose in the .npz')
     ap.add_argument('--quiet', action='store_true', help='no per-pair log line (the reference prints one per iteration, infer.py:62-66)')
     args = ap.parse_args(argv)
@@ -173,7 +176,7 @@ def main(argv=None):
         print(f'Data loader created: {time.time() - t0:.3f}s collapsed.')
         print(f'Calibrate neighbors: {cfg.neighbor_limits}.')
     tester = Tester(cfg, load_state(args.weights, cfg), args.out, save_npz=not args.no_npz, ransac=not args.no_ransac,
-                    write_poses=world == 1, pairs_in_flight=args.pairs_in_flight)
+                    write_poses=world == 1, pairs_in_flight=args.pairs_in_flight, lockstep=args.lockstep)
     mine = sharding.pairs_for_rank(len(data), rank, world)
     # scans are read and staged (pinned host -> HBM on a side stream) two pairs ahead of every in-flight pair
     stager = ds_mod.PairStager(data, mine, depth=2 * args.pairs_in_flight, workers=max(2, args.pairs_in_flight))

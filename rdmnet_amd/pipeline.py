@@ -16,6 +16,10 @@ else that has a stream of pairs:
     launches (`Engine.collate_batch`: the subsampling chains, grid builds and searches of a pair are launch-bound; the pairs of
     a batch share them), then runs the pairs' forwards one by one -- the same bits as the one-by-one schedule, +2-3 % pairs/s
     for 2-4 x the per-pair latency: off by default,
+  * lock step (`lockstep` = B > 1, round 5, the default with two or more streams): a worker owns B engines, draws B jobs and runs
+    them as ONE lock-step group on its stream (`Engine.run_lockstep`): the B runs advance together on the worker's thread, the
+    same kernel of the B pairs goes out as one grouped launch (B x the workgroups per launch, a quarter of the launches and host
+    waits), their collates as one launch sequence.  Every pair keeps the bits of its own run; the B pairs finish together,
   * `rdm_engine_set_pairs_in_flight(N)` (GEMM residency hint from three pairs up; with N = 1 the engine runs in its latency
     mode instead: the wide, independent parts of the pair on a side stream, `Engine.set_overlap`),
   * waits at the engines' size read-backs by spinning (`hipStreamSynchronize`) when the process owns two host
@@ -48,6 +52,14 @@ DEFAULT_STAGGER_MS = 1.5
 # region then share the GPU with more of the other pairs' wide kernels (their event-bracketed durations grow by a fifth).  Default:
 # every pair collates itself, the schedule of rounds 1-4; a throughput-only caller sets 4-8.
 DEFAULT_COLLATE_BATCH = 1
+# Pairs a worker runs as ONE lock-step group on its stream (Engine.run_lockstep, round 5): B engines per worker, their runs advance
+# together on the worker's thread and identical kernels of the B pairs go out as one grouped launch (their collates as one launch
+# sequence).  Every pair keeps the bits of its own run.  Measured (tools/lockstep_lab.py, docs/EXPERIMENTS.md 5g): 4 workers x 4
+# pairs 578 pairs/s against 533 for 4 x 1 -- the B pairs of a group finish together, so a pair's latency is the group's
+# (26 ms against 7.4 ms; 8 per group: no more pairs/s, twice the latency).  The default of a pipeline that builds its own engines
+# and keeps two or more streams busy (one stream = the caller asks for latency: one pair per call, the engine's latency mode);
+# lockstep=1 is the schedule of rounds 1-4.
+DEFAULT_LOCKSTEP = 4
 
 
 def _quota_cpus():
@@ -216,7 +228,7 @@ class PairPipeline:
 
     def __init__(self, cfg, state, device=None, pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None,
                  stagger_ms=DEFAULT_STAGGER_MS, keep_taps=False, local_world=None, engines=None, streams=None,
-                 collate_batch=DEFAULT_COLLATE_BATCH):
+                 collate_batch=DEFAULT_COLLATE_BATCH, lockstep=None):
         self._gpu = torch.cuda.is_available()
         if not self._gpu and engines is None:
             raise RuntimeError('rdmnet_amd.pipeline needs a GPU (no CPU fallback)')
@@ -224,6 +236,9 @@ class PairPipeline:
         self.device = (torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)) if self._gpu else None
         self.n = max(1, int(pairs_in_flight))
         self.collate_batch = max(1, int(collate_batch))
+        if lockstep is None:  # (injected engines: the caller's set is what runs)
+            lockstep = DEFAULT_LOCKSTEP if (engines is None and self.n >= 2 and not keep_taps) else 1
+        self.lockstep = max(1, min(8, int(lockstep)))  # (8 = what one grouped launch carries, lockstep.h)
         self.keep_taps = bool(keep_taps)
         self.stagger_s = max(0.0, float(stagger_ms)) * 1e-3
         local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '1')) if local_world is None else local_world
@@ -233,20 +248,26 @@ class PairPipeline:
         else:  # (also for a single pair in flight: the engine's latency mode does not work on the null stream)
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)] if self._gpu else [None] * self.n
         self.engines = list(engines) if engines is not None else []
-        if len(self.engines) < self.n:
+        want = self.n * self.lockstep  # lock step: worker k runs groups[k] (lockstep engines) on its stream
+        if len(self.engines) < want:
+            if not self._gpu:
+                raise RuntimeError(f'rdmnet_amd.pipeline: {want} injected engines needed ({self.n} workers x {self.lockstep} in lock step)')
             with torch.cuda.device(self.device):
-                while len(self.engines) < self.n:
+                while len(self.engines) < want:
                     self.engines.append(Engine(cfg, state, device=self.device,
                                                share_with=self.engines[0] if self.engines else None))
-        for eng in self.engines:
+        self.groups = [self.engines[k * self.lockstep:(k + 1) * self.lockstep] for k in range(self.n)]
+        spare = self.engines[want:]
+        self.engines = [grp[0] for grp in self.groups] + spare  # (engines[k]: worker k's engine, as without lock step)
+        for eng in [e for grp in self.groups for e in grp] + spare:
             eng.set_wait(self.wait_us)
-            eng.set_pairs_in_flight(self.n)
+            eng.set_pairs_in_flight(self.n * self.lockstep)
             eng.keep_taps(keep_taps)
         self.cfg = cfg
         self.last_stats = None
 
     # ------------------------------------------------------------------ generic scheduler
-    def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None):
+    def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None, prepare=None):
         """Yields fn(engine, job) for every job, in job order.  `window` bounds how far completion may run ahead of
         the consumer (default 4 x pairs_in_flight results held).
 
@@ -254,10 +275,16 @@ class PairPipeline:
         pipeline's `collate_batch` > 1, no stage tensors kept), a worker draws several jobs at a time, collates them with ONE
         sequence of launches (`Engine.collate_batch`: the collate is the launch-bound part of a pair) and then runs fn on each --
         `engine.run` recognises the prepared pair and runs its forward alone; the results are the bits of the one-by-one
-        schedule.  Towards the end of a sized job list the batches shrink so that the workers still finish together."""
+        schedule.  Towards the end of a sized job list the batches shrink so that the workers still finish together.
+
+        With `lockstep` > 1 (and tensors_of given, no stage tensors kept) the drawn jobs run as ONE lock-step group on the worker's
+        engines (`Engine.run_lockstep`) before fn is called on each (engine, job) -- `engine.run` then returns the result that is
+        already in place.  prepare(engine, job, i, n), if given, is called for job i of the n drawn before the group runs (per-run
+        engine settings, e.g. the layer profile)."""
         n = self.n
         window = max(n, 4 * n if window is None else int(window))
-        bmax = self.collate_batch if (tensors_of is not None and not self.keep_taps) else 1
+        lockstep = self.lockstep > 1 and tensors_of is not None and not self.keep_taps
+        bmax = self.lockstep if lockstep else (self.collate_batch if (tensors_of is not None and not self.keep_taps) else 1)
         window = max(window, 2 * n * bmax)
         total = len(jobs) if hasattr(jobs, '__len__') else None
         it = enumerate(iter(jobs))
@@ -270,7 +297,7 @@ class PairPipeline:
         # `latency_ms`: per job (by slot), from the moment its worker had drawn it -- with its batch -- to its result: the batch's
         # collate and the forwards of the pairs before it in the batch included
         stats = self.last_stats = {'draw_s': 0.0, 'work_s': 0.0, 'window_s': 0.0, 'jobs': 0, 'wall_s': 0.0, 'workers': n,
-                                   'collate_batches': 0, 'latency_ms': {}}
+                                   'collate_batches': 0, 'lockstep_groups': 0, 'latency_ms': {}}
         t_begin = time.perf_counter()
 
         def draw():
@@ -316,12 +343,19 @@ class PairPipeline:
                             t2 = time.perf_counter()
                             if got is None:
                                 return
-                            if len(got) > 1:  # one collate for all of them; fn's engine.run then finds each pair prepared
+                            if lockstep and prepare is not None:
+                                for i, (_, job) in enumerate(got):
+                                    prepare(self.groups[k][i], job, i, len(got))
+                            if lockstep and len(got) > 1:  # the pairs as one lock-step group; fn's engine.run finds each result in place
+                                type(self.groups[k][0]).run_lockstep(self.groups[k], [tensors_of(job) for _, job in got])
+                                with cv:
+                                    stats['lockstep_groups'] += 1
+                            elif len(got) > 1:  # one collate for all of them; fn's engine.run then finds each pair prepared
                                 self.engines[k].collate_batch([tensors_of(job) for _, job in got])
                                 with cv:
                                     stats['collate_batches'] += 1
-                            for slot, job in got:
-                                out = fn(self.engines[k], job)
+                            for i, (slot, job) in enumerate(got):
+                                out = fn(self.groups[k][i] if lockstep else self.engines[k], job)
                                 t_done = time.perf_counter()
                                 with cv:
                                     done[slot] = out
@@ -374,8 +408,8 @@ class PairPipeline:
             torch.set_num_threads(torch_threads)
             stats['wall_s'] = time.perf_counter() - t_begin
 
-    def map(self, jobs, fn, stagger=True, tensors_of=None):
-        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30, tensors_of=tensors_of))
+    def map(self, jobs, fn, stagger=True, tensors_of=None, prepare=None):
+        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30, tensors_of=tensors_of, prepare=prepare))
 
     # ------------------------------------------------------------------ the common case
     def run_pairs(self, pairs, stagger=True):
@@ -391,3 +425,4 @@ class PairPipeline:
     def close(self):
         """Drops the engines (their arenas; the shared weights go with the last one)."""
         self.engines = []
+        self.groups = []

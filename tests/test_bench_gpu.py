@@ -28,14 +28,20 @@ def test_two_ranks_self_spawned_on_one_device():
     r = run_bench('--gpus', '2', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--streams', '2', '--pairs', '4',
                   '--host-steps', '4', '--full-steps', '4', '--api-steps', '4', '--no-cpu-baseline', '--dist-backend', 'gloo', env_extra={'RDM_BENCH_SHARE_DEVICE': '1'})
     assert r['n_gpus'] == 2 and r['steps'] == 8 and r['scaling'] == 'weak' and r['unit'] == 'pairs/s'
-    assert r['records'] == {'gathered': 16, 'distinct_steps': 16, 'distinct_pairs': 4}
-    assert r['registration']['pairs'] == 16
-    assert r['value'] > 0 and abs(r['value'] - 16 / (r['ms_per_step'] * 8 / 1e3)) < 1e-6 * r['value']
+    # a step = one engine call = one lock-step group of config.pairs_per_step pairs (round 5; --lockstep 1: one pair)
+    pps = r['config']['pairs_per_step']
+    assert pps == r['config']['lockstep_pairs_per_stream'] >= 2 and r['config']['pairs_in_flight_per_gpu'] == 2 * pps
+    assert r['records'] == {'gathered': 16 * pps, 'distinct_steps': 16 * pps, 'distinct_pairs': 4}
+    assert r['registration']['pairs'] == 16 * pps
+    assert r['value'] > 0 and abs(r['value'] - 16 * pps / (r['ms_per_step'] * 8 / 1e3)) < 1e-6 * r['value']
+    assert r['one_pair_per_call']['value'] > 0
     assert r['host_to_host']['value'] > 0 and r['drop_in_api']['value'] > 0 and r['cpu_baseline'] is None
 
 
 def test_single_rank_line_has_the_contract_fields():
     r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--full-steps', '4', '--api-steps', '8', '--no-cpu-baseline')
+    assert r['config']['pairs_per_step'] >= 2 and r['config']['pairs_per_gpu'] == 8 * r['config']['pairs_per_step']
+    assert r['roofline']['one_pair_in_flight']['frac'] > 0 and r['roofline']['launches'] > 0
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in r, key
@@ -53,7 +59,8 @@ def test_single_rank_through_rccl():
     the all_reduce(MAX) of the elapsed time go through the process group (the multi-GPU run's collectives,
     geotransformer/engine/base_tester.py:70-76,123-128 in the reference)."""
     r = run_bench('--gpus', '1', '--force-dist', '--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4',
-                  '--full-steps', '0', '--api-steps', '4', '--no-cpu-baseline', timeout=600)
+                  '--full-steps', '0', '--api-steps', '4', '--no-cpu-baseline', '--lockstep', '1', timeout=600)  # (one pair per call: rounds 1-4)
+    assert r['config']['pairs_per_step'] == 1
     assert r['collective']['backend'] == 'nccl' and r['collective']['forced_single_rank'] and r['collective']['library'].startswith('RCCL')
     assert r['records'] == {'gathered': 8, 'distinct_steps': 8, 'distinct_pairs': 2}
     assert r['n_gpus'] == 1 and r['value'] > 0 and r['host_to_host']['value'] > 0

@@ -626,5 +626,10 @@ def test_lockstep_runs_give_every_pair_the_bits_of_its_own_run(ctx, golden_dir):
             res = engine.Engine.run_lockstep(engines, pairs[lo:hi], collate_batched=collated)
             for k in range(lo, hi):
                 assert same(snapshot(engines[k - lo], res[k - lo]), want[k]), (collated, lo, hi, k)
+        # the same pair several times in a group: every launch of the runs is then grouped, the size-dependent ones too
+        for collated in (True, False):
+            res = engine.Engine.run_lockstep(engines, [pairs[2], pairs[2], pairs[0], pairs[2]], collate_batched=collated)
+            for k, i in enumerate((2, 2, 0, 2)):
+                assert same(snapshot(engines[k], res[k]), want[i]), (collated, k)
         # an engine of a group runs alone again afterwards
         assert same(snapshot(engines[2], engines[2].run(*pairs[4])), want[4])

@@ -117,6 +117,44 @@ def test_workers_collate_several_drawn_jobs_at_once_and_shrink_the_batches_towar
     assert p.map(range(6), lambda eng, job: job) == list(range(6)) and not any(e.batches for e in p.engines)
 
 
+def test_workers_run_the_jobs_they_draw_as_one_lock_step_group():
+    """Round 5: with `lockstep` = B a worker owns B engines, draws up to B jobs, calls prepare(engine, job, i, n) for each and
+    hands them to run_lockstep ONCE (on exactly its engines, in job order); fn then sees job i on the group's i-th engine.  A single
+    drawn job runs through fn alone; without tensors_of (or with stage tensors kept) jobs run one by one on the first engines."""
+    calls = []
+
+    class Grouped(FakeEngine):
+        @staticmethod
+        def run_lockstep(engines, pairs):
+            calls.append(([e.k for e in engines], list(pairs)))
+
+    def build(n, lb, **kw):
+        return pipeline.PairPipeline(None, None, pairs_in_flight=n, engines=[Grouped(k) for k in range(n * lb)], stagger_ms=0.0, lockstep=lb, **kw)
+    p = build(3, 4)
+    assert [[e.k for e in g] for g in p.groups] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]] and [e.k for e in p.engines] == [0, 4, 8]
+    seen, prepared = [], []
+
+    def fn(eng, job):
+        seen.append((eng.k, job))
+        time.sleep(0.001)
+        return job * 2
+    out = p.map(range(26), fn, tensors_of=lambda job: ('r%d' % job, 's%d' % job), prepare=lambda eng, job, i, n: prepared.append((eng.k, job, i, n)))
+    assert out == [2 * j for j in range(26)] and sorted(j for _, j in seen) == list(range(26))
+    assert p.last_stats['lockstep_groups'] == len(calls) and max(len(c[1]) for c in calls) == 4
+    by_job = dict((j, k) for k, j in seen)
+    for ks, pairs in calls:  # a group's jobs ran on its worker's engines, job i on engine i
+        jobs = [int(r[1:]) for r, _ in pairs]
+        assert ks[0] % 4 == 0 and ks == list(range(ks[0], ks[0] + 4)) and [by_job[j] for j in jobs] == ks[:len(jobs)]
+    assert sorted(prepared) == sorted((by_job[j], j, by_job[j] % 4, n) for (_, j, _, n) in prepared) and len(prepared) == 26
+    # no tensors_of / stage tensors kept: one by one
+    calls.clear()
+    assert build(2, 4).map(range(5), lambda eng, job: eng.k) and not calls
+    p = build(2, 4, keep_taps=True)
+    assert p.map(range(5), lambda eng, job: job, tensors_of=lambda job: (job, job)) == list(range(5)) and not calls
+    with pytest.raises(RuntimeError):  # 2 x 4 needs 8 engines when they are injected
+        pipeline.PairPipeline(None, None, pairs_in_flight=2, engines=[Grouped(0)], lockstep=4)
+
+
 def _fake_sysfs(root, gpu_nodes, node_cpulists):
     """A sysfs tree with one CPU agent and len(gpu_nodes) GPU agents in the KFD topology (GPU k on PCI bus 0x10 + k, NUMA node
     gpu_nodes[k]) and the nodes' cpulist files."""

@@ -56,6 +56,22 @@ def test_pairs_in_flight_equal_the_serial_run_bit_for_bit_in_dataset_order(setup
             assert np.array_equal(g.transform, w.transform) and g.level_sizes == w.level_sizes
             assert np.array_equal(g.ref_corr_points, w.ref_corr_points) and np.array_equal(g.src_corr_points, w.src_corr_points)
             assert np.array_equal(g.corr_scores, w.corr_scores)
+    # round 5: lock-step groups (the default of a pipeline with its own engines): a worker runs the pairs it drew -- of different
+    # sizes -- as one group on its stream, identical kernels of the group's pairs as one grouped launch; still the serial run's
+    # bits, in dataset order
+    for n, lb in ((2, 4), (3, 3), (4, 2)):
+        grouped = pipeline.PairPipeline(cfg, None, pairs_in_flight=n, engines=[serial.engines[0]], lockstep=lb)
+        assert len(grouped.groups) == n and all(len(g) == lb for g in grouped.groups) and grouped.engines[0] is serial.engines[0]
+        for _ in range(2):
+            got = grouped.run_pairs([dev[i] for i in order])
+            assert grouped.last_stats['lockstep_groups'] >= 2 and len(got) == len(want)
+            for g, w in zip(got, want):
+                assert np.array_equal(g.transform, w.transform) and g.level_sizes == w.level_sizes
+                assert g.n_correspondences == w.n_correspondences
+                assert np.array_equal(g.ref_corr_points, w.ref_corr_points) and np.array_equal(g.src_corr_points, w.src_corr_points)
+                assert np.array_equal(g.corr_scores, w.corr_scores)
+    assert pipeline.PairPipeline(cfg, state, pairs_in_flight=2).lockstep == pipeline.DEFAULT_LOCKSTEP
+    assert pipeline.PairPipeline(cfg, state, pairs_in_flight=1).lockstep == 1
 
 
 def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):
