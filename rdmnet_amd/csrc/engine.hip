@@ -185,6 +185,7 @@ void tap(Run& r, const char* name, const void* p, int64_t rows, int64_t cols, in
 void tap(Run& r, const char* name, const Mat& m) { tap(r, name, m.p, m.rows, m.cols, m.ld, 0); }
 
 int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, bool alloc_out = true) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto it = e->params->lin.find(name);
   if (it == e->params->lin.end()) {
@@ -202,6 +203,7 @@ int linear(Run& r, const std::string& name, const Mat& x, Mat& y, int act = 0, b
 
 // two independent Linear layers as one launch when both are transformer-sized (gemm_pair)
 int linear_pair(Run& r, const std::string& name0, const Mat& x0, Mat& y0, const std::string& name1, const Mat& x1, Mat& y1) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto i0 = e->params->lin.find(name0), i1 = e->params->lin.find(name1);
   if (i0 == e->params->lin.end() || i1 == e->params->lin.end()) {
@@ -222,6 +224,7 @@ float* vecp(Run& r, const std::string& name) {
 }
 
 int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   y = e->mat(x.rows, x.cols);
   ENG_ALLOC(y.p);
@@ -237,6 +240,7 @@ int group_norm(Run& r, const std::string& name, const Mat& x, Mat& y, int act, c
 
 // Linear + GroupNorm (+ residual, activation): statistics come out of the GEMM epilogue
 int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const Mat* res, uint8_t* positive) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto it = e->params->lin.find(name + ".mlp");
   if (it == e->params->lin.end()) {
@@ -263,6 +267,7 @@ int unary(Run& r, const std::string& name, const Mat& x, Mat& y, int act, const 
 // finest decoder level) is then neither written nor re-read.
 int decoder_stage(Run& r, const std::string& lin_name, const std::string* norm_name, const Mat& coarse, const int64_t* up_idx,
                   int64_t up_ld, const Mat& skip, int64_t m, Mat& y) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto it = e->params->lin.find(lin_name);
   if (it == e->params->lin.end()) {
@@ -300,6 +305,7 @@ int decoder_stage(Run& r, const std::string& lin_name, const std::string* norm_n
 }
 
 int layer_norm(Run& r, const std::string& name, const Mat& x, const Mat* res, int act, Mat& y, bool alloc_out = true) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   if (alloc_out) {
     y = e->mat(x.rows, x.cols);
@@ -325,6 +331,7 @@ int layer_event(rdm_engine* e, int k, hipStream_t st) {
 int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, const Level& q, const Level& s,
            const Table& t, float sigma, const std::string& norm_name, Mat& y, const float* order,
            const Mat* pool_src = nullptr, Mat* pool_out = nullptr) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto it = e->params->lin.find(name + ".weights");
   if (it == e->params->lin.end()) {
@@ -431,6 +438,7 @@ int kpconv(Run& r, const std::string& name, const Mat& x, const uint8_t* x_pos, 
 // `out` is a pre-allocated view (rows of the stacked [ref; src] state).
 // LayerNorm(Linear(x) + residual): one fused launch at the transformer width (rdm_linear_layer_norm), else two
 int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat& x, const Mat& res, Mat& y, bool alloc_out) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto it = e->params->lin.find(lin);
   if (it == e->params->lin.end()) {
@@ -452,6 +460,7 @@ int linear_ln(Run& r, const std::string& lin, const std::string& norm, const Mat
 }
 
 int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, Mat out) {
+  lockstep_align();  // (lockstep.h: the pairs of a lock-step group start every layer together)
   rdm_engine* e = r.e;
   auto lo = e->params->lin.find(p + ".attention.linear"), l1 = e->params->lin.find(p + ".output.expand"), l2 = e->params->lin.find(p + ".output.squeeze");
   if (lo != e->params->lin.end() && l1 != e->params->lin.end() && l2 != e->params->lin.end() && lo->second.wt && l1->second.wt && l2->second.wt &&

@@ -5,13 +5,19 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
 namespace rdm {
 namespace {
 
-enum class State { Ready, Launch, Sync, Done };
+enum class State { Ready, Launch, Align, Sync, Done };
 
 struct Context {
   ucontext_t uc;
@@ -45,7 +51,10 @@ struct Stacks {  // a host thread's context stacks, kept between runs (a fresh z
 thread_local Stacks g_stacks;
 }  // namespace
 std::atomic<long long> g_stats[8];  // ns in run, ns in waits, waits, grouped launches, records, runs
+std::mutex g_by_kernel_mu;
+std::map<std::pair<const void*, size_t>, std::pair<long long, long long>> g_by_kernel;  // (fire, lds) -> launches, records (RDM_LOCKSTEP_STATS)
 namespace {
+const bool g_by_kernel_on = std::getenv("RDM_LOCKSTEP_STATS") != nullptr;
 inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -75,6 +84,10 @@ void lockstep_submit(const LaunchRecord& rec) {
 }
 
 void lockstep_sync() { yield_to_scheduler(State::Sync); }
+
+void lockstep_align() {
+  if (lockstep_active()) yield_to_scheduler(State::Align);
+}
 
 void lockstep_event(hipEvent_t ev, hipStream_t stream) { g_group->ctx[g_group->cur].events.emplace_back(ev, stream); }
 
@@ -109,31 +122,41 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
       swapcontext(&g.main, &c.uc);
       g.cur = -1;
     }
-    // issue what was recorded: consecutive contexts with the same kernel (and dynamic LDS size) as one launch
+    // issue what was recorded: the contexts that recorded the same kernel as one launch -- wherever they
+    // stand in the group (every context has ONE record pending and only a context's own launches are ordered)
     int launched = 0;
-    for (int k = 0; k < n;) {
-      if (g.ctx[k].state != State::Launch) {
-        ++k;
-        continue;
-      }
+    for (int k = 0; k < n; ++k) {
+      if (g.ctx[k].state != State::Launch) continue;
       const LaunchRecord* recs[kGroupMax];
-      int m = 0, j = k;
-      for (; j < n; ++j) {
-        if (g.ctx[j].state != State::Launch) continue;  // (contexts that wait or ended do not break a group)
-        if (g.ctx[j].rec.fire != g.ctx[k].rec.fire || g.ctx[j].rec.lds != g.ctx[k].rec.lds) break;
+      int m = 0;
+      for (int j = k; j < n; ++j) {
+        if (g.ctx[j].state != State::Launch) continue;
+        if (g.ctx[j].rec.fire != g.ctx[k].rec.fire) continue;
         recs[m++] = &g.ctx[j].rec;
         g.ctx[j].flush_events();
+        g.ctx[j].state = State::Ready;
       }
       g.ctx[k].rec.fire(recs, m);
+      if (g_by_kernel_on) {
+        std::lock_guard<std::mutex> lk(g_by_kernel_mu);
+        auto& e = g_by_kernel[{reinterpret_cast<const void*>(g.ctx[k].rec.fire), g.ctx[k].rec.lds}];
+        e.first += 1;
+        e.second += m;
+      }
       g_stats[3] += 1;
       g_stats[4] += m;
-      for (int i = k; i < j; ++i)
-        if (g.ctx[i].state == State::Launch) g.ctx[i].state = State::Ready;
       launched += m;
-      k = j;
     }
     if (launched > 0) continue;
-    // nothing to issue: the contexts still alive all wait for the stream
+    // nothing to issue: contexts at a layer boundary go on together (before any wait: the others then reach the wait too)
+    bool aligned = false;
+    for (int k = 0; k < n; ++k) {
+      if (g.ctx[k].state != State::Align) continue;
+      g.ctx[k].state = State::Ready;
+      aligned = true;
+    }
+    if (aligned) continue;
+    // the contexts still alive all wait for the stream
     bool waiting = false;
     for (int k = 0; k < n; ++k) {
       waiting |= g.ctx[k].state == State::Sync;
@@ -161,6 +184,15 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
 }  // namespace rdm
 
 // Developer counters (tools/lockstep_lab.py): ns in lock-step runs, ns of them in host waits, waits, grouped launches, records, runs
+extern "C" void rdm_lockstep_stats_dump() {  // (RDM_LOCKSTEP_STATS=1: launches and records per kernel and dynamic LDS size)
+  std::lock_guard<std::mutex> lk(rdm::g_by_kernel_mu);
+  for (auto& kv : rdm::g_by_kernel) {
+    Dl_info info{};
+    const char* name = dladdr(kv.first.first, &info) && info.dli_sname ? info.dli_sname : "?";
+    std::printf("%8lld launches %8lld records  lds %6zu  %.200s\n", kv.second.first, kv.second.second, kv.first.second, name);
+  }
+  rdm::g_by_kernel.clear();
+}
 extern "C" void rdm_lockstep_stats(long long* out, int reset) {
   for (int i = 0; i < 8; ++i) {
     out[i] = rdm::g_stats[i].load();

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(THREADS, MINW) void grouped_kernel(GroupArgs<A...> 
 
 // ---- host side
 struct LaunchRecord {
-  // issues `n` recorded launches (same `fire`, same dynamic LDS size) as one: n == 1 -> the original kernel
+  // issues `n` recorded launches (same `fire`) as one, with the largest of their dynamic LDS sizes: n == 1 -> the original kernel
   int (*fire)(const LaunchRecord* const* recs, int n);
   dim3 grid;
   size_t lds;
@@ -85,6 +85,12 @@ struct LaunchRecord {
 bool lockstep_active();
 void lockstep_submit(const LaunchRecord& rec);  // records the launch of the running context and yields until it has been issued
 void lockstep_sync();                           // parks the running context until the group's stream is idle
+// A layer boundary of the running context (no-op outside a group): parked until every context of the group that can still run has
+// reached a boundary or a wait.  Pairs of different sizes do not launch the same NUMBER of kernels per layer (a split-K product has
+// a reduce kernel, a one-pass one has not): without boundaries a pair that is one launch ahead stays ahead -- and ungrouped --
+// until the next host wait.  Contexts that reach different boundaries are released together all the same (no deadlock; they
+// only group worse).
+void lockstep_align();
 // An event of the running context: recorded on `stream` right before the context's next recorded launch is issued (or before
 // the group waits / the context ends) -- i.e. after everything the context has launched so far, without making it yield.
 void lockstep_event(hipEvent_t ev, hipStream_t stream);
@@ -122,11 +128,13 @@ int fire_records(const LaunchRecord* const* recs, int n) {
     g.first[k + 1] = g.first[n];
     g.gx[k] = g.gy[k] = g.gz[k] = 1;
   }
-  if (recs[0]->lds > 32768) {  // (more than 64 KB of LDS per workgroup needs the attribute on THIS instantiation, per device)
+  size_t lds = 0;  // (dynamic LDS is an upper bound of what a body uses: the group gets the largest request)
+  for (int k = 0; k < n; ++k) lds = recs[k]->lds > lds ? recs[k]->lds : lds;
+  if (lds > 32768) {  // (more than 64 KB of LDS per workgroup needs the attribute on THIS instantiation, per device)
     static std::atomic<uint64_t> done{0};
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(grouped_kernel<Body, THREADS, MINW, P...>), static_cast<int>(recs[0]->lds), done);
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(grouped_kernel<Body, THREADS, MINW, P...>), 160 * 1024 - 4096, done);
   }
-  hipLaunchKernelGGL((grouped_kernel<Body, THREADS, MINW, P...>), dim3(static_cast<unsigned>(g.first[n])), dim3(THREADS), recs[0]->lds,
+  hipLaunchKernelGGL((grouped_kernel<Body, THREADS, MINW, P...>), dim3(static_cast<unsigned>(g.first[n])), dim3(THREADS), lds,
                      recs[0]->stream, g);
   return 0;
 }

@@ -438,22 +438,27 @@ struct GatherItem {
   const int64_t* idx;
   uint32_t* y;
   int ldy;
+  int m, lanes;  // rows; lanes per row: the power of two >= c (at most the workgroup) -- a workgroup copies threads / lanes rows
 };
 struct GatherBatch {
   GatherItem item[4];
-  int first_row[5];
+  int first_block[5];
   int n;
 };
+// (Round 5: several rows per workgroup.  The patch-point gather of a pair is 2 x 16 384 rows of THREE words -- one workgroup per
+// row was 32 768 workgroups for 400 KB, 70 us a pair; rows of 3 words now go 16 to a wavefront.)
 __device__ __forceinline__ void gather_rows_multi_kernel_body(const dim3 blockIdx, const dim3 gridDim, GatherBatch b) {
   (void)blockIdx; (void)gridDim;
   int it = 0;
 #pragma unroll
-  for (int k = 1; k < 4; ++k) it += (k < b.n && static_cast<int>(blockIdx.x) >= b.first_row[k]) ? 1 : 0;
+  for (int k = 1; k < 4; ++k) it += (k < b.n && static_cast<int>(blockIdx.x) >= b.first_block[k]) ? 1 : 0;
   const GatherItem& g = b.item[it];
-  const int row = blockIdx.x - b.first_row[it];
+  const int lanes = g.lanes, per_block = blockDim.x / lanes;
+  const int row = (blockIdx.x - b.first_block[it]) * per_block + threadIdx.x / lanes;
+  if (row >= g.m) return;
   const int64_t id = g.idx[row];
   const bool ok = id >= 0 && id < g.n_src;
-  for (int col = threadIdx.x; col < g.c; col += blockDim.x)
+  for (int col = threadIdx.x % lanes; col < g.c; col += lanes)
     g.y[static_cast<int64_t>(row) * g.ldy + col] = ok ? g.x[id * g.ldx + col] : 0u;
 }
 __global__ void gather_rows_multi_kernel(GatherBatch b) { gather_rows_multi_kernel_body(blockIdx, gridDim, b); }
@@ -466,18 +471,21 @@ int rdm::gather_rows_multi(int n, const void* const* x, const int64_t* n_src, co
   RDM_REQUIRE(n >= 1 && n <= 4, "gather_rows_multi: 1..4 gathers");
   GatherBatch b;
   b.n = n;
-  b.first_row[0] = 0;
+  b.first_block[0] = 0;
   int64_t max_words = 0;
+  for (int k = 0; k < n; ++k) max_words = std::max(max_words, words[k]);
+  const int threads = max_words >= 256 ? 256 : (max_words >= 128 ? 128 : 64);
   for (int k = 0; k < n; ++k) {
     RDM_REQUIRE(x[k] && idx[k] && y[k] && words[k] > 0 && m[k] >= 0, "gather_rows_multi: bad arguments");
+    int lanes = 1;
+    while (lanes < words[k] && lanes < threads) lanes <<= 1;
     b.item[k] = GatherItem{static_cast<const uint32_t*>(x[k]), static_cast<int>(n_src[k]), static_cast<int>(words[k]),
-                           static_cast<int>(ldx[k]), idx[k], static_cast<uint32_t*>(y[k]), static_cast<int>(ldy[k])};
-    b.first_row[k + 1] = b.first_row[k] + static_cast<int>(m[k]);
-    max_words = std::max(max_words, words[k]);
+                           static_cast<int>(ldx[k]), idx[k], static_cast<uint32_t*>(y[k]), static_cast<int>(ldy[k]),
+                           static_cast<int>(m[k]), lanes};
+    b.first_block[k + 1] = b.first_block[k] + static_cast<int>(ceil_div<int64_t>(m[k], threads / lanes));
   }
-  if (b.first_row[n] == 0) return RDM_OK;
-  const int threads = max_words >= 256 ? 256 : (max_words >= 128 ? 128 : 64);
-  const dim3 grid(static_cast<unsigned>(b.first_row[n]));
+  if (b.first_block[n] == 0) return RDM_OK;
+  const dim3 grid(static_cast<unsigned>(b.first_block[n]));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (threads == 256) ::rdm::launch<gather_rows_multi_kernel_body, gather_rows_multi_kernel, 256>(grid, 0, st, b);
   else if (threads == 128) ::rdm::launch<gather_rows_multi_kernel_body, gather_rows_multi_kernel, 128>(grid, 0, st, b);

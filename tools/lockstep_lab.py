@@ -73,3 +73,6 @@ if L is not None and B > 1:
     runs = max(st[5], 1)
     print(f'  per group run: {st[0] / runs / 1e6:.2f} ms on the host thread, {st[1] / runs / 1e6:.2f} ms of it in {st[2] / runs:.1f} waits; '
           f'{st[3] / runs:.0f} grouped launches carrying {st[4] / runs:.0f} records')
+if L is not None and os.environ.get('RDM_LOCKSTEP_STATS'):
+    sys.stdout.flush()
+    L.rdm_lockstep_stats_dump()
