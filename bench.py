@@ -341,7 +341,8 @@ def main():
     # pairs-in-flight hint, and spin-or-poll waits chosen from this rank's CPU budget.
     budget = pipeline.rank_cpu_budget(local_world)
     collate_batch = pipeline.DEFAULT_COLLATE_BATCH if args.collate_batch is None else max(1, args.collate_batch)
-    lockstep = pipeline.DEFAULT_LOCKSTEP if args.lockstep is None else max(1, min(8, args.lockstep))
+    # (the pipeline's own default: lock-step groups with two or more streams; one stream = latency: one pair per call)
+    lockstep = (pipeline.DEFAULT_LOCKSTEP if args.streams >= 2 else 1) if args.lockstep is None else max(1, min(8, args.lockstep))
     if args.path != 'engine':
         collate_batch = lockstep = 1
     pps = lockstep  # pairs per step: one step = one pass of the hot path over one batch = one engine call (a lock-step group)
@@ -675,11 +676,20 @@ def main():
 
     n_layers = max(len(prof), 1)
     traffic, traffic_note = None, None
-    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):  # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels as `achieved`)
-        pmc_file = os.path.join(ROOT, 'profiles', f'{tag}_pmc_kpconv_gather.json')
-        if os.path.exists(pmc_file):
+    # HBM bytes per dispatch from the committed rocprofv3 --pmc passes (same kernels, same kind of dispatch as `achieved`: since
+    # round 5 `*_pmc_kpconv_gather.json` holds the lock-step grouped dispatches, `*_one_pair.json` the one-pair ones)
+    for tag in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
+        names = [f'{tag}_pmc_kpconv_gather.json'] if grouped else [f'{tag}_pmc_kpconv_gather_one_pair.json', f'{tag}_pmc_kpconv_gather.json']
+        for nm in names:
+            pmc_file = os.path.join(ROOT, 'profiles', nm)
+            if not os.path.exists(pmc_file):
+                continue
             pmc = json.load(open(pmc_file))
+            if ('grouped' in pmc['kernel']) != grouped:
+                continue
             traffic, traffic_note = pmc['traffic_bytes_per_dispatch'], pmc['kernel'] + '; ' + pmc['source']
+            break
+        if traffic is not None:
             break
     # `roofline`: the kernels the north star names -- the KPConv neighbourhood kernels, 14 launches per pair.  achieved =
     # SURVEY 8d gather bytes M*H*(8 + 12 + 4*C_in) per launch (padded slots counted: the contract figure) / the launch's

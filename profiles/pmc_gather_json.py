@@ -5,19 +5,22 @@ import sqlite3
 import sys
 
 
-def total(db, counter):
+def total(db, counter, grouped):
+    """grouped: the lock-step grouped dispatches only (rdm::grouped_kernel<kpconv_*_body, ...>: one dispatch serves the pairs of a
+    group) -- the launches of bench.py's timed region since round 5; otherwise the one-pair dispatches."""
     cur = sqlite3.connect(db).cursor()
-    rows = cur.execute("select count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%kpconv_gather%' or name like '%kpconv_fused%' or name like '%kpconv_tile%')",
-                       (counter,)).fetchall()
+    rows = cur.execute("select count(*), sum(counter_value) from pmc_events where counter_name=? and (name like '%kpconv_gather%' or name like '%kpconv_fused%' or name like '%kpconv_tile%') "
+                       "and name " + ("like" if grouped else "not like") + " '%grouped_kernel%'", (counter,)).fetchall()
     return rows[0]
 
 
-def main(fetch_db, write_db, source):
-    nf, f = total(fetch_db, 'FETCH_SIZE')
-    nw, w = total(write_db, 'WRITE_SIZE')
+def main(fetch_db, write_db, source, grouped=False):
+    nf, f = total(fetch_db, 'FETCH_SIZE', grouped)
+    nw, w = total(write_db, 'WRITE_SIZE', grouped)
     fetch_kb, write_kb = f / nf, w / nw
     out = {'source': source,
-           'kernel': 'kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / kpconv_fused_kernel<64> + kpconv_gather_kernel<*> (14 dispatches per pair)',
+           'kernel': ('lock-step grouped dispatches (rdm::grouped_kernel<body>: one dispatch = the 4 pairs of a group) of ' if grouped else '') +
+                     'kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / kpconv_fused_kernel<64> + kpconv_gather_kernel<*> (14 dispatches per pair' + (' group)' if grouped else ')'),
            'dispatches': nf, 'fetch_kb_per_dispatch_raw': fetch_kb, 'write_kb_per_dispatch_raw': write_kb,
            'correction': 'MI355X_MICROARCH.md §HBM: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950 -> reads '
                          'doubled; WRITE_SIZE uncalibrated, taken as is',
@@ -26,4 +29,4 @@ def main(fetch_db, write_db, source):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], len(sys.argv) > 4 and sys.argv[4] == 'grouped')

@@ -12,9 +12,9 @@ def per_kernel(db, counter):
 
 
 def pairs_in(db, counter):
-    """Scan pairs the profiled process ran = dispatches of a once-per-pair kernel (nms_kernel)."""
+    """Scan pairs the profiled process ran = dispatches of a once-per-pair kernel (export_result_kernel)."""
     cur = sqlite3.connect(db).cursor()
-    return cur.execute("select count(*) from pmc_events where counter_name=? and name like '%nms_kernel%'", (counter,)).fetchone()[0]
+    return cur.execute("select count(*) from pmc_events where counter_name=? and name like '%export_result_kernel%'", (counter,)).fetchone()[0]
 
 
 def main(fetch_db, write_db, steps):

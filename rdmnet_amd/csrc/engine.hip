@@ -1920,7 +1920,8 @@ static int engine_run_once(rdm_engine* e, const float* ref_points, int64_t n_ref
     int32_t counts[4];
   } tailbuf;
   float* host_corr = reinterpret_cast<float*>(static_cast<char*>(e->pinned) + 4096);
-  ::rdm::launch<export_result_kernel_body, export_result_kernel, 256>(dim3(16), 0, r.st, T, rc, sc, cs, static_cast<uint32_t*>(e->pinned_dev),
+  // (a plain launch in a lock-step group too: ONE dispatch per pair whatever the schedule -- what the profile summaries count pairs by)
+  hipLaunchKernelGGL(export_result_kernel, dim3(16), dim3(256), 0, r.st, T, rc, sc, cs, static_cast<uint32_t*>(e->pinned_dev),
                      reinterpret_cast<float*>(static_cast<char*>(e->pinned_dev) + 4096), static_cast<int>(e->host_corr_cap));
   ENG_CHECK(launch_status("export_result_kernel"));
   ENG_CHECK(wait_stream(r));
