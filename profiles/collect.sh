@@ -9,7 +9,7 @@ mkdir -p $O
 db() { find "$1" -name "*.db" | head -1; }
 
 rocprofv3 --kernel-trace --stats -d $O/t4 -- python bench.py --steps 20 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --host-steps 0 --api-steps 0 --full-steps 0 --real-slots off > $O/t4.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 4 --ramp-seconds 0 --no-cpu-baseline   (MI355X, $R, default: 4 streams x lock-step groups of 4 pairs -- `grouped <body>` rows are rdm::grouped_kernel launches serving the pairs of a group, steps = pairs; durations include cross-stream sharing; 24 timed + warm-up steps (4 pairs each) and the one-stream passes after them -- 8 pairs with per-layer events, 16 serial, 28 in the engine's latency mode; the __amd_rocclr_copyBuffer rows are the parameter uploads of the first engine's construction (417; the other engines share its parameters), before any pair runs)"; echo; python profiles/summarize_rocprof.py $(db $O/t4) 0; } > $O/${R}_kernel_trace_default_4streams.md
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 4 --ramp-seconds 0 --no-cpu-baseline   (MI355X, $R, default: 4 streams x lock-step groups of 4 pairs -- "grouped <body>" rows are rdm::grouped_kernel launches serving the pairs of a group, steps = pairs; durations include cross-stream sharing; 24 timed + warm-up steps (4 pairs each) and the one-stream passes after them -- 8 pairs with per-layer events, 16 serial, 28 in the engine's latency mode; the __amd_rocclr_copyBuffer rows are the parameter uploads of the first engine's construction (417; the other engines share its parameters), before any pair runs)"; echo; python profiles/summarize_rocprof.py $(db $O/t4) 0; } > $O/${R}_kernel_trace_default_4streams.md
 rocprofv3 --kernel-trace --stats -d $O/t1 -- python bench.py --steps 20 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --streams 1 --host-steps 0 --api-steps 0 --full-steps 0 --real-slots off > $O/t1.log 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 4 --ramp-seconds 0 --no-cpu-baseline --streams 1   (MI355X, $R, one pair in flight, i.e. the engine in its latency mode -- the first level's search and blocks run beside the subsampling chain and the decoder beside the second transformer on a side stream, so some durations include that sharing; 24 steps + the passes after them: 8 pairs with per-layer events and 16 more with the mode off, 28 with it on; the __amd_rocclr_copyBuffer rows are the parameter uploads of the first engine's construction (417; the other engines share its parameters), before any pair runs)"; echo; python profiles/summarize_rocprof.py $(db $O/t1) 0; } > $O/${R}_kernel_trace_stream1.md
 cp gpurun_out/bench_layers.json $O/${R}_kpconv_layers_events.json
