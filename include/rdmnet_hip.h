@@ -539,6 +539,11 @@ int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* result_h
 int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
                             const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
                             int collate_batched, void* stream);
+/* Developer counters of the lock-step scheduler (tools/lockstep_lab.py): out[0..5] = ns spent in lock-step runs, ns of them in
+ * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  With
+ * RDM_LOCKSTEP_STATS in the environment rdm_lockstep_stats_dump prints launches and records per kernel.                    */
+void rdm_lockstep_stats(long long* out, int reset);
+void rdm_lockstep_stats_dump(void);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
 /* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,

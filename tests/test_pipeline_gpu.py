@@ -97,6 +97,17 @@ def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):
         for k in za.files:
             assert np.array_equal(za[k], zb[k]), k
 
+    # round 5: without .npz outputs the Tester's pipeline runs lock-step groups by default (staged pairs drawn four at a time on each
+    # stream): same records, pose lines and report
+    d = tmp_path / 'grouped'
+    t = infer.Tester(cfg, state, str(d), save_npz=False, ransac=False, pairs_in_flight=2)
+    assert t.pipeline.lockstep == 4
+    recs = t.run(dataset.PairStager(dataset.ArrayPairDataset(pairs), depth=8))
+    assert t.pipeline.last_stats['lockstep_groups'] >= 1
+    assert open(d / '00_pose').read() == pose1 and t.summary.lines() == rep1
+    for a, b in zip(r1, recs):
+        assert np.array_equal(a['transform'], b['transform']) and a['n_corr'] == b['n_corr']
+
 
 def test_one_pair_in_flight_through_the_stager_is_not_throttled(setup):
     """Round 4: with two reader threads the stager's pinned-buffer fills went through torch's CPU copy_, whose OpenMP teams (one

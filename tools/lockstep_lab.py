@@ -17,7 +17,7 @@ first = engine.Engine(cfg, state)
 groups = [[first if (g == 0 and k == 0) else engine.Engine(cfg, None, share_with=first) for k in range(B)] for g in range(streams)]
 for grp in groups:
     for e in grp:
-        e.set_pairs_in_flight(streams * B if streams * B >= 3 else streams)
+        e.set_pairs_in_flight(int(os.environ.get('LS_PIF', streams * B if streams * B >= 3 else streams)))
 pool = [torch.cuda.Stream() for _ in range(16)]  # (consecutive streams of torch's pool)
 pick = [int(x) for x in os.environ['LS_STREAMS'].split(',')] if os.environ.get('LS_STREAMS') else list(range(streams))
 lock = threading.Lock()
