@@ -700,7 +700,10 @@ def main():
                 'definition': 'HEADLINE (fixed since r03): padded-slot bytes M*H*(8 + 12 + 4*C_in) of the 14 KPConv neighbourhood '
                               'launches of a pair / their summed durations (HIP events on the launch stream) in the timed region; side keys: '
                               'real_slots (slots holding a neighbour only), by_form (one-kernel vs gather-only layers), one_pair_in_flight '
-                              '(same kernels, GPU to themselves), whole_layer (round-comparable layer figure)',
+                              '(same kernels, GPU to themselves), whole_layer (round-comparable layer figure).  The contract figure counts 8-byte '
+                              'neighbour indices; a plain engine run keeps its tables as int32 and moves 3 % (C = 32) to 17 % (c_in = 1) fewer bytes '
+                              'than it is credited with.  In a lock-step schedule (config.lockstep_pairs_per_stream > 1) a launch is a grouped launch: '
+                              'bytes and duration are those of the group\'s pairs together',
                 'traffic': traffic, 'traffic_scope': traffic_note,
                 'kernel': 'KPConv neighbourhood kernels, 14 launches/pair: kpconv_fused_c1_kernel + kpconv_tile_kernel<32|64> / '
                           'kpconv_fused_kernel<64> (6: gather + weight contraction in one launch) and kpconv_gather_kernel<*> (8)',

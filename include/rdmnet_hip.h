@@ -540,8 +540,8 @@ int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float
                             const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
                             int collate_batched, void* stream);
 /* Developer counters of the lock-step scheduler (tools/lockstep_lab.py): out[0..5] = ns spent in lock-step runs, ns of them in
- * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  With
- * RDM_LOCKSTEP_STATS in the environment rdm_lockstep_stats_dump prints launches and records per kernel.                    */
+ * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  In the lab build
+ * (make lab), with RDM_LOCKSTEP_STATS in the environment, rdm_lockstep_stats_dump prints launches and records per kernel.    */
 void rdm_lockstep_stats(long long* out, int reset);
 void rdm_lockstep_stats_dump(void);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */

@@ -5,7 +5,6 @@
 
 #include <atomic>
 #include <chrono>
-#include <cstdlib>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -54,7 +53,7 @@ std::atomic<long long> g_stats[8];  // ns in run, ns in waits, waits, grouped la
 std::mutex g_by_kernel_mu;
 std::map<std::pair<const void*, size_t>, std::pair<long long, long long>> g_by_kernel;  // (fire, lds) -> launches, records (RDM_LOCKSTEP_STATS)
 namespace {
-const bool g_by_kernel_on = std::getenv("RDM_LOCKSTEP_STATS") != nullptr;
+const bool g_by_kernel_on = dev_knob("RDM_LOCKSTEP_STATS") != nullptr;  // (lab build only: the product library never reads the environment)
 inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
