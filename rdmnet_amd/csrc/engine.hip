@@ -1253,7 +1253,11 @@ extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, 
   LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, collated};
   int rcs[kGroupMax] = {};
   const int wrc = lockstep_run(n_pairs, lockstep_pair, &job, static_cast<hipStream_t>(stream), lockstep_wait, engines[0], rcs);
-  if (wrc != 0) return wrc;
+  if (wrc == -1) {
+    set_error("rdm_engine_run_lockstep: called from inside a lock-step group (a host thread runs one group at a time)");
+    return RDM_ERR_ARG;
+  }
+  if (wrc != 0) return wrc;  // (the group's host wait failed: the error text is the wait's)
   // a pair that exhausted its arena runs again on its own: rdm_engine_run grows the arena (engines[0] last: that rewrites the
   // arena the other pairs' pyramids lie in -- they are done by then)
   for (int k = n_pairs - 1; k >= 0; --k) {

@@ -940,7 +940,8 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // co-limits the 64x64 tile when several pairs share the GPU
   static const int big_min_m = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_BIG"); return v ? atoi(v) : 0; }();
   static const int big_tile = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_BIG"); const char* c = v ? strchr(v, ',') : nullptr; return c ? atoi(c + 1) : 6; }();
-  if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && best_s == 1 && force_splits == 0 && batches == 1)
+  static const bool big_split = ::rdm::dev_knob("RDM_GEMM_BIG_SPLIT") != nullptr;  // (lab: the split-K products too -- same split factor, same bits)
+  if (big_min_m > 0 && exp_tile == 0 && m >= big_min_m && n >= 128 && (best_s == 1 || big_split) && force_splits == 0 && batches == 1)
     exp_tile = big_tile;
   static const bool xcd_env = ::rdm::dev_knob("RDM_GEMM_XCD") != nullptr;  // developer knob (A/B)
   g.xcd_tiles = (xcd_env && ceil_div<long long>(n, 64) > 1 && ceil_div<long long>(m, 64) * ceil_div<long long>(n, 64) >= 64) ? 1 : 0;
