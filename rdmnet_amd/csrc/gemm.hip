@@ -266,37 +266,62 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int lk = lane >> 5, li = lane & 31;
-  // one k-tile: read this tile's MFMA operands from LDS buffer `buf`, then -- interleaved by the scheduling groups
-  // below -- refill the free register stage with tile kt + PF, multiply, and put the next tile into the other buffer
-  auto step = [&](auto& fa, auto& fb, const auto& na, const auto& nb, int kt, int buf) {
-    float af[BK / 2][FM], bf[BK / 2][FN];
+  // One k-tile in two halves (round 5).  The operands of a half live in registers one half-step ahead: while the MFMAs of the
+  // tile's FIRST half run, its second half is read from LDS (and the next tile goes from the register stage into the other LDS
+  // buffer, the tile after it from global memory into the free stage); after the barrier that publishes that buffer, the first
+  // half of the NEXT tile is read while the MFMAs of this tile's second half run.  A wavefront therefore never waits for an LDS
+  // read in front of its MFMAs (the round-4 form read all 32 operands at the top of the tile: ~250 clocks per 1024 of MFMA work
+  // in which the wavefront issued nothing; matrix pipe 65 % busy at full occupancy against the vendor library's 93 %,
+  // tools/gemm_pmc_probe.py).  Every accumulator still receives its MFMAs in ascending k: the same bits.
+  constexpr int HK = BK / 2, HS = HK / 2;  // k per half, MFMA k-steps per half
+  float af_lo[HS][FM], bf_lo[HS][FN], af_hi[HS][FM], bf_hi[HS][FN];
+  auto read_half = [&](float (&af)[HS][FM], float (&bf)[HS][FN], int buf, int kbase) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = 0; kk < HK; kk += 2) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[kk / 2][i] = As[buf][kk + lk][wm * TM + i * 32 + li];
+      for (int i = 0; i < FM; ++i) af[kk / 2][i] = As[buf][kbase + kk + lk][wm * TM + i * 32 + li];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[kk / 2][j] = Bs[buf][kk + lk][wn * TN + j * 32 + li];
+      for (int j = 0; j < FN; ++j) bf[kk / 2][j] = Bs[buf][kbase + kk + lk][wn * TN + j * 32 + li];
     }
-    __builtin_amdgcn_sched_barrier(0);  // the reads stay above (the scheduler would sink each next to its MFMA)
-    load_tiles(fa, fb, kt + PF);
+  };
+  auto mfma_half = [&](const float (&af)[HS][FM], const float (&bf)[HS][FN]) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2)
+    for (int s = 0; s < HS; ++s)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk / 2][i], bf[kk / 2][j], acc[i][j], 0, 0, 0);
-    store_tiles(na, nb, buf ^ 1, kt + 1);  // on the last trip: a copy of the last tile, never read
-    // a wavefront issues in order, and a dependent MFMA holds the stream for 64 clocks: everything else of the trip
-    // goes into those shadows -- per MFMA a few VALU/SALU instructions, one global load, one LDS store
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+  };
+  auto step = [&](auto& fa, auto& fb, const auto& na, const auto& nb, int kt, int buf) {
+    // ---- first half: operands already in af_lo / bf_lo
+    read_half(af_hi, bf_hi, buf, HK);
+    load_tiles(fa, fb, kt + PF);
+    mfma_half(af_lo, bf_lo);
+    store_tiles(na, nb, buf ^ 1, kt + 1);  // on the last trip: a copy of the last tile (read below, never multiplied)
+    // a wavefront issues in order, and a dependent MFMA holds the stream for 64 clocks: everything else of the half goes into
+    // those shadows -- per MFMA a few LDS reads, VALU/SALU instructions, one global load, LDS stores
 #pragma unroll
-    for (int q = 0; q < (BK / 2) * FM * FN; ++q) {
+    for (int q = 0; q < HS * FM * FN; ++q) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();  // LDS only: the register prefetch stages stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second half; the next tile's first half arrives meanwhile
+    read_half(af_lo, bf_lo, buf ^ 1, 0);
+    mfma_half(af_hi, bf_hi);
+#pragma unroll
+    for (int q = 0; q < HS * FM * FN; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
   if (kt0 < kt1) {  // (an empty K range -- more splits than k-tiles -- leaves the accumulators at zero)
     load_tiles(ra0, rb0, kt0);
@@ -306,6 +331,7 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
   lds_barrier();
   GEMM_STAMP(1);
   if (kt0 < kt1) {
+    read_half(af_lo, bf_lo, 0, 0);
     if constexpr (PF == 1) {
       for (int kt = kt0; kt < kt1; ++kt) step(ra0, rb0, ra0, rb0, kt, (kt - kt0) & 1);
     } else {
@@ -405,7 +431,8 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
   GEMM_STAMP(3);
 }
 template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF, bool CAT = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) { gemm_kernel_body<BM, BN, WM, WN, BK, TRANS_B, PF, CAT>(blockIdx, gridDim, g); }
+// (64-row / 128 x 32 tiles: four workgroups per CU = four wavefronts per SIMD, 128 registers each)
+__global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : 1)) void gemm_kernel(GemmArgs g) { gemm_kernel_body<BM, BN, WM, WN, BK, TRANS_B, PF, CAT>(blockIdx, gridDim, g); }
 
 
 // Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
@@ -828,18 +855,18 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
   const unsigned pad = pad_env >= 0 ? static_cast<unsigned>(pad_env) : g_lds_pad;
   if constexpr (BM == 64 && BN == 64 && BK == 32 && PF == 2) {
     if (g.aidx && g.bidx) {  // gathered rows on both sides (patch scores)
-      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>, 256>(grid, pad, st, g);
+      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, true, PF, true>, 256, (BM * BN <= 64 * 64 ? 4 : 1)>(grid, pad, st, g);
       return;
     }
     if (g.aidx) {  // virtual [upsample | skip] A operand
-      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>, 256>(grid, pad, st, g);
+      ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF, true>, gemm_kernel<BM, BN, WM, WN, BK, false, PF, true>, 256, (BM * BN <= 64 * 64 ? 4 : 1)>(grid, pad, st, g);
       return;
     }
   }
   if (trans_b)
-    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF>, gemm_kernel<BM, BN, WM, WN, BK, true, PF>, 256>(grid, pad, st, g);
+    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, true, PF>, gemm_kernel<BM, BN, WM, WN, BK, true, PF>, 256, (BM * BN <= 64 * 64 ? 4 : 1)>(grid, pad, st, g);
   else
-    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF>, gemm_kernel<BM, BN, WM, WN, BK, false, PF>, 256>(grid, pad, st, g);
+    ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF>, gemm_kernel<BM, BN, WM, WN, BK, false, PF>, 256, (BM * BN <= 64 * 64 ? 4 : 1)>(grid, pad, st, g);
 }
 
 }  // namespace
