@@ -168,10 +168,12 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
   // (a) the compiler waits for the stage it needs (vmcnt(N)) and not for all outstanding loads, and (b) the whole
   // trip is one scheduling region in which the address arithmetic, the loads and the LDS stores of the next tile can
   // be placed BETWEEN the MFMAs of this one.  (K, lda, ldb are multiples of 4.)
-  auto load_tiles = [&](float4 (&ra)[A_V], float4 (&rb)[B_V], int kt) {
+  // (pieces [p0, p1) of the A_V + B_V float4 a thread moves per tile: the K loop spreads them over the shadows of its MFMAs)
+  auto load_tiles = [&](float4 (&ra)[A_V], float4 (&rb)[B_V], int kt, int p0 = 0, int p1 = 1 << 20) {
     const int k0 = min(kt, kt1 - 1) * BK;  // past the end: the last tile again (stored to a buffer nobody reads)
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
+      if (i < p0 || i >= p1) continue;
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
       if constexpr (CAT && TRANS_B) {
@@ -186,6 +188,7 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
     }
 #pragma unroll
     for (int i = 0; i < B_V; ++i) {
+      if (A_V + i < p0 || A_V + i >= p1) continue;
       const int idx = tid + i * 256;
       if (TRANS_B) {
         const int row = idx / KC4, kc = (idx % KC4) * 4;
@@ -202,10 +205,11 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
   };
   // (component-wise select: `ok ? v : zero4` on two float4 lvalues is lowered as a select of ADDRESSES through scratch)
   auto masked = [](const float4& v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
-  auto store_tiles = [&](const float4 (&ra)[A_V], const float4 (&rb)[B_V], int buf, int kt) {
+  auto store_tiles = [&](const float4 (&ra)[A_V], const float4 (&rb)[B_V], int buf, int kt, int p0 = 0, int p1 = 1 << 20) {
     const int k0 = min(kt, kt1 - 1) * BK;
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
+      if (i < p0 || i >= p1) continue;
       const int idx = tid + i * 256;
       const int row = idx / KC4, kc = (idx % KC4) * 4;
       if (A_N4 % 256 != 0 && idx >= A_N4) continue;
@@ -221,6 +225,7 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
     if (TRANS_B) {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
+        if (A_V + i < p0 || A_V + i >= p1) continue;
         const int idx = tid + i * 256;
         const int row = idx / KC4, kc = (idx % KC4) * 4;
         if (B_N4 % 256 != 0 && idx >= B_N4) continue;
@@ -235,6 +240,7 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
     } else {
 #pragma unroll
       for (int i = 0; i < B_V; ++i) {
+        if (A_V + i < p0 || A_V + i >= p1) continue;
         const int idx = tid + i * 256;
         const int k = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
         if (B_N4 % 256 != 0 && idx >= B_N4) continue;
@@ -275,53 +281,48 @@ __device__ __forceinline__ void gemm_kernel_body(const dim3 blockIdx, const dim3
   // tools/gemm_pmc_probe.py).  Every accumulator still receives its MFMAs in ascending k: the same bits.
   constexpr int HK = BK / 2, HS = HK / 2;  // k per half, MFMA k-steps per half
   float af_lo[HS][FM], bf_lo[HS][FN], af_hi[HS][FM], bf_hi[HS][FN];
+  // operands of k-step s (two k) of a half: FM + FN LDS reads
+  auto read_kstep = [&](float (&af)[HS][FM], float (&bf)[HS][FN], int buf, int kbase, int s) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[s][i] = As[buf][kbase + 2 * s + lk][wm * TM + i * 32 + li];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bf[s][j] = Bs[buf][kbase + 2 * s + lk][wn * TN + j * 32 + li];
+  };
   auto read_half = [&](float (&af)[HS][FM], float (&bf)[HS][FN], int buf, int kbase) {
 #pragma unroll
-    for (int kk = 0; kk < HK; kk += 2) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[kk / 2][i] = As[buf][kbase + kk + lk][wm * TM + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[kk / 2][j] = Bs[buf][kbase + kk + lk][wn * TN + j * 32 + li];
-    }
+    for (int s = 0; s < HS; ++s) read_kstep(af, bf, buf, kbase, s);
   };
-  auto mfma_half = [&](const float (&af)[HS][FM], const float (&bf)[HS][FN]) {
-#pragma unroll
-    for (int s = 0; s < HS; ++s)
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
-  };
+  // A wavefront issues in order and a dependent MFMA holds its stream for 64 clocks: everything else of a half-tile has to stand
+  // BETWEEN the MFMAs in program order to run in their shadows.  The compiler's scheduler does not keep it there on its own (and
+  // scheduling-group hints held for one of the two unrolled trips only: in the other, ~60 VALU / memory instructions ran after
+  // the last MFMA of the half with the matrix pipe idle), so the half is written as NCH chunks -- one MFMA, then that chunk's
+  // share of the LDS reads, global loads and LDS stores -- fenced by scheduling barriers.
+  constexpr int NCH = HS * FM * FN, NP = A_V + B_V;
   auto step = [&](auto& fa, auto& fb, const auto& na, const auto& nb, int kt, int buf) {
-    // ---- first half: operands already in af_lo / bf_lo
-    read_half(af_hi, bf_hi, buf, HK);
-    load_tiles(fa, fb, kt + PF);
-    mfma_half(af_lo, bf_lo);
-    store_tiles(na, nb, buf ^ 1, kt + 1);  // on the last trip: a copy of the last tile (read below, never multiplied)
-    // a wavefront issues in order, and a dependent MFMA holds the stream for 64 clocks: everything else of the half goes into
-    // those shadows -- per MFMA a few LDS reads, VALU/SALU instructions, one global load, LDS stores
+    // ---- first half: operands already in af_lo / bf_lo; the second half's arrive meanwhile
 #pragma unroll
-    for (int q = 0; q < HS * FM * FN; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 12, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+    for (int c = 0; c < NCH; ++c) {
+      const int s = c / (FM * FN), i = (c / FN) % FM, j = c % FN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_lo[s][i], bf_lo[s][j], acc[i][j], 0, 0, 0);
+      if (c % (FM * FN) == 0) read_kstep(af_hi, bf_hi, buf, HK, s);
+      // this chunk's global loads of tile kt + PF (into the free register stage: pieces in the first chunks) ...
+      load_tiles(fa, fb, kt + PF, NCH >= NP ? (c < NP ? c : NP) : (c * NP) / NCH, NCH >= NP ? (c < NP ? c + 1 : NP) : ((c + 1) * NP) / NCH);
+      // ... and LDS stores of tile kt + 1 (from the other stage, pieces in the last chunks; on the last trip a copy of the last
+      // tile, never multiplied)
+      store_tiles(na, nb, buf ^ 1, kt + 1, NCH >= NP ? (c >= NCH - NP ? c - (NCH - NP) : NP) : (c * NP) / NCH,
+                  NCH >= NP ? (c >= NCH - NP ? c - (NCH - NP) + 1 : NP) : ((c + 1) * NP) / NCH);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();  // LDS only: the register prefetch stages stay in flight
     __builtin_amdgcn_sched_barrier(0);
     // ---- second half; the next tile's first half arrives meanwhile
-    read_half(af_lo, bf_lo, buf ^ 1, 0);
-    mfma_half(af_hi, bf_hi);
 #pragma unroll
-    for (int q = 0; q < HS * FM * FN; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+    for (int c = 0; c < NCH; ++c) {
+      const int s = c / (FM * FN), i = (c / FN) % FM, j = c % FN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_hi[s][i], bf_hi[s][j], acc[i][j], 0, 0, 0);
+      if (c % (FM * FN) == 0) read_kstep(af_lo, bf_lo, buf ^ 1, 0, s);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   };
   if (kt0 < kt1) {  // (an empty K range -- more splits than k-tiles -- leaves the accumulators at zero)
     load_tiles(ra0, rb0, kt0);
