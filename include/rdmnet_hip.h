@@ -543,6 +543,8 @@ int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float
  * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  In the lab build
  * (make lab), with RDM_LOCKSTEP_STATS in the environment, rdm_lockstep_stats_dump prints launches and records per kernel.    */
 void rdm_lockstep_stats(long long* out, int reset);
+/* Self-test of the lock-step scheduler on scripted stand-in launches (no GPU needed; tests/test_lockstep.py, lockstep.cpp). */
+int rdm_lockstep_selftest(int n_ctx, const int* script, int len, int* log, int cap, int* rcs);
 void rdm_lockstep_stats_dump(void);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <dlfcn.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -18,6 +19,18 @@ namespace {
 
 enum class State { Ready, Launch, Align, Sync, Done };
 
+// (self-test, end of this file: the scheduler's actions on scripted stand-in launches are logged instead of issued)
+thread_local int* t_log = nullptr;
+thread_local int t_log_n = 0, t_log_cap = 0, t_waits = 0;
+void log_action(int code, int value) {
+  if (t_log_n + 2 <= t_log_cap) {
+    t_log[t_log_n] = code;
+    t_log[t_log_n + 1] = value;
+  }
+  t_log_n += 2;
+}
+const hipStream_t kSelfTestStream = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1));
+
 struct Context {
   ucontext_t uc;
   char* stack = nullptr;  // (the thread's cached stack k, below)
@@ -26,7 +39,10 @@ struct Context {
   int rc = 0;
   std::vector<std::pair<hipEvent_t, hipStream_t>> events;  // lockstep_event: waiting for the context's next launch
   void flush_events() {
-    for (auto& ev : events) (void)hipEventRecord(ev.first, ev.second);
+    for (auto& ev : events) {
+      if (ev.second == kSelfTestStream) log_action(4, static_cast<int>(reinterpret_cast<uintptr_t>(ev.first)));
+      else (void)hipEventRecord(ev.first, ev.second);
+    }
     events.clear();
   }
 };
@@ -61,7 +77,11 @@ inline long long now_ns() {
 void trampoline() {
   Group* g = g_group;
   Context& c = g->ctx[g->cur];
-  c.rc = g->fn(g->cur, g->user);
+  try {
+    c.rc = g->fn(g->cur, g->user);
+  } catch (...) {  // (an exception must not unwind through makecontext's frame: the run counts as failed)
+    c.rc = -2;
+  }
   c.state = State::Done;
   swapcontext(&c.uc, &g->main);
 }
@@ -181,6 +201,47 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
 }
 
 }  // namespace rdm
+
+// Self-test of the scheduler without a GPU (tests/test_lockstep.py): n contexts run scripted sequences of recorded launches of two
+// stand-in kernels, layer boundaries, deferred events and waits; every scheduler action is logged as (code, value):
+//   1 = kernel A issued for `value` contexts, 2 = kernel B issued for `value` contexts, 3 = the group waited (value = waits so far),
+//   4 = an event of context `value` was recorded.  script[k * len + i]: 1 / 2 = launch A / B, 3 = wait, 4 = layer boundary,
+//   5 = event, 0 = nothing.  Returns the number of log entries (or -1).
+namespace rdm {
+namespace {
+int fire_a(const rdm::LaunchRecord* const*, int n) { log_action(1, n); return 0; }
+int fire_b(const rdm::LaunchRecord* const*, int n) { log_action(2, n); return 0; }
+struct SelfTest { const int* script; int len; };
+int selftest_ctx(int k, void* user) {
+  const SelfTest& t = *static_cast<const SelfTest*>(user);
+  for (int i = 0; i < t.len; ++i) {
+    const int op = t.script[k * t.len + i];
+    if (op == 1 || op == 2) {
+      rdm::LaunchRecord rec{};
+      rec.fire = op == 1 ? fire_a : fire_b;
+      rec.grid = dim3(1);
+      rdm::lockstep_submit(rec);
+    } else if (op == 3) {
+      rdm::lockstep_sync();
+    } else if (op == 4) {
+      rdm::lockstep_align();
+    } else if (op == 5) {  // (a stand-in event: logged as 4, k when the scheduler records it)
+      rdm::lockstep_event(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(k)), kSelfTestStream);
+    }
+  }
+  return 100 + k;
+}
+int selftest_wait(hipStream_t, void*) { log_action(3, ++t_waits); return 0; }
+}  // namespace
+}  // namespace rdm
+extern "C" int rdm_lockstep_selftest(int n_ctx, const int* script, int len, int* log, int cap, int* rcs) {
+  using namespace rdm;
+  t_log = log; t_log_n = 0; t_log_cap = cap; t_waits = 0;
+  SelfTest t{script, len};
+  const int rc = lockstep_run(n_ctx, selftest_ctx, &t, nullptr, selftest_wait, nullptr, rcs);
+  t_log = nullptr;
+  return rc != 0 ? -1 : t_log_n / 2;
+}
 
 // Developer counters (tools/lockstep_lab.py): ns in lock-step runs, ns of them in host waits, waits, grouped launches, records, runs
 extern "C" void rdm_lockstep_stats_dump() {  // (RDM_LOCKSTEP_STATS=1: launches and records per kernel and dynamic LDS size)
