@@ -106,7 +106,10 @@ class Tester:
         it are still committed (pose lines, records) before the error is raised; .npz files of later pairs that had already
         finished on other workers may exist without a pose line."""
         # (tensors_of: the pipeline's workers collate several staged pairs with one sequence of launches, pipeline.PairPipeline.imap)
-        for rec in self.pipeline.imap(stager, self._work, tensors_of=lambda job: (job[1].contiguous(), job[2].contiguous())):
+        for i, rec in enumerate(self.pipeline.imap(stager, self._work, tensors_of=lambda job: (job[1].contiguous(), job[2].contiguous()))):
+            # a pair's time: from the moment its worker drew it to its result (in a lock-step group the pairs finish together, and
+            # `engine.run` in _work only picks the result up)
+            rec['ms'] = self.pipeline.last_stats['latency_ms'].get(i, rec['ms'])
             self._commit(rec)
             if log:
                 log('seq_id: {}, id0: {}, id1: {}, nCorr: {}'.format(rec['seq_id'], rec['ref_frame'], rec['src_frame'],
@@ -197,7 +200,7 @@ def main(argv=None):
                                        row[7:19].astype(np.float32))
         print(f'pairs: {allrec.shape[0]}, mean ms/pair: {allrec[:, 4].mean() if len(allrec) else 0:.2f}, '
               f'{allrec.shape[0] / max(t_run, 1e-9):.1f} pairs/s (rank 0 wall time {t_run:.2f} s: host scans -> staging -> '
-              f'{args.pairs_in_flight} pairs in flight -> poses and correspondences on the host)')
+              f'{tester.pipeline.n} streams x {tester.pipeline.lockstep} pair(s) per lock-step group in flight -> poses and correspondences on the host)')
         st = tester.pipeline.last_stats
         if st and st['jobs']:
             print('  worker time per pair (ms): drawing + staging the next pair {:.2f}, engine + outputs {:.2f}, waiting for the '
