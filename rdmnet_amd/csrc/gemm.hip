@@ -1018,7 +1018,8 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
       // (two k-tiles of register prefetch: -3 % over the path's shapes; four: no further gain -- what bounds these tiles
       // is the ~20 B/clk a CU draws from L2, see tools/tail_lab.hip, not the latency of one load)
       // (gathered / concatenated operands exist in the 32-deep instantiation only; its loads clamp k to K - 4)
-      if (k >= 48 || g.aidx) launch<64, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
+      static const bool bk16 = ::rdm::dev_knob("RDM_GEMM_BK16") != nullptr;  // developer knob (A/B): shallow k-tiles, twice the resident workgroups
+      if ((k >= 48 && !bk16) || g.aidx) launch<64, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
       else launch<64, 64, 2, 2, 16>(g, batches, trans_b, st);
       break;
     case T128x32:
