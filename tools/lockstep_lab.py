@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, streams = int(sys.argv[1]), int(sys.argv[2])
 n_pairs = int(sys.argv[3]) if len(sys.argv) > 3 else 192
 cfg = config.make_cfg()
+if os.environ.get('LS_SINKHORN_ITERS'):  # (experiment: how does the schedule respond to REMOVED work?)
+    cfg.model.num_sinkhorn_iterations = int(os.environ['LS_SINKHORN_ITERS'])
 state = weights.synthetic_state_dict(cfg, seed=0)
 pairs = synthetic.cached_pairs(8, os.path.join(ROOT, 'gpurun_out', 'bench_pairs'), os.path.join(ROOT, 'tests', 'golden', 'synthetic_pairs.npz'))
 dev = [(torch.from_numpy(r).cuda(), torch.from_numpy(s).cuda()) for r, s, _ in pairs]
