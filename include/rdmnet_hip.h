@@ -548,6 +548,10 @@ int rdm_lockstep_selftest(int n_ctx, const int* script, int len, int* log, int c
 void rdm_lockstep_stats_dump(void);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */
 /* Per-KPConv-layer HIP-event timing of the last run; get_profile returns the number of layers. */
+/* Re-allocates the engine's activation arena at `bytes`, growable (rdm_engine_config.arena_bytes != 0 fixes the size instead; the
+ * default is 3 GiB, doubled and the pair re-run when a pair exhausts it).  For callers that know their largest pair or lock-step
+ * group; the reference has no counterpart (torch's caching allocator).  Waits for the device; drops a collated batch.           */
+int rdm_engine_reserve(rdm_engine* e, size_t bytes);
 /* How rdm_engine_run waits for its stream at the size read-backs: sleep_us = 0 (default) uses hipStreamSynchronize,
  * which spins a host core per in-flight pair; sleep_us > 0 polls hipStreamQuery and sleeps that long in between (for
  * hosts whose CPU quota is smaller than ranks x pairs in flight). */

@@ -129,6 +129,7 @@ SIGNATURES = {
     'rdm_lockstep_stats': (None, [c_void, c_int]),
     'rdm_lockstep_stats_dump': (None, []),
     'rdm_lockstep_selftest': (c_int, [c_int, c_void, c_int, c_void, c_int, c_void]),
+    'rdm_engine_reserve': (c_int, [c_void, c_size]),
     'rdm_engine_set_wait': (c_int, [c_void, c_int]),
     'rdm_engine_set_pairs_in_flight': (c_int, [c_void, c_int]),
     'rdm_engine_set_overlap': (c_int, [c_void, c_int]),

@@ -916,6 +916,27 @@ extern "C" int rdm_engine_enable_profile(rdm_engine* e, int enable) {
   return RDM_OK;
 }
 
+// The activation arena re-allocated at `bytes` and left GROWABLE (rdm_engine_config.arena_bytes fixes the size instead): a caller
+// that knows its largest pair -- or the largest lock-step group it will collate on this engine -- sizes the arena once and never
+// meets the grow-and-rerun of the first large pair; a small value makes that path testable.  Any collated batch is dropped.
+extern "C" int rdm_engine_reserve(rdm_engine* e, size_t bytes) {
+  RDM_REQUIRE(e && bytes >= (size_t(1) << 20), "rdm_engine_reserve: at least 1 MiB");
+  RDM_HIP_CHECK(hipDeviceSynchronize());  // (runs of this engine may be in flight on any stream)
+  e->batch.clear();
+  e->arena_base = 0;
+  RDM_HIP_CHECK(hipFree(e->arena));
+  e->arena = nullptr;
+  e->arena_cap = bytes;
+  e->arena_fixed = false;
+  const hipError_t err = hipMalloc(reinterpret_cast<void**>(&e->arena), e->arena_cap);
+  if (err != hipSuccess) {
+    e->arena_cap = 0;
+    set_error("rdm_engine_reserve: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    return RDM_ERR_HIP;
+  }
+  return RDM_OK;
+}
+
 extern "C" int rdm_engine_set_wait(rdm_engine* e, int sleep_us) {
   RDM_REQUIRE(e && sleep_us >= 0, "rdm_engine_set_wait: bad arguments");
   e->wait_sleep_us = sleep_us;

@@ -137,6 +137,12 @@ class Engine:
         in flight (default), 2 = always.  Results are bit-identical in every mode; not used on the null stream."""
         _lib.check(self.L.rdm_engine_set_overlap(self._h, int(mode)), 'rdm_engine_set_overlap')
 
+    def reserve(self, arena_bytes):
+        """Re-allocates the activation arena at `arena_bytes`, growable (rdm_engine_reserve)."""
+        self._prepared = []
+        self._ran = None
+        _lib.check(self.L.rdm_engine_reserve(self._h, int(arena_bytes)), 'rdm_engine_reserve')
+
     def enable_profile(self, enable=True):
         _lib.check(self.L.rdm_engine_enable_profile(self._h, int(enable)), 'rdm_engine_enable_profile')
 

@@ -633,3 +633,29 @@ def test_lockstep_runs_give_every_pair_the_bits_of_its_own_run(ctx, golden_dir):
                 assert same(snapshot(engines[k], res[k]), want[i]), (collated, k)
         # an engine of a group runs alone again afterwards
         assert same(snapshot(engines[2], engines[2].run(*pairs[4])), want[4])
+
+
+def test_lockstep_pairs_that_exhaust_their_arenas_are_rerun_and_keep_their_bits(ctx, golden_dir):
+    """A pair of a lock-step group whose engine runs out of arena ends its run early (the others go on), is run again on its own with
+    a grown arena (as rdm_engine_run does) and returns the bits of its own run; the first engine also grows while it collates the
+    group.  Engines start with 160 MB (rdm_engine_reserve: growable), a 2 x 16 k-point pair needs several times that."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    pairs = [(torch.from_numpy(z['ref0']).cuda(), torch.from_numpy(z['src0']).cuda()), (torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()),
+             (torch.from_numpy(z['ref1']).cuda(), torch.from_numpy(z['src1']).cuda())]
+
+    def snapshot(e, res):
+        return (e.transform().copy(), [c.clone() for c in e.corr()], int(res.n_correspondences), [int(x) for x in res.level_sizes])
+    want = [snapshot(eng, eng.run(r, s)) for r, s in pairs]
+    for collated in (True, False):
+        engines = [engine.Engine(cfg, None, share_with=eng) for _ in range(3)]
+        for e in engines:
+            e.reserve(160 << 20)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(2):  # (the second group finds the arenas grown)
+                res = engine.Engine.run_lockstep(engines, pairs, collate_batched=collated)
+                for k in range(3):
+                    got = snapshot(engines[k], res[k])
+                    assert np.array_equal(got[0], want[k][0]) and all(torch.equal(a, b) for a, b in zip(got[1], want[k][1])) and got[2:] == want[k][2:], (collated, k)
+                assert all(int(r.arena_used) > (160 << 20) for r in res)  # (every engine had to grow)
