@@ -659,3 +659,30 @@ def test_lockstep_pairs_that_exhaust_their_arenas_are_rerun_and_keep_their_bits(
                     got = snapshot(engines[k], res[k])
                     assert np.array_equal(got[0], want[k][0]) and all(torch.equal(a, b) for a, b in zip(got[1], want[k][1])) and got[2:] == want[k][2:], (collated, k)
                 assert all(int(r.arena_used) > (160 << 20) for r in res)  # (every engine had to grow)
+
+
+@pytest.mark.parametrize('variant', ['bf16_attention', 'vote_off'])
+def test_lockstep_groups_of_the_configuration_variants_keep_their_bits(ctx, golden_dir, variant):
+    """BASELINE configs[3] (bf16 attention: another attention kernel instantiation in the grouped launches) and configs[4]'s
+    vote-off mode (another launch sequence): a lock-step group returns what rdm_engine_run returns for each pair."""
+    import copy
+    from rdmnet_amd import engine
+    cfg = copy.deepcopy(ctx['cfg'])
+    if variant == 'bf16_attention':
+        cfg.thdroformer.attention_bf16 = True
+    else:
+        cfg.Vote.inference_use_vote = False
+    first = engine.Engine(cfg, ctx['state'])
+    engines = [first] + [engine.Engine(cfg, None, share_with=first) for _ in range(2)]
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    pairs = [(torch.from_numpy(z['ref0']).cuda(), torch.from_numpy(z['src0']).cuda()), (torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()),
+             (torch.from_numpy(z['ref1']).cuda(), torch.from_numpy(z['src1']).cuda())]
+
+    def snapshot(e, res):
+        return (e.transform().copy(), [c.clone() for c in e.corr()], int(res.n_correspondences), int(res.n_ref_nodes), int(res.n_src_nodes))
+    want = [snapshot(engines[2], engines[2].run(r, s)) for r, s in pairs]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        res = engine.Engine.run_lockstep(engines, pairs)
+        for k in range(3):
+            got = snapshot(engines[k], res[k])
+            assert np.array_equal(got[0], want[k][0]) and all(torch.equal(a, b) for a, b in zip(got[1], want[k][1])) and got[2:] == want[k][2:], k
