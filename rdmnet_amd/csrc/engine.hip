@@ -1269,7 +1269,9 @@ extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, 
     ~PadGuard() { rdm::gemm_set_lds_pad(0); }
   } pad_guard(0u);  // (no GEMM residency cap: a grouped launch is wide enough to want all four workgroups per CU -- 633 against 627 pairs/s at 4 x 4)
   // the collates of all pairs as one launch sequence on engines[0] (exact, tests/test_engine_gpu.py), then the forwards in lock step
-  const bool collated = collate_batched != 0 && n_pairs > 1 && !engines[0]->keep_taps;
+  bool any_taps = false;  // (an engine that keeps its stage tensors builds the reference's full tables: it collates its own pair)
+  for (int k = 0; k < n_pairs; ++k) any_taps |= engines[k]->keep_taps;
+  const bool collated = collate_batched != 0 && n_pairs > 1 && !any_taps;
   if (collated) ENG_CHECK(rdm_engine_collate_batch(engines[0], n_pairs, ref_points, n_ref, src_points, n_src, stream));
   LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, collated};
   int rcs[kGroupMax] = {};
