@@ -61,6 +61,11 @@ struct GemmArgs {
 #else
 #define GEMM_STAMP(k) do { } while (0)
 #endif
+#ifdef RDM_GEMM_TIMING  // (wide form: stamps of workgroup (0,0,0), wavefront 0; per-tile stamps for the first 128 k-tiles)
+#define GEMM_WIDE_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (k) < 392) g.clk[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_WIDE_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.f ? v : 0.f;
@@ -435,6 +440,307 @@ template <int BM, int BN, int WM, int WN, int BK, bool TRANS_B, int PF, bool CAT
 // (64-row / 128 x 32 tiles: four workgroups per CU = four wavefronts per SIMD, 128 registers each)
 __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : 1)) void gemm_kernel(GemmArgs g) { gemm_kernel_body<BM, BN, WM, WN, BK, TRANS_B, PF, CAT>(blockIdx, gridDim, g); }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The WIDE form (round 6): 128 x 128 x 32 tiles for the products with a weight matrix as B ([K, N] row-major), 2 x 2
+// wavefronts of 64 x 64 each -- FOUR 32x32 accumulators per wavefront -- and two workgroups per CU.  What it changes against
+// gemm_kernel<64, 64> (docs/EXPERIMENTS.md 5g: matrix pipe 65 % busy where the vendor library's kernel has 93 %):
+//   * operand bytes per flop through the CU's L2 port and through LDS are halved (a 64 x 64 tile at the fp32 MFMA rate asks
+//     for 16 B/clk per CU from L2, about what a CU gets);
+//   * the LDS images are stored in FRAGMENT order -- plane (k-group g of 8 k, k parity lk) x row x 4 k-steps -- so that the
+//     operands of FOUR k-steps of a 32-row fragment are ONE ds_read_b128 (16 per k-tile and wavefront instead of 64
+//     ds_read_b32 for the same 64 x 64 of output), written as ds_write_b64 (A: a row's float4 of k holds two k-steps of either
+//     parity) and ds_write_b128 (B: a thread loads the four rows k = 8 g + lk + 2 j of its four columns and stores one
+//     column's four k-steps per instruction); XOR swizzles (A: row ^ 2 g, B: n ^ ((n >> 3) & 3)) keep reads and writes
+//     conflict-free in their lane groups (MI355X_MICROARCH.md, LDS);
+//   * ONE workgroup barrier per k-tile (64 MFMAs per wavefront), placed before the tile's last k-group: the next tile's first
+//     operands are read behind it, under that group's MFMAs.
+// Same arithmetic as the 64 x 64 tile on every output element: v_mfma_f32_32x32x2_f32 over the k pairs (2 s, 2 s + 1) in
+// ascending s, the same split-K ranges (multiples of 32), the same epilogue -- and GroupNorm column partials per 64-ROW block
+// in the 64 x 64 tile's combination order (16 row classes mod 16, fp64), so the products that move to this form keep their bits.
+template <bool CAT>
+__device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g) {
+  (void)gridDim;
+  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int IMG = 8 * BM * 4;  // floats of one operand image: 8 planes x 128 rows x 4 k-steps (BM == BN)
+  constexpr int CR = 64, LDC_S = BN + 4, TPR = BN / 4, RPI = 256 / TPR;  // epilogue: 64 rows per pass, 32 threads per row, 8 rows per iteration
+  static_assert(BM == BN && RPI == 8 && CR * LDC_S * 4 <= 4 * IMG * 4 && 16 * BN * 2 * 8 <= 4 * IMG * 4, "wide tile layout");
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG * 4];  // 64 KB: [A0 | A1 | B0 | B1], then the epilogue's staging
+  float* As = reinterpret_cast<float*>(smem);
+  float* Bs = As + 2 * IMG;
+  float (*Cs)[LDC_S] = reinterpret_cast<float (*)[LDC_S]>(smem);
+  double (*stat_red)[BN][2] = reinterpret_cast<double (*)[BN][2]>(smem);  // [16 row classes][BN][sum, sum of squares]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lk = lane >> 5, li = lane & 31;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+  const float* A = g.A + (CAT ? 0 : batch * g.sa);
+  const float* B = g.B + batch * g.sb;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int per = (ktiles + g.splits - 1) / g.splits;
+  const int kt0 = split * per, kt1 = min(ktiles, kt0 + per);
+  GEMM_WIDE_STAMP(0);
+
+  // ---- staging: a thread moves 4 float4 of A (rows a_row + 32 i, k = 4 a_q ..) and 4 float4 of B (rows 8 b_g + b_lk + 2 j, columns b_n4 ..)
+  const int a_q = tid & 7, a_row = tid >> 3;
+  const int b_p = tid >> 5, b_n4 = (tid & 31) * 4;
+  const int b_k = 8 * (b_p >> 1) + (b_p & 1);
+  float4 ra[4], rb[4];
+  const float* a_ptr[4];
+  long long cat_row[CAT ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + a_row + 32 * i, g.M - 1);
+    if constexpr (CAT) {
+      const long long id = g.aidx[static_cast<long long>(row) * g.ldi];
+      cat_row[i] = (id >= 0 && id < g.n_coarse) ? id : -1;
+      a_ptr[i] = A + max(cat_row[i], 0ll) * g.lda;
+    } else {
+      a_ptr[i] = A + static_cast<long long>(row) * g.lda;
+    }
+  }
+  const float* a2_ptr[CAT ? 4 : 1];
+  if constexpr (CAT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a2_ptr[i] = g.A2 + static_cast<long long>(min(m0 + a_row + 32 * i, g.M - 1)) * g.lda2;
+  }
+  const float* b_ptr = B + min(n0 + b_n4, g.ldb - 4);
+  const bool b_col_ok = n0 + b_n4 < g.ldb;
+  auto masked = [](const float4& v, bool ok) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+  auto load_a = [&](int kt, int i) {
+    const int k0 = min(kt, kt1 - 1) * BK;  // past the end: the last tile again (stored to a buffer nobody multiplies)
+    if constexpr (CAT) {  // (a k-tile lies on one side of c1: workgroup-uniform)
+      ra[i] = *reinterpret_cast<const float4*>(k0 < g.c1 ? a_ptr[i] + (k0 + 4 * a_q) : a2_ptr[i] + min(k0 - g.c1 + 4 * a_q, g.K - g.c1 - 4));
+    } else {
+      ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + min(k0 + 4 * a_q, g.K - 4));
+    }
+  };
+  auto load_b = [&](int kt, int j) {
+    const int k0 = min(kt, kt1 - 1) * BK;
+    rb[j] = *reinterpret_cast<const float4*>(b_ptr + static_cast<long long>(min(k0 + b_k + 2 * j, g.K - 1)) * g.ldb);
+  };
+  // A piece i: the float4 (k = 4 q .. 4 q + 3 of one row) is k-steps j, j + 1 of parity 0 (x, z) and of parity 1 (y, w) of k-group q / 2
+  auto store_a = [&](int buf, int kt, int i) {
+    const int k0 = min(kt, kt1 - 1) * BK;
+    const int row = a_row + 32 * i;
+    bool ok = m0 + row < g.M && k0 + 4 * a_q < g.K;
+    if constexpr (CAT) ok = ok && (k0 >= g.c1 || cat_row[i] >= 0);
+    const float4 v = masked(ra[i], ok);
+    const int g2 = a_q & 6;  // 2 x the k-group
+    float* p = As + buf * IMG + ((g2 * BM + (row ^ g2)) * 4 + (a_q & 1) * 2);
+    *reinterpret_cast<float2*>(p) = make_float2(v.x, v.z);
+    *reinterpret_cast<float2*>(p + BM * 4) = make_float2(v.y, v.w);
+  };
+  // B piece c: column b_n4 + c of the thread's four rows = that column's four k-steps of plane b_p
+  auto store_b = [&](int buf, int kt, int c) {
+    const int k0 = min(kt, kt1 - 1) * BK;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4& r = rb[j];
+      const float e = c == 0 ? r.x : (c == 1 ? r.y : (c == 2 ? r.z : r.w));
+      v[j] = (b_col_ok && k0 + b_k + 2 * j < g.K) ? e : 0.f;
+    }
+    const int n = b_n4 + c;
+    *reinterpret_cast<float4*>(Bs + buf * IMG + (b_p * BN + (n ^ ((n >> 3) & 3))) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+
+  const bool partial = g.splits > 1;
+  const int c4 = (tid % TPR) * 4, rsub = tid / TPR;
+  const int gcol = n0 + c4;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!partial && g.bias)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = gcol + e < g.N ? g.bias[gcol + e] : 0.f;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment reads: k-group gq of buffer buf -> four k-steps of the two A and the two B fragments of this wavefront
+  int a_frag[2], b_frag[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_frag[i] = wm * 64 + i * 32 + li;
+    const int n = wn * 64 + i * 32 + li;
+    b_frag[i] = n ^ ((n >> 3) & 3);
+  }
+  float af[2][2][4], bf[2][2][4];  // [register set][fragment][k-step]
+  auto read_group = [&](int set, int buf, int gq) {
+    const float* ab = As + buf * IMG + (2 * gq + lk) * BM * 4;
+    const float* bb = Bs + buf * IMG + (2 * gq + lk) * BN * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 t = *reinterpret_cast<const float4*>(ab + ((a_frag[i] ^ (2 * gq)) * 4));
+      af[set][i][0] = t.x; af[set][i][1] = t.y; af[set][i][2] = t.z; af[set][i][3] = t.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 t = *reinterpret_cast<const float4*>(bb + b_frag[j] * 4);
+      bf[set][j][0] = t.x; bf[set][j][1] = t.y; bf[set][j][2] = t.z; bf[set][j][3] = t.w;
+    }
+  };
+  // One k-group = 16 MFMAs (4 k-steps x 2 x 2 fragments; every accumulator takes its k-steps in ascending order), written as
+  // chunks of one MFMA + one piece of the tile's other work, fenced by scheduling barriers (a wavefront issues in order:
+  // everything else has to stand BETWEEN the MFMAs to run in their shadows -- gemm_kernel_body).
+  auto group = [&](int set, auto&& piece) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int t = c >> 2, i = (c >> 1) & 1, j = c & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][t], bf[set][j][t], acc[i][j], 0, 0, 0);
+      piece(c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#ifndef GW_ABLATE
+#define GW_ABLATE 0  // tools/gemm_wide_lab.hip: 1 = no barrier in the loop, 2 = no global loads, 4 = no LDS stores (timing probes, wrong results)
+#endif
+  auto tile = [&](int kt, int buf) {
+    GEMM_WIDE_STAMP(8 + (kt - kt0));
+    // group 0: operands in set 0; group 1's arrive; tile kt + 1 goes from the register stage into the other buffer
+    group(0, [&](int c) {
+      if (c == 0) read_group(1, buf, 1);
+      if (!(GW_ABLATE & 4)) {
+        if (c >= 1 && c <= 4) store_a(buf ^ 1, kt + 1, c - 1);
+        if (c >= 5 && c <= 8) store_b(buf ^ 1, kt + 1, c - 5);
+      }
+    });
+    // group 1: group 2's operands arrive; tile kt + 2 is requested from global memory
+    group(1, [&](int c) {
+      if (c == 0) read_group(0, buf, 2);
+      if (!(GW_ABLATE & 2)) {
+        if (c >= 1 && c <= 4) load_a(kt + 2, c - 1);
+        if (c >= 5 && c <= 8) load_b(kt + 2, c - 5);
+      }
+    });
+    group(0, [&](int c) {
+      if (c == 0) read_group(1, buf, 3);
+    });
+    GEMM_WIDE_STAMP(136 + (kt - kt0));
+    if (!(GW_ABLATE & 1)) lds_barrier();  // every wavefront has read this tile (its last operands are in registers) and written the next one
+    GEMM_WIDE_STAMP(264 + (kt - kt0));
+    __builtin_amdgcn_sched_barrier(0);
+    group(1, [&](int c) {
+      if (c == 0) read_group(0, buf ^ 1, 0);
+    });
+  };
+  if (kt0 < kt1) {  // (an empty K range -- more splits than k-tiles -- leaves the accumulators at zero)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(kt0, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_b(kt0, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_a(0, kt0, i);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) store_b(0, kt0, c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(kt0 + 1, i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_b(kt0 + 1, j);
+  }
+  lds_barrier();
+  GEMM_WIDE_STAMP(1);
+  if (kt0 < kt1) {
+    read_group(0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) tile(kt, (kt - kt0) & 1);
+  }
+  lds_barrier();  // (the last tile's look-ahead reads are done: the staging tile may overwrite the images)
+  GEMM_WIDE_STAMP(2);
+
+  // ---- epilogue: two passes of 64 rows through LDS into row-major float4 stores; GroupNorm partials per 64-row block
+  const bool stats = g.stats != nullptr && !partial;
+  const bool has_rd = !partial && g.rowdiv != nullptr;
+  const int act = g.act;
+  float* C = partial ? g.part + static_cast<long long>(blockIdx.z) * g.M * g.N : g.C + batch * g.sc;
+  const int ldc = partial ? g.N : g.ldc;
+  const bool vec_ok = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (m0 + pass * CR >= g.M) break;  // (workgroup-uniform: a 64-row block past the last row -- the 64 x 64 grid has no such block)
+    float rdv[CR / RPI];
+#pragma unroll
+    for (int it = 0; it < CR / RPI; ++it) rdv[it] = has_rd ? g.rowdiv[min(m0 + pass * CR + it * RPI + rsub, g.M - 1)] : 1.f;
+    if (wm == pass) {  // wavefront-uniform: the two wavefront rows own one pass each
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Cs[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wn * 64 + j * 32 + li] = acc[i][j][r];
+    }
+    lds_barrier();
+    // row class of the 64 x 64 tile's epilogue: its thread rsub16 = row % 16 sums the rows rsub16, rsub16 + 16, .. in that order
+    double cs[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, css[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int it = 0; it < CR / RPI; ++it) {
+      const int lrow = it * RPI + rsub;
+      const int row = m0 + pass * CR + lrow;
+      if (row < g.M && gcol < g.N) {
+        const float4 t = *reinterpret_cast<const float4*>(&Cs[lrow][c4]);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        if (has_rd) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / rdv[it];
+        }
+        if (!partial) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = v[e] + bv[e];
+            const float neg = act == 2 ? 0.1f * u : 0.f;
+            v[e] = (act != 0 && !(u > 0.f)) ? neg : u;
+          }
+        }
+        float* dst = C + static_cast<long long>(row) * ldc + gcol;
+        if (vec_ok && gcol + 3 < g.N) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gcol + e < g.N) dst[e] = v[e];
+        }
+        if (stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cs[it & 1][e] += v[e];
+            css[it & 1][e] += static_cast<double>(v[e]) * v[e];
+          }
+        }
+      }
+    }
+    lds_barrier();  // Cs is rewritten by the statistics exchange / the next pass
+    if (stats) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          stat_red[par * RPI + rsub][c4 + e][0] = cs[par][e];
+          stat_red[par * RPI + rsub][c4 + e][1] = css[par][e];
+        }
+      lds_barrier();
+      if (tid < BN && n0 + tid < g.N) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          a += stat_red[w][tid][0];
+          b += stat_red[w][tid][1];
+        }
+        const long long blk = static_cast<long long>(blockIdx.y) * 2 + pass;
+        g.stats[(blk * 2 + 0) * g.N + n0 + tid] = a;
+        g.stats[(blk * 2 + 1) * g.N + n0 + tid] = b;
+      }
+      lds_barrier();
+    }
+  }
+  GEMM_WIDE_STAMP(3);
+}
+template <bool CAT>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) { gemm_wide_body<CAT>(blockIdx, gridDim, g); }
 
 // Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
 // one workgroup = ONE 32 x 32 output tile, its four wavefronts split K four ways, operands go straight
@@ -870,6 +1176,13 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
     ::rdm::launch<gemm_kernel_body<BM, BN, WM, WN, BK, false, PF>, gemm_kernel<BM, BN, WM, WN, BK, false, PF>, 256, (BM * BN <= 64 * 64 ? 4 : 1)>(grid, pad, st, g);
 }
 
+// the wide form (gemm_wide_kernel): B = weights [K, N], one product or a batch with strides, optionally the decoder's virtual A
+void launch_wide(const GemmArgs& g, int batches, hipStream_t st) {
+  dim3 grid(ceil_div(g.N, 128), ceil_div(g.M, 128), batches * g.splits);
+  if (g.aidx) ::rdm::launch<gemm_wide_body<true>, gemm_wide_kernel<true>, 256, 2>(grid, 0, st, g);
+  else ::rdm::launch<gemm_wide_body<false>, gemm_wide_kernel<false>, 256, 2>(grid, 0, st, g);
+}
+
 }  // namespace
 
 // Residency of the tiled GEMM for the calling thread's launches: `bytes` of unused dynamic LDS per workgroup.  A 64 x 64 tile
@@ -978,7 +1291,19 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     exp_tile = 0;
     if (g.bidx) best_s = 1, force_splits = 0;  // (256 batches fill the chip; the zero-tile shortcut writes C directly)
   }
+  // The wide form takes the 64 x 64 tile's products (same split factor, same 64-row statistics blocks: the same bits) when the
+  // output is at least `wide_min_n` columns wide and has enough rows to be worth 128-row tiles.
+  static const int wide_min_m = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_WIDE_MIN_M"); return v ? atoi(v) : 256; }();
+  static const int wide_min_n = [] { const char* v = ::rdm::dev_knob("RDM_GEMM_WIDE_MIN_N"); return v ? atoi(v) : 128; }();
+  // Measured (round 6, docs/EXPERIMENTS.md 5h): bit-identical, half the LDS instructions and no bank conflicts, 94 % of the MFMA rate
+  // per k-tile with two workgroups per CU -- and no faster than the 64 x 64 tile, alone or in the lock-step schedule (639-641 against
+  // 638-643 pairs/s): off unless the lab build asks for it (RDM_GEMM_WIDE=1).
+  static const bool wide_off = ::rdm::dev_knob("RDM_GEMM_WIDE") == nullptr;
+  static const bool wide_force = ::rdm::dev_knob("RDM_GEMM_WIDE_FORCE") != nullptr;  // developer knob (probes): whatever tile the model chose
+  if (wide_force && !trans_b && !g.bidx && exp_tile == 0) tile = T64;
+  const bool wide = !wide_off && tile == T64 && exp_tile == 0 && !trans_b && !g.bidx && m >= wide_min_m && n >= wide_min_n;
   int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
+  if (wide) { bm = 128; bn = 128; }
   if (exp_tile == 4) { bm = 128; bn = 64; }
   if (exp_tile == 5) { bm = 64; bn = 128; }
   if (exp_tile == 6) { bm = 128; bn = 128; }
@@ -996,14 +1321,16 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
     if (batches == 1 && g.N % 4 == 0) reduce_stats = g.stats;
     g.stats = nullptr;
   }
-  if (stat_blocks)
-    *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, bm))
+  if (stat_blocks)  // (the wide form writes the 64 x 64 tile's 64-row blocks)
+    *stat_blocks = g.stats ? static_cast<int>(ceil_div<long long>(m, wide ? 64 : bm))
                            : (reduce_stats ? static_cast<int>(ceil_div<long long>(m, stat_rows_per_block(n))) : 0);
   g_last_plan[0] = bm; g_last_plan[1] = bn; g_last_plan[3] = g.splits;
-  g_last_plan[2] = tile == T128 ? 16 : ((tile == T64 ? (k >= 48 || g.aidx) : k >= 32) ? 32 : 16);
+  g_last_plan[2] = wide ? 32 : (tile == T128 ? 16 : ((tile == T64 ? (k >= 48 || g.aidx) : k >= 32) ? 32 : 16));
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   RDM_DUP_LOOP("gemm") {
+  if (wide) launch_wide(g, batches, st);
+  else
 #ifdef RDM_DEV_KNOBS  // the experimental tiles exist in the lab build only (RDM_GEMM_TUNE=4..7, RDM_GEMM_BIG)
   if (exp_tile == 4) launch<128, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
   else if (exp_tile == 5) launch<64, 128, 2, 2, 32, 2>(g, batches, trans_b, st);
