@@ -6,7 +6,8 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
  *     unless the function's comment says so;
  *   - `ws`/`ws_bytes` is caller-owned scratch (query the size with the matching *_workspace_bytes);
- *     the library never allocates or frees caller memory and keeps no global state (re-entrant);
+ *     the library never allocates or frees caller memory and keeps no global state (re-entrant) -- the diagnostic
+ *     counters of the lock-step scheduler (rdm_lockstep_stats*, marked DIAGNOSTIC below) are the one exception;
  *   - return value: 0 = ok, <0 = error (see rdm_last_error(), thread-local);
  *   - data-dependent overflows on the device are reported through a caller-provided int32 `status`
  *     word (device memory, must be zero before the call; non-zero afterwards = RDM_ERR_CAPACITY).
@@ -539,11 +540,18 @@ int rdm_engine_forward_batched(rdm_engine* e, int k, rdm_engine_result* result_h
 int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
                             const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
                             int collate_batched, void* stream);
-/* Developer counters of the lock-step scheduler (tools/lockstep_lab.py): out[0..5] = ns spent in lock-step runs, ns of them in
+/* rdm_engine_forward of `n_pairs` (1 .. 8) callers' data_dicts on as many engines in lock step (round 6): the drop-in operator
+ * API -- model(data_dict), experiments/model_infer.py:109-354 -- for several pairs on one stream; with rdm_engine_keep_taps every
+ * engine holds the stage tensors of ITS pair afterwards (rdm_engine_export per engine).  Every pair: the bits of
+ * rdm_engine_forward on it alone.                                                                                            */
+int rdm_engine_forward_lockstep(rdm_engine* const* engines, int n_pairs, const rdm_data_dict* const* data,
+                                rdm_engine_result* const* results, void* stream);
+/* DIAGNOSTIC, process-global (not part of the stateless compute ABI): developer counters of the lock-step scheduler
+ * (tools/lockstep_lab.py): out[0..5] = ns spent in lock-step runs, ns of them in
  * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  In the lab build
  * (make lab), with RDM_LOCKSTEP_STATS in the environment, rdm_lockstep_stats_dump prints launches and records per kernel.    */
 void rdm_lockstep_stats(long long* out, int reset);
-/* Self-test of the lock-step scheduler on scripted stand-in launches (no GPU needed; tests/test_lockstep.py, lockstep.cpp). */
+/* DIAGNOSTIC: self-test of the lock-step scheduler on scripted stand-in launches (no GPU needed; tests/test_lockstep.py). */
 int rdm_lockstep_selftest(int n_ctx, const int* script, int len, int* log, int cap, int* rcs);
 void rdm_lockstep_stats_dump(void);
 /* Stage intermediates by name (test/inspection aid): enable before a run, query after it. */

@@ -40,7 +40,16 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// Set by rdm::launch (lockstep.h) when the grouped launch that carried the calling context's record failed: the error text is the
+// grouped launch's; the context's next launch_status() reports it (contexts of a lock-step group share their host thread, but a
+// context calls launch_status right after its launch returns, before any other context runs).
+inline thread_local bool t_launch_failed = false;
+
 inline int launch_status(const char* what) {
+  if (t_launch_failed) {
+    t_launch_failed = false;
+    return RDM_ERR_HIP;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("launch of %s failed: %s", what, hipGetErrorString(e));

@@ -1220,11 +1220,16 @@ struct LockstepJob {
   rdm_engine_result* const* results;
   void* stream;
   bool collated;  // the pyramids of all pairs lie in engines[0]'s arena (rdm_engine_collate_batch)
+  const rdm_data_dict* const* dds;  // rdm_engine_forward_lockstep: the callers' data_dicts (the forwards alone), else null
 };
 int lockstep_pair(int k, void* user) {
   const LockstepJob& j = *static_cast<const LockstepJob*>(user);
   rdm_engine* e = j.engines[k];
   e->arena_exhausted = false;
+  if (j.dds) {
+    const rdm_data_dict* dd = j.dds[k];
+    return engine_run_once(e, nullptr, dd->n_ref[0], nullptr, dd->n_points[0] - dd->n_ref[0], dd, j.results[k], j.stream);
+  }
   if (j.collated) {  // (engines 1.. read the pyramid in engines[0]'s arena and keep their activations in their own)
     if (k > 0) {
       e->batch.clear();
@@ -1273,12 +1278,16 @@ extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, 
   for (int k = 0; k < n_pairs; ++k) any_taps |= engines[k]->keep_taps;
   const bool collated = collate_batched != 0 && n_pairs > 1 && !any_taps;
   if (collated) ENG_CHECK(rdm_engine_collate_batch(engines[0], n_pairs, ref_points, n_ref, src_points, n_src, stream));
-  LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, collated};
+  LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, collated, nullptr};
   int rcs[kGroupMax] = {};
   const int wrc = lockstep_run(n_pairs, lockstep_pair, &job, static_cast<hipStream_t>(stream), lockstep_wait, engines[0], rcs);
   if (wrc == -1) {
     set_error("rdm_engine_run_lockstep: called from inside a lock-step group (a host thread runs one group at a time)");
     return RDM_ERR_ARG;
+  }
+  if (wrc == -3) {
+    set_error("rdm_engine_run_lockstep: no memory for the context stacks");
+    return RDM_ERR_HIP;
   }
   if (wrc != 0) return wrc;  // (the group's host wait failed: the error text is the wait's)
   // a pair that exhausted its arena runs again on its own: rdm_engine_run grows the arena (engines[0] last: that rewrites the
@@ -1286,6 +1295,59 @@ extern "C" int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, 
   for (int k = n_pairs - 1; k >= 0; --k) {
     if (rcs[k] == RDM_ERR_WORKSPACE && engines[k]->arena_exhausted && !engines[k]->arena_fixed)
       rcs[k] = engine_run_growing(engines[k], ref_points[k], n_ref[k], src_points[k], n_src[k], nullptr, results[k], stream);
+  }
+  for (int k = 0; k < n_pairs; ++k)
+    if (rcs[k] != RDM_OK) return rcs[k];
+  return RDM_OK;
+}
+
+// RDMNet.forward (model_infer.py:109-354) of n callers' data_dicts on n engines in lock step: rdm_engine_forward per pair, the
+// launches grouped as in rdm_engine_run_lockstep.  Every pair: the bits (and stage tensors, with rdm_engine_keep_taps) of
+// rdm_engine_forward on it alone.
+static int check_data_dict(const rdm_data_dict* dd, const char* who) {
+  for (int i = 0; i < 5; ++i) {
+    RDM_REQUIRE(dd->points[i] && dd->lengths[i] && dd->neighbors[i] && dd->n_points[i] > 1 && dd->n_ref[i] > 0 &&
+                    dd->n_ref[i] < dd->n_points[i] && dd->neighbors_width[i] > 0 && dd->neighbors_ld[i] >= dd->neighbors_width[i],
+                "%s: level %d of the data_dict is incomplete", who, i);
+    if (i < 4)
+      RDM_REQUIRE(dd->subsampling[i] && dd->upsampling[i] && dd->subsampling_width[i] > 0 && dd->upsampling_width[i] > 0 &&
+                      dd->subsampling_ld[i] >= dd->subsampling_width[i] && dd->upsampling_ld[i] >= dd->upsampling_width[i],
+                  "%s: level %d of the data_dict is incomplete", who, i);
+  }
+  RDM_REQUIRE(dd->features && dd->features_ld >= 1, "%s: features missing", who);
+  return RDM_OK;
+}
+
+extern "C" int rdm_engine_forward_lockstep(rdm_engine* const* engines, int n_pairs, const rdm_data_dict* const* data,
+                                           rdm_engine_result* const* results, void* stream) {
+  RDM_REQUIRE(engines && data && results, "rdm_engine_forward_lockstep: null pointer");
+  RDM_REQUIRE(n_pairs >= 1 && n_pairs <= kGroupMax, "rdm_engine_forward_lockstep: 1 .. %d pairs", kGroupMax);
+  for (int k = 0; k < n_pairs; ++k) {
+    RDM_REQUIRE(engines[k] && results[k] && data[k], "rdm_engine_forward_lockstep: pair %d is incomplete", k);
+    RDM_REQUIRE(engines[k]->finalized, "rdm_engine_forward_lockstep: engine %d is not finalized", k);
+    for (int j = 0; j < k; ++j) RDM_REQUIRE(engines[j] != engines[k], "rdm_engine_forward_lockstep: every pair needs an engine of its own");
+    if (int rc = check_data_dict(data[k], "rdm_engine_forward_lockstep")) return rc;
+  }
+  struct PadGuard {
+    explicit PadGuard(unsigned b) { rdm::gemm_set_lds_pad(b); }
+    ~PadGuard() { rdm::gemm_set_lds_pad(0); }
+  } pad_guard(0u);  // (as rdm_engine_run_lockstep)
+  LockstepJob job{engines, nullptr, nullptr, nullptr, nullptr, results, stream, false, data};
+  int rcs[kGroupMax] = {};
+  const int wrc = lockstep_run(n_pairs, lockstep_pair, &job, static_cast<hipStream_t>(stream), lockstep_wait, engines[0], rcs);
+  if (wrc == -1) {
+    set_error("rdm_engine_forward_lockstep: called from inside a lock-step group (a host thread runs one group at a time)");
+    return RDM_ERR_ARG;
+  }
+  if (wrc == -3) {
+    set_error("rdm_engine_forward_lockstep: no memory for the context stacks");
+    return RDM_ERR_HIP;
+  }
+  if (wrc != 0) return wrc;
+  for (int k = n_pairs - 1; k >= 0; --k) {  // a pair that exhausted its arena runs again on its own (the arena grows)
+    if (rcs[k] == RDM_ERR_WORKSPACE && engines[k]->arena_exhausted && !engines[k]->arena_fixed)
+      rcs[k] = engine_run_growing(engines[k], nullptr, data[k]->n_ref[0], nullptr, data[k]->n_points[0] - data[k]->n_ref[0], data[k],
+                                  results[k], stream);
   }
   for (int k = 0; k < n_pairs; ++k)
     if (rcs[k] != RDM_OK) return rcs[k];
@@ -1315,16 +1377,7 @@ extern "C" int rdm_engine_collate(rdm_engine* e, const float* ref_points, int64_
 extern "C" int rdm_engine_forward(rdm_engine* e, const rdm_data_dict* dd, rdm_engine_result* res, void* stream) {
   RDM_REQUIRE(e && dd && res, "rdm_engine_forward: null pointer");
   RDM_REQUIRE(e->finalized, "rdm_engine_forward: call rdm_engine_finalize first");
-  for (int i = 0; i < 5; ++i) {
-    RDM_REQUIRE(dd->points[i] && dd->lengths[i] && dd->neighbors[i] && dd->n_points[i] > 1 && dd->n_ref[i] > 0 &&
-                    dd->n_ref[i] < dd->n_points[i] && dd->neighbors_width[i] > 0 && dd->neighbors_ld[i] >= dd->neighbors_width[i],
-                "rdm_engine_forward: level %d of the data_dict is incomplete", i);
-    if (i < 4)
-      RDM_REQUIRE(dd->subsampling[i] && dd->upsampling[i] && dd->subsampling_width[i] > 0 && dd->upsampling_width[i] > 0 &&
-                      dd->subsampling_ld[i] >= dd->subsampling_width[i] && dd->upsampling_ld[i] >= dd->upsampling_width[i],
-                  "rdm_engine_forward: level %d of the data_dict is incomplete", i);
-  }
-  RDM_REQUIRE(dd->features && dd->features_ld >= 1, "rdm_engine_forward: features missing");
+  if (int rc = check_data_dict(dd, "rdm_engine_forward")) return rc;
   return engine_run_growing(e, nullptr, dd->n_ref[0], nullptr, dd->n_points[0] - dd->n_ref[0], dd, res, stream);
 }
 

@@ -1,7 +1,9 @@
 // Scheduler of the lock-step groups (lockstep.h): stackful contexts of the calling thread, recorded launches, grouped issue.
 #include "lockstep.h"
 
+#include <sys/mman.h>
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -31,12 +33,55 @@ void log_action(int code, int value) {
 }
 const hipStream_t kSelfTestStream = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(1));
 
+// ---- stackful contexts.  On x86-64 the switch is a dozen instructions of user-mode code (callee-saved registers, stack pointer,
+// MXCSR / x87 control word): glibc's swapcontext also saves and restores the signal mask -- two rt_sigprocmask system calls per
+// switch, ~1 000 switches per pair.  Other hosts use ucontext.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define RDM_CTX_ASM 1
+extern "C" void rdm_ctx_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl rdm_ctx_switch
+.type rdm_ctx_switch,@function
+rdm_ctx_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size rdm_ctx_switch,.-rdm_ctx_switch
+)");
+#else
+#define RDM_CTX_ASM 0
+#endif
+
 struct Context {
+#if RDM_CTX_ASM
+  void* sp = nullptr;
+#else
   ucontext_t uc;
+#endif
   char* stack = nullptr;  // (the thread's cached stack k, below)
   State state = State::Ready;
   LaunchRecord rec;
   int rc = 0;
+  int fire_rc = 0;        // what issuing this context's last recorded launch returned (launch_status of ITS launch)
   std::vector<std::pair<hipEvent_t, hipStream_t>> events;  // lockstep_event: waiting for the context's next launch
   void flush_events() {
     for (auto& ev : events) {
@@ -48,7 +93,11 @@ struct Context {
 };
 
 struct Group {
+#if RDM_CTX_ASM
+  void* main_sp = nullptr;
+#else
   ucontext_t main;
+#endif
   std::vector<Context> ctx;
   int cur = -1;
   int (*fn)(int, void*) = nullptr;
@@ -56,11 +105,26 @@ struct Group {
 };
 
 thread_local Group* g_group = nullptr;
-constexpr size_t kStackBytes = size_t(1) << 20;
-struct Stacks {  // a host thread's context stacks, kept between runs (a fresh zero-filled megabyte per pair and run costs more than the switches)
+// A pair's whole run executes on its context's stack -- engine_run_once and every HIP runtime call below it (first-launch code
+// object loading included): 8 MiB of address space each, committed lazily by the kernel, with an inaccessible guard page below
+// (an overflow faults instead of corrupting the heap; ADVICE r5: round 5 used a 1 MiB `new char[]`).
+constexpr size_t kStackBytes = size_t(8) << 20;
+struct Stacks {  // a host thread's context stacks, kept between runs (mapping and faulting them in per pair costs more than the switches)
   char* s[kGroupMax] = {};
+  size_t guard = 0;
+  char* get(int k) {
+    if (!s[k]) {
+      guard = static_cast<size_t>(sysconf(_SC_PAGESIZE));
+      void* p = mmap(nullptr, kStackBytes + guard, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_STACK, -1, 0);
+      if (p == MAP_FAILED) return nullptr;
+      (void)mprotect(p, guard, PROT_NONE);
+      s[k] = static_cast<char*>(p) + guard;
+    }
+    return s[k];
+  }
   ~Stacks() {
-    for (char* p : s) delete[] p;
+    for (char* p : s)
+      if (p) munmap(p - guard, kStackBytes + guard);
   }
 };
 thread_local Stacks g_stacks;
@@ -74,32 +138,80 @@ inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+void switch_to_scheduler(Group* g, Context& c) {
+#if RDM_CTX_ASM
+  rdm_ctx_switch(&c.sp, g->main_sp);
+#else
+  swapcontext(&c.uc, &g->main);
+#endif
+}
+void switch_to_context(Group* g, Context& c) {
+#if RDM_CTX_ASM
+  rdm_ctx_switch(&g->main_sp, c.sp);
+#else
+  swapcontext(&g->main, &c.uc);
+#endif
+}
+
 void trampoline() {
   Group* g = g_group;
   Context& c = g->ctx[g->cur];
   try {
     c.rc = g->fn(g->cur, g->user);
-  } catch (...) {  // (an exception must not unwind through makecontext's frame: the run counts as failed)
+  } catch (...) {  // (an exception must not unwind out of the context's first frame: the run counts as failed)
     c.rc = -2;
   }
   c.state = State::Done;
-  swapcontext(&c.uc, &g->main);
+  switch_to_scheduler(g, c);  // (never resumed)
+  abort();
 }
 
 void yield_to_scheduler(State s) {
   Group* g = g_group;
   Context& c = g->ctx[g->cur];
   c.state = s;
-  swapcontext(&c.uc, &g->main);
+  switch_to_scheduler(g, c);
+}
+
+// a fresh context on `stack`: its first switch-in enters trampoline()
+bool make_context(Group& g, Context& c, char* stack) {
+  if (!stack) return false;
+  c.stack = stack;
+#if RDM_CTX_ASM
+  (void)g;
+  // the frame rdm_ctx_switch pops: {mxcsr, x87 cw}, r15 r14 r13 r12 rbx rbp, return address = trampoline, then the (never used)
+  // return address of trampoline itself -- which leaves the stack pointer at 8 mod 16 on entry, as after a call
+  uintptr_t top = (reinterpret_cast<uintptr_t>(stack) + kStackBytes) & ~uintptr_t(15);
+  uint64_t* f = reinterpret_cast<uint64_t*>(top) - 9;
+  uint32_t mxcsr = 0;
+  uint16_t fpcw = 0;
+  asm volatile("stmxcsr %0" : "=m"(mxcsr));
+  asm volatile("fnstcw %0" : "=m"(fpcw));
+  f[0] = static_cast<uint64_t>(mxcsr) | (static_cast<uint64_t>(fpcw) << 32);
+  for (int i = 1; i <= 6; ++i) f[i] = 0;
+  f[7] = reinterpret_cast<uint64_t>(&trampoline);
+  f[8] = 0;
+  c.sp = f;
+#else
+  getcontext(&c.uc);
+  c.uc.uc_stack.ss_sp = c.stack;
+  c.uc.uc_stack.ss_size = kStackBytes;
+  c.uc.uc_link = &g.main;
+  makecontext(&c.uc, trampoline, 0);
+#endif
+  return true;
 }
 
 }  // namespace
 
 bool lockstep_active() { return g_group != nullptr && g_group->cur >= 0; }
 
-void lockstep_submit(const LaunchRecord& rec) {
-  g_group->ctx[g_group->cur].rec = rec;
+int lockstep_submit(const LaunchRecord& rec) {
+  Context& c = g_group->ctx[g_group->cur];
+  c.rec = rec;
+  c.fire_rc = 0;
   yield_to_scheduler(State::Launch);
+  return c.fire_rc;  // (the grouped launch that carried this record)
 }
 
 void lockstep_sync() { yield_to_scheduler(State::Sync); }
@@ -119,14 +231,10 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
   g.user = user;
   g_group = &g;
   for (int k = 0; k < n; ++k) {
-    Context& c = g.ctx[k];
-    if (!g_stacks.s[k]) g_stacks.s[k] = new char[kStackBytes];
-    c.stack = g_stacks.s[k];
-    getcontext(&c.uc);
-    c.uc.uc_stack.ss_sp = c.stack;
-    c.uc.uc_stack.ss_size = kStackBytes;
-    c.uc.uc_link = &g.main;
-    makecontext(&c.uc, trampoline, 0);
+    if (!make_context(g, g.ctx[k], g_stacks.get(k))) {
+      g_group = nullptr;
+      return -3;  // (no address space for a context stack)
+    }
   }
   int wait_rc = 0;
   const long long t_run = now_ns();
@@ -138,7 +246,7 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
       if (c.state != State::Ready) continue;
       any = true;
       g.cur = k;
-      swapcontext(&g.main, &c.uc);
+      switch_to_context(&g, c);
       g.cur = -1;
     }
     // issue what was recorded: the contexts that recorded the same kernel as one launch -- wherever they
@@ -155,7 +263,11 @@ int lockstep_run(int n, int (*fn)(int, void*), void* user, hipStream_t stream, i
         g.ctx[j].flush_events();
         g.ctx[j].state = State::Ready;
       }
-      g.ctx[k].rec.fire(recs, m);
+      const int frc = g.ctx[k].rec.fire(recs, m);
+      if (frc != 0)  // every context the launch carried learns that ITS launch failed
+        for (int j = k; j < n; ++j)
+          for (int q = 0; q < m; ++q)
+            if (recs[q] == &g.ctx[j].rec) g.ctx[j].fire_rc = frc;
       if (g_by_kernel_on) {
         std::lock_guard<std::mutex> lk(g_by_kernel_mu);
         auto& e = g_by_kernel[{reinterpret_cast<const void*>(g.ctx[k].rec.fire), g.ctx[k].rec.lds}];

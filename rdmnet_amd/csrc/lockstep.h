@@ -84,7 +84,7 @@ struct LaunchRecord {
 
 // The calling thread's lock-step group, if one is running (lockstep.cpp)
 bool lockstep_active();
-void lockstep_submit(const LaunchRecord& rec);  // records the launch of the running context and yields until it has been issued
+int lockstep_submit(const LaunchRecord& rec);   // records the launch of the running context and yields until it has been issued; returns what issuing it returned (0 = ok)
 void lockstep_sync();                           // parks the running context until the group's stream is idle
 // A layer boundary of the running context (no-op outside a group): parked until every context of the group that can still run has
 // reached a boundary or a wait.  Pairs of different sizes do not launch the same NUMBER of kernels per layer (a split-K product has
@@ -114,6 +114,11 @@ int fire_records(const LaunchRecord* const* recs, int n) {
     ArgPack<P...> a;
     std::memcpy(&a, recs[0]->args, sizeof(a));
     apply_host([&](auto... x) { hipLaunchKernelGGL(Kernel, recs[0]->grid, dim3(THREADS), recs[0]->lds, recs[0]->stream, x...); }, a);
+    const hipError_t lerr = hipGetLastError();
+    if (lerr != hipSuccess) {
+      set_error("launch (one record of a lock-step group) failed: %s", hipGetErrorString(lerr));
+      return RDM_ERR_HIP;
+    }
     return 0;
   }
   GroupArgs<P...> g;
@@ -131,12 +136,21 @@ int fire_records(const LaunchRecord* const* recs, int n) {
   }
   size_t lds = 0;  // (dynamic LDS is an upper bound of what a body uses: the group gets the largest request)
   for (int k = 0; k < n; ++k) lds = recs[k]->lds > lds ? recs[k]->lds : lds;
-  if (lds > 32768) {  // (more than 64 KB of LDS per workgroup needs the attribute on THIS instantiation, per device)
+  if (lds > 32768) {  // (dynamic + static LDS beyond 64 KB needs the attribute on THIS instantiation, per device: set from 32 KB of dynamic LDS up)
     static std::atomic<uint64_t> done{0};
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(grouped_kernel<Body, THREADS, MINW, P...>), 160 * 1024 - 4096, done);
+    const hipError_t err = set_max_dynamic_lds(reinterpret_cast<const void*>(grouped_kernel<Body, THREADS, MINW, P...>), 160 * 1024 - 4096, done);
+    if (err != hipSuccess) {
+      set_error("grouped launch: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(err));
+      return RDM_ERR_HIP;
+    }
   }
   hipLaunchKernelGGL((grouped_kernel<Body, THREADS, MINW, P...>), dim3(static_cast<unsigned>(g.first[n])), dim3(THREADS), lds,
                      recs[0]->stream, g);
+  const hipError_t lerr = hipGetLastError();  // (taken here: the contexts of the group would otherwise pick it up in resume order)
+  if (lerr != hipSuccess) {
+    set_error("grouped launch of %d records failed: %s", n, hipGetErrorString(lerr));
+    return RDM_ERR_HIP;
+  }
   return 0;
 }
 template <auto Body, auto Kernel, int THREADS, int MINW, class... P>
@@ -153,7 +167,7 @@ inline void launch_sig(Sig<P...>, dim3 grid, size_t lds, hipStream_t st, typenam
   rec.grid = grid; rec.lds = lds; rec.stream = st;
   const ArgPack<P...> pack = make_pack<P...>(a...);
   std::memcpy(rec.args, &pack, sizeof(pack));
-  lockstep_submit(rec);
+  if (lockstep_submit(rec) != 0) t_launch_failed = true;  // (launch_status of this context's caller reports it)
 }
 // The launch of a converted kernel: issued at once outside a lock-step group, recorded and grouped inside one.
 template <auto Body, auto Kernel, int THREADS, int MINW = 1, class... U>

@@ -114,6 +114,7 @@ class Engine:
                 _lib.check(self.L.rdm_engine_finalize(self._h), 'rdm_engine_finalize')
         self.result = EngineResult()
         self._export_cache = {}
+        self._ran, self._prepared = None, []
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -139,8 +140,7 @@ class Engine:
 
     def reserve(self, arena_bytes):
         """Re-allocates the activation arena at `arena_bytes`, growable (rdm_engine_reserve)."""
-        self._prepared = []
-        self._ran = None
+        self.clear_pending()
         _lib.check(self.L.rdm_engine_reserve(self._h, int(arena_bytes)), 'rdm_engine_reserve')
 
     def enable_profile(self, enable=True):
@@ -159,25 +159,42 @@ class Engine:
         return out
 
     def keep_taps(self, enable=True):
-        self._prepared = []
-        self._ran = None
+        self.clear_pending()
         _lib.check(self.L.rdm_engine_keep_taps(self._h, int(enable)), 'rdm_engine_keep_taps')
+
+    @staticmethod
+    def _held(ref, src):
+        """What a lock-step group / collated batch remembers of a pair's input tensors: the tensors themselves (kept alive, so
+        their addresses cannot be handed to another allocation meanwhile) and their version counters."""
+        return (ref, src, ref._version, src._version)
+
+    @staticmethod
+    def _is_held(held, ref, src):
+        """True if (ref, src) are the tensors `held` was made from, unchanged since: same object (or a view of the same
+        memory and extent) and the same version counter -- an in-place refill of the buffer bumps it (round 5
+        compared addresses and row counts only)."""
+        r, s, vr, vs = held
+        same = lambda a, b: a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride())
+        return same(r, ref) and same(s, src) and ref._version == vr and src._version == vs
+
+    def clear_pending(self):
+        """Forgets a lock-step result that was not picked up and the un-run pairs of a collated batch: the next `run` runs."""
+        self._ran = None
+        self._prepared = []
 
     def run(self, ref_points, src_points):
         """ref/src: float32 CUDA tensors [n,3] on this engine's device.  Returns the EngineResult (host)."""
         assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
         assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
         ran = getattr(self, '_ran', None)
-        if ran is not None:  # this pair has just run in a lock-step group (run_lockstep): its result is in place
+        if ran is not None:  # this pair has just run in a lock-step group (run_lockstep): its result is in place -- once
             self._ran = None
-            if (ran[0].data_ptr(), ran[0].shape[0], ran[1].data_ptr(), ran[1].shape[0]) == (
-                    ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(), src_points.shape[0]):
+            if self._is_held(ran, ref_points, src_points):
                 return self.result
         prepared = getattr(self, '_prepared', None)
         if prepared:  # the next pair of a collated batch (collate_batch): its forward alone
-            k, r, s = prepared[0]
-            if (r.data_ptr(), r.shape[0], s.data_ptr(), s.shape[0]) == (ref_points.data_ptr(), ref_points.shape[0],
-                                                                       src_points.data_ptr(), src_points.shape[0]):
+            k, held = prepared[0]
+            if self._is_held(held, ref_points, src_points):
                 prepared.pop(0)
                 return self.forward_batched(k)
             self._prepared = []  # (another pair: the batch is dropped, rdm_engine_run collates this pair itself)
@@ -197,11 +214,10 @@ class Engine:
         P, I = ctypes.c_void_p * n, ctypes.c_int64 * n
         rp, sp = P(*[r.data_ptr() for r, _ in pairs]), P(*[s.data_ptr() for _, s in pairs])
         rn, sn = I(*[r.shape[0] for r, _ in pairs]), I(*[s.shape[0] for _, s in pairs])
-        self._prepared = []
-        self._ran = None
+        self.clear_pending()
         _lib.check(self.L.rdm_engine_collate_batch(self._h, n, rp, rn, sp, sn, _lib.stream_ptr()), 'rdm_engine_collate_batch')
-        # (the tensors are kept alive until their forwards have run; `run` recognises them by address and size)
-        self._prepared = [(k, r, s) for k, (r, s) in enumerate(pairs)]
+        # (the tensors are kept alive until their forwards have run; `run` recognises them by identity and version)
+        self._prepared = [(k, self._held(r, s)) for k, (r, s) in enumerate(pairs)]
         return n
 
     @staticmethod
@@ -215,16 +231,14 @@ class Engine:
             assert r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()
         P, I = ctypes.c_void_p * n, ctypes.c_int64 * n
         for e in engines[:n]:
-            e._prepared = []
+            e.clear_pending()
         hs = P(*[e._h.value if hasattr(e._h, 'value') else e._h for e in engines[:n]])
         rp, sp = P(*[r.data_ptr() for r, _ in pairs]), P(*[s.data_ptr() for _, s in pairs])
         rn, sn = I(*[r.shape[0] for r, _ in pairs]), I(*[s.shape[0] for _, s in pairs])
         res = P(*[ctypes.addressof(e.result) for e in engines[:n]])
-        for e in engines[:n]:
-            e._ran = None
         _lib.check(engines[0].L.rdm_engine_run_lockstep(hs, n, rp, rn, sp, sn, res, int(bool(collate_batched)), _lib.stream_ptr()), 'rdm_engine_run_lockstep')
-        for e, (r, s) in zip(engines, pairs):  # (`e.run(r, s)` right after this returns the result without running again)
-            e._ran = (r, s)
+        for e, (r, s) in zip(engines, pairs):  # (`e.run(r, s)` right after this returns the result without running again -- once)
+            e._ran = Engine._held(r, s)
         return [e.result for e in engines[:n]]
 
     def forward_batched(self, k):
@@ -243,8 +257,7 @@ class Engine:
         `_widths` / `_flags` (device-resident effective table widths, as rdmnet_amd.collate returns them)."""
         assert ref_points.is_cuda and ref_points.dtype == torch.float32 and ref_points.is_contiguous()
         assert src_points.is_cuda and src_points.dtype == torch.float32 and src_points.is_contiguous()
-        self._prepared = []
-        self._ran = None
+        self.clear_pending()
         _lib.check(self.L.rdm_engine_collate(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
                                              src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()), 'rdm_engine_collate')
         t = self.tensors(self._COLLATE_NAMES)
@@ -267,11 +280,9 @@ class Engine:
                 d['_widths'][('upsampling', i)] = flags[(4, 7, 10, 12)[i]]
         return d
 
-    def forward(self, data_dict):
-        """RDMNet.forward(data_dict) as ONE native call (rdm_engine_forward).  data_dict: the collate's dictionary
-        (rdmnet_amd.collate or the reference's registration_collate_fn_stack_mode moved to this engine's device).
-        Returns the EngineResult; stage tensors through tensor() when keep_taps is on.  One host synchronisation
-        here (the ref/src split of the five levels) besides the engine's own."""
+    def _pack_data_dict(self, data_dict):
+        """The reference's data_dict as an rdm_data_dict of device pointers: -> (DataDict, tensors that must outlive the call).
+        One host synchronisation (the ref/src split of the five levels) unless the dict carries `_level_ref_sizes`."""
         dev = self.device
         keep = []  # tensors that must outlive the call
 
@@ -326,11 +337,38 @@ class Engine:
                 getattr(d, key + '_ld')[i] = t.stride(0) if t.shape[0] > 1 else t.shape[1]
                 w = widths.get((key, i))
                 getattr(d, key + '_count')[i] = w.data_ptr() if w is not None else None
-        self._prepared = []
-        self._ran = None
+        return d, keep
+
+    def forward(self, data_dict):
+        """RDMNet.forward(data_dict) as ONE native call (rdm_engine_forward).  data_dict: the collate's dictionary
+        (rdmnet_amd.collate or the reference's registration_collate_fn_stack_mode moved to this engine's device).
+        Returns the EngineResult; stage tensors through tensor() when keep_taps is on.  One host synchronisation
+        here (the ref/src split of the five levels) besides the engine's own."""
+        d, keep = self._pack_data_dict(data_dict)
+        self.clear_pending()
         _lib.check(self.L.rdm_engine_forward(self._h, ctypes.byref(d), ctypes.byref(self.result), _lib.stream_ptr()),
                    'rdm_engine_forward')
+        del keep
         return self.result
+
+    @staticmethod
+    def forward_lockstep(engines, data_dicts):
+        """RDMNet.forward of len(data_dicts) callers' data_dicts on as many engines (sharing one copy of the weights) on the
+        CURRENT stream, in lock step (rdm_engine_forward_lockstep): the same kernel of all pairs goes out as one grouped
+        launch.  Every engine then holds its pair's result and -- with keep_taps -- its stage tensors, exactly as after
+        `forward` on that pair alone.  Returns the engines' EngineResults."""
+        n = len(data_dicts)
+        assert 1 <= n <= len(engines)
+        packed = [e._pack_data_dict(dd) for e, dd in zip(engines, data_dicts)]
+        P = ctypes.c_void_p * n
+        hs = P(*[e._h.value if hasattr(e._h, 'value') else e._h for e in engines[:n]])
+        dds = P(*[ctypes.addressof(d) for d, _ in packed])
+        res = P(*[ctypes.addressof(e.result) for e in engines[:n]])
+        for e in engines[:n]:
+            e.clear_pending()
+        _lib.check(engines[0].L.rdm_engine_forward_lockstep(hs, n, dds, res, _lib.stream_ptr()), 'rdm_engine_forward_lockstep')
+        del packed
+        return [e.result for e in engines[:n]]
 
     def transform(self):
         return np.ctypeslib.as_array(self.result.transform).reshape(4, 4).copy()

@@ -323,29 +323,37 @@ class RDMNet(torch.nn.Module):
         dict on first use and kept in an LRU cache of `max_engines` entries (>= 3 GiB of HBM each; release_engines() frees them;
         an evicted engine's arena is freed at once -- the shared weights are reference counted by the library and stay
         as long as any engine uses them)."""
+        return self._engine_group(1)[0]
+
+    def _engine_group(self, n):
+        """The current stream's engines for a lock-step group of n data_dicts (`forward([d0, d1, ...])`): the stream's engine of
+        `_engine()` first, further ones created on demand (they share its weights; one cache entry per stream whatever n)."""
         from . import engine as engine_mod
         if self.device is None:
             self.cuda()
         key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
         with self._engines_lock:
-            eng = self._engines.get(key)
-            if eng is not None and self._engines_state is self._state:
-                self._engines.move_to_end(key)
-                return eng
             if self._engines_state is not self._state:  # parameters changed (load_state_dict / .to()): rebuild lazily
                 self._engines.clear()
                 self._engines_state = self._state
+            group = self._engines.get(key)
+            if group is not None:
+                self._engines.move_to_end(key)
+                if len(group) >= n:
+                    return group[:n]
+            owner = next((g[0] for (d, _), g in self._engines.items() if d == self.device.index and g), None)
+        group = list(group or [])
         with torch.cuda.device(self.device):
-            with self._engines_lock:
-                owner = next((x for (d, _), x in self._engines.items() if d == self.device.index), None)
-            eng = engine_mod.Engine(self.cfg, self._state, device=self.device, share_with=owner)
-        eng.keep_taps(True)
-        eng.set_pairs_in_flight(self.pairs_in_flight)
+            while len(group) < n:
+                eng = engine_mod.Engine(self.cfg, self._state, device=self.device, share_with=owner or (group[0] if group else None))
+                eng.keep_taps(True)
+                eng.set_pairs_in_flight(self.pairs_in_flight)
+                group.append(eng)
         with self._engines_lock:
-            self._engines[key] = eng
+            self._engines[key] = group
             while len(self._engines) > max(int(self.max_engines), 1):
-                self._engines.popitem(last=False)  # the least recently used engine (its arena is freed with it)
-        return eng
+                self._engines.popitem(last=False)  # the least recently used stream's engines (their arenas are freed with them)
+        return group[:n]
 
     def release_engines(self):
         """Drops every cached native engine (and its HBM arena); the next forward builds the calling stream's anew."""
@@ -363,14 +371,38 @@ class RDMNet(torch.nn.Module):
 
         Two host paths over the same kernels, bit-identical results (tests/test_engine_gpu.py): by default the whole
         forward is ONE native call (rdm_engine_forward issues the ~550 launches from C++); with a `taps` dictionary
-        the per-op mirror below runs instead and records the stage tensors the parity tests compare."""
+        the per-op mirror below runs instead and records the stage tensors the parity tests compare.
+
+        A LIST of data_dicts (round 6; up to 8) runs as one lock-step group on the current stream
+        (rdm_engine_forward_lockstep: identical kernels of the pairs as one grouped launch) and returns the list of
+        output_dicts -- each `torch.equal` to what `forward(data_dict)` returns for it alone; `model(data_dict)` stays batch 1
+        like the reference's."""
+        if isinstance(data_dict, (list, tuple)):
+            if taps is not None or not self.fast_path:
+                return [self._forward_per_op(d, taps if taps is not None else None) for d in data_dict]
+            return self._forward_native_group(list(data_dict))
         if taps is None and self.fast_path:
             return self._forward_native(data_dict)
         return self._forward_per_op(data_dict, taps)
 
     def _forward_native(self, data_dict):
         eng = self._engine()
-        res = eng.forward(data_dict)
+        return self._output_dict(eng, eng.forward(data_dict), data_dict)
+
+    def _forward_native_group(self, data_dicts):
+        from . import engine as engine_mod
+        if len(data_dicts) == 0:
+            return []
+        if len(data_dicts) > 8:
+            raise ValueError('a lock-step group carries at most 8 data_dicts')
+        if len(data_dicts) == 1:
+            return [self._forward_native(data_dicts[0])]
+        group = self._engine_group(len(data_dicts))
+        results = engine_mod.Engine.forward_lockstep(group, data_dicts)
+        return [self._output_dict(e, r, d) for e, r, d in zip(group, results, data_dicts)]
+
+    def _output_dict(self, eng, res, data_dict):
+        """The reference's output_dict (model_infer.py:117-352) from the engine's result and stage tensors."""
         cfg, k_pts = self.cfg, self.cfg.model.num_points_in_patch
         n_c, n_f, n_0 = (int(res.level_ref_sizes[i]) for i in (4, 1, 0))
         m_r, B = int(res.n_ref_nodes), int(res.n_node_correspondences)

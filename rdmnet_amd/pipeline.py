@@ -15,7 +15,7 @@ else that has a stream of pairs:
   * optionally (`collate_batch` > 1, round 5) a worker draws several jobs at a time and collates them with ONE sequence of
     launches (`Engine.collate_batch`: the subsampling chains, grid builds and searches of a pair are launch-bound; the pairs of
     a batch share them), then runs the pairs' forwards one by one -- the same bits as the one-by-one schedule, +2-3 % pairs/s
-    for 2-4 x the per-pair latency: off by default,
+    for 2-4 x the per-pair latency: off by default (never with stage tensors kept: those runs build the reference's full tables),
   * lock step (`lockstep` = B > 1, round 5, the default with two or more streams): a worker owns B engines, draws B jobs and runs
     them as ONE lock-step group on its stream (`Engine.run_lockstep`): the B runs advance together on the worker's thread, the
     same kernel of the B pairs goes out as one grouped launch (B x the workgroups per launch, a quarter of the launches and host
@@ -237,7 +237,7 @@ class PairPipeline:
         self.n = max(1, int(pairs_in_flight))
         self.collate_batch = max(1, int(collate_batch))
         if lockstep is None:  # (injected engines: the caller's set is what runs)
-            lockstep = DEFAULT_LOCKSTEP if (engines is None and self.n >= 2 and not keep_taps) else 1
+            lockstep = DEFAULT_LOCKSTEP if (engines is None and self.n >= 2) else 1
         self.lockstep = max(1, min(8, int(lockstep)))  # (8 = what one grouped launch carries, lockstep.h)
         self.keep_taps = bool(keep_taps)
         self.stagger_s = max(0.0, float(stagger_ms)) * 1e-3
@@ -267,7 +267,7 @@ class PairPipeline:
         self.last_stats = None
 
     # ------------------------------------------------------------------ generic scheduler
-    def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None, prepare=None):
+    def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None, prepare=None, group_fn=None):
         """Yields fn(engine, job) for every job, in job order.  `window` bounds how far completion may run ahead of
         the consumer (default 4 x pairs_in_flight results held).
 
@@ -277,13 +277,18 @@ class PairPipeline:
         `engine.run` recognises the prepared pair and runs its forward alone; the results are the bits of the one-by-one
         schedule.  Towards the end of a sized job list the batches shrink so that the workers still finish together.
 
-        With `lockstep` > 1 (and tensors_of given, no stage tensors kept) the drawn jobs run as ONE lock-step group on the worker's
-        engines (`Engine.run_lockstep`) before fn is called on each (engine, job) -- `engine.run` then returns the result that is
-        already in place.  prepare(engine, job, i, n), if given, is called for job i of the n drawn before the group runs (per-run
-        engine settings, e.g. the layer profile)."""
+        With `lockstep` > 1 (and tensors_of given) the drawn jobs run as ONE lock-step group on the worker's engines
+        (`Engine.run_lockstep`) before fn is called on each (engine, job) -- `engine.run` then returns the result that is
+        already in place (engines that keep their stage tensors collate their own pair inside the group and hold its tensors
+        afterwards: round 6).  prepare(engine, job, i, n), if given, is called for job i of the n drawn before the group runs
+        (per-run engine settings, e.g. the layer profile).
+
+        group_fn(engines, jobs) -> [result per job], if given (instead of tensors_of; fn is then unused and may be None): the worker
+        hands the jobs it drew (up to `lockstep`) and as many of its engines to ONE call -- for callers that run the group
+        themselves (e.g. `Engine.forward_lockstep` / `model([data_dict, ...])` on data_dicts they collated)."""
         n = self.n
         window = max(n, 4 * n if window is None else int(window))
-        lockstep = self.lockstep > 1 and tensors_of is not None and not self.keep_taps
+        lockstep = self.lockstep > 1 and (tensors_of is not None or group_fn is not None)
         bmax = self.lockstep if lockstep else (self.collate_batch if (tensors_of is not None and not self.keep_taps) else 1)
         window = max(window, 2 * n * bmax)
         total = len(jobs) if hasattr(jobs, '__len__') else None
@@ -297,7 +302,7 @@ class PairPipeline:
         # `latency_ms`: per job (by slot), from the moment its worker had drawn it -- with its batch -- to its result: the batch's
         # collate and the forwards of the pairs before it in the batch included
         stats = self.last_stats = {'draw_s': 0.0, 'work_s': 0.0, 'window_s': 0.0, 'jobs': 0, 'wall_s': 0.0, 'workers': n,
-                                   'collate_batches': 0, 'lockstep_groups': 0, 'latency_ms': {}}
+                                   'collate_batches': 0, 'lockstep_groups': 0, 'group_sizes': {}, 'latency_ms': {}}
         t_begin = time.perf_counter()
 
         def draw():
@@ -346,22 +351,39 @@ class PairPipeline:
                             if lockstep and prepare is not None:
                                 for i, (_, job) in enumerate(got):
                                     prepare(self.groups[k][i], job, i, len(got))
-                            if lockstep and len(got) > 1:  # the pairs as one lock-step group; fn's engine.run finds each result in place
+                            outs = None
+                            if group_fn is not None:  # the caller runs the group itself
+                                outs = group_fn(self.groups[k][:len(got)] if lockstep else [self.engines[k]], [job for _, job in got])
+                                if len(outs) != len(got):
+                                    raise RuntimeError(f'group_fn returned {len(outs)} results for {len(got)} jobs')
+                                with cv:
+                                    stats['lockstep_groups'] += 1 if len(got) > 1 else 0
+                                    stats['group_sizes'][len(got)] = stats['group_sizes'].get(len(got), 0) + 1
+                            elif lockstep and len(got) > 1:  # the pairs as one lock-step group; fn's engine.run finds each result in place
                                 type(self.groups[k][0]).run_lockstep(self.groups[k], [tensors_of(job) for _, job in got])
                                 with cv:
                                     stats['lockstep_groups'] += 1
+                                    stats['group_sizes'][len(got)] = stats['group_sizes'].get(len(got), 0) + 1
                             elif len(got) > 1:  # one collate for all of them; fn's engine.run then finds each pair prepared
                                 self.engines[k].collate_batch([tensors_of(job) for _, job in got])
                                 with cv:
                                     stats['collate_batches'] += 1
-                            for i, (slot, job) in enumerate(got):
-                                out = fn(self.groups[k][i] if lockstep else self.engines[k], job)
-                                t_done = time.perf_counter()
+                            elif lockstep:
                                 with cv:
-                                    done[slot] = out
-                                    stats['jobs'] += 1
-                                    stats['latency_ms'][slot] = (t_done - t2) * 1e3
-                                    cv.notify_all()
+                                    stats['group_sizes'][1] = stats['group_sizes'].get(1, 0) + 1
+                            try:
+                                for i, (slot, job) in enumerate(got):
+                                    out = outs[i] if outs is not None else fn(self.groups[k][i] if lockstep else self.engines[k], job)
+                                    t_done = time.perf_counter()
+                                    with cv:
+                                        done[slot] = out
+                                        stats['jobs'] += 1
+                                        stats['latency_ms'][slot] = (t_done - t2) * 1e3
+                                        cv.notify_all()
+                            finally:  # a result nobody picked up (fn raised, or did not call engine.run) must not answer a later run
+                                for eng in (self.groups[k] if k < len(self.groups) else []):
+                                    if hasattr(eng, 'clear_pending'):
+                                        eng.clear_pending()
                             t3 = time.perf_counter()
                             with cv:
                                 stats['window_s'] += t1 - t0
@@ -408,8 +430,8 @@ class PairPipeline:
             torch.set_num_threads(torch_threads)
             stats['wall_s'] = time.perf_counter() - t_begin
 
-    def map(self, jobs, fn, stagger=True, tensors_of=None, prepare=None):
-        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30, tensors_of=tensors_of, prepare=prepare))
+    def map(self, jobs, fn, stagger=True, tensors_of=None, prepare=None, group_fn=None):
+        return list(self.imap(jobs, fn, stagger=stagger, window=1 << 30, tensors_of=tensors_of, prepare=prepare, group_fn=group_fn))
 
     # ------------------------------------------------------------------ the common case
     def run_pairs(self, pairs, stagger=True):

@@ -686,3 +686,106 @@ def test_lockstep_groups_of_the_configuration_variants_keep_their_bits(ctx, gold
         for k in range(3):
             got = snapshot(engines[k], res[k])
             assert np.array_equal(got[0], want[k][0]) and all(torch.equal(a, b) for a, b in zip(got[1], want[k][1])) and got[2:] == want[k][2:], k
+
+
+def test_model_on_a_list_of_data_dicts_runs_in_lock_step_and_equals_the_batch_1_calls(ctx, golden_dir):
+    """Round 6: the drop-in operator API in lock step -- `model([data_dict, ...])` =
+    rdm_engine_forward_lockstep on the callers' data_dicts (experiments/model_infer.py:109-354 per pair) -- returns, for every
+    pair, the 31-key output_dict of `model(data_dict)` on it alone, `torch.equal` key by key; pairs of very different sizes,
+    groups of 1 .. 4, data_dicts from the native collate and from the per-op collate (other table widths)."""
+    net, cfg, collate = ctx['net'], ctx['cfg'], ctx['collate']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    sc = np.load(os.path.join(golden_dir, 'scans.npz'))
+
+    def crop(p, r):
+        return p[np.linalg.norm(p[:, :2], axis=1) < r]
+    clouds = [(ctx['rp'], ctx['sp']), (z['ref0'], z['src0']), (crop(sc['s000000'], 14.0), crop(sc['s000004'], 12.0)), (z['ref1'], z['src1'])]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        dicts = [collate.collate_pair(r, s, cfg, exact_shapes=(k % 2 == 0)) for k, (r, s) in enumerate(clouds)]
+        want = [net(d) for d in dicts]
+        assert all(len(w) == 31 for w in want)
+        for lo, hi in ((0, 4), (1, 3), (2, 3), (0, 2)):
+            got = net(dicts[lo:hi])
+            assert isinstance(got, list) and len(got) == hi - lo
+            for k, g in zip(range(lo, hi), got):
+                assert set(g) == set(want[k])
+                for key in g:
+                    assert g[key].dtype == want[k][key].dtype and torch.equal(g[key], want[k][key]), (lo, hi, k, key)
+        # batch 1 stays batch 1 (a dict in, a dict out), and still equals itself after the groups
+        again = net(dicts[1])
+        assert isinstance(again, dict) and all(torch.equal(again[key], want[1][key]) for key in again)
+        with pytest.raises(ValueError):
+            net(dicts * 3)  # 12 > 8 per group
+
+
+def test_lockstep_groups_that_keep_their_stage_tensors_hold_every_pairs_tensors(ctx, golden_dir):
+    """Round 6: engines that keep their stage tensors run in lock step too (each collates its own pair
+    inside the group -- the reference's full tables): afterwards every engine holds the tensors of ITS pair, equal to those of a
+    run on the pair alone."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    pairs = [(torch.from_numpy(z['ref0']).cuda(), torch.from_numpy(z['src0']).cuda()), (torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()),
+             (torch.from_numpy(z['ref1']).cuda(), torch.from_numpy(z['src1']).cuda())]
+    names = ['points0', 'points4', 'neighbors0', 'upsampling0', 'subsampling3', 'encoder.encoder1_1', 'encoder.encoder4_3', 't1', 'decoder',
+             'vote_xyz', 'nms_mask', 'feats_c', 'matching_scores', 'ref_corr_points', 'corr_scores', 'estimated_transform']
+    want = []
+    for r, s in pairs:
+        eng.run(r, s)
+        want.append({n: eng.tensor(n).clone() for n in names})
+    engines = [engine.Engine(cfg, None, share_with=eng) for _ in range(3)]
+    for e in engines:
+        e.keep_taps(True)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for _ in range(2):
+            engine.Engine.run_lockstep(engines, pairs)
+            for k, e in enumerate(engines):
+                for n in names:
+                    assert torch.equal(e.tensor(n), want[k][n]), (k, n)
+
+
+def test_a_lock_step_result_answers_one_run_of_exactly_its_tensors(ctx, golden_dir):
+    """`Engine.run` right after a lock-step group returns the pair's result without running again -- but only for the
+    very tensors the group ran on, unchanged (same memory AND same version counter), and only once: an in-place refill of the same
+    buffers, another pair, or a second call run the pair."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    a = (torch.from_numpy(z['ref0']).cuda(), torch.from_numpy(z['src0']).cuda())
+    b = (torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda())
+    engines = [engine.Engine(cfg, None, share_with=eng) for _ in range(2)]
+    Ta = engines[0].run(*a) and engines[0].transform().copy()
+    Tb = engines[0].run(*b) and engines[0].transform().copy()
+    assert not np.array_equal(Ta, Tb)
+    calls = []
+    real = engines[0].L.rdm_engine_run
+
+    class Spy:  # counts the native runs of engines[0]
+        def __getattr__(self, name):
+            if name == 'rdm_engine_run':
+                return lambda *args: (calls.append(1), real(*args))[1]
+            return getattr(engines[0].__dict__['_L_real'], name)
+    engines[0].__dict__['_L_real'] = engines[0].L
+    engines[0].L = Spy()
+    try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            engine.Engine.run_lockstep(engines, [a, b])
+            engines[0].run(*a)                      # picked up: no native run
+            assert not calls and np.array_equal(engines[0].transform(), Ta)
+            engines[0].run(*a)                      # a second call runs
+            assert len(calls) == 1 and np.array_equal(engines[0].transform(), Ta)
+            # the same buffers refilled in place with another pair of the same size: must run, and return the new pair's pose
+            buf = (a[0].clone(), a[1].clone())
+            engine.Engine.run_lockstep(engines, [buf, b])
+            n0, n1 = min(len(buf[0]), len(b[0])), min(len(buf[1]), len(b[1]))
+            buf[0][:n0].copy_(b[0][:n0])
+            buf[1][:n1].copy_(b[1][:n1])
+            engines[0].run(*buf)
+            assert len(calls) == 2 and not np.array_equal(engines[0].transform(), Ta)
+            # clear_pending: what the pipeline does when a job's fn does not pick its result up
+            engine.Engine.run_lockstep(engines, [a, b])
+            engines[0].clear_pending()
+            engines[0].run(*a)
+            assert len(calls) == 3
+    finally:
+        engines[0].L = engines[0].__dict__.pop('_L_real')

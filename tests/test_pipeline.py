@@ -146,11 +146,26 @@ def test_workers_run_the_jobs_they_draw_as_one_lock_step_group():
         jobs = [int(r[1:]) for r, _ in pairs]
         assert ks[0] % 4 == 0 and ks == list(range(ks[0], ks[0] + 4)) and [by_job[j] for j in jobs] == ks[:len(jobs)]
     assert sorted(prepared) == sorted((by_job[j], j, by_job[j] % 4, n) for (_, j, _, n) in prepared) and len(prepared) == 26
-    # no tensors_of / stage tensors kept: one by one
+    # no tensors_of: one by one
     calls.clear()
     assert build(2, 4).map(range(5), lambda eng, job: eng.k) and not calls
+    # stage tensors kept (round 6): still lock-step groups -- the engines collate their own pairs inside the group
     p = build(2, 4, keep_taps=True)
-    assert p.map(range(5), lambda eng, job: job, tensors_of=lambda job: (job, job)) == list(range(5)) and not calls
+    assert p.map(range(9), lambda eng, job: job, tensors_of=lambda job: (job, job)) == list(range(9)) and calls
+    assert sum(sz * cnt for sz, cnt in p.last_stats['group_sizes'].items()) == 9
+    # group_fn: the caller runs the group itself, on the worker's engines, and returns one result per job
+    calls.clear()
+    groups = []
+
+    def group_fn(engines, jobs):
+        groups.append(([e.k for e in engines], list(jobs)))
+        return [j * 3 for j in jobs]
+    p = build(2, 4)
+    assert p.map(range(13), None, group_fn=group_fn) == [3 * j for j in range(13)] and not calls
+    assert sorted(j for _, js in groups for j in js) == list(range(13)) and max(len(js) for _, js in groups) == 4
+    assert all(ks == list(range(ks[0], ks[0] + len(js))) and ks[0] % 4 == 0 for ks, js in groups)
+    with pytest.raises(RuntimeError):  # one result per job
+        p.map(range(4), None, group_fn=lambda engines, jobs: [0])
     with pytest.raises(RuntimeError):  # 2 x 4 needs 8 engines when they are injected
         pipeline.PairPipeline(None, None, pairs_in_flight=2, engines=[Grouped(0)], lockstep=4)
 

@@ -87,6 +87,8 @@ def test_tester_with_pairs_in_flight_writes_the_serial_outputs(setup, tmp_path):
         recs = t.run(dataset.PairStager(dataset.ArrayPairDataset(pairs), depth=2 * n))
         outs[n] = (recs, open(d / '00_pose').read(), t.summary.lines())
         assert [r['ref_frame'] for r in recs] == [2 * i for i in range(len(pairs))]
+        if n == 4:  # round 6: runs that keep their stage tensors (the .npz outputs) are lock-step groups too
+            assert t.pipeline.lockstep == 4 and t.pipeline.keep_taps and t.pipeline.last_stats['lockstep_groups'] >= 1
     (r1, pose1, rep1), (r4, pose4, rep4) = outs[1], outs[4]
     assert pose1 == pose4 and rep1 == rep4
     for a, b in zip(r1, r4):
