@@ -546,6 +546,11 @@ int rdm_engine_run_lockstep(rdm_engine* const* engines, int n_pairs, const float
  * rdm_engine_forward on it alone.                                                                                            */
 int rdm_engine_forward_lockstep(rdm_engine* const* engines, int n_pairs, const rdm_data_dict* const* data,
                                 rdm_engine_result* const* results, void* stream);
+/* rdm_engine_collate of `n_pairs` (1 .. 8) pairs on as many engines in lock step: what the reference's DataLoader workers do pair
+ * by pair (registration_collate_fn_stack_mode, geotransformer/utils/data.py:139-192); every engine then holds its pair's
+ * pyramid and 13 tables as stage tensors, exactly as after rdm_engine_collate on the pair alone.                              */
+int rdm_engine_collate_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                                const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results, void* stream);
 /* DIAGNOSTIC, process-global (not part of the stateless compute ABI): developer counters of the lock-step scheduler
  * (tools/lockstep_lab.py): out[0..5] = ns spent in lock-step runs, ns of them in
  * host waits, waits, grouped launches, records carried, runs (summed over threads; reset != 0 clears them).  In the lab build

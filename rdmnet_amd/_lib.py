@@ -127,6 +127,7 @@ SIGNATURES = {
     'rdm_engine_forward_batched': (c_int, [c_void, c_int, c_void, c_void]),
     'rdm_engine_run_lockstep': (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_void]),
     'rdm_engine_forward_lockstep': (c_int, [c_void, c_int, c_void, c_void, c_void]),
+    'rdm_engine_collate_lockstep': (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
     'rdm_lockstep_stats': (None, [c_void, c_int]),
     'rdm_lockstep_stats_dump': (None, []),
     'rdm_lockstep_selftest': (c_int, [c_int, c_void, c_int, c_void, c_int, c_void]),

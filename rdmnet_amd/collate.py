@@ -120,6 +120,27 @@ def registration_collate_fn_stack_mode(data_dicts, num_stages, voxel_size, searc
     return collated
 
 
+def registration_collate_lockstep(items, num_stages, voxel_size, search_radius, neighbor_limits, engines, device=None):
+    """`registration_collate_fn_stack_mode([item], ..., engine=e)` for every item of `items` (one pair each) as ONE lock-step
+    group on `engines` (e.g. `model.engine_group(len(items))`; round 6): -> the list of collated data_dicts, each equal to the
+    one-pair call's.  What the reference's DataLoader workers do pair by pair on the CPU; `model(list_of_dicts)` runs the forwards
+    the same way."""
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    c = engines[0].cfg
+    if (num_stages != c.backbone.num_stages or abs(voxel_size - c.backbone.init_voxel_size) > 1e-9 or
+            abs(search_radius - c.backbone.init_radius) > 1e-9 or list(neighbor_limits) != list(c.neighbor_limits)):
+        raise ValueError('the engines were built for another pyramid configuration')
+    pairs = [(torch.as_tensor(d['ref_points']).to(device=device, dtype=torch.float32).contiguous(),
+              torch.as_tensor(d['src_points']).to(device=device, dtype=torch.float32).contiguous()) for d in items]
+    out = []
+    for d, tables in zip(items, type(engines[0]).collate_lockstep(engines, pairs)):
+        collated = {k: v for k, v in d.items() if k not in ('ref_points', 'src_points', 'ref_feats', 'src_feats')}
+        collated.update(tables)
+        collated['features'] = torch.cat([torch.as_tensor(d['ref_feats']), torch.as_tensor(d['src_feats'])], 0).to(device=device, dtype=torch.float32)
+        out.append(collated)
+    return out
+
+
 def collate_pair(ref_points, src_points, cfg, device=None, exact_shapes=False):
     """Convenience: two f32 [N,3] clouds -> data_dict ready for RDMNet.forward."""
     item = {'ref_points': ref_points, 'src_points': src_points,

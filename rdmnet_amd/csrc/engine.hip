@@ -1221,11 +1221,21 @@ struct LockstepJob {
   void* stream;
   bool collated;  // the pyramids of all pairs lie in engines[0]'s arena (rdm_engine_collate_batch)
   const rdm_data_dict* const* dds;  // rdm_engine_forward_lockstep: the callers' data_dicts (the forwards alone), else null
+  bool collate_only = false;        // rdm_engine_collate_lockstep: the collates alone (full tables kept as stage tensors)
 };
 int lockstep_pair(int k, void* user) {
   const LockstepJob& j = *static_cast<const LockstepJob*>(user);
   rdm_engine* e = j.engines[k];
   e->arena_exhausted = false;
+  if (j.collate_only) {  // (as rdm_engine_collate: the stage tensors of THIS call are kept whatever rdm_engine_keep_taps says)
+    const bool keep_before = e->keep_taps;
+    e->keep_taps = true;
+    e->collate_only = true;
+    const int rc = engine_run_once(e, j.refs[k], j.n_refs[k], j.srcs[k], j.n_srcs[k], nullptr, j.results[k], j.stream);
+    e->collate_only = false;
+    e->keep_taps = keep_before;
+    return rc;
+  }
   if (j.dds) {
     const rdm_data_dict* dd = j.dds[k];
     return engine_run_once(e, nullptr, dd->n_ref[0], nullptr, dd->n_points[0] - dd->n_ref[0], dd, j.results[k], j.stream);
@@ -1348,6 +1358,40 @@ extern "C" int rdm_engine_forward_lockstep(rdm_engine* const* engines, int n_pai
     if (rcs[k] == RDM_ERR_WORKSPACE && engines[k]->arena_exhausted && !engines[k]->arena_fixed)
       rcs[k] = engine_run_growing(engines[k], nullptr, data[k]->n_ref[0], nullptr, data[k]->n_points[0] - data[k]->n_ref[0], data[k],
                                   results[k], stream);
+  }
+  for (int k = 0; k < n_pairs; ++k)
+    if (rcs[k] != RDM_OK) return rcs[k];
+  return RDM_OK;
+}
+
+// The collates of n pairs (rdm_engine_collate each: full tables at the reference's widths, kept as stage tensors of the pair's
+// engine) on n engines in lock step.
+extern "C" int rdm_engine_collate_lockstep(rdm_engine* const* engines, int n_pairs, const float* const* ref_points, const int64_t* n_ref,
+                                           const float* const* src_points, const int64_t* n_src, rdm_engine_result* const* results,
+                                           void* stream) {
+  RDM_REQUIRE(engines && ref_points && n_ref && src_points && n_src && results, "rdm_engine_collate_lockstep: null pointer");
+  RDM_REQUIRE(n_pairs >= 1 && n_pairs <= kGroupMax, "rdm_engine_collate_lockstep: 1 .. %d pairs", kGroupMax);
+  for (int k = 0; k < n_pairs; ++k) {
+    RDM_REQUIRE(engines[k] && results[k] && ref_points[k] && src_points[k] && n_ref[k] > 0 && n_src[k] > 0,
+                "rdm_engine_collate_lockstep: pair %d is incomplete", k);
+    RDM_REQUIRE(engines[k]->finalized, "rdm_engine_collate_lockstep: engine %d is not finalized", k);
+    for (int j = 0; j < k; ++j) RDM_REQUIRE(engines[j] != engines[k], "rdm_engine_collate_lockstep: every pair needs an engine of its own");
+  }
+  LockstepJob job{engines, ref_points, n_ref, src_points, n_src, results, stream, false, nullptr, true};
+  int rcs[kGroupMax] = {};
+  const int wrc = lockstep_run(n_pairs, lockstep_pair, &job, static_cast<hipStream_t>(stream), lockstep_wait, engines[0], rcs);
+  if (wrc == -1) {
+    set_error("rdm_engine_collate_lockstep: called from inside a lock-step group (a host thread runs one group at a time)");
+    return RDM_ERR_ARG;
+  }
+  if (wrc == -3) {
+    set_error("rdm_engine_collate_lockstep: no memory for the context stacks");
+    return RDM_ERR_HIP;
+  }
+  if (wrc != 0) return wrc;
+  for (int k = n_pairs - 1; k >= 0; --k) {  // a pair that exhausted its arena collates again on its own (the arena grows)
+    if (rcs[k] == RDM_ERR_WORKSPACE && engines[k]->arena_exhausted && !engines[k]->arena_fixed)
+      rcs[k] = rdm_engine_collate(engines[k], ref_points[k], n_ref[k], src_points[k], n_src[k], results[k], stream);
   }
   for (int k = 0; k < n_pairs; ++k)
     if (rcs[k] != RDM_OK) return rcs[k];

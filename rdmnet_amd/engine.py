@@ -241,6 +241,14 @@ class Engine:
             e._ran = Engine._held(r, s)
         return [e.result for e in engines[:n]]
 
+    @staticmethod
+    def lockstep_stats(reset=False):
+        """DIAGNOSTIC, process-global counters of the lock-step scheduler (rdm_lockstep_stats): dict with ns in runs / waits,
+        waits, grouped launches, records carried, runs since the last reset."""
+        out = (ctypes.c_longlong * 8)()
+        _lib.lib().rdm_lockstep_stats(out, int(bool(reset)))
+        return {'run_ns': out[0], 'wait_ns': out[1], 'waits': out[2], 'launches': out[3], 'records': out[4], 'runs': out[5]}
+
     def forward_batched(self, k):
         """RDMNet.forward of pair k of the collated batch; returns the EngineResult (as `run`)."""
         _lib.check(self.L.rdm_engine_forward_batched(self._h, int(k), ctypes.byref(self.result), _lib.stream_ptr()),
@@ -249,6 +257,24 @@ class Engine:
 
     _COLLATE_NAMES = ([f'points{i}' for i in range(5)] + [f'lengths{i}' for i in range(5)] + [f'neighbors{i}' for i in range(5)] +
                       [f'subsampling{i}' for i in range(4)] + [f'upsampling{i}' for i in range(4)] + ['search_flags'])
+
+    @staticmethod
+    def collate_lockstep(engines, pairs):
+        """`collate` of len(pairs) pairs on as many engines on the CURRENT stream in lock step (rdm_engine_collate_lockstep):
+        -> the list of data_dicts, each equal to `collate` on the pair alone (fresh tensors, independent of the arenas)."""
+        n = len(pairs)
+        assert 1 <= n <= len(engines)
+        for r, s in pairs:
+            assert r.is_cuda and r.dtype == torch.float32 and r.is_contiguous() and s.is_cuda and s.dtype == torch.float32 and s.is_contiguous()
+        P, I = ctypes.c_void_p * n, ctypes.c_int64 * n
+        hs = P(*[e._h.value if hasattr(e._h, 'value') else e._h for e in engines[:n]])
+        rp, sp = P(*[r.data_ptr() for r, _ in pairs]), P(*[s.data_ptr() for _, s in pairs])
+        rn, sn = I(*[r.shape[0] for r, _ in pairs]), I(*[s.shape[0] for _, s in pairs])
+        res = P(*[ctypes.addressof(e.result) for e in engines[:n]])
+        for e in engines[:n]:
+            e.clear_pending()
+        _lib.check(engines[0].L.rdm_engine_collate_lockstep(hs, n, rp, rn, sp, sn, res, _lib.stream_ptr()), 'rdm_engine_collate_lockstep')
+        return [e._collated_dict(r.shape[0] + s.shape[0]) for e, (r, s) in zip(engines, pairs)]
 
     def collate(self, ref_points, src_points):
         """The reference's collate (registration_collate_fn_stack_mode, geotransformer/utils/data.py:139-192) for one pair as
@@ -260,12 +286,16 @@ class Engine:
         self.clear_pending()
         _lib.check(self.L.rdm_engine_collate(self._h, ref_points.data_ptr(), ref_points.shape[0], src_points.data_ptr(),
                                              src_points.shape[0], ctypes.byref(self.result), _lib.stream_ptr()), 'rdm_engine_collate')
+        return self._collated_dict(ref_points.shape[0] + src_points.shape[0])
+
+    def _collated_dict(self, n_points):
+        """The data_dict of the collate this engine has just run (its stage tensors exported with one batched copy)."""
         t = self.tensors(self._COLLATE_NAMES)
         flags = t['search_flags'][:13]
         d = {'points': [t[f'points{i}'] for i in range(5)], 'lengths': [t[f'lengths{i}'][0] for i in range(5)],
              'neighbors': [t[f'neighbors{i}'] for i in range(5)], 'subsampling': [t[f'subsampling{i}'] for i in range(4)],
              'upsampling': [t[f'upsampling{i}'] for i in range(4)], '_flags': flags, '_widths': {},
-             'features': torch.ones((ref_points.shape[0] + src_points.shape[0], 1), dtype=torch.float32, device=self.device),
+             'features': torch.ones((n_points, 1), dtype=torch.float32, device=self.device),
              'batch_size': 1,
              # host copies of the ref/src split of every level (the collate already read them back): forward() then
              # needs no synchronisation of its own before the native call

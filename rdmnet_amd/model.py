@@ -364,6 +364,11 @@ class RDMNet(torch.nn.Module):
         """The calling thread's native engine (for rdmnet_amd.collate.registration_collate_fn_stack_mode(..., engine=...))."""
         return self._engine()
 
+    def engine_group(self, n):
+        """The calling thread's engines for a lock-step group of n pairs (rdmnet_amd.collate.registration_collate_lockstep(...,
+        engines=...); `forward([d0, ...])` runs on the same ones)."""
+        return self._engine_group(n)
+
     @torch.no_grad()
     def forward(self, data_dict, taps=None):
         """experiments/model_infer.py:109-354 (inference).  `data_dict` as produced by the collate

@@ -36,12 +36,18 @@ def test_two_ranks_self_spawned_on_one_device():
     assert r['value'] > 0 and abs(r['value'] - 16 * pps / (r['ms_per_step'] * 8 / 1e3)) < 1e-6 * r['value']
     assert r['one_pair_per_call']['value'] > 0
     assert r['host_to_host']['value'] > 0 and r['drop_in_api']['value'] > 0 and r['cpu_baseline'] is None
+    # round 6: the contract-faithful side figures are measured in the headline's schedule, the one-pair-per-call ones beside them
+    for key in ('host_to_host', 'full_tables', 'drop_in_api'):
+        assert 'lock-step' in r[key]['schedule'] and r[key]['one_pair_per_call']['value'] > 0, key
+    # every pair of the two ranks' streams came from a different step; with 4 distinct clouds and 2 ranks a rank's steps cycle
+    # through all of them (the pair index does not depend on the world size alone)
+    assert r['config']['lockstep_records_per_launch'] > 1.5
 
 
 def test_single_rank_line_has_the_contract_fields():
     r = run_bench('--steps', '8', '--warmup', '2', '--ramp-seconds', '0', '--pairs', '2', '--host-steps', '4', '--full-steps', '4', '--api-steps', '8', '--no-cpu-baseline')
     assert r['config']['pairs_per_step'] >= 2 and r['config']['pairs_per_gpu'] == 8 * r['config']['pairs_per_step']
-    assert r['roofline']['one_pair_in_flight']['frac'] > 0 and r['roofline']['launches'] > 0
+    assert r['roofline']['group_alone']['frac'] > 0 and r['roofline']['single_pair_alone']['frac'] > 0 and r['roofline']['launches'] > 0
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in r, key
@@ -49,7 +55,18 @@ def test_single_rank_line_has_the_contract_fields():
     rf = r['roofline']
     assert rf['bound'] in ('hbm', 'mfma') and rf['peak'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
     # round-stable side keys of the roofline, the all-13-tables figure beside `value`, and the product scheduler
-    assert 'definition' in rf and rf['whole_layer']['one_pair_in_flight']['frac'] > 0 and rf['by_form'] and rf['real_slots']['fill'] <= 1
+    assert 'definition' in rf and rf['whole_layer']['group_alone']['frac'] > 0 and rf['by_form'] and rf['real_slots']['fill'] <= 1
+    # round 6: no fraction of the HBM peak above 1 in the moved-bytes variants, whatever the form; a launch of
+    # the timed region carries a FULL group's bytes
+    def fracs(d, path=''):
+        for k, v in (d.items() if isinstance(d, dict) else []):
+            if k == 'moved_bytes' and isinstance(v, dict):
+                yield path + '/' + k, v['frac']
+            else:
+                yield from fracs(v, path + '/' + k)
+    moved = list(fracs(rf))
+    assert moved and all(0 < f <= 1.0 for _, f in moved), moved
+    assert abs(rf['bytes_per_launch'] / rf['group_alone']['bytes_per_launch'] - 1) < 0.25
     assert r['full_tables']['value'] > 0 and r['config']['searches_per_pair'] == 12
     assert r['config']['scheduler'] == 'rdmnet_amd.pipeline.PairPipeline'
 

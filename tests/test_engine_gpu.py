@@ -789,3 +789,30 @@ def test_a_lock_step_result_answers_one_run_of_exactly_its_tensors(ctx, golden_d
             assert len(calls) == 3
     finally:
         engines[0].L = engines[0].__dict__.pop('_L_real')
+
+
+def test_collates_in_lock_step_equal_the_one_pair_collates(ctx, golden_dir):
+    """Round 6: `registration_collate_lockstep` = the drop-in collate of several pairs as one lock-step group
+    (rdm_engine_collate_lockstep): every data_dict equals `registration_collate_fn_stack_mode([item], ..., engine=e)` on its pair
+    -- all 13 tables at the reference's widths, points, lengths, status words -- and the dicts feed `model([...])`."""
+    net, cfg, collate = ctx['net'], ctx['cfg'], ctx['collate']
+    b = cfg.backbone
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    clouds = [(ctx['rp'], ctx['sp']), (z['ref0'], z['src0']), (z['ref1'], z['src1'])]
+    items = [{'ref_points': r, 'src_points': s, 'ref_feats': np.ones((len(r), 1), np.float32), 'src_feats': np.ones((len(s), 1), np.float32),
+              'seq_id': k} for k, (r, s) in enumerate(clouds)]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        want = [collate.registration_collate_fn_stack_mode([it], b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, engine=net.engine())
+                for it in items]
+        got = collate.registration_collate_lockstep(items, b.num_stages, b.init_voxel_size, b.init_radius, cfg.neighbor_limits, net.engine_group(3))
+        assert len(got) == 3
+        for g, w in zip(got, want):
+            assert g['seq_id'] == w['seq_id'] and g['_level_ref_sizes'] == w['_level_ref_sizes']
+            assert torch.equal(g['features'], w['features']) and torch.equal(g['_flags'], w['_flags'])
+            for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+                assert len(g[key]) == len(w[key]) and all(torch.equal(a, c) for a, c in zip(g[key], w[key])), key
+        for g in got:
+            g['testing'] = True
+        outs, ref = net(got), [net(w) for w in want]
+        for o, r in zip(outs, ref):
+            assert all(torch.equal(o[key], r[key]) for key in r)

@@ -146,6 +146,12 @@ def test_workers_run_the_jobs_they_draw_as_one_lock_step_group():
         jobs = [int(r[1:]) for r, _ in pairs]
         assert ks[0] % 4 == 0 and ks == list(range(ks[0], ks[0] + 4)) and [by_job[j] for j in jobs] == ks[:len(jobs)]
     assert sorted(prepared) == sorted((by_job[j], j, by_job[j] % 4, n) for (_, j, _, n) in prepared) and len(prepared) == 26
+    # the end of a sized job list: the remainder is split once, evenly (80 jobs on 4 x 4: twenty full groups, not 4 3 3 2 1 1 1 1)
+    p = build(4, 4)
+    assert p.map(range(80), fn, tensors_of=lambda job: (job, job)) == [2 * j for j in range(80)] and p.last_stats['group_sizes'] == {4: 20}
+    p = build(3, 4)
+    p.map(range(26), fn, tensors_of=lambda job: (job, job))
+    assert p.last_stats['group_sizes'] == {4: 5, 3: 2}, p.last_stats['group_sizes']
     # no tensors_of: one by one
     calls.clear()
     assert build(2, 4).map(range(5), lambda eng, job: eng.k) and not calls

@@ -5,7 +5,7 @@ run() {
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); r=d['roofline']; print('$1 ->', round(d['value'],1),'pairs/s p50',round(d['p50_ms_per_pair'],2), 'gather alone', round((r.get('one_pair_in_flight') or {}).get('frac',0),3))
+        d=json.loads(l); r=d['roofline']; print('$1 ->', round(d['value'],1),'pairs/s p50',round(d['p50_ms_per_pair'],2), 'gather alone', round((r.get('group_alone') or r.get('single_pair_alone') or {}).get('frac',0),3))
 "
 }
 for i in $(seq $N); do
