@@ -206,6 +206,9 @@ def main():
                          'pairs of a group go out as one grouped launch, their collates as one launch sequence; default:\n'
                          'rdmnet_amd.pipeline.DEFAULT_LOCKSTEP; 1 = one pair per engine call, the schedule of rounds 1-4).  A step is then\n'
                          'one group: --steps K times this many pairs.  Same results bit for bit.')
+    ap.add_argument('--arena-mb', type=int, default=0,
+                    help='activation arena of every engine in MiB (growable; 0 = the library default of 3 GiB per engine, 48 GiB for the\n'
+                         'default 4 streams x 4 engines): what several ranks sharing one device pass')
     ap.add_argument('--dry-run', action='store_true',
                     help='construct the communicator (RCCL for --dist-backend nccl), run the pre-flight -- the barrier, the ragged\n'
                          'record gather and the timing reduction of a real run on dummy records -- print one JSON line and exit\n'
@@ -357,7 +360,7 @@ def main():
     n_timed, n_warm = args.steps * pps, args.warmup * pps
     pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
                                  stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams,
-                                 collate_batch=collate_batch, lockstep=lockstep)
+                                 collate_batch=collate_batch, lockstep=lockstep, arena_bytes=(args.arena_mb << 20) if args.arena_mb > 0 else None)
     wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
     worker_of = {id(e): k for k, grp in enumerate(pipe.groups) for e in grp}
     for eng in engines:
@@ -864,6 +867,7 @@ def main():
                        'scheduler': 'rdmnet_amd.pipeline.PairPipeline', 'points_per_pair': n_points,
                        'pairs_per_step': pps, 'pairs_per_gpu': n_timed, 'pairs_in_flight_per_gpu': args.streams * lockstep,
                        'streams_per_gpu': args.streams, 'lockstep_pairs_per_stream': lockstep, 'collate_batch': collate_batch,
+                       'arena_mb_per_engine': args.arena_mb if args.arena_mb > 0 else 3072,
                        'lockstep_groups_by_size': {str(k): v for k, v in sorted(group_sizes.items())} if grouped else None,
                        'lockstep_records_per_launch': (ls['records'] / ls['launches'] if ls['launches'] else None) if grouped else None,
                        'host_path': args.path,

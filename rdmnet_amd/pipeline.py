@@ -228,7 +228,7 @@ class PairPipeline:
 
     def __init__(self, cfg, state, device=None, pairs_in_flight=DEFAULT_PAIRS_IN_FLIGHT, wait_us=None,
                  stagger_ms=DEFAULT_STAGGER_MS, keep_taps=False, local_world=None, engines=None, streams=None,
-                 collate_batch=DEFAULT_COLLATE_BATCH, lockstep=None):
+                 collate_batch=DEFAULT_COLLATE_BATCH, lockstep=None, arena_bytes=None):
         self._gpu = torch.cuda.is_available()
         if not self._gpu and engines is None:
             raise RuntimeError('rdmnet_amd.pipeline needs a GPU (no CPU fallback)')
@@ -259,7 +259,15 @@ class PairPipeline:
         self.groups = [self.engines[k * self.lockstep:(k + 1) * self.lockstep] for k in range(self.n)]
         spare = self.engines[want:]
         self.engines = [grp[0] for grp in self.groups] + spare  # (engines[k]: worker k's engine, as without lock step)
+        # HBM: an engine's activation arena defaults to 3 GiB (growable: a pair that exhausts it is re-run on a doubled one), so a
+        # pipeline of n x lockstep engines reserves 3 GiB x n x lockstep -- 48 GiB of the 288 at the default 4 x 4, whether or not a
+        # pair ever needs it (measured, tools/dbg/arena_probe.py: a 2 x 16 k-point pair bumps through 0.85-1.2 GiB of it).
+        # `arena_bytes` re-allocates every engine's arena at that size instead (still growable): what several ranks on one
+        # device, or a GPU with less memory, pass.
+        self.arena_bytes = None if arena_bytes is None else int(arena_bytes)
         for eng in [e for grp in self.groups for e in grp] + spare:
+            if self.arena_bytes is not None and hasattr(eng, 'reserve'):
+                eng.reserve(self.arena_bytes)
             eng.set_wait(self.wait_us)
             eng.set_pairs_in_flight(self.n * self.lockstep)
             eng.keep_taps(keep_taps)
