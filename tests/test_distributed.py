@@ -130,7 +130,7 @@ def test_module_is_wrappable_by_distributed_data_parallel():
     assert same and n_keys == n_keys_ddp == 497 and n_par == 497 - 14  # 14 kernel_points buffers
 
 
-@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+@pytest.mark.parametrize('launcher', ['self', 'torchrun', 'self8'])
 def test_bench_dry_run_exercises_the_multi_rank_half_without_a_gpu(launcher):
     """VERDICT r4 (next 6): `bench.py --gpus N --dry-run` builds the process group, runs the pre-flight -- barrier, ragged record
     gather, timing reduction: the calls every multi-rank run starts AND ends with -- and prints one line without running a
@@ -141,8 +141,9 @@ def test_bench_dry_run_exercises_the_multi_rank_half_without_a_gpu(launcher):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bench = os.path.join(root, 'bench.py')
-    tail = [bench, '--gpus', '2', '--dry-run', '--dist-backend', 'gloo']
-    if launcher == 'self':
+    world = 8 if launcher == 'self8' else 2  # (round 6: the driver's `--gpus 8` command line itself, eight ranks)
+    tail = [bench, '--gpus', str(world), '--dry-run', '--dist-backend', 'gloo']
+    if launcher.startswith('self'):
         cmd = [sys.executable] + tail
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
@@ -153,5 +154,5 @@ def test_bench_dry_run_exercises_the_multi_rank_half_without_a_gpu(launcher):
     lines = [json.loads(line) for line in p.stdout.splitlines() if line.startswith('{')]
     assert len(lines) == 1  # rank 0 alone prints
     d = lines[0]
-    assert d['dry_run'] and d['n_gpus'] == 2 and d['backend'] == 'gloo' and d['preflight']['ok']
+    assert d['dry_run'] and d['n_gpus'] == world and d['backend'] == 'gloo' and d['preflight']['ok']
     assert d['gpu_max_hw_queues'] == int(os.environ.get('GPU_MAX_HW_QUEUES', '8'))  # explicit in the ranks' environment
