@@ -47,7 +47,7 @@ from .engine import Engine
 DEFAULT_PAIRS_IN_FLIGHT = 4   # the 5th in-flight pair shares a hardware pipe with another one (docs/EXPERIMENTS.md 5b)
 DEFAULT_STAGGER_MS = 1.5
 # Pairs a worker collates with one sequence of launches (Engine.collate_batch) before it runs their forwards one by one.  Measured
-# (round 5, tools/ab_collate_batch.sh): 4 per batch +3 % pairs/s on a 20-pair run (505 against 490) and +1.5 % on a long one, 8 per
+# (round 5, profiles/r05_collate_batch_ab.txt): 4 per batch +3 % pairs/s on a 20-pair run (505 against 490) and +1.5 % on a long one, 8 per
 # batch +2.7 % -- for twice / four times the per-pair latency (13.9 / 32 ms against 7.3), and the KPConv kernels of the timed
 # region then share the GPU with more of the other pairs' wide kernels (their event-bracketed durations grow by a fifth).  Default:
 # every pair collates itself, the schedule of rounds 1-4; a throughput-only caller sets 4-8.
