@@ -143,6 +143,17 @@ int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const float* b, int6
              int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c, int64_t m,
              int64_t n, int64_t k, int batches, const float* bias, const float* rowdiv, int act,
              void* ws, size_t ws_bytes, void* stream);
+/* The same with the kernel form chosen by the caller (tests, A/B runs; also rdm_linear_group_norm_form, rdm_decoder_stage_form):
+ * form 0 = the library's choice; 1 / 2 = the products the dispatch model gives to its 64 x 64 tile (weights as B, no batched
+ * gathers) run on the WIDE form instead -- 128 x 128 x 32 tiles, fragment-ordered LDS images, one barrier per k-tile -- on
+ * v_mfma_f32_32x32x2_f32 (1) or v_mfma_f32_16x16x4_f32 (2).  Every form returns the same bits: an output element is one fp32 fma
+ * chain over ascending k inside the same split-K ranges whatever the tile or the MFMA shape (tools/mfma_order_probe.hip), and
+ * the GroupNorm partials keep their 64-row blocks and combination order (tests/test_ops_gpu.py; docs/EXPERIMENTS.md 5h for why
+ * the default stays the 64 x 64 tile).                                                                                        */
+int rdm_gemm_form(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,
+                  int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c, int64_t m,
+                  int64_t n, int64_t k, int batches, const float* bias, const float* rowdiv, int act,
+                  void* ws, size_t ws_bytes, int form, void* stream);
 /* The tile and split-K factor the dispatch model chose for the calling thread's last rdm_gemm / fused Linear call:
  * out4_host = {tile rows, tile columns, k-tile depth, split-K factor} (diagnostic: profiles/r03_gemm_shapes.md).  */
 int rdm_gemm_last_plan(int* out4_host);
@@ -246,6 +257,11 @@ int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w, int64_t l
                           const float* beta, float eps, const float* residual, int64_t ldr, int act, float* lin_out,
                           int64_t ld_lin, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
                           void* stream);
+int rdm_linear_group_norm_form(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                               const float* rowdiv, int64_t m, int64_t n, int64_t k, int groups, const float* gamma,
+                               const float* beta, float eps, const float* residual, int64_t ldr, int act, float* lin_out,
+                               int64_t ld_lin, float* y, int64_t ldy, uint8_t* positive, void* ws, size_t ws_bytes,
+                               int form, void* stream);  /* form: see rdm_gemm_form */
 /* rdm_patch_scores: the patch score matrices of the fine matching (experiments/model_infer.py:291-311: index_select of the
  * patch features + einsum('bnd,bmd->bnm') / sqrt(d)): scores[b, i, j] = <ref_feats[ref_idx[b, i]], src_feats[src_idx[b, j]]>
  * / rowdiv[i], ref_idx / src_idx [batch, side] int64 with the reference's padded gather (an index outside the tensor selects a
@@ -264,6 +280,10 @@ int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t c1, int64_t
                       const float* skip, int64_t c2, int64_t ld2, int64_t m, const float* w, int64_t ldw, const float* bias,
                       int64_t n, int groups, const float* gamma, const float* beta, float eps, int act, float* lin_out,
                       int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+int rdm_decoder_stage_form(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1, const int64_t* idx, int64_t ldi,
+                           const float* skip, int64_t c2, int64_t ld2, int64_t m, const float* w, int64_t ldw, const float* bias,
+                           int64_t n, int groups, const float* gamma, const float* beta, float eps, int act, float* lin_out,
+                           int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes, int form, void* stream);  /* form: see rdm_gemm_form */
 int rdm_layer_norm(const float* x, int64_t n, int64_t c, int64_t ldx, const float* residual,
                    int64_t ldr, const float* gamma, const float* beta, float eps, int act, float* y,
                    int64_t ldy, void* stream);

@@ -35,6 +35,8 @@ SIGNATURES = {
     'rdm_gemm_workspace_bytes': (c_size, [c_i64, c_i64, c_int]),
     'rdm_gemm': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_i64, c_i64, c_i64, c_i64,
                          c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_void]),
+    'rdm_gemm_form': (c_int, [c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_int, c_void, c_i64, c_i64, c_i64, c_i64,
+                              c_i64, c_int, c_void, c_void, c_int, c_void, c_size, c_int, c_void]),
     'rdm_gemm_last_plan': (c_int, [c_void]),
     'rdm_kpconv_gather': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_void, c_void, c_i64,
                                   c_i64, c_void, c_void, c_f32, c_void, c_i64, c_void, c_void]),
@@ -72,6 +74,10 @@ SIGNATURES = {
     'rdm_linear_group_norm_workspace_bytes': (c_size, [c_i64, c_i64]),
     'rdm_linear_group_norm': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void,
                                       c_f32, c_void, c_i64, c_int, c_void, c_i64, c_void, c_i64, c_void, c_void, c_size, c_void]),
+    'rdm_linear_group_norm_form': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_void, c_i64, c_i64, c_i64, c_int, c_void, c_void,
+                                           c_f32, c_void, c_i64, c_int, c_void, c_i64, c_void, c_i64, c_void, c_void, c_size, c_int, c_void]),
+    'rdm_decoder_stage_form': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void,
+                                       c_i64, c_int, c_void, c_void, c_f32, c_int, c_void, c_i64, c_void, c_i64, c_void, c_size, c_int, c_void]),
     'rdm_patch_scores': (c_int, [c_void, c_i64, c_i64, c_void, c_void, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void,
                                  c_void]),
     'rdm_decoder_stage_workspace_bytes': (c_size, [c_i64, c_i64, c_i64]),

@@ -16,6 +16,7 @@
 #include "../../include/rdmnet_hip.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "internal.h"
@@ -26,6 +27,7 @@ namespace {
 using namespace rdm;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   const float* A;
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : 1)) void gemm_kernel
 // Same arithmetic as the 64 x 64 tile on every output element: v_mfma_f32_32x32x2_f32 over the k pairs (2 s, 2 s + 1) in
 // ascending s, the same split-K ranges (multiples of 32), the same epilogue -- and GroupNorm column partials per 64-ROW block
 // in the 64 x 64 tile's combination order (16 row classes mod 16, fp64), so the products that move to this form keep their bits.
-template <bool CAT>
+template <bool CAT, bool MI16 = false>
 __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g) {
   (void)gridDim;
   constexpr int BM = 128, BN = 128, BK = 32;
@@ -473,7 +475,14 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int lk = lane >> 5, li = lane & 31;
+  // MI16: the same products on v_mfma_f32_16x16x4_f32 -- like 32x32x2 an fp32 fma chain over ascending k (tools/mfma_order_probe.hip: the
+  // two instructions and the fmaf chain agree bit for bit), with a quarter of the accumulator registers moved per flop
+  constexpr int NF = MI16 ? 4 : 2;    // fragments per wavefront and operand (16 or 32 rows each)
+  constexpr int FR = MI16 ? 16 : 32;  // rows of a fragment
+  constexpr int KG = MI16 ? 16 : 8;   // k per group of four k-steps (= one ds_read_b128 per fragment)
+  constexpr int NG = BK / KG;         // k-groups per tile
+  constexpr int KL = MI16 ? 4 : 2;    // lane groups along k of one MFMA
+  const int lk = MI16 ? lane >> 4 : lane >> 5, li = MI16 ? lane & 15 : lane & 31;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
   const float* A = g.A + (CAT ? 0 : batch * g.sa);
@@ -486,7 +495,7 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
   // ---- staging: a thread moves 4 float4 of A (rows a_row + 32 i, k = 4 a_q ..) and 4 float4 of B (rows 8 b_g + b_lk + 2 j, columns b_n4 ..)
   const int a_q = tid & 7, a_row = tid >> 3;
   const int b_p = tid >> 5, b_n4 = (tid & 31) * 4;
-  const int b_k = 8 * (b_p >> 1) + (b_p & 1);
+  const int b_k = MI16 ? 16 * (b_p >> 2) + (b_p & 3) : 8 * (b_p >> 1) + (b_p & 1);  // first of the thread's four rows (stride KL)
   float4 ra[4], rb[4];
   const float* a_ptr[4];
   long long cat_row[CAT ? 4 : 1];
@@ -519,7 +528,7 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
   };
   auto load_b = [&](int kt, int j) {
     const int k0 = min(kt, kt1 - 1) * BK;
-    rb[j] = *reinterpret_cast<const float4*>(b_ptr + static_cast<long long>(min(k0 + b_k + 2 * j, g.K - 1)) * g.ldb);
+    rb[j] = *reinterpret_cast<const float4*>(b_ptr + static_cast<long long>(min(k0 + b_k + KL * j, g.K - 1)) * g.ldb);
   };
   // A piece i: the float4 (k = 4 q .. 4 q + 3 of one row) is k-steps j, j + 1 of parity 0 (x, z) and of parity 1 (y, w) of k-group q / 2
   auto store_a = [&](int buf, int kt, int i) {
@@ -528,10 +537,15 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
     bool ok = m0 + row < g.M && k0 + 4 * a_q < g.K;
     if constexpr (CAT) ok = ok && (k0 >= g.c1 || cat_row[i] >= 0);
     const float4 v = masked(ra[i], ok);
-    const int g2 = a_q & 6;  // 2 x the k-group
-    float* p = As + buf * IMG + ((g2 * BM + (row ^ g2)) * 4 + (a_q & 1) * 2);
-    *reinterpret_cast<float2*>(p) = make_float2(v.x, v.z);
-    *reinterpret_cast<float2*>(p + BM * 4) = make_float2(v.y, v.w);
+    if constexpr (MI16) {  // k = 4 q + e: k-step q % 4 of lane group e of k-group q / 4 -> four planes, one float each
+      float* p = As + buf * IMG + (((a_q >> 2) * 4 * BM + row) * 4 + (a_q & 3));
+      p[0] = v.x; p[BM * 4] = v.y; p[2 * BM * 4] = v.z; p[3 * BM * 4] = v.w;
+    } else {
+      const int g2 = a_q & 6;  // 2 x the k-group
+      float* p = As + buf * IMG + ((g2 * BM + (row ^ g2)) * 4 + (a_q & 1) * 2);
+      *reinterpret_cast<float2*>(p) = make_float2(v.x, v.z);
+      *reinterpret_cast<float2*>(p + BM * 4) = make_float2(v.y, v.w);
+    }
   };
   // B piece c: column b_n4 + c of the thread's four rows = that column's four k-steps of plane b_p
   auto store_b = [&](int buf, int kt, int c) {
@@ -541,7 +555,7 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
     for (int j = 0; j < 4; ++j) {
       const float4& r = rb[j];
       const float e = c == 0 ? r.x : (c == 1 ? r.y : (c == 2 ? r.z : r.w));
-      v[j] = (b_col_ok && k0 + b_k + 2 * j < g.K) ? e : 0.f;
+      v[j] = (b_col_ok && k0 + b_k + KL * j < g.K) ? e : 0.f;
     }
     const int n = b_n4 + c;
     *reinterpret_cast<float4*>(Bs + buf * IMG + (b_p * BN + (n ^ ((n >> 3) & 3))) * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -555,33 +569,35 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = gcol + e < g.N ? g.bias[gcol + e] : 0.f;
 
-  f32x16 acc[2][2];
+  using Acc = typename std::conditional<MI16, f32x4_t, f32x16>::type;
+  constexpr int AR = MI16 ? 4 : 16;
+  Acc acc[NF][NF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NF; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < AR; ++r) acc[i][j][r] = 0.f;
 
   // ---- fragment reads: k-group gq of buffer buf -> four k-steps of the two A and the two B fragments of this wavefront
-  int a_frag[2], b_frag[2];
+  int a_frag[NF], b_frag[NF];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    a_frag[i] = wm * 64 + i * 32 + li;
-    const int n = wn * 64 + i * 32 + li;
+  for (int i = 0; i < NF; ++i) {
+    a_frag[i] = wm * 64 + i * FR + li;
+    const int n = wn * 64 + i * FR + li;
     b_frag[i] = n ^ ((n >> 3) & 3);
   }
-  float af[2][2][4], bf[2][2][4];  // [register set][fragment][k-step]
+  float af[2][NF][4], bf[2][NF][4];  // [register set][fragment][k-step]
   auto read_group = [&](int set, int buf, int gq) {
-    const float* ab = As + buf * IMG + (2 * gq + lk) * BM * 4;
-    const float* bb = Bs + buf * IMG + (2 * gq + lk) * BN * 4;
+    const float* ab = As + buf * IMG + (KL * gq + lk) * BM * 4;
+    const float* bb = Bs + buf * IMG + (KL * gq + lk) * BN * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4 t = *reinterpret_cast<const float4*>(ab + ((a_frag[i] ^ (2 * gq)) * 4));
+    for (int i = 0; i < NF; ++i) {
+      const float4 t = *reinterpret_cast<const float4*>(ab + ((MI16 ? a_frag[i] : a_frag[i] ^ (2 * gq)) * 4));
       af[set][i][0] = t.x; af[set][i][1] = t.y; af[set][i][2] = t.z; af[set][i][3] = t.w;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NF; ++j) {
       const float4 t = *reinterpret_cast<const float4*>(bb + b_frag[j] * 4);
       bf[set][j][0] = t.x; bf[set][j][1] = t.y; bf[set][j][2] = t.z; bf[set][j][3] = t.w;
     }
@@ -591,9 +607,10 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
   // everything else has to stand BETWEEN the MFMAs to run in their shadows -- gemm_kernel_body).
   auto group = [&](int set, auto&& piece) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const int t = c >> 2, i = (c >> 1) & 1, j = c & 1;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][t], bf[set][j][t], acc[i][j], 0, 0, 0);
+    for (int c = 0; c < 4 * NF * NF; ++c) {
+      const int t = c / (NF * NF), i = (c / NF) % NF, j = c % NF;
+      if constexpr (MI16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[set][i][t], bf[set][j][t], acc[i][j], 0, 0, 0);
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][t], bf[set][j][t], acc[i][j], 0, 0, 0);
       piece(c);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -603,6 +620,27 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
 #endif
   auto tile = [&](int kt, int buf) {
     GEMM_WIDE_STAMP(8 + (kt - kt0));
+    if constexpr (MI16) {  // two k-groups of 64 MFMAs (32 clocks each): stores and the other group's operands under the first, barrier, loads under the second
+      group(0, [&](int c) {
+        if (c == 0) read_group(1, buf, 1);
+        if (!(GW_ABLATE & 4)) {
+          if (c >= 2 && c <= 16 && (c & 3) == 2) store_a(buf ^ 1, kt + 1, (c - 2) >> 2);
+          if (c >= 20 && c <= 32 && (c & 3) == 0) store_b(buf ^ 1, kt + 1, (c - 20) >> 2);
+        }
+      });
+      GEMM_WIDE_STAMP(136 + (kt - kt0));
+      if (!(GW_ABLATE & 1)) lds_barrier();
+      GEMM_WIDE_STAMP(264 + (kt - kt0));
+      __builtin_amdgcn_sched_barrier(0);
+      group(1, [&](int c) {
+        if (c == 0) read_group(0, buf ^ 1, 0);
+        if (!(GW_ABLATE & 2)) {
+          if (c >= 2 && c <= 16 && (c & 3) == 2) load_a(kt + 2, (c - 2) >> 2);
+          if (c >= 20 && c <= 32 && (c & 3) == 0) load_b(kt + 2, (c - 20) >> 2);
+        }
+      });
+      return;
+    }
     // group 0: operands in set 0; group 1's arrive; tile kt + 1 goes from the register stage into the other buffer
     group(0, [&](int c) {
       if (c == 0) read_group(1, buf, 1);
@@ -668,11 +706,14 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
     for (int it = 0; it < CR / RPI; ++it) rdv[it] = has_rd ? g.rowdiv[min(m0 + pass * CR + it * RPI + rsub, g.M - 1)] : 1.f;
     if (wm == pass) {  // wavefront-uniform: the two wavefront rows own one pass each
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Cs[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wn * 64 + j * 32 + li] = acc[i][j][r];
+          for (int r = 0; r < AR; ++r) {
+            if constexpr (MI16) Cs[i * 16 + 4 * lk + r][wn * 64 + j * 16 + li] = acc[i][j][r];
+            else Cs[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk][wn * 64 + j * 32 + li] = acc[i][j][r];
+          }
     }
     lds_barrier();
     // row class of the 64 x 64 tile's epilogue: its thread rsub16 = row % 16 sums the rows rsub16, rsub16 + 16, .. in that order
@@ -739,8 +780,8 @@ __device__ __forceinline__ void gemm_wide_body(const dim3 blockIdx, const dim3 g
   }
   GEMM_WIDE_STAMP(3);
 }
-template <bool CAT>
-__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) { gemm_wide_body<CAT>(blockIdx, gridDim, g); }
+template <bool CAT, bool MI16 = false>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(GemmArgs g) { gemm_wide_body<CAT, MI16>(blockIdx, gridDim, g); }
 
 // Latency-oriented kernel for the transformer-sized products (M up to ~1k rows, K a multiple of 16):
 // one workgroup = ONE 32 x 32 output tile, its four wavefronts split K four ways, operands go straight
@@ -819,7 +860,6 @@ struct LinLnArgs {
   int M, K, lda, ldb, ldr, ldo, act;
   float eps;
 };
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void linear_ln128_body(const dim3 blockIdx, const dim3 gridDim, LinLnArgs a) {
   (void)gridDim;
   __shared__ float red[2][4][16];
@@ -1177,8 +1217,14 @@ void launch(const GemmArgs& g, int batches, bool trans_b, hipStream_t st) {
 }
 
 // the wide form (gemm_wide_kernel): B = weights [K, N], one product or a batch with strides, optionally the decoder's virtual A
-void launch_wide(const GemmArgs& g, int batches, hipStream_t st) {
+void launch_wide(const GemmArgs& g, int batches, hipStream_t st, bool mi16_form) {
   dim3 grid(ceil_div(g.N, 128), ceil_div(g.M, 128), batches * g.splits);
+  static const bool mi16 = ::rdm::dev_knob("RDM_GEMM_WIDE_MI16") != nullptr;  // developer knob (A/B): the 16x16x4 MFMA, same bits
+  if (mi16 || mi16_form) {
+    if (g.aidx) ::rdm::launch<gemm_wide_body<true, true>, gemm_wide_kernel<true, true>, 256, 2>(grid, 0, st, g);
+    else ::rdm::launch<gemm_wide_body<false, true>, gemm_wide_kernel<false, true>, 256, 2>(grid, 0, st, g);
+    return;
+  }
   if (g.aidx) ::rdm::launch<gemm_wide_body<true>, gemm_wide_kernel<true>, 256, 2>(grid, 0, st, g);
   else ::rdm::launch<gemm_wide_body<false>, gemm_wide_kernel<false>, 256, 2>(grid, 0, st, g);
 }
@@ -1203,7 +1249,9 @@ namespace {
 
 thread_local int g_last_plan[4] = {0, 0, 0, 0};  // tile rows, tile columns, k-tile depth, split-K factor of the last dispatch
 
-int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st) {
+// form (tests, A/B runs; rdm_gemm_form): 0 = the library's choice; 1 / 2 = the products the model gives to the 64 x 64 tile run on the
+// wide form instead (128 x 128 x 32 tiles; 1: v_mfma_f32_32x32x2_f32, 2: v_mfma_f32_16x16x4_f32) -- same split factor, same bits.
+int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_bytes, int* stat_blocks, hipStream_t st, int form = 0) {
   const long long m = g.M, n = g.N, k = g.K;
   const char* tune_env = ::rdm::dev_knob("RDM_GEMM_TUNE");  // developer knob, see below; any value also bypasses the small kernel
   if (batches == 1 && !trans_b && !g.rowdiv && !g.stats && !g.aidx && m <= 1536 && k % 16 == 0 && k >= 64 && k <= 1024 &&
@@ -1298,10 +1346,11 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // Measured (round 6, docs/EXPERIMENTS.md 5h): bit-identical, half the LDS instructions and no bank conflicts, 94 % of the MFMA rate
   // per k-tile with two workgroups per CU -- and no faster than the 64 x 64 tile, alone or in the lock-step schedule (639-641 against
   // 638-643 pairs/s): off unless the lab build asks for it (RDM_GEMM_WIDE=1).
-  static const bool wide_off = ::rdm::dev_knob("RDM_GEMM_WIDE") == nullptr;
+  static const bool wide_knob = ::rdm::dev_knob("RDM_GEMM_WIDE") != nullptr;
+  const bool wide_off = !wide_knob && form == 0;
   static const bool wide_force = ::rdm::dev_knob("RDM_GEMM_WIDE_FORCE") != nullptr;  // developer knob (probes): whatever tile the model chose
   if (wide_force && !trans_b && !g.bidx && exp_tile == 0) tile = T64;
-  const bool wide = !wide_off && tile == T64 && exp_tile == 0 && !trans_b && !g.bidx && m >= wide_min_m && n >= wide_min_n;
+  const bool wide = !wide_off && tile == T64 && exp_tile == 0 && !trans_b && !g.bidx && (form != 0 || (m >= wide_min_m && n >= wide_min_n));
   int bm = tile == T64 ? 64 : 128, bn = tile == T128 ? 128 : (tile == T64 ? 64 : 32);
   if (wide) { bm = 128; bn = 128; }
   if (exp_tile == 4) { bm = 128; bn = 64; }
@@ -1329,7 +1378,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
   // k-tile depth: deep tiles for the latency-bound small configurations (a 350 x 128 x 128 projection
   // is two 64-deep steps instead of eight 16-deep ones), shallow where K itself is tiny
   RDM_DUP_LOOP("gemm") {
-  if (wide) launch_wide(g, batches, st);
+  if (wide) launch_wide(g, batches, st, form == 2);
   else
 #ifdef RDM_DEV_KNOBS  // the experimental tiles exist in the lab build only (RDM_GEMM_TUNE=4..7, RDM_GEMM_BIG)
   if (exp_tile == 4) launch<128, 64, 2, 2, 32, 2>(g, batches, trans_b, st);
@@ -1374,7 +1423,7 @@ int gemm_dispatch(GemmArgs g, int batches, bool trans_b, void* ws, size_t ws_byt
 
 int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t m,
                          int64_t n, int64_t k, const float* bias, const float* rowdiv, void* ws, size_t ws_bytes,
-                         double* gn_partial, int* gn_blocks, void* stream) {
+                         double* gn_partial, int* gn_blocks, void* stream, int form) {
   GemmArgs g;
   g.A = a; g.B = b; g.C = c; g.bias = bias; g.rowdiv = rowdiv;
   g.M = static_cast<int>(m); g.N = static_cast<int>(n); g.K = static_cast<int>(k);
@@ -1382,7 +1431,7 @@ int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ld
   g.sa = g.sb = g.sc = 0;
   g.act = 0; g.splits = 1; g.part = nullptr; g.stats = gn_partial;
   g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0; g.bidx = nullptr; g.n_b = 0;
-  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
+  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream), form);
 }
 
 // C = [nearest_upsample(coarse)[idx[:, 0]] | skip] B + bias (decoder, backbone.py:118-151) without materialising the
@@ -1391,7 +1440,7 @@ int rdm::gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ld
 int rdm::gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, int64_t n_coarse, const int64_t* idx, int64_t ldi,
                                 const float* skip, int64_t ld2, int64_t c2, const float* b, int64_t ldb, float* c, int64_t ldc,
                                 int64_t m, int64_t n, const float* bias, int act, void* ws, size_t ws_bytes, double* gn_partial,
-                                int* gn_blocks, void* stream) {
+                                int* gn_blocks, void* stream, int form) {
   if (c1 % 32 != 0 || c2 % 4 != 0 || c2 < 4 || ld1 % 4 != 0 || ld2 % 4 != 0 || ldb % 4 != 0 || m <= 0 ||
       ((reinterpret_cast<uintptr_t>(coarse) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(b)) & 15) != 0)
     return 1;
@@ -1404,7 +1453,7 @@ int rdm::gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, in
   g.A2 = skip; g.aidx = idx; g.lda2 = static_cast<int>(ld2); g.ldi = static_cast<int>(ldi); g.c1 = static_cast<int>(c1);
   g.n_coarse = static_cast<int>(n_coarse);
   g.bidx = nullptr; g.n_b = 0;
-  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream));
+  return gemm_dispatch(g, 1, false, ws, ws_bytes, gn_blocks, static_cast<hipStream_t>(stream), form);
 }
 
 namespace {
@@ -1452,7 +1501,15 @@ extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const flo
                         int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c,
                         int64_t m, int64_t n, int64_t k, int batches, const float* bias,
                         const float* rowdiv, int act, void* ws, size_t ws_bytes, void* stream) {
+  return rdm_gemm_form(a, lda, stride_a, b, ldb, stride_b, trans_b, c, ldc, stride_c, m, n, k, batches, bias, rowdiv, act, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int rdm_gemm_form(const float* a, int64_t lda, int64_t stride_a, const float* b, int64_t ldb,
+                             int64_t stride_b, int trans_b, float* c, int64_t ldc, int64_t stride_c,
+                             int64_t m, int64_t n, int64_t k, int batches, const float* bias,
+                             const float* rowdiv, int act, void* ws, size_t ws_bytes, int form, void* stream) {
   using namespace rdm;
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_gemm_form: unknown form %d", form);
   RDM_REQUIRE(a && b && c, "rdm_gemm: null pointer");
   RDM_REQUIRE(m >= 0 && n >= 0 && k >= 0 && batches >= 1, "rdm_gemm: bad sizes");
   if (m == 0 || n == 0) return RDM_OK;
@@ -1469,7 +1526,7 @@ extern "C" int rdm_gemm(const float* a, int64_t lda, int64_t stride_a, const flo
   g.sa = stride_a; g.sb = stride_b; g.sc = stride_c;
   g.act = act; g.splits = 1; g.part = nullptr; g.stats = nullptr;
   g.A2 = nullptr; g.aidx = nullptr; g.lda2 = g.ldi = g.c1 = g.n_coarse = 0; g.bidx = nullptr; g.n_b = 0;
-  return gemm_dispatch(g, batches, trans_b != 0, ws, ws_bytes, nullptr, static_cast<hipStream_t>(stream));
+  return gemm_dispatch(g, batches, trans_b != 0, ws, ws_bytes, nullptr, static_cast<hipStream_t>(stream), form);
 }
 
 // y = act(GroupNorm(x W + b [/ rowdiv]) [+ residual]): the Linear/KPConv-weight GEMM writes its
@@ -1485,7 +1542,17 @@ extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w
                                      const float* gamma, const float* beta, float eps, const float* residual,
                                      int64_t ldr, int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy,
                                      uint8_t* positive, void* ws, size_t ws_bytes, void* stream) {
+  return rdm_linear_group_norm_form(x, ldx, w, ldw, bias, rowdiv, m, n, k, groups, gamma, beta, eps, residual, ldr, act, lin_out, ld_lin, y, ldy,
+                                    positive, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int rdm_linear_group_norm_form(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                          const float* rowdiv, int64_t m, int64_t n, int64_t k, int groups,
+                                          const float* gamma, const float* beta, float eps, const float* residual,
+                                          int64_t ldr, int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy,
+                                          uint8_t* positive, void* ws, size_t ws_bytes, int form, void* stream) {
   using namespace rdm;
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_linear_group_norm_form: unknown form %d", form);
   RDM_REQUIRE(x && w && gamma && beta && lin_out && y, "rdm_linear_group_norm: null pointer");
   RDM_REQUIRE(k % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, "rdm_linear_group_norm: K, ldx, ldw must be multiples of 4");
   if (m == 0) return RDM_OK;
@@ -1500,7 +1567,7 @@ extern "C" int rdm_linear_group_norm(const float* x, int64_t ldx, const float* w
     return RDM_ERR_WORKSPACE;
   }
   int nblk = 0;
-  if (int e = gemm_with_stats(x, ldx, w, ldw, lin_out, ld_lin, m, n, k, bias, rowdiv, gws, gemm_ws, partial, &nblk, stream))
+  if (int e = gemm_with_stats(x, ldx, w, ldw, lin_out, ld_lin, m, n, k, bias, rowdiv, gws, gemm_ws, partial, &nblk, stream, form))
     return e;
   return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, residual, ldr, act, y, ldy,
                            positive, nws, gn_ws, stream);
@@ -1543,7 +1610,17 @@ extern "C" int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t 
                                  const float* bias, int64_t n, int groups, const float* gamma, const float* beta, float eps,
                                  int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes,
                                  void* stream) {
+  return rdm_decoder_stage_form(coarse, n_coarse, c1, ld1, idx, ldi, skip, c2, ld2, m, w, ldw, bias, n, groups, gamma, beta, eps, act, lin_out, ld_lin,
+                                y, ldy, ws, ws_bytes, 0, stream);
+}
+
+extern "C" int rdm_decoder_stage_form(const float* coarse, int64_t n_coarse, int64_t c1, int64_t ld1, const int64_t* idx, int64_t ldi,
+                                      const float* skip, int64_t c2, int64_t ld2, int64_t m, const float* w, int64_t ldw,
+                                      const float* bias, int64_t n, int groups, const float* gamma, const float* beta, float eps,
+                                      int act, float* lin_out, int64_t ld_lin, float* y, int64_t ldy, void* ws, size_t ws_bytes,
+                                      int form, void* stream) {
   using namespace rdm;
+  RDM_REQUIRE(form >= 0 && form <= 2, "rdm_decoder_stage_form: unknown form %d", form);
   RDM_REQUIRE(coarse && idx && skip && w && lin_out && (!gamma || (beta && y)), "rdm_decoder_stage: null pointer");
   RDM_REQUIRE(c1 > 0 && c2 > 0 && n > 0 && m >= 0 && ldw % 4 == 0, "rdm_decoder_stage: bad sizes");
   if (m == 0) return RDM_OK;
@@ -1564,11 +1641,11 @@ extern "C" int rdm_decoder_stage(const float* coarse, int64_t n_coarse, int64_t 
   int rc = 1;
   if (!no_virtual && k == kpad)
     rc = gemm_concat_with_stats(coarse, ld1, c1, n_coarse, idx, ldi, skip, ld2, c2, w, ldw, lin_out, ld_lin, m, n, bias, 0, gws,
-                                gemm_ws, gamma ? partial : nullptr, &nblk, stream);
+                                gemm_ws, gamma ? partial : nullptr, &nblk, stream, form);
   if (rc == 1) {
     if (int e = rdm_upsample_concat(coarse, n_coarse, c1, ld1, idx, ldi, skip, c2, ld2, m, cat, kpad, stream)) return e;
     rc = gemm_with_stats(cat, kpad, w, ldw, lin_out, ld_lin, m, n, kpad, bias, nullptr, gws, gemm_ws, gamma ? partial : nullptr,
-                         &nblk, stream);
+                         &nblk, stream, form);
   }
   if (rc != 0 || !gamma) return rc;
   return group_norm_finish(partial, nblk, lin_out, m, n, ld_lin, groups, gamma, beta, eps, nullptr, 0, act, y, ldy, nullptr, nws,

@@ -11,7 +11,7 @@ namespace rdm {
 // otherwise *gn_blocks = 0 and the caller must compute the statistics itself.
 int gemm_with_stats(const float* a, int64_t lda, const float* b, int64_t ldb, float* c, int64_t ldc, int64_t m,
                     int64_t n, int64_t k, const float* bias, const float* rowdiv, void* ws, size_t ws_bytes,
-                    double* gn_partial, int* gn_blocks, void* stream);
+                    double* gn_partial, int* gn_blocks, void* stream, int form = 0);
 
 // gemm_with_stats with A = [coarse[idx[:, 0]] | skip] formed inside the kernel (the decoder's upsample + concatenation,
 // backbone.py:118-151); returns 1 (nothing launched) when the shapes need the materialised concatenation instead.
@@ -19,7 +19,7 @@ void gemm_set_lds_pad(unsigned bytes);
 int gemm_concat_with_stats(const float* coarse, int64_t ld1, int64_t c1, int64_t n_coarse, const int64_t* idx, int64_t ldi,
                            const float* skip, int64_t ld2, int64_t c2, const float* b, int64_t ldb, float* c, int64_t ldc,
                            int64_t m, int64_t n, const float* bias, int act, void* ws, size_t ws_bytes, double* gn_partial,
-                           int* gn_blocks, void* stream);
+                           int* gn_blocks, void* stream, int form = 0);
 
 // Two independent products C_i = A_i B_i + bias_i (rdm_gemm semantics, no activation) in one launch when both are
 // transformer-sized; otherwise two rdm_gemm calls.

@@ -50,9 +50,10 @@ def _ld(t):
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
 
 
-def gemm(a, b, k, n, *, trans_b=False, bias=None, rowdiv=None, act=ACT_NONE, out=None):
+def gemm(a, b, k, n, *, trans_b=False, bias=None, rowdiv=None, act=ACT_NONE, out=None, form=0):
     """out[m, :n] = act(a[m, :k] @ op(b) / rowdiv + bias).  a: [m, >=k] view, b: [k(pad), n(pad)]
-    (trans_b False) or [n, >=k] view (trans_b True); k must be a multiple of 4."""
+    (trans_b False) or [n, >=k] view (trans_b True); k must be a multiple of 4.  form: rdm_gemm_form (0 = the library's choice,
+    1 / 2 = the wide tile forms; same bits)."""
     L = _lib.lib()
     m = a.shape[0]
     if a.stride(-1) != 1 or b.stride(-1) != 1:
@@ -61,9 +62,9 @@ def gemm(a, b, k, n, *, trans_b=False, bias=None, rowdiv=None, act=ACT_NONE, out
         out = feat_empty(m, n, a.device)
     ws_bytes = L.rdm_gemm_workspace_bytes(m, n, 1)
     ws = scratch(a.device, ws_bytes)
-    _lib.check(L.rdm_gemm(a.data_ptr(), _ld(a), 0, b.data_ptr(), _ld(b), 0, int(trans_b), out.data_ptr(), _ld(out),
-                          0, m, n, k, 1, _lib.ptr(bias), _lib.ptr(rowdiv), act, ws.data_ptr(), ws.numel(),
-                          _lib.stream_ptr()), 'rdm_gemm')
+    _lib.check(L.rdm_gemm_form(a.data_ptr(), _ld(a), 0, b.data_ptr(), _ld(b), 0, int(trans_b), out.data_ptr(), _ld(out),
+                               0, m, n, k, 1, _lib.ptr(bias), _lib.ptr(rowdiv), act, ws.data_ptr(), ws.numel(), int(form),
+                               _lib.stream_ptr()), 'rdm_gemm')
     return out
 
 
@@ -184,7 +185,7 @@ def group_norm(x, gamma, beta, groups, *, act=ACT_NONE, residual=None, want_posi
 
 
 def linear_group_norm(x, b, k, n, bias, gamma, beta, groups, *, rowdiv=None, act=ACT_NONE, residual=None,
-                      want_positive=False, eps=1e-5):
+                      want_positive=False, eps=1e-5, form=0):
     """act(GroupNorm(x[:, :k] @ b + bias [/ rowdiv]) [+ residual]); statistics from the GEMM epilogue."""
     L = _lib.lib()
     m = x.shape[0]
@@ -192,15 +193,15 @@ def linear_group_norm(x, b, k, n, bias, gamma, beta, groups, *, rowdiv=None, act
     y = feat_empty(m, n, x.device)
     pos = torch.empty((max(m, 1),), dtype=torch.uint8, device=x.device) if want_positive else None
     ws = scratch(x.device, L.rdm_linear_group_norm_workspace_bytes(m, n))
-    _lib.check(L.rdm_linear_group_norm(x.data_ptr(), _ld(x), b.data_ptr(), _ld(b), _lib.ptr(bias), _lib.ptr(rowdiv), m, n, k,
-                                       groups, gamma.data_ptr(), beta.data_ptr(), eps, _lib.ptr(residual),
-                                       _ld(residual) if residual is not None else 0, act, lin.data_ptr(), _ld(lin),
-                                       y.data_ptr(), _ld(y), _lib.ptr(pos), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+    _lib.check(L.rdm_linear_group_norm_form(x.data_ptr(), _ld(x), b.data_ptr(), _ld(b), _lib.ptr(bias), _lib.ptr(rowdiv), m, n, k,
+                                            groups, gamma.data_ptr(), beta.data_ptr(), eps, _lib.ptr(residual),
+                                            _ld(residual) if residual is not None else 0, act, lin.data_ptr(), _ld(lin),
+                                            y.data_ptr(), _ld(y), _lib.ptr(pos), ws.data_ptr(), ws.numel(), int(form), _lib.stream_ptr()),
                'rdm_linear_group_norm')
     return (y, pos) if want_positive else y
 
 
-def decoder_stage(coarse, idx, skip, b, n, bias, gamma=None, beta=None, groups=32, *, act=ACT_NONE, eps=1e-5):
+def decoder_stage(coarse, idx, skip, b, n, bias, gamma=None, beta=None, groups=32, *, act=ACT_NONE, eps=1e-5, form=0):
     """One decoder stage (backbone.py:118-151): act(GroupNorm([coarse[idx[:, 0]] | skip] @ b + bias)), or the plain Linear when
     gamma is None.  b: [pad4(c1 + c2), pad4(n)] as for gemm."""
     L = _lib.lib()
@@ -208,10 +209,10 @@ def decoder_stage(coarse, idx, skip, b, n, bias, gamma=None, beta=None, groups=3
     lin = feat_empty(m, n, skip.device)
     y = feat_empty(m, n, skip.device) if gamma is not None else None
     ws = scratch(skip.device, L.rdm_decoder_stage_workspace_bytes(m, n, c1 + c2))
-    _lib.check(L.rdm_decoder_stage(coarse.data_ptr(), coarse.shape[0], c1, _ld(coarse), idx.data_ptr(), _ld(idx), skip.data_ptr(),
-                                   c2, _ld(skip), m, b.data_ptr(), _ld(b), _lib.ptr(bias), n, groups, _lib.ptr(gamma),
-                                   _lib.ptr(beta), eps, act, lin.data_ptr(), _ld(lin), _lib.ptr(y), _ld(y) if y is not None else 0,
-                                   ws.data_ptr(), ws.numel(), _lib.stream_ptr()), 'rdm_decoder_stage')
+    _lib.check(L.rdm_decoder_stage_form(coarse.data_ptr(), coarse.shape[0], c1, _ld(coarse), idx.data_ptr(), _ld(idx), skip.data_ptr(),
+                                        c2, _ld(skip), m, b.data_ptr(), _ld(b), _lib.ptr(bias), n, groups, _lib.ptr(gamma),
+                                        _lib.ptr(beta), eps, act, lin.data_ptr(), _ld(lin), _lib.ptr(y), _ld(y) if y is not None else 0,
+                                        ws.data_ptr(), ws.numel(), int(form), _lib.stream_ptr()), 'rdm_decoder_stage')
     return y if gamma is not None else lin
 
 

@@ -501,3 +501,43 @@ def test_kpconv_gather_lds_tile_form_has_the_bits_of_the_per_neighbour_form(ops,
         a, na = ops.kpconv_gather(*args, width=cap, order=rec, form=2)
         b, nb = ops.kpconv_gather(*args, width=cap, form=1)
         assert torch.equal(a[:, :15 * c], b[:, :15 * c]) and torch.equal(na[:m], nb[:m])
+
+
+@pytest.mark.parametrize('m,k,n', [(563, 7680, 512), (1310, 3840, 256), (3879, 1920, 128), (10961, 64, 256), (3879, 128, 512), (300, 36, 132),
+                                   (257, 1284, 260), (129, 68, 1028), (32000, 32, 128)])
+def test_gemm_forms_return_the_same_bits(ops, m, k, n):
+    """Round 6: the WIDE forms of the tiled GEMM (rdm_gemm_form 1 / 2: 128 x 128 x 32 tiles with fragment-ordered LDS images, on
+    v_mfma_f32_32x32x2_f32 or v_mfma_f32_16x16x4_f32) return the bits of the library's choice (form 0: the 64 x 64 tile) -- an
+    output element is one fp32 fma chain over ascending k inside the same split-K ranges whatever the tile and the MFMA shape,
+    and the GroupNorm column partials keep their 64-row blocks and their combination order.  Products with and without split-K,
+    with bias / activation / row divisor / statistics, ragged edges in M, N and K."""
+    g = torch.Generator().manual_seed(m + k + n)
+    kp, n_p = (k + 3) // 4 * 4, (n + 3) // 4 * 4
+    a = torch.zeros(m, kp)
+    a[:, :k] = torch.randn(m, k, generator=g)
+    w = torch.zeros(kp, n_p)
+    w[:k, :n] = torch.randn(k, n, generator=g) / k ** 0.5
+    bias, gamma, beta = torch.randn(n, generator=g), torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+    rowdiv = torch.randint(1, 40, (m,), generator=g).float()
+    a, w, bias, gamma, beta, rowdiv = (t.cuda() for t in (a, w, bias, gamma, beta, rowdiv))
+    groups = 32 if n % 32 == 0 else 4
+    want_plain = ops.gemm(a, w, kp, n, bias=bias, act=ops.ACT_LEAKY)
+    want_gn = ops.linear_group_norm(a, w, kp, n, bias, gamma, beta, groups, rowdiv=rowdiv, act=ops.ACT_LEAKY)
+    for form in (1, 2):
+        assert torch.equal(ops.gemm(a, w, kp, n, bias=bias, act=ops.ACT_LEAKY, form=form), want_plain), form
+        assert torch.equal(ops.linear_group_norm(a, w, kp, n, bias, gamma, beta, groups, rowdiv=rowdiv, act=ops.ACT_LEAKY, form=form), want_gn), form
+
+
+@pytest.mark.parametrize('ns,m,c1,c2,n,norm', [(1310, 3879, 1024, 512, 512, True), (900, 2500, 512, 256, 257, False), (100, 333, 64, 36, 132, True)])
+def test_decoder_stage_forms_return_the_same_bits(ops, ns, m, c1, c2, n, norm):
+    """The decoder's virtual [upsample | skip] operand on the wide forms (rdm_decoder_stage_form 1 / 2): the bits of form 0."""
+    g = torch.Generator().manual_seed(m + c1)
+    coarse, skip = torch.randn(ns, c1, generator=g).cuda(), torch.randn(m, c2, generator=g).cuda()
+    idx = torch.randint(0, ns + 3, (m, 4), generator=g).cuda()  # (rows past the coarse level: zero rows)
+    w = torch.zeros(c1 + c2, (n + 3) // 4 * 4)
+    w[:, :n] = torch.randn(c1 + c2, n, generator=g) / (c1 + c2) ** 0.5
+    w, bias, gamma, beta = w.cuda(), torch.randn(n, generator=g).cuda(), (torch.rand(n, generator=g) + 0.5).cuda(), torch.randn(n, generator=g).cuda()
+    groups = 32 if n % 32 == 0 else 4
+    run = lambda form: ops.decoder_stage(coarse, idx, skip, w, n, bias, gamma if norm else None, beta if norm else None, groups, act=ops.ACT_LEAKY, form=form)
+    want = run(0)
+    assert torch.equal(run(1), want) and torch.equal(run(2), want)

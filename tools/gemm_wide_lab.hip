@@ -2,7 +2,7 @@
 // (0,0,0), the clocks of prologue / main loop / epilogue, the clocks per k-tile (median, min, max) and the share of a tile spent
 // at its barrier, plus the kernel time.  -DGW_ABLATE=<bits> removes parts of the loop (timing probes: wrong results).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRDM_GEMM_TIMING [-DGW_ABLATE=n] tools/gemm_wide_lab.hip rdmnet_amd/csrc/capi.cpp
-//         rdmnet_amd/csrc/norm.hip rdmnet_amd/csrc/lockstep.cpp -o tools/bin/gemm_wide_lab;   ./tools/bin/gemm_wide_lab M K N splits
+//         rdmnet_amd/csrc/norm.hip rdmnet_amd/csrc/lockstep.cpp -o tools/bin/gemm_wide_lab;   ./tools/bin/gemm_wide_lab M K N splits [1 = 16x16x4 MFMA]
 #include "../rdmnet_amd/csrc/gemm.hip"
 #include <algorithm>
 #include <cstdio>
@@ -12,6 +12,7 @@
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 15516, K = argc > 2 ? atoi(argv[2]) : 1536, N = argc > 3 ? atoi(argv[3]) : 512;
   const int splits = argc > 4 ? atoi(argv[4]) : 1;
+  const int mi16 = argc > 5 ? atoi(argv[5]) : 0;  // 1: the v_mfma_f32_16x16x4_f32 variant
   auto dev = [](size_t n) { float* p; (void)hipMalloc(&p, n * 4); std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = float((i * 2654435761u) % 1000) / 1000.f - 0.5f; (void)hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice); return p; };
   GemmArgs g;
   g.A = dev(size_t(M) * K); g.B = dev(size_t(K) * N); g.C = dev(size_t(M) * N); g.bias = dev(N); g.rowdiv = nullptr;
@@ -26,7 +27,8 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 4; ++it) {
     (void)hipMemset(g.clk, 0, 400 * 8);
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((gemm_wide_kernel<false>), grid, dim3(256), 0, 0, g);
+    if (mi16) hipLaunchKernelGGL((gemm_wide_kernel<false, true>), grid, dim3(256), 0, 0, g);
+    else hipLaunchKernelGGL((gemm_wide_kernel<false>), grid, dim3(256), 0, 0, g);
     (void)hipEventRecord(e1, 0);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -36,8 +38,8 @@ int main(int argc, char** argv) {
     for (int t = 0; t < tiles; ++t) bar.push_back((long long)(h[264 + t] - h[136 + t]));
     std::sort(per.begin(), per.end()); std::sort(bar.begin(), bar.end());
     const double flops = 2.0 * M * K * N;
-    printf("GW_ABLATE=%d M=%d K=%d N=%d splits=%d blocks=%d run %d: %.1f us = %.1f TF; prologue %llu, main %llu (%d k-tiles), epilogue %llu clocks; per tile median %lld min %lld max %lld; "
-           "at the barrier median %lld max %lld\n", GW_ABLATE, M, K, N, splits, grid.x * grid.y * grid.z, it, ms * 1e3, flops / ms / 1e9, h[1] - h[0], h[2] - h[1], tiles, h[3] - h[2],
+    printf("GW_ABLATE=%d mi16=%d M=%d K=%d N=%d splits=%d blocks=%d run %d: %.1f us = %.1f TF; prologue %llu, main %llu (%d k-tiles), epilogue %llu clocks; per tile median %lld min %lld max %lld; "
+           "at the barrier median %lld max %lld\n", GW_ABLATE, mi16, M, K, N, splits, grid.x * grid.y * grid.z, it, ms * 1e3, flops / ms / 1e9, h[1] - h[0], h[2] - h[1], tiles, h[3] - h[2],
            per.empty() ? 0 : per[per.size() / 2], per.empty() ? 0 : per.front(), per.empty() ? 0 : per.back(), bar[bar.size() / 2], bar.back());
   }
   return 0;
