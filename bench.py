@@ -361,6 +361,7 @@ def main():
     pipe = pipeline.PairPipeline(cfg, state, device=dev, pairs_in_flight=args.streams, wait_us=args.wait_us,
                                  stagger_ms=args.stagger_ms, local_world=local_world, streams=custom_streams,
                                  collate_batch=collate_batch, lockstep=lockstep, arena_bytes=(args.arena_mb << 20) if args.arena_mb > 0 else None)
+    pipe.ensure_groups()  # (the pipeline completes its lock-step groups on their first draw; the layer profile addresses them before)
     wait_us, engines, streams = pipe.wait_us, pipe.engines, pipe.streams
     worker_of = {id(e): k for k, grp in enumerate(pipe.groups) for e in grp}
     for eng in engines:

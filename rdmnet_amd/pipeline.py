@@ -247,32 +247,60 @@ class PairPipeline:
             self.streams = list(streams)
         else:  # (also for a single pair in flight: the engine's latency mode does not work on the null stream)
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)] if self._gpu else [None] * self.n
-        self.engines = list(engines) if engines is not None else []
-        want = self.n * self.lockstep  # lock step: worker k runs groups[k] (lockstep engines) on its stream
-        if len(self.engines) < want:
+        # Engines.  Worker k owns groups[k]: `lockstep` engines sharing ONE copy of the weights.  A pipeline that builds its own engines
+        # creates ONE per worker here and the other lockstep - 1 of every group on the first draw that runs in lock step
+        # (`ensure_groups`; ADVICE r5: callers that never pass `tensors_of` / `group_fn` -- one job per engine call -- do not pay for
+        # 4 x the arenas).  HBM: an engine's activation arena defaults to 3 GiB (growable: a pair that exhausts it is re-run on a
+        # doubled one), i.e. 48 GiB of the 288 at the default 4 x 4 once the groups exist, whether or not a pair ever needs it
+        # (measured, tools/dbg/arena_probe.py: a 2 x 16 k-point pair bumps through 0.85-1.2 GiB).  `arena_bytes` re-allocates every
+        # engine's arena at that size instead (still growable): what several ranks on one device, or a GPU with less memory, pass.
+        self.arena_bytes = None if arena_bytes is None else int(arena_bytes)
+        self._cfg_state = (cfg, state)
+        self._groups_lock = threading.Lock()
+        given = list(engines) if engines is not None else []
+        want = self.n * self.lockstep
+        if given and len(given) >= want:  # injected: the caller's set is what runs
+            self.groups = [given[k * self.lockstep:(k + 1) * self.lockstep] for k in range(self.n)]
+            spare = given[want:]
+        else:
             if not self._gpu:
                 raise RuntimeError(f'rdmnet_amd.pipeline: {want} injected engines needed ({self.n} workers x {self.lockstep} in lock step)')
             with torch.cuda.device(self.device):
-                while len(self.engines) < want:
-                    self.engines.append(Engine(cfg, state, device=self.device,
-                                               share_with=self.engines[0] if self.engines else None))
-        self.groups = [self.engines[k * self.lockstep:(k + 1) * self.lockstep] for k in range(self.n)]
-        spare = self.engines[want:]
+                while len(given) < self.n:
+                    given.append(Engine(cfg, state, device=self.device, share_with=given[0] if given else None))
+            self.groups = [[given[k]] for k in range(self.n)]
+            spare = given[self.n:]  # (injected engines beyond one per worker join the groups first, ensure_groups)
+        self._spare = spare
         self.engines = [grp[0] for grp in self.groups] + spare  # (engines[k]: worker k's engine, as without lock step)
-        # HBM: an engine's activation arena defaults to 3 GiB (growable: a pair that exhausts it is re-run on a doubled one), so a
-        # pipeline of n x lockstep engines reserves 3 GiB x n x lockstep -- 48 GiB of the 288 at the default 4 x 4, whether or not a
-        # pair ever needs it (measured, tools/dbg/arena_probe.py: a 2 x 16 k-point pair bumps through 0.85-1.2 GiB of it).
-        # `arena_bytes` re-allocates every engine's arena at that size instead (still growable): what several ranks on one
-        # device, or a GPU with less memory, pass.
-        self.arena_bytes = None if arena_bytes is None else int(arena_bytes)
         for eng in [e for grp in self.groups for e in grp] + spare:
-            if self.arena_bytes is not None and hasattr(eng, 'reserve'):
-                eng.reserve(self.arena_bytes)
-            eng.set_wait(self.wait_us)
-            eng.set_pairs_in_flight(self.n * self.lockstep)
-            eng.keep_taps(keep_taps)
+            self._configure(eng)
         self.cfg = cfg
         self.last_stats = None
+
+    def _configure(self, eng):
+        if self.arena_bytes is not None and hasattr(eng, 'reserve'):
+            eng.reserve(self.arena_bytes)
+        eng.set_wait(self.wait_us)
+        eng.set_pairs_in_flight(self.n * self.lockstep)
+        eng.keep_taps(self.keep_taps)
+
+    def ensure_groups(self, k=None):
+        """Completes worker k's lock-step group (every group with k = None) to `lockstep` engines; no-op once they exist.
+        Called by the workers on their first lock-step draw, and by callers that address `groups` before running."""
+        for g in (range(self.n) if k is None else [k]):
+            if len(self.groups[g]) >= self.lockstep:
+                continue
+            with self._groups_lock:
+                cfg, state = self._cfg_state
+                with torch.cuda.device(self.device):
+                    while len(self.groups[g]) < self.lockstep:
+                        if self._spare:
+                            eng = self._spare.pop(0)
+                        else:
+                            eng = Engine(cfg, state, device=self.device, share_with=self.groups[0][0])
+                            self._configure(eng)
+                        self.groups[g].append(eng)
+        return self.groups
 
     # ------------------------------------------------------------------ generic scheduler
     def imap(self, jobs, fn, stagger=True, window=None, tensors_of=None, prepare=None, group_fn=None):
@@ -366,6 +394,8 @@ class PairPipeline:
                             t2 = time.perf_counter()
                             if got is None:
                                 return
+                            if lockstep and len(self.groups[k]) < self.lockstep:
+                                self.ensure_groups(k)
                             if lockstep and prepare is not None:
                                 for i, (_, job) in enumerate(got):
                                     prepare(self.groups[k][i], job, i, len(got))
@@ -466,3 +496,4 @@ class PairPipeline:
         """Drops the engines (their arenas; the shared weights go with the last one)."""
         self.engines = []
         self.groups = []
+        self._spare = []

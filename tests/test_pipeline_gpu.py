@@ -61,9 +61,11 @@ def test_pairs_in_flight_equal_the_serial_run_bit_for_bit_in_dataset_order(setup
     # bits, in dataset order
     for n, lb in ((2, 4), (3, 3), (4, 2)):
         grouped = pipeline.PairPipeline(cfg, None, pairs_in_flight=n, engines=[serial.engines[0]], lockstep=lb)
-        assert len(grouped.groups) == n and all(len(g) == lb for g in grouped.groups) and grouped.engines[0] is serial.engines[0]
+        # (round 6: a pipeline builds one engine per worker and completes its lock-step groups on their first draw)
+        assert len(grouped.groups) == n and all(len(g) == 1 for g in grouped.groups) and grouped.engines[0] is serial.engines[0]
         for _ in range(2):
             got = grouped.run_pairs([dev[i] for i in order])
+            assert all(len(g) == lb for g in grouped.groups)
             assert grouped.last_stats['lockstep_groups'] >= 2 and len(got) == len(want)
             for g, w in zip(got, want):
                 assert np.array_equal(g.transform, w.transform) and g.level_sizes == w.level_sizes
