@@ -816,3 +816,37 @@ def test_collates_in_lock_step_equal_the_one_pair_collates(ctx, golden_dir):
         outs, ref = net(got), [net(w) for w in want]
         for o, r in zip(outs, ref):
             assert all(torch.equal(o[key], r[key]) for key in r)
+
+
+def test_lockstep_collates_and_forwards_that_exhaust_their_arenas_are_rerun(ctx, golden_dir):
+    """The arena-growth path of the round-6 lock-step entry points: engines that start with 160 MB (rdm_engine_reserve: growable)
+    cannot hold a 2 x 16 k-point pair; `rdm_engine_collate_lockstep` / `rdm_engine_forward_lockstep` end such a pair's run early,
+    run it again on its own with a grown arena, and return what the one-pair calls return."""
+    from rdmnet_amd import engine
+    cfg, eng = ctx['cfg'], ctx['eng']
+    z = np.load(os.path.join(golden_dir, 'synthetic_pairs.npz'))
+    pairs = [(torch.from_numpy(z['ref0']).cuda(), torch.from_numpy(z['src0']).cuda()), (torch.from_numpy(ctx['rp']).cuda(), torch.from_numpy(ctx['sp']).cuda()),
+             (torch.from_numpy(z['ref1']).cuda(), torch.from_numpy(z['src1']).cuda())]
+    names = ['decoder', 'feats_c', 'matching_scores', 'ref_corr_points', 'src_corr_points', 'corr_scores', 'estimated_transform']
+    want_d, want_t = [], []
+    for r, s in pairs:
+        d = eng.collate(r, s)
+        eng.forward(d)
+        want_d.append(d)
+        want_t.append({n: eng.tensor(n).clone() for n in names})
+    engines = [engine.Engine(cfg, None, share_with=eng) for _ in range(3)]
+    for e in engines:
+        e.keep_taps(True)
+        e.reserve(160 << 20)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        dicts = engine.Engine.collate_lockstep(engines, pairs)
+        for d, w in zip(dicts, want_d):
+            for key in ('points', 'lengths', 'neighbors', 'subsampling', 'upsampling'):
+                assert all(torch.equal(a, b) for a, b in zip(d[key], w[key])), key
+        for e in engines:
+            e.reserve(160 << 20)  # (the collates grew the arenas: start small again for the forwards)
+        res = engine.Engine.forward_lockstep(engines, dicts)
+        assert any(int(r.arena_used) > (160 << 20) for r in res)
+        for k, e in enumerate(engines):
+            for n in names:
+                assert torch.equal(e.tensor(n), want_t[k][n]), (k, n)
