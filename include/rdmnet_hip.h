@@ -304,6 +304,17 @@ int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const float* x, i
                        const float* wo, int64_t ld_wo, const float* bo, const float* gamma1, const float* beta1,
                        const float* w1, int64_t ld_w1, const float* b1, const float* w2, int64_t ld_w2, const float* b2,
                        const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out, void* stream);
+/* The same on weights stored once in OPERAND order (round 6): rdm_attention_tail_pack_weights writes wo | w1 | w2 as float4
+ * [(wavefront, step), lane] into `packed` (rdm_attention_tail_packed_floats() floats, 16-byte aligned), so that every weight load
+ * instruction of the kernel reads one contiguous KB instead of 16 rows x 64 B (28 k -> 19.5 k clocks per workgroup: the kernel
+ * is bound by the CU's L2 fill path).  Same values in the same lanes: the bits of rdm_attention_tail.                        */
+size_t rdm_attention_tail_packed_floats(void);
+int rdm_attention_tail_pack_weights(const float* wo, int64_t ld_wo, const float* w1, int64_t ld_w1, const float* w2, int64_t ld_w2,
+                                    float* packed, void* stream);
+int rdm_attention_tail_packed(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                              const float* packed, const float* bo, const float* gamma1, const float* beta1, const float* b1,
+                              const float* b2, const float* gamma2, const float* beta2, float eps, float* out, int64_t ld_out,
+                              void* stream);
 int rdm_gather_max(const float* x, int64_t n_s, int64_t c, int64_t ldx, const int64_t* idx, int64_t m,
                    int64_t h, int64_t ldi, const int32_t* width, float* y, int64_t ldy, void* stream);
 /* rdm_gather_rows: y[i,:] = x[idx[i],:] on raw 32-bit words, out-of-range index -> zero row (the

@@ -89,6 +89,10 @@ SIGNATURES = {
                                       c_f32, c_int, c_void, c_i64, c_void]),
     'rdm_attention_tail': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_void, c_void, c_void, c_i64,
                                    c_void, c_void, c_i64, c_void, c_void, c_void, c_f32, c_void, c_i64, c_void]),
+    'rdm_attention_tail_packed_floats': (c_size, []),
+    'rdm_attention_tail_pack_weights': (c_int, [c_void, c_i64, c_void, c_i64, c_void, c_i64, c_void, c_void]),
+    'rdm_attention_tail_packed': (c_int, [c_void, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_void, c_void, c_void, c_void,
+                                          c_void, c_void, c_f32, c_void, c_i64, c_void]),
     'rdm_gather_max': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_i64, c_i64, c_void, c_void, c_i64,
                                c_void]),
     'rdm_upsample_concat': (c_int, [c_void, c_i64, c_i64, c_i64, c_void, c_i64, c_void, c_i64, c_i64, c_i64,

@@ -467,6 +467,11 @@ int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, M
       lo->second.out == 128 && lo->second.kpad == 128 && l1->second.out == 256 && l1->second.kpad == 128 &&
       l2->second.out == 128 && l2->second.kpad == 256) {
     const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
+    auto pk = e->params->vec.find(p + ".__tail_packed");
+    if (pk != e->params->vec.end())
+      return rdm_attention_tail_packed(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, pk->second, Lo.bias, vecp(r, p + ".attention.norm.weight"),
+                                       vecp(r, p + ".attention.norm.bias"), L1.bias, L2.bias, vecp(r, p + ".output.norm.weight"),
+                                       vecp(r, p + ".output.norm.bias"), 1e-5f, out.p, out.ld, r.st);
     return rdm_attention_tail(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, Lo.wt, Lo.kpad, Lo.bias, vecp(r, p + ".attention.norm.weight"),
                               vecp(r, p + ".attention.norm.bias"), L1.wt, L1.kpad, L1.bias, L2.wt, L2.kpad, L2.bias,
                               vecp(r, p + ".output.norm.weight"), vecp(r, p + ".output.norm.bias"), 1e-5f, out.p, out.ld, r.st);
@@ -877,6 +882,24 @@ extern "C" int rdm_engine_finalize(rdm_engine* e) {
     float* d = nullptr;
     ENG_CHECK(upload(e, std::vector<float>(static_cast<size_t>(e->cfg.points_in_patch), std::sqrt(static_cast<float>(e->cfg.out_dim))), &d));
     e->params->vec["__sqrt_out_dim"] = d;
+  }
+  // the attention tails' weights in operand order (rdm_attention_tail_pack_weights: every weight load of the kernel one contiguous KB)
+  {
+    std::vector<std::string> layers;
+    for (auto& kv : e->params->lin)
+      if (ends_with(kv.first, ".attention.linear")) layers.push_back(kv.first.substr(0, kv.first.size() - std::strlen(".attention.linear")));
+    for (const std::string& p : layers) {
+      auto lo = e->params->lin.find(p + ".attention.linear"), l1 = e->params->lin.find(p + ".output.expand"), l2 = e->params->lin.find(p + ".output.squeeze");
+      if (l1 == e->params->lin.end() || l2 == e->params->lin.end() || !lo->second.wt || !l1->second.wt || !l2->second.wt ||
+          lo->second.out != 128 || lo->second.kpad != 128 || l1->second.out != 256 || l1->second.kpad != 128 || l2->second.out != 128 || l2->second.kpad != 256)
+        continue;
+      float* d = nullptr;
+      RDM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), rdm_attention_tail_packed_floats() * sizeof(float)));
+      e->params->owned.push_back(d);
+      ENG_CHECK(rdm_attention_tail_pack_weights(lo->second.wt, lo->second.kpad, l1->second.wt, l1->second.kpad, l2->second.wt, l2->second.kpad, d, nullptr));
+      e->params->vec[p + ".__tail_packed"] = d;
+    }
+    RDM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->finalized = true;
   return RDM_OK;

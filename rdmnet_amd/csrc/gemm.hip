@@ -956,6 +956,10 @@ struct TailArgs {
   float* out;
   int M, ldh, ldx, ldo, ldwo, ldw1, ldw2;
   float eps;
+  // round 6: the three weight matrices in OPERAND order (rdm_attention_tail_pack_weights): float4 [(wavefront, step), lane] so that
+  // every weight load instruction of a wavefront reads ONE contiguous KB (8 full lines) instead of 16 rows x 64 B; same values in
+  // the same lanes: same bits.  wo at 0, w1 at 4096, w2 at 12288 (float4 units); null = the checkpoint layout (wo / w1 / w2).
+  const float4* packed;
 #ifdef RDM_TAIL_TIMING
   unsigned long long* clk;  // tools/tail_lab.hip: shader-clock stamps of workgroup 0, wavefront 0
 #endif
@@ -965,6 +969,7 @@ struct TailArgs {
 #else
 #define TAIL_STAMP(k) do { } while (0)
 #endif
+template <bool PACKED>
 __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, const dim3 gridDim, TailArgs a) {
   (void)gridDim;
   __shared__ __attribute__((aligned(16))) float ys[16][132];
@@ -999,7 +1004,7 @@ __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, cons
     const float4 hv = *reinterpret_cast<const float4*>(a.hid + static_cast<long long>(min(m0 + hr, a.M - 1)) * a.ldh + hc);
     const float* p0 = a.wo + static_cast<long long>(c) * a.ldwo + 4 * kb;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bw0[s] = *reinterpret_cast<const float4*>(p0 + 16 * s);
+    for (int s = 0; s < 8; ++s) bw0[s] = PACKED ? a.packed[(w * 8 + s) * 64 + lane] : *reinterpret_cast<const float4*>(p0 + 16 * s);
     *reinterpret_cast<float4*>(&zs[hr][hc]) = hv;
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -1041,8 +1046,8 @@ __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, cons
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    bw1[0][s] = *reinterpret_cast<const float4*>(p1a + 16 * s);
-    bw1[1][s] = *reinterpret_cast<const float4*>(p1b + 16 * s);
+    bw1[0][s] = PACKED ? a.packed[4096 + ((w * 2 + 0) * 8 + s) * 64 + lane] : *reinterpret_cast<const float4*>(p1a + 16 * s);
+    bw1[1][s] = PACKED ? a.packed[4096 + ((w * 2 + 1) * 8 + s) * 64 + lane] : *reinterpret_cast<const float4*>(p1b + 16 * s);
     const float4 ha = *reinterpret_cast<const float4*>(&zs[i][16 * s + 4 * kb]);
     const float at[4] = {ha.x, ha.y, ha.z, ha.w}, bt[4] = {bw0[s].x, bw0[s].y, bw0[s].z, bw0[s].w};
 #pragma unroll
@@ -1050,7 +1055,7 @@ __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, cons
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int s = 0; s < 8; ++s) bw2[s] = *reinterpret_cast<const float4*>(p2 + 16 * s);
+  for (int s = 0; s < 8; ++s) bw2[s] = PACKED ? a.packed[12288 + (w * 16 + s) * 64 + lane] : *reinterpret_cast<const float4*>(p2 + 16 * s);
   __builtin_amdgcn_sched_barrier(0);
   float y[4];
 #pragma unroll
@@ -1067,7 +1072,7 @@ __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, cons
   f32x4_t z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    bw2[8 + s] = *reinterpret_cast<const float4*>(p2 + 16 * (8 + s));
+    bw2[8 + s] = PACKED ? a.packed[12288 + (w * 16 + 8 + s) * 64 + lane] : *reinterpret_cast<const float4*>(p2 + 16 * (8 + s));
     const float4 ya = *reinterpret_cast<const float4*>(&ys[i][16 * s + 4 * kb]);
     const float at[4] = {ya.x, ya.y, ya.z, ya.w};
     const float u0[4] = {bw1[0][s].x, bw1[0][s].y, bw1[0][s].z, bw1[0][s].w};
@@ -1109,7 +1114,27 @@ __device__ __forceinline__ void attention_tail128_body(const dim3 blockIdx, cons
     if (row < a.M) a.out[static_cast<long long>(row) * a.ldo + c] = o[r];
   }
 }
-__global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) { attention_tail128_body(blockIdx, gridDim, a); }
+template <bool PACKED>
+__global__ __launch_bounds__(512) void attention_tail128_kernel(TailArgs a) { attention_tail128_body<PACKED>(blockIdx, gridDim, a); }
+
+// The tail's weights in operand order (TailArgs::packed): one thread per float4.
+__global__ void attention_tail_pack_kernel(const float* wo, int ldwo, const float* w1, int ldw1, const float* w2, int ldw2, float4* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 20480) return;
+  const int lane = e & 63, i = lane & 15, kb = lane >> 4;
+  const float* src;
+  if (e < 4096) {
+    const int w = e >> 9, s = (e >> 6) & 7;
+    src = wo + static_cast<long long>(16 * w + i) * ldwo + 16 * s + 4 * kb;
+  } else if (e < 12288) {
+    const int t = e - 4096, w = t >> 10, h = (t >> 9) & 1, s = (t >> 6) & 7;
+    src = w1 + static_cast<long long>(32 * w + 16 * h + i) * ldw1 + 16 * s + 4 * kb;
+  } else {
+    const int t = e - 12288, w = t >> 10, s = (t >> 6) & 15;
+    src = w2 + static_cast<long long>(16 * w + i) * ldw2 + 16 * s + 4 * kb;
+  }
+  out[e] = *reinterpret_cast<const float4*>(src);
+}
 
 __device__ __forceinline__ void splitk_reduce_kernel_body(const dim3 blockIdx, const dim3 gridDim, GemmArgs g, int batches) {
   (void)blockIdx; (void)gridDim;
@@ -1695,8 +1720,46 @@ extern "C" int rdm_attention_tail(const float* hidden, int64_t ld_hidden, const 
   a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
   a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = static_cast<int>(ld_wo);
   a.ldw1 = static_cast<int>(ld_w1); a.ldw2 = static_cast<int>(ld_w2); a.eps = eps;
+  a.packed = nullptr;
   RDM_DUP_LOOP("tail")
-  ::rdm::launch<attention_tail128_body, attention_tail128_kernel, 512>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), 0, static_cast<hipStream_t>(stream), a);
+  ::rdm::launch<attention_tail128_body<false>, attention_tail128_kernel<false>, 512>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), 0, static_cast<hipStream_t>(stream), a);
+  return launch_status("attention_tail128_kernel");
+}
+
+// The same on weights in operand order (rdm_attention_tail_pack_weights): every weight load of a wavefront is one contiguous KB.
+extern "C" size_t rdm_attention_tail_packed_floats(void) { return 81920; }
+
+extern "C" int rdm_attention_tail_pack_weights(const float* wo, int64_t ld_wo, const float* w1, int64_t ld_w1, const float* w2,
+                                               int64_t ld_w2, float* packed, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(wo && w1 && w2 && packed, "rdm_attention_tail_pack_weights: null pointer");
+  RDM_REQUIRE(ld_wo % 4 == 0 && ld_w1 % 4 == 0 && ld_w2 % 4 == 0 && ld_wo >= 128 && ld_w1 >= 128 && ld_w2 >= 256,
+              "rdm_attention_tail_pack_weights: bad leading dimensions");
+  RDM_REQUIRE(((reinterpret_cast<uintptr_t>(wo) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2) |
+                reinterpret_cast<uintptr_t>(packed)) & 15) == 0, "rdm_attention_tail_pack_weights: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(attention_tail_pack_kernel, dim3(80), dim3(256), 0, static_cast<hipStream_t>(stream), wo, static_cast<int>(ld_wo), w1,
+                     static_cast<int>(ld_w1), w2, static_cast<int>(ld_w2), reinterpret_cast<float4*>(packed));
+  return launch_status("attention_tail_pack_kernel");
+}
+
+extern "C" int rdm_attention_tail_packed(const float* hidden, int64_t ld_hidden, const float* x, int64_t ldx, int64_t m, int64_t d,
+                                         const float* packed, const float* bo, const float* gamma1, const float* beta1,
+                                         const float* b1, const float* b2, const float* gamma2, const float* beta2, float eps,
+                                         float* out, int64_t ld_out, void* stream) {
+  using namespace rdm;
+  RDM_REQUIRE(hidden && x && packed && gamma1 && beta1 && gamma2 && beta2 && out, "rdm_attention_tail_packed: null pointer");
+  RDM_REQUIRE(d == 128 && m >= 0, "rdm_attention_tail_packed: supports d = 128 with a 256-wide FFN (d=%lld)", (long long)d);
+  RDM_REQUIRE(ld_hidden % 4 == 0 && ld_hidden >= 128 && ldx >= 128 && ld_out >= 128, "rdm_attention_tail_packed: bad leading dimensions");
+  RDM_REQUIRE(((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(packed)) & 15) == 0,
+              "rdm_attention_tail_packed: hidden and the packed weights must be 16-byte aligned");
+  if (m == 0) return RDM_OK;
+  TailArgs a;
+  a.hid = hidden; a.x = x; a.wo = nullptr; a.bo = bo; a.g1 = gamma1; a.be1 = beta1; a.w1 = nullptr; a.b1 = b1; a.w2 = nullptr; a.b2 = b2;
+  a.g2 = gamma2; a.be2 = beta2; a.out = out; a.M = static_cast<int>(m); a.ldh = static_cast<int>(ld_hidden);
+  a.ldx = static_cast<int>(ldx); a.ldo = static_cast<int>(ld_out); a.ldwo = a.ldw1 = a.ldw2 = 0; a.eps = eps;
+  a.packed = reinterpret_cast<const float4*>(packed);
+  RDM_DUP_LOOP("tail")
+  ::rdm::launch<attention_tail128_body<true>, attention_tail128_kernel<true>, 512>(dim3(static_cast<unsigned>(ceil_div<int64_t>(m, 16))), 0, static_cast<hipStream_t>(stream), a);
   return launch_status("attention_tail128_kernel");
 }
 

@@ -262,9 +262,11 @@ class RDMNet(torch.nn.Module):
         lo, l1, l2 = p + '.attention.linear', p + '.output.expand', p + '.output.squeeze'
         wts = [W.get(k + '.wt') for k in (lo, l1, l2)]
         if all(w is not None for w in wts) and [tuple(w.shape) for w in wts] == [(128, 128), (256, 128), (128, 256)]:
-            return ops.attention_tail(hid, x, wts[0], W[lo][1], W[p + '.attention.norm.weight'], W[p + '.attention.norm.bias'],
-                                      wts[1], W[l1][1], wts[2], W[l2][1], W[p + '.output.norm.weight'],
-                                      W[p + '.output.norm.bias'], out=out)
+            if (p + '.tail_packed') not in W:  # the three matrices in the kernel's operand order, once (as the native engine keeps them)
+                W[p + '.tail_packed'] = ops.attention_tail_pack_weights(*wts)
+            return ops.attention_tail_packed(hid, x, W[p + '.tail_packed'], W[lo][1], W[p + '.attention.norm.weight'],
+                                             W[p + '.attention.norm.bias'], W[l1][1], W[l2][1], W[p + '.output.norm.weight'],
+                                             W[p + '.output.norm.bias'], out=out)
         y = self._linear_ln(p + '.attention.linear', p + '.attention.norm', hid, x)
         z = self._linear(p + '.output.expand', y, act=ACT_RELU)
         return self._linear_ln(p + '.output.squeeze', p + '.output.norm', z, y, out=out)

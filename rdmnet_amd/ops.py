@@ -239,6 +239,26 @@ def attention_tail(hidden, x, wo, bo, gamma1, beta1, w1, b1, w2, b2, gamma2, bet
     return y
 
 
+def attention_tail_pack_weights(wo, w1, w2):
+    """wo [128,128], w1 [256,128], w2 [128,256] (nn.Linear layout) -> the tail kernel's operand order (one 81 920-float tensor)."""
+    L = _lib.lib()
+    packed = torch.empty((L.rdm_attention_tail_packed_floats(),), dtype=torch.float32, device=wo.device)
+    _lib.check(L.rdm_attention_tail_pack_weights(wo.data_ptr(), _ld(wo), w1.data_ptr(), _ld(w1), w2.data_ptr(), _ld(w2), packed.data_ptr(),
+                                                 _lib.stream_ptr()), 'rdm_attention_tail_pack_weights')
+    return packed
+
+
+def attention_tail_packed(hidden, x, packed, bo, gamma1, beta1, b1, b2, gamma2, beta2, *, eps=1e-5, out=None):
+    """attention_tail on weights packed by attention_tail_pack_weights: the same bits, contiguous weight loads."""
+    L = _lib.lib()
+    m = hidden.shape[0]
+    y = out if out is not None else feat_empty(m, 128, hidden.device)
+    _lib.check(L.rdm_attention_tail_packed(hidden.data_ptr(), _ld(hidden), x.data_ptr(), _ld(x), m, 128, packed.data_ptr(), _lib.ptr(bo),
+                                           gamma1.data_ptr(), beta1.data_ptr(), _lib.ptr(b1), _lib.ptr(b2), gamma2.data_ptr(), beta2.data_ptr(),
+                                           eps, y.data_ptr(), _ld(y), _lib.stream_ptr()), 'rdm_attention_tail_packed')
+    return y
+
+
 def linear_layer_norm(x, w, k, n, bias, gamma, beta, *, residual=None, act=ACT_NONE, eps=1e-5, out=None):
     """act(LayerNorm(x[:, :k] @ w.T + bias [+ residual])) in one launch; w = nn.Linear weight [128, k] (n must be 128,
     k a multiple of 16)."""

@@ -367,6 +367,10 @@ def test_attention_tail_fused_matches_torch(ops, m):
     z3 = ops.gemm(y3, c(w1.t().contiguous()), 128, 256, bias=c(b1), act=1)
     o3 = ops.linear_layer_norm(z3, c(w2), 256, 128, c(b2), c(g2), c(be2), residual=y3).cpu()
     assert (got - o3).abs().max() <= 3e-5 * want.abs().max()
+    # round 6: the weights in the kernel's operand order (what the engine and the module keep): the same bits
+    packed = ops.attention_tail_pack_weights(c(wo), c(w1), c(w2))
+    got_p = ops.attention_tail_packed(padded(hid), padded(x), packed, c(bo), c(g1), c(be1), c(b1), c(b2), c(g2), c(be2)).cpu()
+    assert torch.equal(got_p, got)
 
 
 @pytest.mark.parametrize('c,cout,h,m,ns', [(1, 64, 65, 1000, 1500), (32, 32, 65, 1000, 2000), (64, 64, 63, 700, 900), (32, 32, 3, 50, 60),
