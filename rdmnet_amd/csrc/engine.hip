@@ -468,7 +468,8 @@ int attention_tail(Run& r, const std::string& p, const Mat& hid, const Mat& x, M
       l2->second.out == 128 && l2->second.kpad == 256) {
     const Linear &Lo = lo->second, &L1 = l1->second, &L2 = l2->second;  // the whole tail in one launch
     auto pk = e->params->vec.find(p + ".__tail_packed");
-    if (pk != e->params->vec.end())
+    static const bool unpacked = ::rdm::dev_knob("RDM_TAIL_UNPACKED") != nullptr;  // developer knob (A/B): the checkpoint layout
+    if (pk != e->params->vec.end() && !unpacked)
       return rdm_attention_tail_packed(hid.p, hid.ld, x.p, x.ld, hid.rows, 128, pk->second, Lo.bias, vecp(r, p + ".attention.norm.weight"),
                                        vecp(r, p + ".attention.norm.bias"), L1.bias, L2.bias, vecp(r, p + ".output.norm.weight"),
                                        vecp(r, p + ".output.norm.bias"), 1e-5f, out.p, out.ld, r.st);
