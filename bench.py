@@ -529,7 +529,10 @@ def main():
             res = eng.run(*dev_tensors(i))
             assert eng.host_corr()[0].shape[0] == res.n_correspondences
         pipe.map(range(4 * len(streams)), single_step)
-        one_by_one = {'value': timed_pass(2 * args.full_steps, single_step), 'unit': 'pairs/s', 'steps': 2 * args.full_steps,
+        v_single = timed_pass(2 * args.full_steps, single_step)
+        lat_single = sorted(pipe.last_stats.get('latency_ms', {}).values())
+        one_by_one = {'value': v_single, 'unit': 'pairs/s', 'steps': 2 * args.full_steps,
+                      'p50_ms_per_pair': float(np.median(lat_single)) if lat_single else None,
                       'note': f'rdm_engine_run, one pair per call, {len(streams)} pairs in flight (the schedule `value` was measured on up to '
                               'round 4; --lockstep 1 makes it the timed region)'}
 
