@@ -244,3 +244,21 @@ def test_pin_rank_keeps_a_rank_on_its_gpus_numa_node(tmp_path, monkeypatch):
         pipeline._pinned = False
     assert pipeline.choose_wait_us(4, local_world=10 ** 6) == 50  # no cores to spin on
     assert pipeline.rank_cpu_budget(2) == min(len(before) / 2.0, pipeline._quota_cpus() / 2)  # shared mask: divided
+
+
+def test_a_held_pair_is_recognised_by_identity_and_version_only():
+    """ADVICE r5 (round 6): what a lock-step group remembers of a pair's tensors -- the tensors themselves and their version counters --
+    answers `Engine.run` only for the same memory, extent AND version: an in-place refill, another tensor of the same shape, or a
+    tensor that merely took over the address do not match.  (Pure host logic: CPU tensors.)"""
+    import torch
+    from rdmnet_amd.engine import Engine
+    r, s = torch.zeros(10, 3), torch.ones(12, 3)
+    held = Engine._held(r, s)
+    assert Engine._is_held(held, r, s)
+    assert Engine._is_held(held, r[:], s.view(12, 3))          # views of the same memory and extent
+    assert not Engine._is_held(held, r.clone(), s)             # same values, other memory
+    assert not Engine._is_held(held, r[:5], s)                 # same address, other extent
+    assert not Engine._is_held(held, s, r)
+    r.add_(1.0)                                                # refilled in place: the version counter moved
+    assert not Engine._is_held(held, r, s)
+    assert Engine._is_held(Engine._held(r, s), r, s)
